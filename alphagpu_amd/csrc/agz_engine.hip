@@ -1,0 +1,755 @@
+// agz_engine.hip — libagz: host side of the engine and the C ABI of include/agz.h.
+//
+// One engine = one device + one HIP stream.  The engine owns the trees (HBM), the network weights and the
+// sample store; the per-move loop of mcts_single (mcts_gpu.jl:376-462) is V x { k_rollout, network } with no
+// host synchronisation, and the per-generation loop of mcts() (:477-579) crosses PCIe with 4 bytes per ply.
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/agz.h"
+#include "agz_games.hpp"
+#include "agz_device.hpp"
+#include "agz_tree.hpp"
+#include "agz_nn.hpp"
+#include "agz_selfplay.hpp"
+
+using namespace agz;
+
+static thread_local std::string g_create_error;
+
+#define HIPCHK(h, call)                                                                              \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess) { (h)->fail("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); return AGZ_ERR_HIP; } \
+    } while (0)
+
+struct DevNet {
+    int H = 0, T = 0, in = 0, A = 0, INP = 0, AOP = 0;
+    bool loaded = false;
+    // exact mode: Flux-layout fp32
+    float *W0 = nullptr, *Wres = nullptr, *Wp = nullptr, *bp = nullptr, *Wv = nullptr, *bv = nullptr;
+    // bf16 mode: pre-tiled B fragments
+    uint16_t *t0 = nullptr, *tres = nullptr, *thead = nullptr;
+    float* bias_head = nullptr;
+    int NT_h = 0, NT_head = 0;
+};
+
+typedef void (*rollout_fn)(const TreePar);
+typedef void (*advance_fn)(const PlyPar);
+typedef void (*softmax_fn)(const float*, int, float*, int, int, int);
+
+struct agz_engine {
+    agz_config cfg;
+    GamePar G;
+    agz_game_info info;
+    std::string err;
+    hipStream_t stream = nullptr;
+    int L = 0;                 // active slots
+    int Lmax = 0, V = 0, NRV = 1;
+    TreePar tp;                // template of kernel arguments
+    // tree memory
+    uint8_t* recs = nullptr; Pos* states = nullptr; uint32_t* meta = nullptr;
+    uint32_t *ncount = nullptr, *leaf = nullptr, *game_id = nullptr, *game_id2 = nullptr, *cnt_p = nullptr, *cnt_new = nullptr;
+    // network i/o
+    void* planes = nullptr; float* logits = nullptr; float *prior_eval = nullptr, *v_eval = nullptr, *policy_final = nullptr;
+    uint16_t *act0 = nullptr, *act1 = nullptr; float *actf0 = nullptr, *actf1 = nullptr;
+    int INP = 0, LGS = 0, Hcap = 0;
+    DevNet net[2];
+    // selfplay
+    Pos* newpos = nullptr; uint32_t *alive = nullptr, *newslot = nullptr, *d_count = nullptr;
+    int sample_games = 0;
+    uint64_t* s_boards = nullptr; float* s_policy = nullptr; int16_t* s_move = nullptr;
+    int32_t* g_nplies = nullptr; int8_t* g_result = nullptr; Pos* g_final = nullptr;
+    unsigned long long* d_stats = nullptr;
+    int sp_games = 0;          // games of the last selfplay
+    bool cnt_live = false;     // per-slot counters of the last search not yet folded into acc_*
+    float* scratch_f = nullptr; // [Lmax][max(A,2VS)] getter staging
+    // search state
+    float cpuct = 1.5f; int training = 1; uint32_t step = 0; bool need_reset = true; bool injected = false;
+    uint64_t total_rollouts = 0, acc_p = 0, acc_new = 0;
+    // profiling
+    bool profiling = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_tree, ev_nn;
+    size_t ev_tree_used = 0, ev_nn_used = 0;
+    double tree_ms = 0, nn_ms = 0; int64_t tree_launches = 0;
+    rollout_fn k_roll = nullptr; advance_fn k_adv = nullptr; softmax_fn k_soft = nullptr;
+
+    int fail(const char* fmt, ...) {
+        char buf[512]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+        err = buf; return 0;
+    }
+};
+
+// ---- kernel dispatch tables -------------------------------------------------------------------------
+template <int FAM, int NR, int NC> static rollout_fn pick_rollout(int NRV) {
+    switch (NRV) {
+    case 1: return k_rollout<FAM, NR, NC, 1>;
+    case 2: return k_rollout<FAM, NR, NC, 2>;
+    default: return k_rollout<FAM, NR, NC, 4>;
+    }
+}
+#define AGZ_COMBOS(X) \
+    X(F_LINE, 1, 1) X(F_LINE, 2, 2) X(F_LINE, 3, 3) X(F_C4, 1, 1) \
+    X(F_HEX, 1, 1) X(F_HEX, 1, 2) X(F_HEX, 2, 2) X(F_HEX, 2, 3) X(F_HEX, 3, 3) \
+    X(F_REV, 1, 1) X(F_REV, 2, 1)
+
+static bool bind_kernels(agz_engine* h) {
+    const GamePar& P = h->G;
+#define X(F, R, C) \
+    if (P.fam == F && P.NR == R && P.NC == C) { h->k_roll = pick_rollout<F, R, C>(h->NRV); h->k_adv = k_advance<F, R, C>; }
+    AGZ_COMBOS(X)
+#undef X
+    if (P.NR == 1) h->k_soft = k_softmax<1>; else if (P.NR == 2) h->k_soft = k_softmax<2>; else h->k_soft = k_softmax<3>;
+    return h->k_roll != nullptr;
+}
+
+// ---- helpers ----------------------------------------------------------------------------------------
+static inline uint16_t host_f2bf(float x) {
+    uint32_t u; memcpy(&u, &x, 4);
+    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+static int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// tile W (Flux (out,in) column-major, N x K) into MFMA B-operand fragments [KT][NT][64][8]
+static void tile_weights(const float* W, int N, int K, int NT, int KT, std::vector<uint16_t>& out, int row_off = 0, int ldn = -1) {
+    if (ldn < 0) ldn = N;
+    for (int kt = 0; kt < KT; ++kt)
+        for (int nt = 0; nt < NT; ++nt)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    int n = 32 * nt + (l & 31) - row_off, k = 16 * kt + 8 * (l >> 5) + j;
+                    size_t o = (((size_t)kt * NT + nt) * 64 + l) * 8 + j;
+                    if (n >= 0 && n < N && k < K) out[o] = host_f2bf(W[(size_t)n + (size_t)ldn * k]);
+                }
+}
+
+template <typename T> static hipError_t dmalloc(T** p, size_t n) { return hipMalloc((void**)p, n * sizeof(T)); }
+
+static void free_net(DevNet& n) {
+    hipFree(n.W0); hipFree(n.Wres); hipFree(n.Wp); hipFree(n.bp); hipFree(n.Wv); hipFree(n.bv);
+    hipFree(n.t0); hipFree(n.tres); hipFree(n.thead); hipFree(n.bias_head);
+    n = DevNet();
+}
+
+// ======================================================================================================
+extern "C" {
+
+int agz_query_game(const agz_config* cfg, agz_game_info* out) {
+    if (!cfg || !out) return AGZ_ERR_ARG;
+    GamePar P;
+    if (make_game_par(cfg->game, cfg->n, cfg->nvict, P) != 0) return AGZ_ERR_ARG;
+    out->A = P.A; out->VS = P.VS; out->FS = P.FS; out->ML = P.ML; out->max_plies = P.max_plies;
+    out->pos_image_bytes = (P.fam == F_REV) ? 152 : 104;
+    out->rec_bytes = round_up(20 + 4 * P.A + 2 * P.VS + P.FS, 16);
+    out->reserved = 0;
+    return AGZ_OK;
+}
+
+const char* agz_last_error(const agz_engine* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+void agz_destroy(agz_engine* h) {
+    if (!h) return;
+    hipSetDevice(h->cfg.device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    hipFree(h->recs); hipFree(h->states); hipFree(h->meta); hipFree(h->ncount); hipFree(h->leaf); hipFree(h->game_id);
+    hipFree(h->game_id2); hipFree(h->cnt_p); hipFree(h->cnt_new); hipFree(h->planes); hipFree(h->logits);
+    hipFree(h->prior_eval); hipFree(h->v_eval); hipFree(h->policy_final); hipFree(h->act0); hipFree(h->act1);
+    hipFree(h->actf0); hipFree(h->actf1); hipFree(h->newpos); hipFree(h->alive); hipFree(h->newslot); hipFree(h->d_count);
+    hipFree(h->s_boards); hipFree(h->s_policy); hipFree(h->s_move); hipFree(h->g_nplies); hipFree(h->g_result);
+    hipFree(h->g_final); hipFree(h->d_stats); hipFree(h->scratch_f);
+    free_net(h->net[0]); free_net(h->net[1]);
+    for (auto& e : h->ev_tree) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    for (auto& e : h->ev_nn) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int agz_create(const agz_config* cfg, agz_engine** out) {
+    if (!cfg || !out) { g_create_error = "null argument"; return AGZ_ERR_ARG; }
+    *out = nullptr;
+    agz_engine* h = new agz_engine();
+    h->cfg = *cfg;
+    auto bail = [&](int rc) { g_create_error = h->err; agz_destroy(h); return rc; };
+    if (make_game_par(cfg->game, cfg->n, cfg->nvict, h->G) != 0) { h->fail("unsupported game parameters"); return bail(AGZ_ERR_ARG); }
+    if (cfg->max_games < 1 || cfg->max_visits < 1 || cfg->max_visits > 256) { h->fail("max_games >= 1 and 1 <= max_visits <= 256 required"); return bail(AGZ_ERR_ARG); }
+    if (cfg->nn_mode != AGZ_NN_BF16 && cfg->nn_mode != AGZ_NN_EXACT) { h->fail("bad nn_mode"); return bail(AGZ_ERR_ARG); }
+    agz_query_game(cfg, &h->info);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { h->fail("no HIP device available (libagz has no CPU fallback)"); return bail(AGZ_ERR_HIP); }
+    if (cfg->device < 0 || cfg->device >= ndev) { h->fail("device %d out of range (%d devices)", cfg->device, ndev); return bail(AGZ_ERR_ARG); }
+    if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        h->fail("cannot initialise device %d", cfg->device); return bail(AGZ_ERR_HIP);
+    }
+    const GamePar& P = h->G;
+    h->Lmax = cfg->max_games; h->V = cfg->max_visits;
+    h->NRV = h->V <= 64 ? 1 : (h->V <= 128 ? 2 : 4);
+    if (!bind_kernels(h)) { h->fail("no kernel instantiation for this game shape"); return bail(AGZ_ERR_UNSUPPORTED); }
+    hipFuncSetAttribute((const void*)k_layer_exact<EX_RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)k_layer_exact<EX_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)k_layer_exact<EX_POLICY>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)k_layer_exact<EX_VALUE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const uint32_t A2 = (uint32_t)round_up(P.A, 2);
+    const uint32_t rec_bytes = (uint32_t)round_up((int)(A2 * 10), 64);
+    const size_t Lm = (size_t)h->Lmax, V = (size_t)h->V;
+    h->INP = round_up(2 * P.VS, 32);
+    h->LGS = round_up(P.A + 1, 32);
+    hipError_t e = hipSuccess;
+    auto A_ = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+    A_(dmalloc(&h->recs, Lm * V * rec_bytes));
+    A_(dmalloc(&h->states, Lm * V));
+    A_(dmalloc(&h->meta, Lm * V));
+    A_(dmalloc(&h->ncount, Lm)); A_(dmalloc(&h->leaf, Lm)); A_(dmalloc(&h->game_id, Lm)); A_(dmalloc(&h->game_id2, Lm));
+    A_(dmalloc(&h->cnt_p, Lm)); A_(dmalloc(&h->cnt_new, Lm));
+    if (cfg->nn_mode == AGZ_NN_BF16) { uint16_t* p = nullptr; A_(dmalloc(&p, Lm * h->INP)); h->planes = p; }
+    else { float* p = nullptr; A_(dmalloc(&p, Lm * h->INP)); h->planes = p; }
+    A_(dmalloc(&h->logits, Lm * h->LGS));
+    A_(dmalloc(&h->prior_eval, Lm * P.A)); A_(dmalloc(&h->v_eval, Lm)); A_(dmalloc(&h->policy_final, Lm * P.A));
+    A_(dmalloc(&h->newpos, Lm)); A_(dmalloc(&h->alive, Lm)); A_(dmalloc(&h->newslot, Lm)); A_(dmalloc(&h->d_count, 4));
+    A_(dmalloc(&h->d_stats, 8));
+    A_(dmalloc(&h->scratch_f, Lm * (size_t)((P.A > 2 * P.VS) ? P.A : 2 * P.VS)));
+    h->sample_games = cfg->sample_capacity_games > 0 ? cfg->sample_capacity_games : h->Lmax;
+    const size_t SG = (size_t)h->sample_games, MP = (size_t)P.max_plies;
+    A_(dmalloc(&h->s_boards, SG * MP * 6)); A_(dmalloc(&h->s_policy, SG * MP * P.A)); A_(dmalloc(&h->s_move, SG * MP));
+    A_(dmalloc(&h->g_nplies, SG)); A_(dmalloc(&h->g_result, SG)); A_(dmalloc(&h->g_final, SG));
+    if (e != hipSuccess) { h->fail("device allocation failed: %s", hipGetErrorString(e)); return bail(AGZ_ERR_NOMEM); }
+    hipMemsetAsync(h->meta, 0, Lm * V * 4, h->stream);
+    hipMemsetAsync(h->policy_final, 0, Lm * P.A * 4, h->stream);
+    hipMemsetAsync(h->planes, 0, Lm * h->INP * (cfg->nn_mode == AGZ_NN_BF16 ? 2 : 4), h->stream);
+    hipMemsetAsync(h->logits, 0, Lm * h->LGS * 4, h->stream);
+    hipMemsetAsync(h->prior_eval, 0, Lm * P.A * 4, h->stream);
+    hipMemsetAsync(h->v_eval, 0, Lm * 4, h->stream);
+    hipMemsetAsync(h->cnt_p, 0, Lm * 4, h->stream); hipMemsetAsync(h->cnt_new, 0, Lm * 4, h->stream);
+    hipMemsetAsync(h->g_nplies, 0, SG * 4, h->stream);
+
+    TreePar& T = h->tp;
+    memset(&T, 0, sizeof T);
+    T.G = P; T.V = h->V; T.rec_bytes = rec_bytes; T.off_q = A2 * 4; T.off_vc = A2 * 8; T.A2 = A2;
+    T.recs = h->recs; T.states = h->states; T.meta = h->meta; T.ncount = h->ncount; T.leaf = h->leaf; T.game_id = h->game_id;
+    T.cnt_p = h->cnt_p; T.cnt_new = h->cnt_new; T.planes = h->planes; T.INP = h->INP; T.planes_f32 = cfg->nn_mode == AGZ_NN_EXACT;
+    T.logits = h->logits; T.LGS = h->LGS; T.prior_eval = h->prior_eval; T.v_eval = h->v_eval; T.policy_final = h->policy_final;
+    T.seed = cfg->seed; T.exact = cfg->nn_mode == AGZ_NN_EXACT;
+    if (hipStreamSynchronize(h->stream) != hipSuccess) { h->fail("device init failed"); return bail(AGZ_ERR_HIP); }
+    *out = h;
+    return AGZ_OK;
+}
+
+int agz_get_info(const agz_engine* h, agz_game_info* out) {
+    if (!h || !out) return AGZ_ERR_ARG;
+    *out = h->info; return AGZ_OK;
+}
+void* agz_stream(agz_engine* h) { return h ? (void*)h->stream : nullptr; }
+int agz_synchronize(agz_engine* h) {
+    if (!h) return AGZ_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return AGZ_OK;
+}
+
+int agz_init_weights(uint64_t seed, int in, int H, int T, int A, float* W0, float* Wres, float* Wp, float* bp, float* Wv, float* bv) {
+    // Flux 0.12 Dense default: glorot_uniform weights U(+-sqrt(6/(fan_in+fan_out))), zero bias (DenseNet.jl:195-197)
+    auto glorot = [&](uint32_t tensor, int out, int inn, float* W) {
+        float limit = sqrtf(6.0f / (float)(inn + out));
+        for (long e = 0; e < (long)out * inn; ++e) {
+            uint32_t o[4];
+            philox4x32_10((uint32_t)e, tensor, 0u, 0x57454947u, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+            float u = (float)(o[0] >> 8) * 5.9604644775390625e-8f;
+            W[e] = (2.0f * u - 1.0f) * limit;
+        }
+    };
+    if (!W0 || !Wp || !bp || !Wv || !bv || (T > 0 && !Wres)) return AGZ_ERR_ARG;
+    glorot(0, H, in, W0);
+    for (int t = 0; t < T; ++t) glorot((uint32_t)(1 + t), H, H, Wres + (size_t)t * H * H);
+    glorot((uint32_t)(T + 1), A, H, Wp);
+    glorot((uint32_t)(T + 2), 1, H, Wv);
+    for (int a = 0; a < A; ++a) bp[a] = 0.0f;
+    bv[0] = 0.0f;
+    return AGZ_OK;
+}
+
+int agz_set_network_slot(agz_engine* h, int which, int H, int T, const float* W0, const float* Wres, const float* Wp,
+                         const float* bp, const float* Wv, const float* bv) {
+    if (!h) return AGZ_ERR_ARG;
+    if (which < 0 || which > 1 || H < 1 || H > 1024 || T < 0 || !W0 || !Wp || !bp || !Wv || !bv || (T > 0 && !Wres)) {
+        h->fail("agz_set_network: bad arguments"); return AGZ_ERR_ARG;
+    }
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const GamePar& P = h->G;
+    DevNet& n = h->net[which];
+    free_net(n);
+    n.H = H; n.T = T; n.in = 2 * P.VS; n.A = P.A; n.INP = h->INP; n.AOP = h->LGS;
+    const size_t Lm = (size_t)h->Lmax;
+    if (h->cfg.nn_mode == AGZ_NN_EXACT) {
+        HIPCHK(h, dmalloc(&n.W0, (size_t)H * n.in)); HIPCHK(h, dmalloc(&n.Wres, (size_t)(T > 0 ? T : 1) * H * H));
+        HIPCHK(h, dmalloc(&n.Wp, (size_t)P.A * H)); HIPCHK(h, dmalloc(&n.bp, (size_t)P.A)); HIPCHK(h, dmalloc(&n.Wv, (size_t)H)); HIPCHK(h, dmalloc(&n.bv, 1));
+        HIPCHK(h, hipMemcpy(n.W0, W0, (size_t)H * n.in * 4, hipMemcpyHostToDevice));
+        if (T > 0) HIPCHK(h, hipMemcpy(n.Wres, Wres, (size_t)T * H * H * 4, hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(n.Wp, Wp, (size_t)P.A * H * 4, hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(n.bp, bp, (size_t)P.A * 4, hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(n.Wv, Wv, (size_t)H * 4, hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(n.bv, bv, 4, hipMemcpyHostToDevice));
+        if (H > h->Hcap || !h->actf0) {
+            hipFree(h->actf0); hipFree(h->actf1); h->actf0 = h->actf1 = nullptr;
+            HIPCHK(h, dmalloc(&h->actf0, Lm * H)); HIPCHK(h, dmalloc(&h->actf1, Lm * H));
+            h->Hcap = H;
+        }
+    } else {
+        if (H % 32 != 0) { h->fail("bf16 mode needs H to be a multiple of 32 (got %d)", H); return AGZ_ERR_ARG; }
+        const int KT0 = n.INP / 16, NTh = H / 32, KTh = H / 16, NThead = n.AOP / 32;
+        n.NT_h = NTh; n.NT_head = NThead;
+        std::vector<uint16_t> buf;
+        buf.assign((size_t)KT0 * NTh * 512, 0);
+        tile_weights(W0, H, n.in, NTh, KT0, buf);
+        HIPCHK(h, dmalloc(&n.t0, buf.size()));
+        HIPCHK(h, hipMemcpy(n.t0, buf.data(), buf.size() * 2, hipMemcpyHostToDevice));
+        const size_t per = (size_t)KTh * NTh * 512;
+        HIPCHK(h, dmalloc(&n.tres, per * (T > 0 ? T : 1)));
+        for (int t = 0; t < T; ++t) {
+            buf.assign(per, 0);
+            tile_weights(Wres + (size_t)t * H * H, H, H, NTh, KTh, buf);
+            HIPCHK(h, hipMemcpy(n.tres + per * t, buf.data(), per * 2, hipMemcpyHostToDevice));
+        }
+        buf.assign((size_t)KTh * NThead * 512, 0);
+        tile_weights(Wp, P.A, H, NThead, KTh, buf);                 // rows 0..A-1: policy head
+        tile_weights(Wv, 1, H, NThead, KTh, buf, P.A, 1);           // row A: value head
+        HIPCHK(h, dmalloc(&n.thead, buf.size()));
+        HIPCHK(h, hipMemcpy(n.thead, buf.data(), buf.size() * 2, hipMemcpyHostToDevice));
+        std::vector<float> bh((size_t)n.AOP, 0.0f);
+        for (int a = 0; a < P.A; ++a) bh[a] = bp[a];
+        bh[P.A] = bv[0];
+        HIPCHK(h, dmalloc(&n.bias_head, bh.size()));
+        HIPCHK(h, hipMemcpy(n.bias_head, bh.data(), bh.size() * 4, hipMemcpyHostToDevice));
+        if (H > h->Hcap || !h->act0) {
+            hipFree(h->act0); hipFree(h->act1); h->act0 = h->act1 = nullptr;
+            HIPCHK(h, dmalloc(&h->act0, Lm * H)); HIPCHK(h, dmalloc(&h->act1, Lm * H));
+            h->Hcap = H;
+        }
+    }
+    n.loaded = true;
+    return AGZ_OK;
+}
+int agz_set_network(agz_engine* h, int H, int T, const float* W0, const float* Wres, const float* Wp, const float* bp,
+                    const float* Wv, const float* bv) {
+    return agz_set_network_slot(h, 0, H, T, W0, Wres, Wp, bp, Wv, bv);
+}
+
+// ---- roots ------------------------------------------------------------------------------------------
+static void image_to_pos(const GamePar& P, const uint8_t* s, Pos& p) {     // SURVEY Appendix B memory image
+    p = Pos();
+    memcpy(p.p, s, 24); memcpy(p.o, s + 48, 24);
+    if (P.fam == F_REV) { memcpy(p.lg, s + 96, 24); p.player = (int8_t)s[144]; }
+    else { p.player = (int8_t)s[96]; p.aux = (int8_t)s[97]; }
+}
+
+int agz_set_roots(agz_engine* h, const void* positions, int format, const uint32_t* game_ids, int L) {
+    if (!h) return AGZ_ERR_ARG;
+    if (L < 0 || L > h->Lmax) { h->fail("agz_set_roots: L=%d outside [0,%d]", L, h->Lmax); return AGZ_ERR_ARG; }
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const GamePar& P = h->G;
+    std::vector<Pos> roots((size_t)L);
+    std::vector<uint32_t> ids((size_t)L);
+    const int ib = h->info.pos_image_bytes;
+    for (int i = 0; i < L; ++i) {
+        if (!positions) roots[i] = start_pos(P);
+        else if (format == AGZ_POS_JULIA) image_to_pos(P, (const uint8_t*)positions + (size_t)i * ib, roots[i]);
+        else if (format == AGZ_POS_COMPACT) memcpy(&roots[i], (const uint8_t*)positions + (size_t)i * sizeof(Pos), sizeof(Pos));
+        else { h->fail("agz_set_roots: unknown position format %d", format); return AGZ_ERR_ARG; }
+        ids[i] = game_ids ? game_ids[i] : h->cfg.game_id_base + (uint32_t)i;
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (L > 0) {
+        HIPCHK(h, hipMemcpy2D(h->states, (size_t)h->V * sizeof(Pos), roots.data(), sizeof(Pos), sizeof(Pos), (size_t)L, hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(h->game_id, ids.data(), (size_t)L * 4, hipMemcpyHostToDevice));
+    }
+    h->L = L; h->need_reset = true;
+    return AGZ_OK;
+}
+
+// ---- launches ---------------------------------------------------------------------------------------
+static std::pair<hipEvent_t, hipEvent_t>* next_events(agz_engine* h, std::vector<std::pair<hipEvent_t, hipEvent_t>>& pool, size_t& used) {
+    if (used == pool.size()) {
+        hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+        pool.push_back({a, b});
+    }
+    return &pool[used++];
+}
+static void drain_events(agz_engine* h) {     // stream must be idle
+    for (size_t i = 0; i < h->ev_tree_used; ++i) { float ms = 0; if (hipEventElapsedTime(&ms, h->ev_tree[i].first, h->ev_tree[i].second) == hipSuccess) h->tree_ms += ms; }
+    h->tree_launches += (int64_t)h->ev_tree_used;
+    for (size_t i = 0; i < h->ev_nn_used; ++i) { float ms = 0; if (hipEventElapsedTime(&ms, h->ev_nn[i].first, h->ev_nn[i].second) == hipSuccess) h->nn_ms += ms; }
+    h->ev_tree_used = h->ev_nn_used = 0;
+}
+
+static int launch_rollout(agz_engine* h, uint32_t rollout, int do_reset, int do_expand, int do_select, int last, int inject, int capture) {
+    if (h->L == 0) return AGZ_OK;
+    TreePar T = h->tp;
+    T.L = h->L; T.step = h->step; T.rollout = rollout; T.cpuct = h->cpuct; T.training = h->training;
+    T.do_reset = do_reset; T.do_expand = do_expand; T.do_select = do_select; T.last = last; T.inject = inject; T.capture = capture;
+    dim3 grid((unsigned)((h->L + 3) / 4)), block(256);
+    std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
+    if (h->profiling) { ev = next_events(h, h->ev_tree, h->ev_tree_used); hipEventRecord(ev->first, h->stream); }
+    hipLaunchKernelGGL(h->k_roll, grid, block, 0, h->stream, T);
+    if (ev) hipEventRecord(ev->second, h->stream);
+    h->cnt_live = true;
+    HIPCHK(h, hipGetLastError());
+    return AGZ_OK;
+}
+
+static int launch_network(agz_engine* h, int which) {
+    if (h->L == 0) return AGZ_OK;
+    DevNet& n = h->net[which];
+    if (!n.loaded) { h->fail("no network loaded in slot %d (call agz_set_network)", which); return AGZ_ERR_STATE; }
+    const int L = h->L;
+    std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
+    if (h->profiling) { ev = next_events(h, h->ev_nn, h->ev_nn_used); hipEventRecord(ev->first, h->stream); }
+    if (h->cfg.nn_mode == AGZ_NN_BF16) {
+        dim3 block(256);
+        dim3 gh((unsigned)((L + GB_M - 1) / GB_M), (unsigned)((n.H + GB_N - 1) / GB_N));
+        const uint16_t* x = (const uint16_t*)h->planes;
+        hipLaunchKernelGGL(k_layer_bf16<EPI_RELU>, gh, block, 0, h->stream, x, n.INP, n.INP, n.t0, n.NT_h, h->act0, n.H, n.H, L,
+                           (const float*)nullptr, (float*)nullptr, 0, (float*)nullptr, 0);
+        uint16_t *a = h->act0, *b = h->act1;
+        const size_t per = (size_t)(n.H / 16) * n.NT_h * 512;
+        for (int t = 0; t < n.T; ++t) {
+            hipLaunchKernelGGL(k_layer_bf16<EPI_RES>, gh, block, 0, h->stream, (const uint16_t*)a, n.H, n.H, n.tres + per * t, n.NT_h, b, n.H,
+                               n.H, L, (const float*)nullptr, (float*)nullptr, 0, (float*)nullptr, 0);
+            uint16_t* s = a; a = b; b = s;
+        }
+        dim3 gp((unsigned)((L + GB_M - 1) / GB_M), (unsigned)((n.AOP + GB_N - 1) / GB_N));
+        hipLaunchKernelGGL(k_layer_bf16<EPI_HEAD>, gp, block, 0, h->stream, (const uint16_t*)a, n.H, n.H, n.thead, n.NT_head, (uint16_t*)nullptr, 0,
+                           n.AOP, L, (const float*)n.bias_head, h->logits, h->LGS, h->v_eval, h->G.A);
+    } else {
+        dim3 block(64, 4);
+        auto grid = [&](int O) { return dim3((unsigned)((L + EX_TL - 1) / EX_TL), (unsigned)((O + 63) / 64)); };
+        auto shm = [&](int K) { return (size_t)EX_TL * (size_t)((K + 3) & ~3) * 4; };
+        const float* x = (const float*)h->planes;
+        hipLaunchKernelGGL(k_layer_exact<EX_RELU>, grid(n.H), block, shm(n.in), h->stream, x, h->INP, n.in, (const float*)n.W0, n.H, h->actf0, n.H, L, (const float*)nullptr);
+        float *a = h->actf0, *b = h->actf1;
+        for (int t = 0; t < n.T; ++t) {
+            hipLaunchKernelGGL(k_layer_exact<EX_RES>, grid(n.H), block, shm(n.H), h->stream, (const float*)a, n.H, n.H,
+                               (const float*)(n.Wres + (size_t)t * n.H * n.H), n.H, b, n.H, L, (const float*)nullptr);
+            float* s = a; a = b; b = s;
+        }
+        hipLaunchKernelGGL(k_layer_exact<EX_POLICY>, grid(n.A), block, shm(n.H), h->stream, (const float*)a, n.H, n.H, (const float*)n.Wp, n.A,
+                           h->logits, h->LGS, L, (const float*)n.bp);
+        hipLaunchKernelGGL(k_layer_exact<EX_VALUE>, grid(1), block, shm(n.H), h->stream, (const float*)a, n.H, n.H, (const float*)n.Wv, 1,
+                           h->v_eval, 1, L, (const float*)n.bv);
+    }
+    if (ev) hipEventRecord(ev->second, h->stream);
+    HIPCHK(h, hipGetLastError());
+    return AGZ_OK;
+}
+
+static int check_search_args(agz_engine* h, int V) {
+    if (V < 1 || V > h->V) { h->fail("V=%d outside [1,%d]", V, h->V); return AGZ_ERR_ARG; }
+    return AGZ_OK;
+}
+
+int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training, uint32_t step) {
+    if (!h) return AGZ_ERR_ARG;
+    int rc = check_search_args(h, V); if (rc) return rc;
+    if (which < 0 || which > 1 || !h->net[which].loaded) { h->fail("no network loaded in slot %d", which); return AGZ_ERR_STATE; }
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    h->cpuct = cpuct; h->training = training; h->step = step;
+    for (int k = 0; k < V; ++k) {
+        rc = launch_rollout(h, (uint32_t)k, k == 0, k > 0, 1, k == V - 1, 0, 0); if (rc) return rc;
+        rc = launch_network(h, which); if (rc) return rc;
+    }
+    rc = launch_rollout(h, (uint32_t)V, 0, 1, 0, 0, 0, 0); if (rc) return rc;
+    h->need_reset = true; h->injected = false;
+    h->total_rollouts += (uint64_t)h->L * (uint64_t)V;
+    return AGZ_OK;
+}
+int agz_search(agz_engine* h, int V, float cpuct, int training, uint32_t step) { return agz_search_actor(h, 0, V, cpuct, training, step); }
+
+// ---- stepwise (teacher-forced parity) ---------------------------------------------------------------
+int agz_search_begin(agz_engine* h, float cpuct, int training, uint32_t step) {
+    if (!h) return AGZ_ERR_ARG;
+    h->cpuct = cpuct; h->training = training; h->step = step; h->need_reset = true; h->injected = false;
+    return AGZ_OK;
+}
+int agz_rollout_select(agz_engine* h, uint32_t rollout, int last) {
+    if (!h) return AGZ_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    int rc = launch_rollout(h, rollout, h->need_reset ? 1 : 0, 0, 1, last, 0, 0);
+    h->need_reset = false;
+    return rc;
+}
+int agz_rollout_eval(agz_engine* h) {
+    if (!h) return AGZ_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    int rc = launch_network(h, 0); if (rc) return rc;
+    if (h->L > 0)
+        hipLaunchKernelGGL(h->k_soft, dim3((unsigned)((h->L + 3) / 4)), dim3(256), 0, h->stream, (const float*)h->logits, h->LGS,
+                           h->prior_eval, h->G.A, h->L, (int)(h->cfg.nn_mode == AGZ_NN_EXACT));
+    HIPCHK(h, hipGetLastError());
+    h->injected = true;
+    return AGZ_OK;
+}
+int agz_get_eval(agz_engine* h, float* prior, float* v) {
+    if (!h) return AGZ_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (prior) HIPCHK(h, hipMemcpy(prior, h->prior_eval, (size_t)h->L * h->G.A * 4, hipMemcpyDeviceToHost));
+    if (v) HIPCHK(h, hipMemcpy(v, h->v_eval, (size_t)h->L * 4, hipMemcpyDeviceToHost));
+    return AGZ_OK;
+}
+int agz_inject_eval(agz_engine* h, const float* prior, const float* v) {
+    if (!h || !prior || !v) return AGZ_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(h->prior_eval, prior, (size_t)h->L * h->G.A * 4, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->v_eval, v, (size_t)h->L * 4, hipMemcpyHostToDevice));
+    h->injected = true;
+    return AGZ_OK;
+}
+int agz_rollout_expand_backup(agz_engine* h) {
+    if (!h) return AGZ_ERR_ARG;
+    if (!h->injected) { h->fail("agz_rollout_expand_backup: call agz_rollout_eval or agz_inject_eval first"); return AGZ_ERR_STATE; }
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    h->injected = false;
+    h->total_rollouts += (uint64_t)h->L;
+    return launch_rollout(h, 0, 0, 1, 0, 0, 1, 0);
+}
+int agz_search_end(agz_engine* h) {
+    if (!h) return AGZ_ERR_ARG;
+    h->need_reset = true;
+    return AGZ_OK;
+}
+
+// ---- getters ----------------------------------------------------------------------------------------
+static int fetch(agz_engine* h, void* dst, const void* src, size_t bytes) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (bytes) HIPCHK(h, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return AGZ_OK;
+}
+int agz_get_policy(agz_engine* h, float* out) {
+    if (!h || !out) return AGZ_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    return fetch(h, out, h->policy_final, (size_t)h->L * h->G.A * 4);
+}
+static int planes_getter(agz_engine* h, float* out, int use_leaf) {
+    if (!h || !out) return AGZ_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (h->L == 0) return AGZ_OK;
+    hipLaunchKernelGGL(k_planes, dim3((unsigned)h->L), dim3(128), 0, h->stream, (const Pos*)h->states, (const uint32_t*)h->leaf, use_leaf, h->V,
+                       h->G.VS, h->L, h->scratch_f);
+    HIPCHK(h, hipGetLastError());
+    return fetch(h, out, h->scratch_f, (size_t)h->L * 2 * h->G.VS * 4);
+}
+int agz_get_batch(agz_engine* h, float* out) { return planes_getter(h, out, 0); }
+int agz_get_leaf_batch(agz_engine* h, float* out) { return planes_getter(h, out, 1); }
+static int stats_getter(agz_engine* h, float* out, int want_q) {
+    if (!h || !out) return AGZ_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (h->L == 0) return AGZ_OK;
+    hipLaunchKernelGGL(k_root_stats, dim3((unsigned)h->L), dim3(128), 0, h->stream, (const uint8_t*)h->recs, (const uint32_t*)h->meta, h->V,
+                       h->tp.rec_bytes, h->tp.off_q, h->tp.off_vc, h->G.A, h->L, want_q ? (float*)nullptr : h->scratch_f,
+                       want_q ? h->scratch_f : (float*)nullptr);
+    HIPCHK(h, hipGetLastError());
+    return fetch(h, out, h->scratch_f, (size_t)h->L * h->G.A * 4);
+}
+int agz_get_root_visits(agz_engine* h, float* out) { return stats_getter(h, out, 0); }
+int agz_get_root_q(agz_engine* h, float* out) { return stats_getter(h, out, 1); }
+int agz_get_leaf(agz_engine* h, int32_t* out) {
+    if (!h || !out) return AGZ_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    return fetch(h, out, h->leaf, (size_t)h->L * 4);
+}
+int agz_get_node_count(agz_engine* h, int32_t* out) {
+    if (!h || !out) return AGZ_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    return fetch(h, out, h->ncount, (size_t)h->L * 4);
+}
+static int fold_counters(agz_engine* h) {      // adds the per-slot counters of the LAST search to the running totals
+    if (h->L == 0) return AGZ_OK;
+    std::vector<uint32_t> a((size_t)h->L), b((size_t)h->L);
+    int rc = fetch(h, a.data(), h->cnt_p, (size_t)h->L * 4); if (rc) return rc;
+    rc = fetch(h, b.data(), h->cnt_new, (size_t)h->L * 4); if (rc) return rc;
+    for (int i = 0; i < h->L; ++i) { h->acc_p += a[i]; h->acc_new += b[i]; }
+    h->cnt_live = false;
+    return AGZ_OK;
+}
+int agz_get_counters(agz_engine* h, uint64_t* sum_p, uint64_t* sum_new, uint64_t* rollouts) {
+    if (!h) return AGZ_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    // counters of the last search are folded lazily: acc_* holds completed folds (selfplay folds every ply)
+    uint64_t p = h->acc_p, n = h->acc_new;
+    if (h->L > 0 && h->cnt_live) {
+        std::vector<uint32_t> a((size_t)h->L), b((size_t)h->L);
+        int rc = fetch(h, a.data(), h->cnt_p, (size_t)h->L * 4); if (rc) return rc;
+        rc = fetch(h, b.data(), h->cnt_new, (size_t)h->L * 4); if (rc) return rc;
+        for (int i = 0; i < h->L; ++i) { p += a[i]; n += b[i]; }
+    }
+    if (sum_p) *sum_p = p;
+    if (sum_new) *sum_new = n;
+    if (rollouts) *rollouts = h->total_rollouts;
+    return AGZ_OK;
+}
+
+int agz_set_profiling(agz_engine* h, int enable) {
+    if (!h) return AGZ_ERR_ARG;
+    h->profiling = enable != 0;
+    return AGZ_OK;
+}
+int agz_get_kernel_times(agz_engine* h, double* tree_ms, double* nn_ms, int64_t* tree_launches, int reset) {
+    if (!h) return AGZ_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    drain_events(h);
+    if (tree_ms) *tree_ms = h->tree_ms;
+    if (nn_ms) *nn_ms = h->nn_ms;
+    if (tree_launches) *tree_launches = h->tree_launches;
+    if (reset) { h->tree_ms = h->nn_ms = 0; h->tree_launches = 0; h->acc_p = h->acc_new = 0; h->total_rollouts = 0; }
+    return AGZ_OK;
+}
+
+// ---- self-play --------------------------------------------------------------------------------------
+static void fill_plypar(agz_engine* h, PlyPar& T, int ply, int tau_plies) {
+    memset(&T, 0, sizeof T);
+    T.G = h->G; T.L = h->L; T.V = h->V; T.ply = ply; T.tau_plies = tau_plies; T.seed = h->cfg.seed; T.game_id_base = h->cfg.game_id_base;
+    T.states = h->states; T.game_id = h->game_id; T.policy_final = h->policy_final; T.newpos = h->newpos; T.alive = h->alive;
+    T.sample_games = h->sample_games; T.max_plies = h->G.max_plies;
+    T.s_boards = h->s_boards; T.s_policy = h->s_policy; T.s_move = h->s_move; T.g_nplies = h->g_nplies; T.g_result = h->g_result;
+    T.g_final = h->g_final; T.stats = h->d_stats;
+}
+
+static int run_games(agz_engine* h, int ngames, int V, float cpuct, int tau_plies, int training, int duel_first, bool duel,
+                     agz_selfplay_stats* st) {
+    int rc = check_search_args(h, V); if (rc) return rc;
+    if (ngames < 1 || ngames > h->Lmax) { h->fail("ngames=%d outside [1,%d]", ngames, h->Lmax); return AGZ_ERR_ARG; }
+    auto t0 = std::chrono::steady_clock::now();
+    rc = agz_set_roots(h, nullptr, 0, nullptr, ngames); if (rc) return rc;       // Position() for every game (:479)
+    HIPCHK(h, hipMemsetAsync(h->d_stats, 0, 8 * sizeof(unsigned long long), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->g_nplies, 0, (size_t)h->sample_games * 4, h->stream));
+    h->sp_games = ngames;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    double search_ms = 0; int64_t rollouts = 0; int ply = 0;
+    uint32_t* hcount = nullptr;
+    HIPCHK(h, hipHostMalloc((void**)&hcount, 4, 0));
+    while (h->L > 0) {                                                          // :494
+        const int which = duel ? ((ply & 1) == 0 ? duel_first : 1 - duel_first) : 0;   // :592-596
+        hipEventRecord(e0, h->stream);
+        rc = agz_search_actor(h, which, V, cpuct, training, (uint32_t)ply); if (rc) break;      // :503
+        hipEventRecord(e1, h->stream);
+        rollouts += (int64_t)h->L * V;
+        PlyPar T; fill_plypar(h, T, ply, tau_plies);
+        hipLaunchKernelGGL(h->k_adv, dim3((unsigned)((h->L + 3) / 4)), dim3(256), 0, h->stream, T);          // :513-549
+        hipLaunchKernelGGL(k_scan_alive, dim3(1), dim3(1024), 0, h->stream, (const uint32_t*)h->alive, h->newslot, h->L, h->d_count);
+        hipLaunchKernelGGL(k_compact, dim3((unsigned)((h->L + 255) / 256)), dim3(256), 0, h->stream, T, (const uint32_t*)h->newslot,
+                           (const uint32_t*)h->game_id, h->game_id2);           // :550-561
+        if (hipMemcpyAsync(hcount, h->d_count, 4, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+            hipStreamSynchronize(h->stream) != hipSuccess) { h->fail("ply loop failed: %s", hipGetErrorString(hipGetLastError())); rc = AGZ_ERR_HIP; break; }
+        float ms = 0; hipEventElapsedTime(&ms, e0, e1); search_ms += ms;
+        if (h->profiling) { fold_counters(h); drain_events(h); }
+        { uint32_t* s = h->game_id; h->game_id = h->game_id2; h->game_id2 = s; h->tp.game_id = h->game_id; }
+        h->L = (int)*hcount;
+        ++ply;
+        if (ply > 255) { h->fail("game exceeded 255 plies"); rc = AGZ_ERR_STATE; break; }
+    }
+    hipHostFree(hcount); hipEventDestroy(e0); hipEventDestroy(e1);
+    if (rc) return rc;
+    unsigned long long hs[8];
+    HIPCHK(h, hipMemcpy(hs, h->d_stats, sizeof hs, hipMemcpyDeviceToHost));
+    if (st) {
+        memset(st, 0, sizeof *st);
+        st->wins = (int64_t)hs[0]; st->draws = (int64_t)hs[1]; st->losses = (int64_t)hs[2]; st->total_plies = (int64_t)hs[3];
+        st->faults = (int32_t)hs[4]; st->rollouts = rollouts; st->plies = ply; st->search_seconds = search_ms * 1e-3;
+        st->total_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        // nsamples = sum of plies per game
+        std::vector<int32_t> np((size_t)(ngames < h->sample_games ? ngames : h->sample_games));
+        HIPCHK(h, hipMemcpy(np.data(), h->g_nplies, np.size() * 4, hipMemcpyDeviceToHost));
+        int64_t n = 0; for (int32_t x : np) n += x;
+        st->nsamples = n;
+    }
+    if (hs[4]) { h->fail("%llu illegal sampled move(s) (\"faute\", mcts_gpu.jl:526-529)", hs[4]); return AGZ_ERR_ILLEGAL_MOVE; }
+    return AGZ_OK;
+}
+
+int agz_selfplay(agz_engine* h, int ngames, int V, float cpuct, int tau_plies, agz_selfplay_stats* stats) {
+    if (!h) return AGZ_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (!h->net[0].loaded) { h->fail("no network loaded"); return AGZ_ERR_STATE; }
+    return run_games(h, ngames, V, cpuct, tau_plies, 1, 0, false, stats);
+}
+int agz_duel(agz_engine* h, int ngames, int V, float cpuct, int tau_plies, int first, int64_t wdl[3]) {
+    if (!h || !wdl) return AGZ_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (!h->net[0].loaded || !h->net[1].loaded) { h->fail("agz_duel needs both network slots"); return AGZ_ERR_STATE; }
+    agz_selfplay_stats st;
+    int rc = run_games(h, ngames, V, cpuct, tau_plies, 0, first ? 1 : 0, true, &st);
+    wdl[0] = st.wins; wdl[1] = st.draws; wdl[2] = st.losses;
+    return rc;
+}
+
+// ---- samples ----------------------------------------------------------------------------------------
+static int build_order(agz_engine* h, std::vector<uint32_t>& order) {
+    const int G = h->sp_games < h->sample_games ? h->sp_games : h->sample_games;
+    std::vector<int32_t> np((size_t)G);
+    if (G > 0) HIPCHK(h, hipMemcpy(np.data(), h->g_nplies, (size_t)G * 4, hipMemcpyDeviceToHost));
+    int maxp = 0; for (int g = 0; g < G; ++g) maxp = np[g] > maxp ? np[g] : maxp;
+    order.clear();
+    for (int p = 0; p < maxp; ++p)                      // PoolSample order: ply-major, then slot (= game id) order
+        for (int g = 0; g < G; ++g) if (np[g] > p) order.push_back(((uint32_t)g << 8) | (uint32_t)p);
+    return AGZ_OK;
+}
+int agz_get_samples_packed(agz_engine* h, void* dev_out, int64_t capacity_records, int64_t* n_out) {
+    if (!h || !n_out) return AGZ_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    std::vector<uint32_t> order;
+    int rc = build_order(h, order); if (rc) return rc;
+    *n_out = (int64_t)order.size();
+    if (!dev_out) return AGZ_OK;                         // size query
+    if ((int64_t)order.size() > capacity_records) { h->fail("sample buffer too small: %zu > %lld", order.size(), (long long)capacity_records); return AGZ_ERR_ARG; }
+    if (order.empty()) return AGZ_OK;
+    uint32_t* d_order = nullptr;
+    HIPCHK(h, dmalloc(&d_order, order.size()));
+    HIPCHK(h, hipMemcpy(d_order, order.data(), order.size() * 4, hipMemcpyHostToDevice));
+    PackPar T;
+    T.A = h->G.A; T.VS = h->G.VS; T.FS = h->G.FS; T.max_plies = h->G.max_plies; T.rec_bytes = h->info.rec_bytes;
+    T.game_id_base = h->cfg.game_id_base; T.s_boards = h->s_boards; T.s_policy = h->s_policy; T.s_move = h->s_move;
+    T.g_nplies = h->g_nplies; T.g_result = h->g_result; T.g_final = h->g_final; T.order = d_order; T.n = (int64_t)order.size();
+    T.out = (uint8_t*)dev_out;
+    hipLaunchKernelGGL(k_pack_samples, dim3((unsigned)order.size()), dim3(64), 0, h->stream, T);
+    hipError_t e = hipStreamSynchronize(h->stream);
+    hipFree(d_order);
+    if (e != hipSuccess) { h->fail("k_pack_samples failed: %s", hipGetErrorString(e)); return AGZ_ERR_HIP; }
+    return AGZ_OK;
+}
+int agz_get_samples(agz_engine* h, int8_t* state, float* policy, int8_t* player, float* value, int8_t* fstate,
+                    uint32_t* game_id, int32_t* ply, int32_t* move) {
+    if (!h) return AGZ_ERR_ARG;
+    int64_t n = 0;
+    int rc = agz_get_samples_packed(h, nullptr, 0, &n); if (rc) return rc;
+    if (n == 0) return AGZ_OK;
+    const size_t rb = (size_t)h->info.rec_bytes;
+    uint8_t* dev = nullptr;
+    HIPCHK(h, dmalloc(&dev, (size_t)n * rb));
+    rc = agz_get_samples_packed(h, dev, n, &n);
+    std::vector<uint8_t> host((size_t)n * rb);
+    if (!rc && hipMemcpy(host.data(), dev, host.size(), hipMemcpyDeviceToHost) != hipSuccess) { h->fail("sample D2H failed"); rc = AGZ_ERR_HIP; }
+    hipFree(dev);
+    if (rc) return rc;
+    const int A = h->G.A, VS = h->G.VS, FS = h->G.FS;
+    for (int64_t s = 0; s < n; ++s) {
+        const uint8_t* r = host.data() + (size_t)s * rb;
+        if (game_id) memcpy(&game_id[s], r, 4);
+        if (ply) memcpy(&ply[s], r + 4, 4);
+        if (move) memcpy(&move[s], r + 8, 4);
+        if (value) memcpy(&value[s], r + 12, 4);
+        if (player) player[s] = (int8_t)r[16];
+        if (policy) memcpy(policy + (size_t)s * A, r + 20, (size_t)A * 4);
+        if (state) memcpy(state + (size_t)s * 2 * VS, r + 20 + 4 * A, (size_t)2 * VS);
+        if (fstate) memcpy(fstate + (size_t)s * FS, r + 20 + 4 * A + 2 * VS, (size_t)FS);
+    }
+    return AGZ_OK;
+}
+
+}  // extern "C"

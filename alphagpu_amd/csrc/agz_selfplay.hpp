@@ -1,0 +1,193 @@
+// agz_selfplay.hpp — the ply loop of mcts(actor,visits,ngames,buffer) (mcts_gpu.jl:494-561) on the device:
+// sample capture (push_buffer, mainGobang.jl:54-68), move choice (:518-524), play / isOver (:530-531),
+// order-preserving compaction of finished games (:550-553) and re_init (:557-561).  The reference does this
+// in a single-threaded host loop with a 32 MB D2H + H2D per ply; here only one 4-byte count crosses PCIe.
+#pragma once
+#include "agz_device.hpp"
+
+namespace agz {
+
+struct PlyPar {
+    GamePar G;
+    int32_t L, V, ply, tau_plies, all_actions;
+    uint64_t seed;
+    uint32_t game_id_base;
+    Pos* states;              // [L][V] roots at node 0
+    uint32_t* game_id;        // [L]
+    const float* policy_final;// [L][A]
+    // per-slot scratch
+    Pos* newpos;              // [L]
+    uint32_t* alive;          // [L]
+    // sample store, indexed by local game g = game_id - game_id_base (< sample_games)
+    int32_t sample_games, max_plies;
+    uint64_t* s_boards;       // [G][max_plies][6]  bplayer[3], bopponent[3] of the root
+    float* s_policy;          // [G][max_plies][A]
+    int16_t* s_move;          // [G][max_plies]
+    int32_t* g_nplies;        // [G]
+    int8_t* g_result;         // [G]
+    Pos* g_final;             // [G]
+    unsigned long long* stats;// [0] wins [1] draws [2] losses [3] total_plies [4] faults
+};
+
+// one wavefront per slot
+template <int FAM, int NR, int NC>
+__global__ __launch_bounds__(256) void k_advance(const PlyPar T) {
+    using G = Game<FAM, NC>;
+    const GamePar& P = T.G;
+    const int lane = lane_id();
+    const int slot = ufirst((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    if (slot >= T.L) return;
+    const int A = P.A;
+    const uint32_t gid = ufirst(T.game_id[slot]);
+    const int g = (int)(gid - T.game_id_base);
+    WPos<NC> root = load_pos<NC>(T.states + (size_t)slot * T.V);
+    float pol[NR];
+    for (int r = 0; r < NR; ++r) { int k = 64 * r + lane; pol[r] = k < A ? T.policy_final[(size_t)slot * A + k] : 0.0f; }
+    const bool in_range = g >= 0 && g < T.sample_games;
+    const bool keep = in_range && T.ply < T.max_plies;
+    const int np_end = T.ply + 1 < T.max_plies ? T.ply + 1 : T.max_plies;
+    if (keep) {                                                     // push_buffer: root planes (as boards) + policy
+        size_t sidx = (size_t)g * T.max_plies + T.ply;
+        for (int r = 0; r < NR; ++r) { int k = 64 * r + lane; if (k < A) T.s_policy[sidx * A + k] = pol[r]; }
+        if (lane < 6) {
+            uint64_t w = 0;
+            for (int i = 0; i < NC; ++i) { if (lane == i) w = root.p.c[i]; if (lane == 3 + i) w = root.o.c[i]; }
+            T.s_boards[sidx * 6 + lane] = w;
+        }
+    }
+    // ---- move choice (:518-524)
+    int c = -1;
+    if (T.ply < T.tau_plies) {
+        // sample(lp, Weights(pol[lp])): t = u * sum(w), first index whose running sum >= t (source order)
+        float total = 0.0f; bool st = false; uint64_t nzm[NR];
+        for (int r = 0; r < NR; ++r) {
+            nzm[r] = __ballot(64 * r + lane < A && pol[r] != 0.0f);
+            (void)chain64(pol[r], nzm[r], total, false, 0.0f, st);
+        }
+        const float u = ufirst(uniform_move(T.seed, gid, (uint32_t)T.ply));
+        const float tt = u * total;
+        float carry = 0.0f; bool stopped = false; int last = -1;
+        for (int r = 0; r < NR; ++r) {
+            if (!nzm[r]) continue;
+            last = 64 * r + 63 - __builtin_clzll(nzm[r]);
+            if (c >= 0) continue;
+            bool s2 = false;
+            float pre = chain64(pol[r], nzm[r], carry, false, 0.0f, s2);
+            uint64_t ge = __ballot(((nzm[r] >> lane) & 1ull) && !(pre < tt));
+            if (ge) { c = 64 * r + __builtin_ctzll(ge); stopped = true; }
+        }
+        (void)stopped;
+        if (c < 0) c = last;
+    } else {
+        // argmax(pol): first maximum
+        float best = -__builtin_inff();
+        for (int r = 0; r < NR; ++r) { int k = 64 * r + lane; best = (k < A && pol[r] > best) ? pol[r] : best; }
+        best = ufirst(wave_max(best));
+        for (int r = 0; r < NR && c < 0; ++r) {
+            uint64_t eq = __ballot(64 * r + lane < A && pol[r] == best);
+            if (eq) c = 64 * r + __builtin_ctzll(eq);
+        }
+        if (c < 0) c = 0;
+    }
+    bool fault = c < 0;
+    if (!fault) {
+        bool ok = __ballot(lane == 0 && G::canPlay(P, root, c)) != 0;   // "faute" guard (:526-529)
+        fault = !ok;
+    }
+    if (fault) {
+        if (lane == 0) { atomicAdd(&T.stats[4], 1ull); T.alive[slot] = 0; if (keep) T.s_move[(size_t)g * T.max_plies + T.ply] = (int16_t)c; if (in_range) { T.g_nplies[g] = np_end; T.g_result[g] = 0; T.g_final[g] = pack(root); } }
+        return;
+    }
+    WPos<NC> np = G::play(P, root, c);
+    int res; const bool f = G::isOver(P, np, res);
+    if (lane == 0) {
+        if (keep) T.s_move[(size_t)g * T.max_plies + T.ply] = (int16_t)c;
+        T.newpos[slot] = pack(np);
+        T.alive[slot] = f ? 0u : 1u;
+        if (f) {
+            if (in_range) { T.g_nplies[g] = np_end; T.g_result[g] = (int8_t)res; T.g_final[g] = pack(np); }
+            atomicAdd(&T.stats[res == 1 ? 0 : (res == 0 ? 1 : 2)], 1ull);     // :541-547
+            atomicAdd(&T.stats[3], (unsigned long long)T.ply);                 // tot_length += round (:535)
+        }
+    }
+}
+
+// exclusive scan of alive[0..L) by one workgroup of 1024 threads -> newslot[], total -> *count
+__global__ __launch_bounds__(1024) void k_scan_alive(const uint32_t* alive, uint32_t* newslot, int L, uint32_t* count) {
+    __shared__ uint32_t part[1024];
+    const int t = threadIdx.x;
+    const int per = (L + 1023) / 1024;
+    const int b = t * per, e = (b + per < L) ? b + per : L;
+    uint32_t s = 0;
+    for (int i = b; i < e; ++i) s += alive[i];
+    part[t] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        uint32_t v = t >= off ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t base = part[t] - s;
+    for (int i = b; i < e; ++i) { newslot[i] = base; base += alive[i]; }
+    if (t == 1023) *count = part[1023];
+}
+
+// re_init (:359-373): move surviving games to their compacted slots
+__global__ void k_compact(const PlyPar T, const uint32_t* newslot, const uint32_t* gid_in, uint32_t* gid_out) {
+    int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= T.L || !T.alive[slot]) return;
+    uint32_t ns = newslot[slot];
+    T.states[(size_t)ns * T.V] = T.newpos[slot];
+    gid_out[ns] = gid_in[slot];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// packed sample records (Sample, mainGobang.jl:34-43 + update_buffer :70-80 + decode mcts_gpu.jl:464-474)
+//   {u32 game_id, i32 ply, i32 move, f32 value, i8 player, i8 pad[3], f32 policy[A], i8 state[2VS], i8 fstate[FS]}
+// ---------------------------------------------------------------------------------------------------
+struct PackPar {
+    int32_t A, VS, FS, max_plies, rec_bytes;
+    uint32_t game_id_base;
+    const uint64_t* s_boards; const float* s_policy; const int16_t* s_move;
+    const int32_t* g_nplies; const int8_t* g_result; const Pos* g_final;
+    const uint32_t* order;   // [n] (g << 8 | ply)  PoolSample order
+    int64_t n;
+    uint8_t* out;
+};
+__global__ void k_pack_samples(const PackPar T) {
+    int64_t s = blockIdx.x;
+    if (s >= T.n) return;
+    uint32_t key = T.order[s];
+    int g = (int)(key >> 8), ply = (int)(key & 0xff);
+    uint8_t* rec = T.out + (size_t)s * T.rec_bytes;
+    const size_t sidx = (size_t)g * T.max_plies + ply;
+    const int player = (ply & 1) ? -1 : 1;                  // Position().player == 1 and play() flips it
+    const int res = T.g_result[g];
+    if (threadIdx.x == 0) {
+        reinterpret_cast<uint32_t*>(rec)[0] = T.game_id_base + (uint32_t)g;
+        reinterpret_cast<int32_t*>(rec)[1] = ply;
+        reinterpret_cast<int32_t*>(rec)[2] = T.s_move[sidx];
+        reinterpret_cast<float*>(rec)[3] = (float)((1 + res * player) / 2.0);      // mainGobang.jl:76
+        reinterpret_cast<int8_t*>(rec)[16] = (int8_t)player;
+        rec[17] = rec[18] = rec[19] = 0;
+    }
+    float* pol = reinterpret_cast<float*>(rec + 20);
+    int8_t* st = reinterpret_cast<int8_t*>(rec + 20 + 4 * T.A);
+    int8_t* fs = st + 2 * T.VS;
+    const Pos fin = T.g_final[g];
+    for (int k = threadIdx.x; k < T.A; k += blockDim.x) pol[k] = T.s_policy[sidx * T.A + k];
+    for (int j = threadIdx.x; j < 2 * T.VS; j += blockDim.x) {
+        int b = j < T.VS ? j : j - T.VS;
+        uint64_t w = T.s_boards[sidx * 6 + (j < T.VS ? 0 : 3) + (b >> 6)];
+        st[j] = (int8_t)((w >> (b & 63)) & 1);
+    }
+    for (int j = threadIdx.x; j < T.FS; j += blockDim.x) {
+        int bit = (int)((fin.p[j >> 6] >> (j & 63)) & 1);
+        int v = bit ? fin.player : -fin.player;                                    // decode :464-474
+        fs[j] = (int8_t)(v * player);                                              // fstate * player :77
+    }
+    for (int j = 20 + 4 * T.A + 2 * T.VS + T.FS + threadIdx.x; j < T.rec_bytes; j += blockDim.x) rec[j] = 0;
+}
+
+}  // namespace agz

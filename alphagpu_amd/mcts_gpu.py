@@ -1,0 +1,285 @@
+"""Host-side mirror of the reference's `module mcts_gpu` (mcts_gpu.jl) over libagz.
+
+Same entry points and argument meaning as the Julia module:
+
+    init(positions_or_L, visits, game, ...)          mcts_gpu.jl:342-357
+    re_init(positions, engine)                       :368-373
+    mcts_single(actor, visits, engine; training, cpuct)   :376-462
+    mcts(actor, visits, ngames, buffer; cpuct)       :477-579   -> (data, valid)
+    mcts(actor1, actor2, ...) == mcts_duel           :581-651   -> [v, n, d]
+    duelnetwork(actor1, actor2, visits, ngames)      :653-668   -> (v, n, d)
+
+The CUDA arrays the reference passes around (vnodes, vnodesStats, leaf, newindex) live inside the
+engine handle; `Engine` is what `init` returns.  All compute happens in HIP kernels; there is no CPU path.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import lib as _lib
+from .game import GameSpec
+from .net import SNetwork2
+
+NN_BF16, NN_EXACT = 0, 1
+POS_JULIA, POS_COMPACT = 0, 1
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Engine:
+    """Owns the device-side trees for up to `max_games` games of `visits` rollouts (create_cunodes_stats /
+    create_roots, mcts_gpu.jl:35-53)."""
+
+    def __init__(self, game, max_games, visits, device=0, seed=1, game_id_base=0, nn_mode=NN_BF16,
+                 sample_capacity_games=0):
+        self.game = game
+        self.L = _lib.load_library()
+        cfg = _lib.Config(game=game.kind, n=game.n, nvict=game.nvict, max_games=int(max_games), max_visits=int(visits),
+                          device=int(device), seed=int(seed), game_id_base=int(game_id_base), nn_mode=int(nn_mode),
+                          sample_capacity_games=int(sample_capacity_games))
+        self.h = C.c_void_p()
+        rc = self.L.agz_create(C.byref(cfg), C.byref(self.h))
+        if rc != 0:
+            msg = self.L.agz_last_error(None)
+            raise _lib.AgzError(rc, msg.decode() if msg else "agz_create failed")
+        self.max_games, self.visits, self.nn_mode = int(max_games), int(visits), int(nn_mode)
+        self.nslots = 0
+        self._nets = {}
+
+    # -- plumbing ------------------------------------------------------------------------------------
+    def _chk(self, rc):
+        if rc != 0:
+            msg = self.L.agz_last_error(self.h)
+            raise _lib.AgzError(rc, msg.decode() if msg else "")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.agz_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- network ----------------------------------------------------------------------------------------
+    def set_network(self, net, which=0):
+        """actor = convert_back(net) (DenseNet.jl:331-333)."""
+        self._chk(self.L.agz_set_network_slot(self.h, which, net.H, net.T, *net.pointers()))
+        self._nets[which] = net
+
+    # -- roots ------------------------------------------------------------------------------------------
+    def set_roots(self, positions=None, L=None, game_ids=None, fmt=POS_COMPACT):
+        """re_init(positions, ...) (mcts_gpu.jl:368-373).  positions: None -> Position() x L; bytes-like/ndarray of
+        Julia images (104/152 B) or compact 80-B records."""
+        if positions is None:
+            n = int(L)
+            buf = None
+        else:
+            buf = np.ascontiguousarray(np.frombuffer(positions, np.uint8) if not isinstance(positions, np.ndarray)
+                                       else positions.view(np.uint8).reshape(-1))
+            rec = 80 if fmt == POS_COMPACT else self.game.pos_image_bytes
+            n = buf.size // rec if L is None else int(L)
+        ids = None if game_ids is None else np.ascontiguousarray(game_ids, np.uint32)
+        self._chk(self.L.agz_set_roots(self.h, _p(buf), fmt, _p(ids), n))
+        self.nslots = n
+
+    # -- search -----------------------------------------------------------------------------------------
+    def search(self, visits, cpuct=2.0, training=True, step=0, which=0):
+        self._chk(self.L.agz_search_actor(self.h, which, int(visits), float(cpuct), int(bool(training)), int(step)))
+
+    def search_begin(self, cpuct, training, step):
+        self._chk(self.L.agz_search_begin(self.h, float(cpuct), int(bool(training)), int(step)))
+
+    def rollout_select(self, rollout, last=False):
+        self._chk(self.L.agz_rollout_select(self.h, int(rollout), int(bool(last))))
+
+    def rollout_eval(self):
+        self._chk(self.L.agz_rollout_eval(self.h))
+
+    def get_eval(self):
+        pr = np.zeros((self.nslots, self.game.A), np.float32)
+        v = np.zeros(self.nslots, np.float32)
+        self._chk(self.L.agz_get_eval(self.h, _p(pr), _p(v)))
+        return pr, v
+
+    def inject_eval(self, prior, v):
+        prior = np.ascontiguousarray(prior, np.float32)
+        v = np.ascontiguousarray(v, np.float32)
+        assert prior.shape == (self.nslots, self.game.A) and v.shape == (self.nslots,)
+        self._chk(self.L.agz_inject_eval(self.h, _p(prior), _p(v)))
+
+    def rollout_expand_backup(self):
+        self._chk(self.L.agz_rollout_expand_backup(self.h))
+
+    def search_end(self):
+        self._chk(self.L.agz_search_end(self.h))
+
+    def _get(self, name, shape, dtype=np.float32):
+        out = np.zeros(shape, dtype)
+        self._chk(getattr(self.L, "agz_get_" + name)(self.h, _p(out)))
+        return out
+
+    def policy(self):          # Array(vnodesStats.policy_final)  (A,L) column-major == [L][A]
+        return self._get("policy", (self.nslots, self.game.A))
+
+    def batch(self):           # Array(vnodesStats.batch) after decoder_roots
+        return self._get("batch", (self.nslots, 2 * self.game.VS))
+
+    def leaf_batch(self):
+        return self._get("leaf_batch", (self.nslots, 2 * self.game.VS))
+
+    def root_visits(self):
+        return self._get("root_visits", (self.nslots, self.game.A))
+
+    def root_q(self):
+        return self._get("root_q", (self.nslots, self.game.A))
+
+    def leaf(self):
+        return self._get("leaf", (self.nslots,), np.int32)
+
+    def node_count(self):
+        return self._get("node_count", (self.nslots,), np.int32)
+
+    def counters(self):
+        a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        self._chk(self.L.agz_get_counters(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def set_profiling(self, on):
+        self._chk(self.L.agz_set_profiling(self.h, int(bool(on))))
+
+    def kernel_times(self, reset=False):
+        t, n, k = C.c_double(0), C.c_double(0), C.c_int64(0)
+        self._chk(self.L.agz_get_kernel_times(self.h, C.byref(t), C.byref(n), C.byref(k), int(reset)))
+        return t.value, n.value, k.value
+
+    def synchronize(self):
+        self._chk(self.L.agz_synchronize(self.h))
+
+    # -- generation ---------------------------------------------------------------------------------------
+    def selfplay(self, ngames, visits, cpuct=2.0, tau_plies=25):
+        st = _lib.SelfplayStats()
+        rc = self.L.agz_selfplay(self.h, int(ngames), int(visits), float(cpuct), int(tau_plies), C.byref(st))
+        self.nslots = 0
+        stats = {f: getattr(st, f) for f, _ in _lib.SelfplayStats._fields_}
+        if rc == -5:            # AGZ_ERR_ILLEGAL_MOVE == the reference's "faute" (valid=false)
+            stats["valid"] = False
+            return stats
+        self._chk(rc)
+        stats["valid"] = True
+        return stats
+
+    def duel(self, ngames, visits, cpuct=2.0, tau_plies=15, first=0):
+        wdl = (C.c_int64 * 3)()
+        self._chk(self.L.agz_duel(self.h, int(ngames), int(visits), float(cpuct), int(tau_plies), int(first), C.byref(wdl)))
+        self.nslots = 0
+        return [int(wdl[0]), int(wdl[1]), int(wdl[2])]
+
+    def samples(self):
+        """Samples of the last selfplay in PoolSample order (ply-major, then game id)."""
+        n = C.c_int64(0)
+        self._chk(self.L.agz_get_samples_packed(self.h, None, 0, C.byref(n)))
+        n = n.value
+        g = self.game
+        out = dict(state=np.zeros((n, 2 * g.VS), np.int8), policy=np.zeros((n, g.A), np.float32),
+                   player=np.zeros(n, np.int8), value=np.zeros(n, np.float32), fstate=np.zeros((n, g.FS), np.int8),
+                   game_id=np.zeros(n, np.uint32), ply=np.zeros(n, np.int32), move=np.zeros(n, np.int32))
+        self._chk(self.L.agz_get_samples(self.h, _p(out["state"]), _p(out["policy"]), _p(out["player"]), _p(out["value"]),
+                                         _p(out["fstate"]), _p(out["game_id"]), _p(out["ply"]), _p(out["move"])))
+        return out
+
+    def samples_packed_into(self, dev_ptr, capacity_records):
+        """Write packed sample records to DEVICE memory (for the RCCL all-gather); returns the record count."""
+        n = C.c_int64(0)
+        self._chk(self.L.agz_get_samples_packed(self.h, C.c_void_p(dev_ptr), int(capacity_records), C.byref(n)))
+        return n.value
+
+    def num_samples(self):
+        n = C.c_int64(0)
+        self._chk(self.L.agz_get_samples_packed(self.h, None, 0, C.byref(n)))
+        return n.value
+
+
+# ---------------------------------------------------------------------------------------------------------
+# module-level functions with the reference's names
+# ---------------------------------------------------------------------------------------------------------
+def init(positions_or_L, visits, game, **kw):
+    """init(positions::Vector{Position}, visits) / init(visits, L) — mcts_gpu.jl:342-357."""
+    if isinstance(positions_or_L, (int, np.integer)):
+        eng = Engine(game, int(positions_or_L), visits, **kw)
+        eng.set_roots(None, L=int(positions_or_L))
+    else:
+        fmt = kw.pop("fmt", POS_COMPACT)
+        buf = np.frombuffer(positions_or_L, np.uint8) if not isinstance(positions_or_L, np.ndarray) else positions_or_L.view(np.uint8).reshape(-1)
+        rec = 80 if fmt == POS_COMPACT else game.pos_image_bytes
+        eng = Engine(game, buf.size // rec, visits, **kw)
+        eng.set_roots(buf, fmt=fmt)
+    return eng
+
+
+def re_init(positions, engine, fmt=POS_COMPACT, game_ids=None):
+    """re_init(positions, vnodes, L, nthreads, numblocks) — mcts_gpu.jl:368-373."""
+    engine.set_roots(positions, fmt=fmt, game_ids=game_ids)
+
+
+def mcts_single(actor, visits, engine, training=True, cpuct=2.0, step=0):
+    """mcts_single(actor, visits, nthreads, vnodes, vnodesStats, leaf, newindex, L; training, cpuct) — :376-462.
+    Results: engine.policy() (policy_final), engine.batch() (root planes)."""
+    if actor is not None and engine._nets.get(0) is not actor:
+        engine.set_network(actor, 0)
+    engine.search(visits, cpuct=cpuct, training=training, step=step)
+
+
+def mcts(actor, visits, ngames, buffer, game=None, cpuct=2.0, engine=None, tau_plies=25, **kw):
+    """mcts(actor, visits, ngames, buffer::PoolSample; cpuct) — mcts_gpu.jl:477-579.
+    Plays `ngames` self-play games to the end, pushes every (state, policy, player, value, fstate) sample into
+    `buffer` in the reference's order and returns (data, valid) like the reference's named tuple."""
+    own = engine is None
+    if own:
+        engine = Engine(game if game is not None else buffer.game, ngames, visits, **kw)
+    try:
+        if engine._nets.get(0) is not actor:
+            engine.set_network(actor, 0)
+        stats = engine.selfplay(ngames, visits, cpuct=cpuct, tau_plies=tau_plies)
+        if stats["valid"] and buffer is not None:
+            buffer.push_generation(engine.samples())
+        return stats, stats["valid"]
+    finally:
+        if own:
+            engine.close()
+
+
+def mcts_duel(actor1, actor2, visits, ngames, game, cpuct=2.0, engine=None, tau_plies=15, **kw):
+    """mcts(actor1, actor2, visits, ngames; cpuct) — mcts_gpu.jl:581-651 -> [v, n, d] (actor1 moves first)."""
+    own = engine is None
+    if own:
+        engine = Engine(game, ngames, visits, **kw)
+    try:
+        engine.set_network(actor1, 0)
+        engine.set_network(actor2, 1)
+        return engine.duel(ngames, visits, cpuct=cpuct, tau_plies=tau_plies, first=0)
+    finally:
+        if own:
+            engine.close()
+
+
+def duelnetwork(actor1, actor2, visits, ngames, game, **kw):
+    """duelnetwork(actor1, actor2, visits, ngames) — mcts_gpu.jl:653-668 -> (v, n, d) from actor1's side."""
+    hn = ngames // 2
+    v1, n1, d1 = mcts_duel(actor1, actor2, visits, hn, game, **kw)
+    d2, n2, v2 = mcts_duel(actor2, actor1, visits, hn, game, **kw)
+    return v1 + v2, n1 + n2, d1 + d2
+
+
+__all__ = ["Engine", "GameSpec", "SNetwork2", "init", "re_init", "mcts_single", "mcts", "mcts_duel", "duelnetwork",
+           "NN_BF16", "NN_EXACT", "POS_JULIA", "POS_COMPACT"]

@@ -1,0 +1,65 @@
+"""PoolSample ring buffer — mainGobang.jl:34-82 (duplicated in every main*.jl of the reference)."""
+import numpy as np
+
+
+class Sample:
+    __slots__ = ("state", "policy", "player", "value", "fstate")
+
+    def __init__(self, game):
+        self.state = np.zeros(2 * game.VS, np.int8)
+        self.policy = np.zeros(game.A, np.float32)
+        self.player = 1
+        self.value = 0.0
+        self.fstate = np.zeros(game.FS, np.int8)
+
+
+class PoolSample:
+    """Structure-of-arrays ring buffer with the reference's semantics: 1-based write index that wraps,
+    `full` flag, push_buffer / update_buffer / length_buffer."""
+
+    def __init__(self, game, length):
+        self.game, self.length = game, int(length)
+        self.currentIndex, self.full = 1, False
+        self.state = np.zeros((self.length, 2 * game.VS), np.int8)
+        self.policy = np.zeros((self.length, game.A), np.float32)
+        self.player = np.ones(self.length, np.int8)
+        self.value = np.zeros(self.length, np.float32)
+        self.fstate = np.zeros((self.length, game.FS), np.int8)
+
+    def push_buffer(self, state, policy, player, i):                      # mainGobang.jl:54-68
+        index = self.currentIndex
+        self.state[index - 1] = state[i]
+        self.policy[index - 1] = policy[i]
+        self.player[index - 1] = player
+        newindex = 1 if index == self.length else index + 1
+        if newindex == 1:
+            self.full = True
+        self.currentIndex = newindex
+        return index
+
+    def update_buffer(self, index, result, fstate):                       # mainGobang.jl:70-80
+        for idx in index:
+            player = int(self.player[idx - 1])
+            self.value[idx - 1] = (1 + result * player) / 2
+            self.fstate[idx - 1] = np.asarray(fstate, np.int8) * player
+
+    def push_generation(self, s):
+        """Append a whole generation of finished samples (dict from Engine.samples(), already in PoolSample
+        order) — equivalent to the reference's interleaved push_buffer/update_buffer calls."""
+        n = len(s["player"])
+        idx = (self.currentIndex - 1 + np.arange(n)) % self.length
+        self.state[idx], self.policy[idx], self.player[idx] = s["state"], s["policy"], s["player"]
+        self.value[idx], self.fstate[idx] = s["value"], s["fstate"]
+        if self.currentIndex - 1 + n >= self.length:
+            self.full = True
+        self.currentIndex = int((self.currentIndex - 1 + n) % self.length) + 1
+        return idx + 1
+
+    def length_buffer(self):                                              # mainGobang.jl:82
+        return self.length if self.full else self.currentIndex - 1
+
+    def __getitem__(self, index):
+        s = Sample(self.game)
+        s.state, s.policy = self.state[index - 1], self.policy[index - 1]
+        s.player, s.value, s.fstate = int(self.player[index - 1]), float(self.value[index - 1]), self.fstate[index - 1]
+        return s

@@ -1,0 +1,146 @@
+/*
+ * agz.h — C ABI of libagz: MI355X-native batched AlphaZero self-play search.
+ *
+ * Drop-in boundary for the mcts_gpu.jl / selfplay.jl hot path of fabricerosay/AlphaGPU.
+ * Every entry point names the reference interface it replaces (file:line under /root/reference).
+ * Plain pointers and sizes only; the handle owns all device memory; host buffers are caller-owned.
+ * One handle = one device + one HIP stream; a handle is not thread-safe; handles are independent.
+ * All functions return 0 on success or a negative agz_status; agz_last_error() gives the message.
+ *
+ * Index conventions: actions, nodes and slots are 0-based (reference index k <-> k-1).
+ * Host arrays are row-major with the game/slot index slowest, which is byte-identical to the
+ * reference's column-major (A,L) / (2VS,L) Julia arrays.
+ */
+#ifndef AGZ_H
+#define AGZ_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct agz_engine agz_engine;
+
+enum agz_status {
+    AGZ_OK = 0, AGZ_ERR_ARG = -1, AGZ_ERR_HIP = -2, AGZ_ERR_STATE = -3, AGZ_ERR_NOMEM = -4,
+    AGZ_ERR_ILLEGAL_MOVE = -5,   /* the reference's "faute" abort, mcts_gpu.jl:526-529 */
+    AGZ_ERR_UNSUPPORTED = -6
+};
+
+/* game plugins: Gobang.jl, 4IARow.jl, Hex.jl, Reversi8x8.jl, Reversi6x6.jl */
+enum agz_game_kind { AGZ_GOBANG = 0, AGZ_CONNECT4 = 1, AGZ_HEX = 2, AGZ_REVERSI8 = 3, AGZ_REVERSI6 = 4 };
+
+/* network evaluation modes */
+enum agz_nn_mode {
+    AGZ_NN_BF16 = 0,   /* bf16 MFMA contraction, fp32 accumulate (throughput mode) */
+    AGZ_NN_EXACT = 1   /* fp32, k-ordered fma chains + source-order softmax: bit-identical to the CPU oracle */
+};
+
+typedef struct {
+    int32_t  game;          /* agz_game_kind */
+    int32_t  n;             /* board size N (Gobang <= 13, Hex <= 12); mainGobang.jl:24 `const N` */
+    int32_t  nvict;         /* stones in a row to win (Gobang); mainGobang.jl:26 `const Nvict` */
+    int32_t  max_games;     /* Lmax: slots allocated (mcts_gpu.jl:350 init(positions,visits)) */
+    int32_t  max_visits;    /* V: tree nodes per slot (= rollouts per move), <= 256 */
+    int32_t  device;        /* HIP device ordinal */
+    uint64_t seed;          /* Philox key: search uniforms (CUDA.rand, mcts_gpu.jl:397) and move sampling (:520) */
+    uint32_t game_id_base;  /* global id of slot 0; results depend on game ids, never on slot/GPU placement */
+    int32_t  nn_mode;       /* agz_nn_mode */
+    int32_t  sample_capacity_games; /* games whose samples are retained by agz_selfplay (0 = max_games) */
+    int32_t  reserved[3];
+} agz_config;
+
+typedef struct {            /* constants every game module exports: Gobang.jl:2,8-11 */
+    int32_t A;              /* maxActions */
+    int32_t VS;             /* VectorizedState */
+    int32_t FS;             /* FeatureSize */
+    int32_t ML;             /* maxLengthGame */
+    int32_t max_plies;      /* hard bound on plies per game (sample slots per game) */
+    int32_t pos_image_bytes;/* sizeof(Position) in Julia: 104 or 152 */
+    int32_t rec_bytes;      /* bytes of one packed sample record (agz_get_samples_packed) */
+    int32_t reserved;
+} agz_game_info;
+
+/* positions handed over in the reference's own memory image (Vector{Position}) or as compact 80-byte
+ * records {u64 bplayer[3], bopponent[3], legalplay[3]; i8 player, aux; pad[6]} */
+enum agz_pos_format { AGZ_POS_JULIA = 0, AGZ_POS_COMPACT = 1 };
+
+int  agz_query_game(const agz_config *cfg, agz_game_info *out);
+int  agz_create(const agz_config *cfg, agz_engine **out);          /* mcts_gpu.jl:342-357 init */
+void agz_destroy(agz_engine *h);
+const char *agz_last_error(const agz_engine *h);                   /* NULL handle: last create error */
+int  agz_get_info(const agz_engine *h, agz_game_info *out);
+
+/* convert_back(net) -> snetwork2 (DenseNet.jl:331-333, 279-286).  Host fp32, Flux (out,in) column-major:
+ * W0 H x in, Wres T consecutive H x H blocks, Wp A x H, bp A, Wv 1 x H, bv 1.  in = 2*VS. */
+int  agz_set_network(agz_engine *h, int H, int T, const float *W0, const float *Wres,
+                     const float *Wp, const float *bp, const float *Wv, const float *bv);
+/* second actor for duels (mcts_gpu.jl:581 mcts(actor1,actor2,...)); which = 0 or 1 */
+int  agz_set_network_slot(agz_engine *h, int which, int H, int T, const float *W0, const float *Wres,
+                          const float *Wp, const float *bp, const float *Wv, const float *bv);
+/* Flux glorot_uniform / zero-bias random init from Philox (DenseNet.jl:193-198 ressimplesf): host helper */
+int  agz_init_weights(uint64_t seed, int in, int H, int T, int A,
+                      float *W0, float *Wres, float *Wp, float *bp, float *Wv, float *bv);
+
+/* re_init(positions, vnodes, L, ...) mcts_gpu.jl:359-373 (+ Position() for NULL positions :479).
+ * game_ids may be NULL (slot i -> game_id_base + i). */
+int  agz_set_roots(agz_engine *h, const void *positions, int format, const uint32_t *game_ids, int L);
+
+/* mcts_single(actor, visits, ..., L; training, cpuct) mcts_gpu.jl:376-462.  step = ply index (keys the uniforms). */
+int  agz_search(agz_engine *h, int V, float cpuct, int training, uint32_t step);
+int  agz_search_actor(agz_engine *h, int which, int V, float cpuct, int training, uint32_t step);
+
+/* ---- stepwise form of mcts_single for teacher-forced parity (one call per reference kernel group) ---- */
+int  agz_search_begin(agz_engine *h, float cpuct, int training, uint32_t step);   /* :380-387 */
+int  agz_rollout_select(agz_engine *h, uint32_t rollout, int last);               /* :397-407 kdescendTree! + decoder */
+int  agz_rollout_eval(agz_engine *h);                                             /* :414-417 actor + softmax! */
+int  agz_get_eval(agz_engine *h, float *prior /*[L][A]*/, float *v /*[L]*/);      /* softmaxed priors as used */
+int  agz_inject_eval(agz_engine *h, const float *prior, const float *v);          /* replaces the actor output */
+int  agz_rollout_expand_backup(agz_engine *h);                                    /* :424-431 expand + backUp */
+int  agz_search_end(agz_engine *h);                                               /* :441-444 decoder_roots, copy_pol */
+
+/* ---- results of the last search ---- */
+int  agz_get_policy(agz_engine *h, float *out);        /* policy_final [L][A]   (copy_pol :330-339) */
+int  agz_get_batch(agz_engine *h, float *out);         /* root planes  [L][2VS] (decoder_roots :225-246) */
+int  agz_get_leaf_batch(agz_engine *h, float *out);    /* leaf planes  [L][2VS] (decoder :202-223) */
+int  agz_get_root_visits(agz_engine *h, float *out);   /* visits[:,1,:] [L][A] */
+int  agz_get_root_q(agz_engine *h, float *out);        /* q[:,1,:]      [L][A] */
+int  agz_get_leaf(agz_engine *h, int32_t *out);        /* leaf          [L] */
+int  agz_get_node_count(agz_engine *h, int32_t *out);  /* newindex      [L] */
+int  agz_get_counters(agz_engine *h, uint64_t *sum_p, uint64_t *sum_new, uint64_t *rollouts); /* for the roofline */
+
+/* ---- whole-generation self-play on the device: mcts(actor,visits,ngames,buffer;cpuct) mcts_gpu.jl:477-579 ---- */
+typedef struct {
+    int64_t nsamples;       /* samples produced (= sum of plies over games) */
+    int64_t total_plies;    /* "tot_length" :535 */
+    int64_t wins, draws, losses;      /* res == 1 / 0 / -1  :541-547 */
+    int64_t rollouts;       /* sum over plies of L_ply * V */
+    int32_t plies;          /* number of lock-step rounds played */
+    int32_t faults;         /* illegal sampled moves ("faute") */
+    double  search_seconds; /* HIP-event time inside mcts_single ("temps mcts" :566) */
+    double  total_seconds;  /* wall time of the call */
+} agz_selfplay_stats;
+int  agz_selfplay(agz_engine *h, int ngames, int V, float cpuct, int tau_plies, agz_selfplay_stats *stats);
+/* duelnetwork half: mcts(actor1,actor2,visits,ngames;cpuct) :581-651; first = actor to move at ply 0 */
+int  agz_duel(agz_engine *h, int ngames, int V, float cpuct, int tau_plies, int first, int64_t wdl[3]);
+
+/* Samples of the last agz_selfplay in PoolSample order (ply-major, then game id): mainGobang.jl:34-82.
+ * Any pointer may be NULL.  state [n][2VS] i8, policy [n][A] f32, player [n] i8, value [n] f32,
+ * fstate [n][FS] i8, game_id [n] u32, ply [n] i32, move [n] i32. */
+int  agz_get_samples(agz_engine *h, int8_t *state, float *policy, int8_t *player, float *value,
+                     int8_t *fstate, uint32_t *game_id, int32_t *ply, int32_t *move);
+/* Packed records in DEVICE memory for the RCCL all-gather: writes n records of rec_bytes
+ * (see agz_game_info) to dev_out; returns n via *n_out.  Record: {u32 game_id, i32 ply, i32 move, f32 value,
+ * i8 player, i8 pad[3], f32 policy[A], i8 state[2VS], i8 fstate[FS], pad to 16 B}. */
+int  agz_get_samples_packed(agz_engine *h, void *dev_out, int64_t capacity_records, int64_t *n_out);
+
+/* stream / timing plumbing */
+void *agz_stream(agz_engine *h);                       /* the engine's hipStream_t */
+int  agz_synchronize(agz_engine *h);
+/* HIP-event timings (ms) accumulated since the last reset: [0] tree kernels, [1] network kernels, [2] launches */
+int  agz_get_kernel_times(agz_engine *h, double *tree_ms, double *nn_ms, int64_t *tree_launches, int reset);
+int  agz_set_profiling(agz_engine *h, int enable);     /* per-kernel HIP events (serialises tree/nn kernels) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

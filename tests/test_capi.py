@@ -1,0 +1,81 @@
+"""C-ABI surface without a GPU: the library loads, exports every symbol include/agz.h declares, answers the
+GPU-free queries, and refuses to compute without a device (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import alphagpu_amd as ag
+from alphagpu_amd import lib as aglib
+from alphagpu_amd import mcts_gpu as M
+import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_are_exported():
+    hdr = open(os.path.join(ROOT, "include", "agz.h")).read()
+    names = sorted(set(re.findall(r"\b(agz_[a-z_0-9]+)\s*\(", hdr)))
+    assert len(names) >= 30
+    L = aglib.load_library()
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+
+
+@pytest.mark.parametrize("game,n,k,A,VS,ML,img", [
+    ("gobang", 3, 3, 9, 9, 9, 104), ("gobang", 9, 5, 81, 81, 81, 104), ("connect4", 0, 0, 7, 42, 42, 104),
+    ("hex", 9, 0, 81, 100, 81, 104), ("reversi8", 0, 0, 65, 64, 70, 152), ("reversi6", 0, 0, 37, 36, 50, 152)])
+def test_game_constants_match_reference_and_oracle(game, n, k, A, VS, ML, img):
+    g = ag.GameSpec(game, n, k)
+    assert (g.A, g.VS, g.FS, g.ML, g.pos_image_bytes) == (A, VS, VS, ML, img)
+    og = O.make_game(game, n, k)
+    assert (og.A, og.VS, og.FS, og.ML) == (g.A, g.VS, g.FS, g.ML)
+
+
+def test_bad_game_parameters_rejected():
+    with pytest.raises(ValueError):
+        ag.GameSpec("gobang", 14, 5)
+    with pytest.raises(ValueError):
+        ag.GameSpec("hex", 13, 0)
+
+
+def test_weight_init_matches_oracle_definition():
+    g = ag.GameSpec("connect4")
+    net = ag.SNetwork2.random(g, 64, 3, seed=123)
+    on = O.OracleNet(O.make_game("connect4"), 64, 3, seed=123)
+    for a, b in ((net.W0, on.W0), (net.Wres, on.Wres), (net.Wp, on.Wp), (net.Wv, on.Wv), (net.bp, on.bp)):
+        assert np.array_equal(a, b)
+    lim = np.sqrt(6.0 / (84 + 64))
+    assert np.abs(net.W0).max() <= lim and np.abs(net.W0).max() > 0.9 * lim
+
+
+def test_no_cpu_fallback_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(aglib.AgzError) as e:
+        M.Engine(ag.GameSpec("gobang", 3, 3), 4, 4)
+    assert "no HIP device" in str(e.value)
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "alphagpu_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")) or f == "Makefile":
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.lower() or f in ("agz_nn.hpp", "agz_device.hpp", "__init__.py"), f
+                assert "agz_oracle" not in txt and "oracle_lib" not in txt and "libagz_oracle" not in txt, f
+
+
+def test_pool_sample_ring_semantics():
+    g = ag.GameSpec("gobang", 3, 3)
+    buf = ag.PoolSample(g, 5)
+    st = np.arange(2 * 18, dtype=np.int8).reshape(2, 18) % 2
+    pol = np.ones((2, 9), np.float32) / 9
+    idx = [buf.push_buffer(st, pol, 1 if i % 2 == 0 else -1, i % 2) for i in range(7)]
+    assert idx == [1, 2, 3, 4, 5, 1, 2] and buf.full and buf.currentIndex == 3 and buf.length_buffer() == 5
+    buf.update_buffer([1, 2], -1, np.ones(9, np.int8))
+    assert buf.value[0] == 1.0 and buf.value[1] == 0.0 and (buf.fstate[0] == -1).all() and (buf.fstate[1] == 1).all()

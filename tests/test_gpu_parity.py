@@ -1,0 +1,258 @@
+"""GPU parity (-m gpu): the HIP path, called through the libagz C ABI, against the CPU oracle.
+
+EXACT mode  : whole search / whole self-play generation bit-identical to the oracle (visits, leaves, moves,
+              policy and Q bits; |dQ| <= 1e-4 is asserted as well, as BASELINE.json states it).
+BF16 mode   : teacher-forced — the GPU's own (softmaxed prior, v) are handed to the oracle rollout by rollout,
+              after which visits / leaves / policy / Q must again be bit-identical; the bf16 network itself is
+              checked against the oracle's fp32 forward with a tolerance written below.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import alphagpu_amd as ag
+from alphagpu_amd import mcts_gpu as M
+import common
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+BF16_PRIOR_TOL = 2e-2      # max |prior_bf16 - prior_fp32| (absolute, priors are in [0,1])
+BF16_VALUE_TOL = 2e-2
+
+
+def spec(name):
+    kind, n, k = common.GAMES[name]
+    return ag.GameSpec(kind, n, k), O.make_game(kind, n, k)
+
+
+def nets(g, og, H, T, seed=0x5EED):
+    return ag.SNetwork2.random(g, H, T, seed), O.OracleNet(og, H, T, seed)
+
+
+def assert_same_bits(a, b, what):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, what
+    if a.dtype == np.float32:
+        bad = common.bits(a) != common.bits(b)
+        assert not bad.any(), f"{what}: {int(bad.sum())} of {bad.size} differ; max|d|={np.abs(a - b).max()}"
+    else:
+        assert np.array_equal(a, b), what
+
+
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "search_*.npz"))))
+def test_exact_search_matches_golden(path):
+    z = np.load(path)
+    name = os.path.basename(path)[len("search_"):-4]
+    g, og = spec(name)
+    net, _ = nets(g, og, int(z["H"]), int(z["T"]), int(z["netseed"]))
+    L, V = int(z["L"]), int(z["V"])
+    with M.Engine(g, L, V, seed=int(z["seed"]), nn_mode=M.NN_EXACT) as e:
+        e.set_network(net)
+        e.set_roots(z["roots"], game_ids=z["game_ids"])
+        e.search(V, cpuct=float(z["cpuct"]), training=bool(z["training"]), step=int(z["step"]))
+        assert_same_bits(e.leaf(), z["leaf"], "leaf")
+        assert_same_bits(e.node_count(), z["newindex"], "newindex")
+        assert_same_bits(e.root_visits(), z["visits"], "visits")
+        assert np.abs(e.root_q() - z["q"]).max() <= 1e-4
+        assert_same_bits(e.root_q(), z["q"], "q")
+        assert_same_bits(e.policy(), z["policy"], "policy_final")
+        assert_same_bits(e.batch(), z["root_planes"], "root planes")
+        p, n, r = e.counters()
+        assert [p, n] == z["counters"][:2].tolist() and r == L * V
+
+
+@pytest.mark.parametrize("name,L,V,H,T", [
+    ("tictactoe", 64, 16, 128, 6), ("gobang9", 48, 64, 128, 6), ("connect4", 64, 64, 128, 6),
+    ("hex9", 24, 128, 64, 2), ("reversi8", 32, 64, 64, 3), ("reversi6", 32, 48, 32, 2),
+    ("gobang13", 12, 32, 32, 1), ("hex11", 8, 24, 32, 1)])
+def test_exact_search_matches_oracle(name, L, V, H, T):
+    g, og = spec(name)
+    net, onet = nets(g, og, H, T)
+    roots = common.diverse_roots(og, L, seed=3)
+    ids = (1000 + 7 * np.arange(L)).astype(np.uint32)
+    t = O.OracleTree(og, L, V)
+    t.set_roots(roots, ids)
+    t.search(onet, V, 1.5, True, 42, 5)
+    with M.Engine(g, L, V, seed=42, nn_mode=M.NN_EXACT) as e:
+        e.set_network(net)
+        e.set_roots(common.pos_bytes(roots), game_ids=ids)
+        e.search(V, cpuct=1.5, training=True, step=5)
+        assert_same_bits(e.leaf(), t.leaf(), "leaf")
+        assert_same_bits(e.node_count(), t.newindex(), "newindex")
+        assert_same_bits(e.root_visits(), t.root_visits(), "visits")
+        assert np.abs(e.root_q() - t.root_q()).max() <= 1e-4
+        assert_same_bits(e.root_q(), t.root_q(), "q")
+        assert_same_bits(e.policy(), t.policy(), "policy_final")
+        p, n, f = t.counters()
+        assert e.counters()[:2] == (p, n)
+
+
+@pytest.mark.parametrize("name,L,V,H,T", [
+    ("gobang9", 64, 64, 128, 6), ("connect4", 64, 32, 128, 6), ("hex9", 32, 48, 128, 2), ("reversi8", 32, 32, 128, 2)])
+def test_bf16_teacher_forced_parity(name, L, V, H, T):
+    g, og = spec(name)
+    net, onet = nets(g, og, H, T)
+    roots = common.diverse_roots(og, L, seed=5)
+    t = O.OracleTree(og, L, V)
+    t.set_roots(roots)
+    t.reset()
+    worst_p = worst_v = 0.0
+    with M.Engine(g, L, V, seed=9, nn_mode=M.NN_BF16) as e:
+        e.set_network(net)
+        e.set_roots(common.pos_bytes(roots))
+        e.search_begin(1.5, True, 2)
+        for k in range(V):
+            e.rollout_select(k, last=(k == V - 1))
+            t.select(9, 2, k, 1.5)
+            assert_same_bits(e.leaf(), t.leaf(), f"leaf @rollout {k}")
+            assert_same_bits(e.leaf_batch(), t.encode_leaves(), f"leaf planes @rollout {k}")
+            e.rollout_eval()
+            pr, v = e.get_eval()
+            opr, ov = onet.forward(t.encode_leaves())
+            worst_p = max(worst_p, float(np.abs(pr - opr).max()))
+            worst_v = max(worst_v, float(np.abs(v - ov).max()))
+            t.expand(pr, True)
+            t.backup(v)
+            e.rollout_expand_backup()
+        e.search_end()
+        assert_same_bits(e.root_visits(), t.root_visits(), "visits")
+        assert np.abs(e.root_q() - t.root_q()).max() <= 1e-4
+        assert_same_bits(e.root_q(), t.root_q(), "q")
+        assert_same_bits(e.node_count(), t.newindex(), "newindex")
+    assert worst_p <= BF16_PRIOR_TOL and worst_v <= BF16_VALUE_TOL, (worst_p, worst_v)
+
+
+@pytest.mark.parametrize("mode", [M.NN_BF16, M.NN_EXACT])
+def test_fused_search_equals_stepwise(mode):
+    g, og = spec("gobang9")
+    net, _ = nets(g, og, 128, 6)
+    roots = common.pos_bytes(common.diverse_roots(og, 40, seed=8))
+    L, V = 40, 32
+    with M.Engine(g, L, V, seed=4, nn_mode=mode) as e:
+        e.set_network(net)
+        e.set_roots(roots)
+        e.search(V, cpuct=1.5, training=True, step=1)
+        a = (e.policy(), e.root_visits(), e.root_q(), e.leaf(), e.node_count())
+        e.set_roots(roots)
+        e.search_begin(1.5, True, 1)
+        for k in range(V):
+            e.rollout_select(k, last=(k == V - 1))
+            e.rollout_eval()
+            e.rollout_expand_backup()
+        e.search_end()
+        b = (e.policy(), e.root_visits(), e.root_q(), e.leaf(), e.node_count())
+    for x, y, w in zip(a, b, ("policy", "visits", "q", "leaf", "count")):
+        assert_same_bits(x, y, w)
+
+
+def test_exact_selfplay_generation_matches_golden():
+    """BASELINE.json configs[0] family: Gobang N=3, 128x6 net, whole generation on the device."""
+    z = np.load(os.path.join(GOLD, "selfplay_tictactoe.npz"))
+    g, og = spec("tictactoe")
+    net, _ = nets(g, og, int(z["H"]), int(z["T"]), int(z["netseed"]))
+    n = int(z["ngames"])
+    with M.Engine(g, n, int(z["V"]), seed=int(z["seed"]), game_id_base=int(z["base"]), nn_mode=M.NN_EXACT) as e:
+        e.set_network(net)
+        st = e.selfplay(n, int(z["V"]), cpuct=float(z["cpuct"]), tau_plies=int(z["tau"]))
+        s = e.samples()
+    assert st["valid"] and st["faults"] == 0
+    assert [st["wins"], st["draws"], st["losses"], st["total_plies"]] == z["wdl"].tolist()
+    assert st["nsamples"] == len(z["ply"])
+    for key in ("game_id", "ply", "move", "player", "state", "fstate"):
+        assert_same_bits(s[key], z[key], key)
+    assert_same_bits(s["policy"], z["policy"], "policy")
+    assert_same_bits(s["value"], z["value"], "value")
+
+
+@pytest.mark.parametrize("name,n,V,H,T,tau", [
+    ("tictactoe", 256, 16, 128, 6, 25),      # BASELINE.json configs[0]
+    ("connect4", 48, 16, 32, 2, 25), ("reversi6", 24, 12, 32, 1, 25), ("hex5", 32, 16, 32, 1, 4), ("gobang9", 12, 8, 32, 1, 25)])
+def test_exact_selfplay_generation_matches_oracle(name, n, V, H, T, tau):
+    g, og = spec(name)
+    net, onet = nets(g, og, H, T)
+    ref = O.selfplay(og, onet, n, V, 1.5, tau, 77, 500)
+    assert ref["rc"] == 0
+    with M.Engine(g, n, V, seed=77, game_id_base=500, nn_mode=M.NN_EXACT) as e:
+        e.set_network(net)
+        st = e.selfplay(n, V, cpuct=1.5, tau_plies=tau)
+        s = e.samples()
+    assert st["valid"]
+    assert (st["wins"], st["draws"], st["losses"], st["total_plies"]) == (ref["wins"], ref["draws"], ref["losses"], ref["total_plies"])
+    for key in ("game_id", "ply", "move", "player", "state", "fstate", "policy", "value"):
+        assert_same_bits(s[key], ref[key], key)
+
+
+def test_mcts_module_api_fills_pool_like_reference():
+    g, og = spec("tictactoe")
+    net, onet = nets(g, og, 32, 1)
+    buf = ag.PoolSample(g, 1000)
+    stats, valid = M.mcts(net, 8, 16, buf, cpuct=1.5, seed=3, nn_mode=M.NN_EXACT)
+    ref = O.selfplay(og, onet, 16, 8, 1.5, 25, 3, 0)
+    assert valid and buf.length_buffer() == ref["n"] == stats["nsamples"]
+    assert_same_bits(buf.policy[:ref["n"]], ref["policy"], "pool policy")
+    assert np.array_equal(buf.state[:ref["n"]], ref["state"]) and np.array_equal(buf.fstate[:ref["n"]], ref["fstate"])
+    assert np.array_equal(buf.value[:ref["n"]], ref["value"])
+
+
+def test_julia_position_image_roundtrip_through_set_roots():
+    g, og = spec("reversi8")
+    net, onet = nets(g, og, 32, 1)
+    roots = common.diverse_roots(og, 6, seed=2)
+    img = np.concatenate([O.pos_image(og, p) for p in roots])
+    with M.Engine(g, 6, 8, seed=1, nn_mode=M.NN_EXACT) as e:
+        e.set_network(net)
+        e.set_roots(img, fmt=M.POS_JULIA)
+        e.search(8, cpuct=1.5, training=True, step=0)
+        a = e.policy()
+        e.set_roots(common.pos_bytes(roots), fmt=M.POS_COMPACT)
+        e.search(8, cpuct=1.5, training=True, step=0)
+        assert_same_bits(a, e.policy(), "policy")
+
+
+# ---- full-size, size-independent properties (BASELINE.json metric shape) -------------------------------
+def test_full_size_properties_and_sharding_invariance():
+    g, og = spec("gobang9")
+    net, _ = nets(g, og, 128, 6)
+    L, V = 32768, 64
+    with M.Engine(g, L, V, seed=1, nn_mode=M.NN_BF16) as e:
+        e.set_network(net)
+        e.set_roots(None, L=L)
+        e.search(V, cpuct=1.5, training=True, step=0)
+        vis, pol, cnt = e.root_visits(), e.policy(), e.node_count()
+        assert (vis.sum(1) == V - 1).all()                       # rollout 1 only expands the root
+        assert (cnt >= 2).all() and (cnt <= V).all()
+        assert np.isfinite(pol).all() and np.allclose(pol.sum(1), 1.0, atol=5e-3)
+        p, n, r = e.counters()
+        assert r == L * V and n == int((cnt - 1).sum()) and p >= L * (V - 1)
+        e.set_roots(None, L=L)                                   # idempotence: same seed, same bits
+        e.search(V, cpuct=1.5, training=True, step=0)
+        assert_same_bits(e.root_visits(), vis, "visits rerun")
+        assert_same_bits(e.policy(), pol, "policy rerun")
+    # sharding: games 1000..1063 computed in a 64-slot engine must equal the same game ids inside the big one
+    with M.Engine(g, 64, V, seed=1, game_id_base=1000, nn_mode=M.NN_BF16) as e:
+        e.set_network(net)
+        e.set_roots(None, L=64)
+        e.search(V, cpuct=1.5, training=True, step=0)
+        assert_same_bits(e.root_visits(), vis[1000:1064], "shard visits")
+
+
+def test_errors_are_reported_not_swallowed():
+    g, _ = spec("tictactoe")
+    with M.Engine(g, 4, 8) as e:
+        with pytest.raises(ag.AgzError):
+            e.set_roots(None, L=5)                               # more than max_games
+        e.set_roots(None, L=4)
+        with pytest.raises(ag.AgzError):
+            e.search(8)                                          # no network loaded
+        e.set_network(ag.SNetwork2.random(g, 32, 1))
+        with pytest.raises(ag.AgzError):
+            e.search(9)                                          # V > max_visits
+        with pytest.raises(ag.AgzError):
+            e.rollout_expand_backup()                            # nothing evaluated
+        e.set_roots(None, L=0)                                   # empty batch is legal
+        e.search(8)
+        assert e.policy().shape == (0, 9)

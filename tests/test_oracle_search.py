@@ -1,0 +1,144 @@
+"""Oracle search semantics: hand-derivable micro-cases and the committed golden fixtures."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import common
+import oracle_lib as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _setup(name, L, V, H=32, T=2):
+    kind, n, k = common.GAMES[name]
+    g = O.make_game(kind, n, k)
+    net = O.OracleNet(g, H, T)
+    roots = common.diverse_roots(g, L, seed=11)
+    t = O.OracleTree(g, L, V)
+    t.set_roots(roots)
+    return g, net, roots, t
+
+
+@pytest.mark.parametrize("name", ["gobang9", "connect4", "hex5", "reversi8"])
+def test_v1_policy_is_noise_mixed_softmax(name):
+    """V=1: only the root is expanded, so policy_final = 0.75*p/sum_legal(p) + 0.25/A_legal on legal moves
+    (mcts_gpu.jl:259-275, :297-299, :330-339)."""
+    g, net, roots, t = _setup(name, 6, 4)
+    t.search(net, 1, 1.5, True, 1, 0)
+    planes = np.stack([np.array(_planes(g, r)) for r in roots])
+    pr, _ = net.forward(planes)
+    pol = t.policy()
+    for i, r in enumerate(roots):
+        legal = np.array([O.can_play(g, r, a) for a in range(g.A)])
+        norm = np.float32(0)
+        for a in range(g.A):
+            if legal[a]:
+                norm = np.float32(norm + pr[i, a])
+        exp = np.where(legal, np.float32(0.75) * pr[i] / norm + np.float32(0.25) / np.float32(legal.sum()), 0).astype(np.float32)
+        assert np.array_equal(common.bits(pol[i]), common.bits(exp))
+        assert t.root_visits()[i].sum() == 0 and t.newindex()[i] == 1
+
+
+def _planes(g, p):
+    out = np.zeros(2 * g.VS, np.float32)
+    O.lib().agzo_encode(g, p, out.ctypes.data)
+    return out
+
+
+@pytest.mark.parametrize("name", ["gobang9", "reversi6"])
+def test_v2_one_child_with_q_one_minus_v(name):
+    """V=2: exactly one child, visits=1 on its action and q = 1 - v_child (mcts_gpu.jl:319)."""
+    g, net, roots, t = _setup(name, 6, 4)
+    pc, vc = t.search(net, 2, 1.5, True, 1, 0, capture=True)
+    vis, q, leaf = t.root_visits(), t.root_q(), t.leaf()
+    for i in range(len(roots)):
+        assert vis[i].sum() == 1 and t.newindex()[i] == 2 and leaf[i] == 1
+        a = int(np.argmax(vis[i]))
+        child = O.play(g, roots[i], a)
+        f, r = O.is_over(g, child)
+        val = np.float32((1 + child.player * r) / 2) if f else vc[1][i]
+        assert q[i, a] == np.float32(np.float32(1) - val)
+
+
+@pytest.mark.parametrize("name", ["tictactoe", "gobang9", "connect4", "hex9", "reversi8"])
+def test_root_visits_sum_and_policy_mass(name):
+    g, net, roots, t = _setup(name, 8, 24)
+    t.search(net, 24, 1.5, True, 5, 2)
+    assert (t.root_visits().sum(1) == 23).all()                # rollout 1 only expands the root
+    assert (t.newindex() <= 24).all()
+    assert np.allclose(t.policy().sum(1), 1.0, atol=5e-3)     # Newton stops at S-1 < 1e-3
+    p, n, f = t.counters()
+    assert f == 0 and n <= 8 * 23
+
+
+def test_teacher_forcing_reproduces_search():
+    g, net, roots, t = _setup("gobang9", 6, 16)
+    pc, vc = t.search(net, 16, 1.5, True, 9, 1, capture=True)
+    a = (t.policy().copy(), t.root_visits().copy(), t.root_q().copy())
+    t2 = O.OracleTree(g, 6, 16)
+    t2.set_roots(roots)
+    t2.search(None, 16, 1.5, True, 9, 1, prior_inject=pc, v_inject=vc)
+    for x, y in zip(a, (t2.policy(), t2.root_visits(), t2.root_q())):
+        assert np.array_equal(common.bits(x), common.bits(y))
+
+
+def test_results_depend_on_game_id_not_slot():
+    g, net, roots, t = _setup("gobang9", 6, 12)
+    ids = np.array([40, 41, 42, 43, 44, 45], np.uint32)
+    t.set_roots(roots, ids)
+    t.search(net, 12, 1.5, True, 3, 7)
+    pol = t.policy().copy()
+    perm = [3, 1, 5, 0, 2, 4]
+    t2 = O.OracleTree(g, 6, 12)
+    t2.set_roots([roots[j] for j in perm], ids[perm])
+    t2.search(net, 12, 1.5, True, 3, 7)
+    assert np.array_equal(common.bits(t2.policy()), common.bits(pol[perm]))
+
+
+def test_expf_and_softmax_definition():
+    xs = np.linspace(-100, 5, 4001).astype(np.float32)
+    ys = np.array([O.lib().agzo_expf(float(x)) for x in xs], np.float64)
+    ref = np.exp(xs.astype(np.float64))
+    big = ref > 1e-37
+    assert np.max(np.abs(ys[big] - ref[big]) / ref[big]) < 3e-7
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "search_*.npz"))))
+def test_oracle_reproduces_golden_search(path):
+    z = np.load(path)
+    name = os.path.basename(path)[len("search_"):-4]
+    kind, n, k = common.GAMES[name]
+    g = O.make_game(kind, n, k)
+    net = O.OracleNet(g, int(z["H"]), int(z["T"]), int(z["netseed"]))
+    t = O.OracleTree(g, int(z["L"]), int(z["V"]))
+    t.set_roots(common.pos_from_bytes(z["roots"]), z["game_ids"])
+    t.search(net, int(z["V"]), float(z["cpuct"]), int(z["training"]), int(z["seed"]), int(z["step"]))
+    for key, got in (("policy", t.policy()), ("visits", t.root_visits()), ("q", t.root_q())):
+        assert np.array_equal(common.bits(z[key]), common.bits(got)), key
+    assert np.array_equal(z["leaf"], t.leaf()) and np.array_equal(z["newindex"], t.newindex())
+
+
+def test_oracle_reproduces_golden_selfplay():
+    z = np.load(os.path.join(GOLD, "selfplay_tictactoe.npz"))
+    g = O.make_game("gobang", 3, 3)
+    net = O.OracleNet(g, int(z["H"]), int(z["T"]), int(z["netseed"]))
+    s = O.selfplay(g, net, int(z["ngames"]), int(z["V"]), float(z["cpuct"]), int(z["tau"]), int(z["seed"]), int(z["base"]))
+    assert s["rc"] == 0
+    for key in ("state", "player", "fstate", "game_id", "ply", "move"):
+        assert np.array_equal(z[key], s[key]), key
+    assert np.array_equal(common.bits(z["policy"]), common.bits(s["policy"]))
+    assert np.array_equal(common.bits(z["value"]), common.bits(s["value"]))
+    assert z["wdl"].tolist() == [s["wins"], s["draws"], s["losses"], s["total_plies"]]
+    # sample invariants (mainGobang.jl:70-80): value = (1 + res*player)/2, every game ends, plies <= 9
+    assert set(np.unique(s["value"])) <= {0.0, 0.5, 1.0}
+    assert s["ply"].max() <= 8 and len(np.unique(s["game_id"])) == int(z["ngames"])
+
+
+def test_fmcts_baseline_runs():
+    g = O.make_game("gobang", 3, 3)
+    net = O.OracleNet(g, 32, 2)
+    pol, val = O.fmcts(g, net, O.pos_init(g), 32, 1.5, 1)
+    assert abs(pol.sum() - 1.0) < 5e-3 and 0.0 <= val <= 1.0
+    assert O.fmcts_selfplay(g, net, 8, 8, 1.5, 25, 1, 2) > 0
