@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void k_rollout(const TreePar T) {
                 }
                 const float nf = 1.0f + (float)ufirst(wave_sum_i(vsum));  // :117,121 (integers: order-free)
                 const float Af = (float)npos;
-                const float lambda = T.cpuct * __fsqrt_rn(nf) / (Af + nf); // :132
+                const float lambda = T.cpuct * __builtin_sqrtf(nf) / (Af + nf); // :132
                 const float prior_rem = carry * lambda;                    // :134
                 float am = 0.0f;                                           // :133-138
                 for (int r = 0; r < NR; ++r) {
@@ -331,8 +331,8 @@ __global__ __launch_bounds__(256) void k_rollout(const TreePar T) {
             if (f) mn |= M_TERM | ((uint32_t)(1 + lst.player * rr) << M_TV_SHIFT);
             M.set(node, mn);
         }
-        if (!(mn & M_TERM)) {                                               // decoder (:202-223): planes of the leaf
-            if (!have_state) lst = load_pos<NC>(states + node);
+        {                                                                   // decoder (:202-223): planes of the leaf
+            if (!have_state) lst = load_pos<NC>(states + node);             // (terminal leaves too, as the reference does)
             for (int j0 = 0; j0 < T.INP; j0 += 64) {
                 int j = j0 + lane;
                 if (j < T.INP) {

@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py — self-play rollouts/s, the BASELINE.json metric.
+
+A step = ONE whole self-play generation of the configuration the metric is quoted on: Gobang 9x9 (Nvict=5),
+32768 games per GPU x 64 rollouts per move, random-init 128x6 snetwork2, bf16 MFMA network + fp32 tree
+arithmetic, all games played to the end on the device (mcts(), mcts_gpu.jl:477-579).  Inputs (start positions,
+weights) are resident in HBM before the timed region.  value = rollouts of all ranks / max-over-ranks time.
+With N > 1 ranks each rank plays its own shard of game ids and the step ends with the RCCL all-gather of the
+packed sample records.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def algorithmic_bytes(game, sum_p, sum_new, rollouts, S):
+    """B = p(18A+16) + new*2S + (48+4VS) + (4A+4) + 8A + S per (game, rollout)."""
+    A, VS = game.A, game.VS
+    return sum_p * (18 * A + 16) + sum_new * 2 * S + rollouts * ((48 + 4 * VS) + (4 * A + 4) + 8 * A + S)
+
+
+def cpu_baseline(args):
+    """fast_mcts.jl restatement (oracle/agz_oracle.c agzo_fmcts_selfplay, kind 'port') on the host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    og = O.make_game("gobang", args.n, args.nvict)
+    net = O.OracleNet(og, args.filters, args.towers)
+    cores = os.cpu_count() or 1
+    ngames, plies = 4 * cores, 1
+    t0 = time.time()
+    r = O.fmcts_selfplay(og, net, ngames, args.rollouts, args.cpuct, 25, 1, cores, plies)     # calibration
+    dt = max(time.time() - t0, 1e-3)
+    plies = max(1, min(og.ML, int(args.cpu_seconds / dt)))
+    t0 = time.time()
+    r = O.fmcts_selfplay(og, net, ngames, args.rollouts, args.cpuct, 25, 1, cores, plies)
+    dt = time.time() - t0
+    return {"value": r / dt, "unit": "rollouts/s", "cores": cores, "kind": "port",
+            "sample": f"{ngames} games x first {plies} plies x {args.rollouts} readouts, fast_mcts.jl semantics, "
+                      f"fp32 {args.filters}x{args.towers} net, OpenMP over games ({r} rollouts in {dt:.1f}s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--games", type=int, default=32768, help="games per GPU (--samples, mainGobang.jl:96)")
+    ap.add_argument("--rollouts", type=int, default=64, help="--rollout, mainGobang.jl:100")
+    ap.add_argument("--cpuct", type=float, default=1.5, help="--cpuct, mainGobang.jl:113")
+    ap.add_argument("--n", type=int, default=9)
+    ap.add_argument("--nvict", type=int, default=5)
+    ap.add_argument("--filters", type=int, default=128)
+    ap.add_argument("--towers", type=int, default=6)
+    ap.add_argument("--mode", choices=["bf16", "exact"], default="bf16")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import alphagpu_amd as ag
+    from alphagpu_amd import mcts_gpu as M
+    from alphagpu_amd import shard
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (libagz has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    game = ag.GameSpec("gobang", args.n, args.nvict)
+    net = ag.SNetwork2.random(game, args.filters, args.towers)
+    G, V = args.games, args.rollouts
+    eng = M.Engine(game, G, V, device=local_rank, seed=1, game_id_base=shard.shard_base(rank, G),
+                   nn_mode=M.NN_BF16 if args.mode == "bf16" else M.NN_EXACT)
+    eng.set_network(net)
+    eng.set_profiling(True)
+    rb = game.rec_bytes
+    sample_buf = torch.empty(G * game.max_plies * rb, dtype=torch.uint8, device="cuda") if world > 1 else None
+
+    def step():
+        st = eng.selfplay(G, V, cpuct=args.cpuct, tau_plies=25)
+        if not st["valid"]:
+            raise SystemExit("illegal move sampled ('faute')")
+        if world > 1:                       # the one exchange step: all-gather of the generated samples
+            n = eng.samples_packed_into(sample_buf.data_ptr(), G * game.max_plies)
+            shard.allgather_records(sample_buf, n, rb)
+        return st
+
+    def fence():
+        eng.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    eng.kernel_times(reset=True)
+    fence()
+    t0 = time.perf_counter()
+    rollouts = 0
+    search_s = 0.0
+    plies = 0
+    nsamples = 0
+    for _ in range(args.steps):
+        st = step()
+        rollouts += st["rollouts"]
+        search_s += st["search_seconds"]
+        plies += st["plies"]
+        nsamples += st["nsamples"]
+    fence()
+    dt = time.perf_counter() - t0
+    tree_ms, nn_ms, launches = eng.kernel_times()
+    sum_p, sum_new, r_cnt = eng.counters()
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tot = torch.tensor([float(rollouts)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    dt_max, total_rollouts = float(tmax.item()), float(tot.item())
+
+    if rank == 0:
+        S = game.pos_image_bytes
+        alg = algorithmic_bytes(game, sum_p, sum_new, r_cnt, S)
+        achieved = alg / (tree_ms * 1e-3) / 1e9 if tree_ms > 0 else 0.0
+        out = {
+            "metric": "self-play rollouts/sec at 32768 games x 64 rollouts, Gobang 9x9",
+            "value": total_rollouts / dt_max, "unit": "rollouts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt_max * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if args.mode == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": f"gobang{args.n}x{args.n}_nvict{args.nvict}_{G}games_per_gpu_x{V}rollouts_"
+                                   f"snetwork2_{args.filters}x{args.towers}_full_generation",
+                       "games_per_gpu": G, "rollouts_per_move": V, "cpuct": args.cpuct, "tau_plies": 25,
+                       "tree_arithmetic": "f32 strict IEEE", "network": "bf16 MFMA, fp32 accumulate" if args.mode == "bf16" else "f32 exact",
+                       "parallelism": f"game-shard x{world}, RCCL all-gather of samples at generation end" if world > 1 else "single GPU"},
+            "roofline": {"kernel": "k_rollout (expand+backup+select+encode, one wavefront per game tree)",
+                         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg / max(launches, 1), "avg_launch_ms": tree_ms / max(launches, 1),
+                         "launches": launches, "mean_depth_p": sum_p / max(r_cnt, 1)},
+            "rank0": {"search_only_rollouts_per_s": rollouts / search_s if search_s > 0 else None,
+                      "tree_kernel_ms": tree_ms, "network_kernel_ms": nn_ms, "plies": plies, "samples": nsamples,
+                      "wall_s": dt},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args)
+        elif not args.no_cpu_baseline:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

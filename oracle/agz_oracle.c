@@ -707,6 +707,9 @@ void agzo_get_root_visits(const agzo_tree *t, float *out) {
 void agzo_get_root_q(const agzo_tree *t, float *out) {
     for (int i = 0; i < t->L; ++i) for (int k = 0; k < t->g.A; ++k) out[(size_t)i * t->g.A + k] = t->q[ST(t, k, 0, i)];
 }
+void agzo_get_root_policy_row(const agzo_tree *t, float *out) {
+    for (int i = 0; i < t->L; ++i) for (int k = 0; k < t->g.A; ++k) out[(size_t)i * t->g.A + k] = t->policy[ST(t, k, 0, i)];
+}
 void agzo_get_leaf(const agzo_tree *t, int *out) { memcpy(out, t->leaf, (size_t)t->L * sizeof(int)); }
 void agzo_get_newindex(const agzo_tree *t, int *out) { memcpy(out, t->newindex, (size_t)t->L * sizeof(int)); }
 long agzo_get_counters(const agzo_tree *t, long *sum_p, long *sum_new) {

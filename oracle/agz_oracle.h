@@ -103,6 +103,7 @@ void agzo_get_policy(const agzo_tree *t, float *out);        /* policy_final  [L
 void agzo_get_root_planes(const agzo_tree *t, float *out);   /* decoder_roots [L][2VS] :225-246 */
 void agzo_get_root_visits(const agzo_tree *t, float *out);   /* visits[:,1,:] [L][A] */
 void agzo_get_root_q(const agzo_tree *t, float *out);        /* q[:,1,:]      [L][A] */
+void agzo_get_root_policy_row(const agzo_tree *t, float *out); /* policy[:,1,:] as of now */
 void agzo_get_leaf(const agzo_tree *t, int *out);            /* leaf          [L] (0-based) */
 void agzo_get_newindex(const agzo_tree *t, int *out);        /* nodes used    [L] */
 long agzo_get_counters(const agzo_tree *t, long *sum_p, long *sum_new);

@@ -76,7 +76,7 @@ def lib():
         L.agzo_backup.argtypes = [C.c_void_p, C.c_void_p]
         L.agzo_search.argtypes = [C.c_void_p, C.POINTER(Net), C.c_int, C.c_float, C.c_int, C.c_uint64,
                                   C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-        for n in ("policy", "root_planes", "root_visits", "root_q", "leaf", "newindex"):
+        for n in ("policy", "root_planes", "root_visits", "root_q", "leaf", "newindex", "root_policy_row"):
             getattr(L, "agzo_get_" + n).argtypes = [C.c_void_p, C.c_void_p]
         L.agzo_get_counters.restype = C.c_long
         L.agzo_get_counters.argtypes = [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]
@@ -260,6 +260,9 @@ class OracleTree:
 
     def policy(self):
         return self._get("policy", (self.L, self.g.A))
+
+    def root_policy_row(self):
+        return self._get("root_policy_row", (self.L, self.g.A))
 
     def root_planes(self):
         return self._get("root_planes", (self.L, 2 * self.g.VS))
