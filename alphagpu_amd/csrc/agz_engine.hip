@@ -17,6 +17,7 @@
 #include "agz_device.hpp"
 #include "agz_tree.hpp"
 #include "agz_nn.hpp"
+#include "agz_nn_fused.hpp"
 #include "agz_selfplay.hpp"
 
 using namespace agz;
@@ -133,7 +134,7 @@ template <typename T> static hipError_t dmalloc(T** p, size_t n) { return hipMal
 
 static void free_net(DevNet& n) {
     hipFree(n.W0); hipFree(n.Wres); hipFree(n.Wp); hipFree(n.bp); hipFree(n.Wv); hipFree(n.bv);
-    hipFree(n.t0); hipFree(n.tres); hipFree(n.thead); hipFree(n.bias_head);
+    hipFree(n.t0); hipFree(n.bias_head);          // tres / thead point into t0's allocation
     n = DevNet();
 }
 
@@ -194,6 +195,8 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     hipFuncSetAttribute((const void*)k_layer_exact<EX_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)k_layer_exact<EX_POLICY>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)k_layer_exact<EX_VALUE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)k_mlp_fused2<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)k_mlp_fused2<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     const uint32_t A2 = (uint32_t)round_up(P.A, 2);
     const uint32_t rec_bytes = (uint32_t)round_up((int)(A2 * 10), 64);
     const size_t Lm = (size_t)h->Lmax, V = (size_t)h->V;
@@ -303,22 +306,22 @@ int agz_set_network_slot(agz_engine* h, int which, int H, int T, const float* W0
         if (H % 32 != 0) { h->fail("bf16 mode needs H to be a multiple of 32 (got %d)", H); return AGZ_ERR_ARG; }
         const int KT0 = n.INP / 16, NTh = H / 32, KTh = H / 16, NThead = n.AOP / 32;
         n.NT_h = NTh; n.NT_head = NThead;
+        // all fragments live in ONE allocation [layer 0 | T residual layers | head] (t0 owns it)
         std::vector<uint16_t> buf;
-        buf.assign((size_t)KT0 * NTh * 512, 0);
+        const size_t sz0 = (size_t)KT0 * NTh * 512, per = (size_t)KTh * NTh * 512, szh = (size_t)KTh * NThead * 512;
+        HIPCHK(h, dmalloc(&n.t0, sz0 + per * T + szh));
+        n.tres = n.t0 + sz0; n.thead = n.tres + per * T;
+        buf.assign(sz0, 0);
         tile_weights(W0, H, n.in, NTh, KT0, buf);
-        HIPCHK(h, dmalloc(&n.t0, buf.size()));
         HIPCHK(h, hipMemcpy(n.t0, buf.data(), buf.size() * 2, hipMemcpyHostToDevice));
-        const size_t per = (size_t)KTh * NTh * 512;
-        HIPCHK(h, dmalloc(&n.tres, per * (T > 0 ? T : 1)));
         for (int t = 0; t < T; ++t) {
             buf.assign(per, 0);
             tile_weights(Wres + (size_t)t * H * H, H, H, NTh, KTh, buf);
             HIPCHK(h, hipMemcpy(n.tres + per * t, buf.data(), per * 2, hipMemcpyHostToDevice));
         }
-        buf.assign((size_t)KTh * NThead * 512, 0);
+        buf.assign(szh, 0);
         tile_weights(Wp, P.A, H, NThead, KTh, buf);                 // rows 0..A-1: policy head
         tile_weights(Wv, 1, H, NThead, KTh, buf, P.A, 1);           // row A: value head
-        HIPCHK(h, dmalloc(&n.thead, buf.size()));
         HIPCHK(h, hipMemcpy(n.thead, buf.data(), buf.size() * 2, hipMemcpyHostToDevice));
         std::vector<float> bh((size_t)n.AOP, 0.0f);
         for (int a = 0; a < P.A; ++a) bh[a] = bp[a];
@@ -408,7 +411,17 @@ static int launch_network(agz_engine* h, int which) {
     const int L = h->L;
     std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
     if (h->profiling) { ev = next_events(h, h->ev_nn, h->ev_nn_used); hipEventRecord(ev->first, h->stream); }
-    if (h->cfg.nn_mode == AGZ_NN_BF16) {
+    size_t fused_lds = 0;
+    if (h->cfg.nn_mode == AGZ_NN_BF16 && (n.H == 64 || n.H == 128) && n.AOP / 32 <= n.H / 32 && !getenv("AGZ_NO_FUSED_NN"))
+        fused_lds = (size_t)F2_M * (n.H * 2 + 16) + F2_WCHUNK;
+    if (fused_lds) {                    // the whole forward in one launch, activations never leave LDS
+        Fused2Par F;
+        F.planes = (const uint16_t*)h->planes; F.INP = n.INP; F.t0 = n.t0; F.tres = n.tres; F.thead = n.thead; F.bias_head = n.bias_head;
+        F.logits = h->logits; F.LGS = h->LGS; F.vout = h->v_eval; F.L = L; F.T = n.T; F.A = h->G.A; F.AOP = n.AOP;
+        dim3 grid((unsigned)((L + F2_M - 1) / F2_M)), block(256);
+        if (n.H == 128) hipLaunchKernelGGL(k_mlp_fused2<128>, grid, block, fused_lds, h->stream, F);
+        else hipLaunchKernelGGL(k_mlp_fused2<64>, grid, block, fused_lds, h->stream, F);
+    } else if (h->cfg.nn_mode == AGZ_NN_BF16) {
         dim3 block(256);
         dim3 gh((unsigned)((L + GB_M - 1) / GB_M), (unsigned)((n.H + GB_N - 1) / GB_N));
         const uint16_t* x = (const uint16_t*)h->planes;

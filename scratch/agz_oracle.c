@@ -1,0 +1,949 @@
+/*
+ * agz_oracle.c — CPU ORACLE (test infrastructure, NOT product code).  See agz_oracle.h.
+ * PARITY UNPINNED by the reference (no tests / golden vectors exist there, Julia absent).
+ *
+ * Build: gcc -O2 -std=c11 -ffp-contract=off -fno-fast-math -mfma -fopenmp -shared -fPIC
+ * All fp32 arithmetic is written in reference source order; fmaf() is used only where the
+ * oracle itself DEFINES the operation (network dot products, expf polynomial).
+ */
+#include "agz_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ============================================================================================
+ * Bitboard.jl
+ * ========================================================================================== */
+static const uint64_t MSK64 = ~(uint64_t)0;
+static inline uint64_t msk_end(int l) { return MSK64 >> ((-l) & 63); }            /* Bitboard.jl:31 */
+
+static inline agzo_bb bb_msk(int len) {                                             /* Bitboard.jl:33-41 */
+    agzo_bb m;
+    if (len <= 64)       { m.c[0] = msk_end(len); m.c[1] = 0;            m.c[2] = 0; }
+    else if (len <= 128) { m.c[0] = MSK64;        m.c[1] = msk_end(len); m.c[2] = 0; }
+    else                 { m.c[0] = MSK64;        m.c[1] = MSK64;        m.c[2] = msk_end(len); }
+    return m;
+}
+static inline agzo_bb bb_zero(void) { agzo_bb b = {{0, 0, 0}}; return b; }
+int agzo_bb_get(const agzo_bb *b, int bit) { return (int)((b->c[bit >> 6] >> (bit & 63)) & 1); } /* :47-52 */
+static inline int bb_get(agzo_bb b, int bit) { return (int)((b.c[bit >> 6] >> (bit & 63)) & 1); }
+static inline agzo_bb bb_set(agzo_bb b, int bit) { b.c[bit >> 6] |= (uint64_t)1 << (bit & 63); return b; } /* :60-74 */
+static inline int bb_count(agzo_bb b) {                                             /* :177-180 */
+    return __builtin_popcountll(b.c[0]) + __builtin_popcountll(b.c[1]) + __builtin_popcountll(b.c[2]);
+}
+static inline agzo_bb bb_and(agzo_bb a, agzo_bb b) { agzo_bb r = {{a.c[0] & b.c[0], a.c[1] & b.c[1], a.c[2] & b.c[2]}}; return r; }
+static inline agzo_bb bb_or (agzo_bb a, agzo_bb b) { agzo_bb r = {{a.c[0] | b.c[0], a.c[1] | b.c[1], a.c[2] | b.c[2]}}; return r; }
+static inline agzo_bb bb_xor(agzo_bb a, agzo_bb b) { agzo_bb r = {{a.c[0] ^ b.c[0], a.c[1] ^ b.c[1], a.c[2] ^ b.c[2]}}; return r; }
+static inline agzo_bb bb_not(const agzo_game *g, agzo_bb a) {                       /* :182-187 */
+    agzo_bb m = bb_msk(g->len);
+    agzo_bb r = {{(~a.c[0]) & m.c[0], (~a.c[1]) & m.c[1], (~a.c[2]) & m.c[2]}};
+    return r;
+}
+/* Bitboard.jl:85-107, only the n<64 path is ever taken (n = 1 or dims[1] <= 14) */
+static inline agzo_bb bb_shl(const agzo_game *g, agzo_bb b, int n) {
+    uint64_t x = b.c[0], y = b.c[1], z = b.c[2];
+    uint64_t newx = x << n, headx = x >> (64 - n), heady = y >> (64 - n);
+    uint64_t newy = (y << n) | headx, newz = (z << n) | heady;
+    agzo_bb m = bb_msk(g->len);
+    agzo_bb r = {{newx & m.c[0], newy & m.c[1], newz & m.c[2]}};
+    return r;
+}
+/* Bitboard.jl:110-134 */
+static inline agzo_bb bb_shr(const agzo_game *g, agzo_bb b, int n) {
+    uint64_t x = b.c[0], y = b.c[1], z = b.c[2];
+    uint64_t newz = z >> n, headz = z << (64 - n), heady = y << (64 - n);
+    uint64_t newy = (y >> n) | headz, newx = (x >> n) | heady;
+    agzo_bb m = bb_msk(g->len);
+    agzo_bb r = {{newx & m.c[0], newy & m.c[1], newz & m.c[2]}};
+    return r;
+}
+static inline agzo_bb bb_right(const agzo_game *g, agzo_bb b) { return bb_shl(g, b, g->d1); }  /* :136-139 */
+static inline agzo_bb bb_left (const agzo_game *g, agzo_bb b) { return bb_shr(g, b, g->d1); }  /* :142-145 */
+static inline agzo_bb bb_down(const agzo_game *g, agzo_bb b) {                                  /* :146-160 */
+    agzo_bb d = bb_shl(g, b, 1);
+    for (int i = 0; i < g->len; i += g->d1) d.c[i >> 6] &= ~((uint64_t)1 << (i & 63));
+    return d;
+}
+static inline agzo_bb bb_up(const agzo_game *g, agzo_bb b) {                                    /* :162-176 */
+    agzo_bb d = bb_shr(g, b, 1);
+    for (int i = g->d1 - 1; i < g->len; i += g->d1) d.c[i >> 6] &= ~((uint64_t)1 << (i & 63));
+    return d;
+}
+static inline int idx2(const agzo_game *g, int i1, int i2) { return g->d1 * (i2 - 1) + (i1 - 1); } /* :54-57, 1-based in */
+
+void agzo_bb_shift(const agzo_game *g, const agzo_bb *b, int op, agzo_bb *out) {
+    switch (op) {
+    case 0: *out = bb_right(g, *b); break;
+    case 1: *out = bb_left(g, *b); break;
+    case 2: *out = bb_down(g, *b); break;
+    default: *out = bb_up(g, *b); break;
+    }
+}
+
+/* ============================================================================================
+ * Games
+ * ========================================================================================== */
+int agzo_game_init(agzo_game *g, int kind, int n, int nvict) {
+    memset(g, 0, sizeof(*g));
+    g->kind = kind; g->n = n; g->nvict = nvict;
+    switch (kind) {
+    case AGZO_GOBANG:                                      /* Gobang.jl:8-11, mainGobang.jl:24-26 */
+        if (n < 1 || n > 13 || nvict < 1) return -1;
+        g->d1 = n; g->d2 = n; g->len = n * n;
+        g->A = g->VS = g->FS = g->ML = n * n; break;
+    case AGZO_CONNECT4:                                    /* 4IARow.jl:6-12 */
+        g->n = 6; g->nvict = 4; g->d1 = 6; g->d2 = 7; g->len = 42;
+        g->A = 7; g->VS = g->FS = g->ML = 42; break;
+    case AGZO_HEX:                                         /* Hex.jl:8-11 */
+        if (n < 2 || n > 12) return -1;
+        g->d1 = n + 1; g->d2 = n + 1; g->len = (n + 1) * (n + 1);
+        g->VS = g->FS = g->len; g->A = g->ML = n * n; break;
+    case AGZO_REVERSI8:                                    /* Reversi8x8.jl:5-8 */
+        g->n = 8; g->d1 = 8; g->d2 = 8; g->len = 64; g->VS = g->FS = 64; g->A = 65; g->ML = 70; break;
+    case AGZO_REVERSI6:                                    /* Reversi6x6.jl:6-9 */
+        g->n = 6; g->d1 = 6; g->d2 = 6; g->len = 36; g->VS = g->FS = 36; g->A = 37; g->ML = 50; break;
+    default: return -1;
+    }
+    return 0;
+}
+
+/* ---- Reversi helpers (Reversi8x8.jl:16-70 == Reversi6x6.jl:16-70) ---- */
+typedef agzo_bb (*dirfn)(const agzo_game *, agzo_bb);
+static agzo_bb d_up(const agzo_game *g, agzo_bb x) { return bb_up(g, x); }
+static agzo_bb d_down(const agzo_game *g, agzo_bb x) { return bb_down(g, x); }
+static agzo_bb d_left(const agzo_game *g, agzo_bb x) { return bb_left(g, x); }
+static agzo_bb d_right(const agzo_game *g, agzo_bb x) { return bb_right(g, x); }
+static agzo_bb d_hd(const agzo_game *g, agzo_bb x) { return bb_up(g, bb_right(g, x)); }   /* diaghd :16 */
+static agzo_bb d_hg(const agzo_game *g, agzo_bb x) { return bb_up(g, bb_left(g, x)); }    /* diaghg :18 */
+static agzo_bb d_bd(const agzo_game *g, agzo_bb x) { return bb_down(g, bb_right(g, x)); } /* diagbd :20 */
+static agzo_bb d_bg(const agzo_game *g, agzo_bb x) { return bb_down(g, bb_left(g, x)); }  /* diagbg :22 */
+static const dirfn DIRS[8] = { d_up, d_down, d_left, d_right, d_hg, d_bg, d_hd, d_bd };
+
+static agzo_bb rev_legal_dir(const agzo_game *g, agzo_bb tj, agzo_bb ta, dirfn dir) {     /* legal_play :25-34 */
+    agzo_bb vide = bb_and(bb_not(g, tj), bb_not(g, ta));
+    agzo_bb moves = bb_zero();
+    agzo_bb cand = bb_and(dir(g, tj), ta);
+    while (bb_count(cand) != 0) {
+        moves = bb_or(moves, bb_and(vide, dir(g, cand)));
+        cand = bb_and(ta, dir(g, cand));
+    }
+    return moves;
+}
+static agzo_bb rev_legal(const agzo_game *g, agzo_bb tj, agzo_bb ta) {                    /* legalplay :36-39 */
+    agzo_bb m = bb_zero();
+    for (int d = 0; d < 8; ++d) m = bb_or(m, rev_legal_dir(g, tj, ta, DIRS[d]));
+    return m;
+}
+static agzo_bb rev_flippar(const agzo_game *g, agzo_bb tj, agzo_bb ta, agzo_bb play, dirfn dir) { /* :43-55 */
+    agzo_bb cand = bb_and(dir(g, play), ta);
+    agzo_bb toflip = cand;
+    while (bb_count(cand) != 0) {
+        cand = bb_and(ta, dir(g, cand));
+        toflip = bb_or(toflip, cand);
+    }
+    if (bb_count(bb_and(dir(g, toflip), tj)) != 0) return toflip;
+    return bb_zero();
+}
+static agzo_bb rev_flip(const agzo_game *g, agzo_bb tj, agzo_bb ta, int bit) {            /* flip :57-69 */
+    agzo_bb test = bb_set(bb_zero(), bit), h = bb_zero();
+    for (int d = 0; d < 8; ++d) h = bb_or(h, rev_flippar(g, tj, ta, test, DIRS[d]));
+    return h;
+}
+
+void agzo_pos_init(const agzo_game *g, agzo_pos *p) {
+    memset(p, 0, sizeof(*p));
+    switch (g->kind) {
+    case AGZO_GOBANG:   p->player = 1; p->aux = 0; break;                 /* Gobang.jl:23 */
+    case AGZO_CONNECT4: p->player = 1; p->aux = 1; break;                 /* 4IARow.jl:23 */
+    case AGZO_HEX: {                                                      /* Hex.jl:22-35 */
+        agzo_bb sx = bb_zero(), so = bb_zero();
+        for (int i = 3; i <= g->n + 1; ++i) {
+            sx = bb_set(sx, idx2(g, i, 1));
+            so = bb_set(so, idx2(g, 1, i));
+        }
+        p->bplayer = sx; p->bopponent = so; p->player = 1; p->aux = (int8_t)(g->n * g->n);
+        break;
+    }
+    case AGZO_REVERSI8: {                                                 /* Reversi8x8.jl:10-14,80-82 */
+        agzo_bb so = bb_set(bb_set(bb_zero(), idx2(g, 4, 5)), idx2(g, 5, 4));
+        agzo_bb sp = bb_set(bb_set(bb_zero(), idx2(g, 5, 5)), idx2(g, 4, 4));
+        p->bplayer = so; p->bopponent = sp; p->legalplay = rev_legal(g, so, sp); p->player = 1;
+        break;
+    }
+    case AGZO_REVERSI6: {                                                 /* Reversi6x6.jl:11-14,80-82 */
+        agzo_bb so = bb_set(bb_set(bb_zero(), idx2(g, 4, 3)), idx2(g, 3, 4));
+        agzo_bb sp = bb_set(bb_set(bb_zero(), idx2(g, 3, 3)), idx2(g, 4, 4));
+        p->bplayer = so; p->bopponent = sp; p->legalplay = rev_legal(g, so, sp); p->player = 1;
+        break;
+    }
+    }
+}
+
+static inline int hex_cell(const agzo_game *g, int a) {                   /* Hex.jl:37-41 (a 0-based) */
+    int col = a + 1, N = g->n;
+    int x = (col - 1) / N, y = col - N * x;
+    int newcol = (N + 1) * (x + 1) + y + 1;                               /* 1-based bit */
+    return newcol - 1;
+}
+
+int agzo_can_play(const agzo_game *g, const agzo_pos *p, int a) {
+    switch (g->kind) {
+    case AGZO_GOBANG:                                                     /* Gobang.jl:25-27 */
+        return !bb_get(p->bplayer, a) && !bb_get(p->bopponent, a);
+    case AGZO_CONNECT4: {                                                 /* 4IARow.jl:25-27 */
+        int b = idx2(g, 1, a + 1);
+        return !bb_get(p->bplayer, b) && !bb_get(p->bopponent, b);
+    }
+    case AGZO_HEX: {                                                      /* Hex.jl:37-42 */
+        int b = hex_cell(g, a);
+        return !bb_get(p->bplayer, b) && !bb_get(p->bopponent, b);
+    }
+    default:                                                              /* Reversi8x8.jl:84-90 */
+        if (a == g->A - 1) return bb_count(p->legalplay) == 0;
+        return bb_get(p->legalplay, a);
+    }
+}
+
+void agzo_play(const agzo_game *g, const agzo_pos *p, int a, agzo_pos *out) {
+    agzo_pos r; memset(&r, 0, sizeof(r));
+    switch (g->kind) {
+    case AGZO_GOBANG:                                                     /* Gobang.jl:30-33 */
+        r.bplayer = p->bopponent; r.bopponent = bb_set(p->bplayer, a);
+        r.player = (int8_t)(-p->player); r.aux = (int8_t)(p->aux + 1); break;
+    case AGZO_CONNECT4: {                                                 /* 4IARow.jl:30-44 */
+        int col = a + 1, free_ = 1;
+        agzo_bb empty = bb_not(g, bb_or(p->bplayer, p->bopponent));
+        for (int i = 1; i <= 6; ++i) { if (bb_get(empty, idx2(g, i, col))) free_ = i; else break; }
+        int c = 6 * (col - 1) + free_;                                    /* 1-based */
+        r.bplayer = p->bopponent; r.bopponent = bb_set(p->bplayer, c - 1);
+        r.player = (int8_t)(-p->player); r.aux = (int8_t)(p->aux + 1); break;
+    }
+    case AGZO_HEX:                                                        /* Hex.jl:45-51 */
+        r.bplayer = p->bopponent; r.bopponent = bb_set(p->bplayer, hex_cell(g, a));
+        r.player = (int8_t)(-p->player); r.aux = (int8_t)(p->aux - 1); break;
+    default: {                                                            /* Reversi8x8.jl:93-106 */
+        agzo_bb tj = p->bplayer, ta = p->bopponent;
+        if (a == g->A - 1) {
+            r.bplayer = p->bopponent; r.bopponent = p->bplayer;
+            r.legalplay = rev_legal(g, ta, tj); r.player = (int8_t)(-p->player);
+            break;
+        }
+        agzo_bb h = rev_flip(g, tj, ta, a);
+        tj = bb_xor(tj, h); ta = bb_xor(ta, h);
+        tj = bb_set(tj, a);
+        r.bplayer = ta; r.bopponent = tj; r.legalplay = rev_legal(g, ta, tj);
+        r.player = (int8_t)(-p->player);
+        break;
+    }
+    }
+    *out = r;
+}
+
+static int line_is_over(const agzo_game *g, const agzo_pos *p, int full, int *result) { /* Gobang.jl:36-70 = 4IARow.jl:47-81 */
+    agzo_bb board;
+    board = p->bopponent;
+    for (int j = 1; j <= g->nvict - 1; ++j) board = bb_and(board, bb_right(g, board));
+    if (bb_count(board) != 0) { *result = -p->player; return 1; }
+    board = p->bopponent;
+    for (int j = 1; j <= g->nvict - 1; ++j) board = bb_and(board, bb_down(g, board));
+    if (bb_count(board) != 0) { *result = -p->player; return 1; }
+    board = p->bopponent;
+    for (int j = 1; j <= g->nvict - 1; ++j) board = bb_and(board, bb_down(g, bb_right(g, board)));
+    if (bb_count(board) != 0) { *result = -p->player; return 1; }
+    board = p->bopponent;
+    for (int j = 1; j <= g->nvict - 1; ++j) board = bb_and(board, bb_left(g, bb_down(g, board)));
+    if (bb_count(board) != 0) { *result = -p->player; return 1; }
+    *result = 0;
+    return bb_count(p->bplayer) + bb_count(p->bopponent) == full;
+}
+
+int agzo_is_over(const agzo_game *g, const agzo_pos *p, int *result) {
+    switch (g->kind) {
+    case AGZO_GOBANG:   return line_is_over(g, p, g->n * g->n, result);
+    case AGZO_CONNECT4: return line_is_over(g, p, 42, result);
+    case AGZO_HEX: {                                                      /* Hex.jl:54-67 */
+        agzo_bb a = p->bopponent; int N = g->n;
+        for (int j = 1; j <= 2 * N - 2; ++j) {
+            agzo_bb b = bb_up(g, a);
+            agzo_bb c = bb_right(g, b);
+            a = bb_down(g, bb_or(bb_and(a, bb_or(b, c)), bb_and(b, c)));
+            if (p->player == 1)
+                for (int k = 3 + j; k <= N + 1; ++k) a = bb_set(a, idx2(g, 1, k));
+        }
+        *result = -p->player;
+        return bb_get(a, idx2(g, N + 1, N + 1));
+    }
+    case AGZO_REVERSI8: {                                                 /* Reversi8x8.jl:109-121 */
+        int test = (int8_t)(bb_count(p->bplayer) - bb_count(p->bopponent));
+        int sgn = (test > 0) - (test < 0);
+        *result = sgn * p->player;
+        return bb_count(p->legalplay) == 0 && bb_count(rev_legal(g, p->bopponent, p->bplayer)) == 0;
+    }
+    default: {                                                            /* Reversi6x6.jl:109-121 */
+        if (bb_count(p->legalplay) != 0 || bb_count(rev_legal(g, p->bopponent, p->bplayer)) != 0) {
+            *result = 0; return 0;
+        }
+        int test = (int8_t)(bb_count(p->bplayer) - bb_count(p->bopponent));
+        *result = test > 0 ? p->player : (test == 0 ? 0 : -p->player);
+        return 1;
+    }
+    }
+}
+
+/* perft: counts the positions reached after exactly `depth` plies (terminal positions are not extended);
+ * terminal[0..2] accumulate finished games met at ANY ply <= depth with result +1 / 0 / -1 (absolute colours).
+ * Test helper for the known-answer tests. */
+long agzo_perft(const agzo_game *g, const agzo_pos *p, int depth, long *terminal) {
+    int r;
+    if (agzo_is_over(g, p, &r)) { if (terminal) terminal[r == 1 ? 0 : (r == 0 ? 1 : 2)]++; return depth == 0 ? 1 : 0; }
+    if (depth == 0) return 1;
+    long n = 0;
+    for (int a = 0; a < g->A; ++a)
+        if (agzo_can_play(g, p, a)) { agzo_pos q; agzo_play(g, p, a, &q); n += agzo_perft(g, &q, depth - 1, terminal); }
+    return n;
+}
+
+/* ---- Julia memory image ---- */
+static int is_reversi(const agzo_game *g) { return g->kind == AGZO_REVERSI8 || g->kind == AGZO_REVERSI6; }
+int agzo_pos_image_bytes(const agzo_game *g) { return is_reversi(g) ? 152 : 104; }
+static void put_bb(const agzo_game *g, agzo_bb b, unsigned char *dst) {
+    int64_t meta[3] = { g->len, g->d1, g->d2 };
+    memcpy(dst, b.c, 24); memcpy(dst + 24, meta, 24);
+}
+void agzo_pos_to_image(const agzo_game *g, const agzo_pos *p, void *img) {
+    unsigned char *d = (unsigned char *)img;
+    memset(d, 0, (size_t)agzo_pos_image_bytes(g));
+    put_bb(g, p->bplayer, d); put_bb(g, p->bopponent, d + 48);
+    if (is_reversi(g)) { put_bb(g, p->legalplay, d + 96); d[144] = (unsigned char)p->player; }
+    else { d[96] = (unsigned char)p->player; d[97] = (unsigned char)p->aux; }
+}
+void agzo_pos_from_image(const agzo_game *g, const void *img, agzo_pos *p) {
+    const unsigned char *s = (const unsigned char *)img;
+    memset(p, 0, sizeof(*p));
+    memcpy(p->bplayer.c, s, 24); memcpy(p->bopponent.c, s + 48, 24);
+    if (is_reversi(g)) { memcpy(p->legalplay.c, s + 96, 24); p->player = (int8_t)s[144]; }
+    else { p->player = (int8_t)s[96]; p->aux = (int8_t)s[97]; }
+}
+
+/* ============================================================================================
+ * Randomness: Philox4x32-10 (Salmon et al., SC'11 "Parallel random numbers: as easy as 1,2,3").
+ * Replaces the reference's unseeded CUDA.rand (mcts_gpu.jl:397) and StatsBase.sample (:520).
+ * ========================================================================================== */
+void agzo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+/* search uniform in (0,1]: stands for prob[cpt,i] (mcts_gpu.jl:178, 397); keyed by GAME id, not slot */
+float agzo_uniform_search(uint64_t seed, uint32_t game_id, uint32_t step, uint32_t rollout, uint32_t depth) {
+    uint32_t ctr[4] = { game_id, step, rollout, depth }, key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) }, o[4];
+    agzo_philox4x32_10(ctr, key, o);
+    return (float)((o[0] >> 8) + 1u) * 5.9604644775390625e-8f;           /* 2^-24 */
+}
+/* move uniform in [0,1): stands for rand() inside StatsBase.sample (mcts_gpu.jl:520) */
+float agzo_uniform_move(uint64_t seed, uint32_t game_id, uint32_t step) {
+    uint32_t ctr[4] = { game_id, step, 0u, 0x80000000u }, key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) }, o[4];
+    agzo_philox4x32_10(ctr, key, o);
+    return (float)(o[0] >> 8) * 5.9604644775390625e-8f;
+}
+/* Flux 0.12 Dense default init: glorot_uniform weights, zero bias (DenseNet.jl:195-197) */
+static void glorot(uint64_t seed, uint32_t tensor, int out, int in, float *W) {
+    float limit = sqrtf(6.0f / (float)(in + out));
+    uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
+    for (long e = 0; e < (long)out * in; ++e) {
+        uint32_t ctr[4] = { (uint32_t)e, tensor, 0u, 0x57454947u }, o[4];
+        agzo_philox4x32_10(ctr, key, o);
+        float u = (float)(o[0] >> 8) * 5.9604644775390625e-8f;
+        W[e] = (2.0f * u - 1.0f) * limit;
+    }
+}
+void agzo_init_weights(uint64_t seed, int in, int H, int T, int A,
+                       float *W0, float *Wres, float *Wp, float *bp, float *Wv, float *bv) {
+    glorot(seed, 0, H, in, W0);
+    for (int t = 0; t < T; ++t) glorot(seed, (uint32_t)(1 + t), H, H, Wres + (size_t)t * H * H);
+    glorot(seed, (uint32_t)(T + 1), A, H, Wp);
+    glorot(seed, (uint32_t)(T + 2), 1, H, Wv);
+    for (int a = 0; a < A; ++a) bp[a] = 0.0f;
+    bv[0] = 0.0f;
+}
+
+/* ============================================================================================
+ * Network: snetwork2 (DenseNet.jl:294-304) + softmax (mcts_gpu.jl:417)
+ * Definitions fixed by this oracle: dot products are k-ordered fmaf chains starting from 0
+ * (== gfx950 v_mfma_f32 semantics); exp is the polynomial below.
+ * ========================================================================================== */
+float agzo_expf(float x) {
+    if (x < -104.0f) return 0.0f;
+    if (x > 88.5f) return INFINITY;
+    float kf = rintf(x * 1.44269504088896341f);
+    float r = fmaf(kf, -0.693145751953125f, x);
+    r = fmaf(kf, -1.42860682030941723212e-6f, r);
+    float z = r * r;
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    float y = fmaf(p, z, r);
+    y = y + 1.0f;
+    int k = (int)kf;
+    union { uint32_t u; float f; } s;
+    if (k >= -126) { s.u = (uint32_t)(k + 127) << 23; return y * s.f; }
+    s.u = (uint32_t)(k + 127 + 64) << 23;
+    return (y * s.f) * 5.42101086242752217e-20f;                          /* 2^-64 */
+}
+static inline float sigmoidf_(float x) {                                  /* NNlib σ */
+    float t = agzo_expf(-fabsf(x));
+    return x >= 0.0f ? 1.0f / (1.0f + t) : t / (1.0f + t);
+}
+void agzo_encode(const agzo_game *g, const agzo_pos *p, float *planes) {  /* mcts_gpu.jl:202-223 */
+    for (int j = 0; j < g->VS; ++j) {
+        planes[j] = bb_get(p->bplayer, j) ? 1.0f : 0.0f;
+        planes[j + g->VS] = bb_get(p->bopponent, j) ? 1.0f : 0.0f;
+    }
+}
+static void dense_nobias(const float *W, int out, int in, const float *x, float *y) {
+    for (int o = 0; o < out; ++o) y[o] = 0.0f;
+    for (int i = 0; i < in; ++i) {
+        const float *w = W + (size_t)i * out; float xi = x[i];
+        for (int o = 0; o < out; ++o) y[o] = fmaf(w[o], xi, y[o]);
+    }
+}
+void agzo_forward(const agzo_net *net, const float *planes, float *logits, float *v) {
+    int H = net->H;
+    float b[1024], t[1024];
+    dense_nobias(net->W0, H, net->in, planes, b);
+    for (int o = 0; o < H; ++o) b[o] = b[o] > 0.0f ? b[o] : 0.0f;
+    for (int l = 0; l < net->T; ++l) {
+        dense_nobias(net->Wres + (size_t)l * H * H, H, H, b, t);
+        for (int o = 0; o < H; ++o) {
+            float r = t[o] > 0.0f ? t[o] : 0.0f;
+            float s = b[o] + r;
+            b[o] = s > 0.0f ? s : 0.0f;
+        }
+    }
+    dense_nobias(net->Wp, net->A, H, b, logits);
+    for (int a = 0; a < net->A; ++a) logits[a] = logits[a] + net->bp[a];
+    float vv;
+    dense_nobias(net->Wv, 1, H, b, &vv);
+    *v = sigmoidf_(vv + net->bv[0]);
+}
+void agzo_softmax(float *x, int n) {                                      /* exp(x-max) / sum, source order */
+    float m = x[0];
+    for (int i = 1; i < n; ++i) m = x[i] > m ? x[i] : m;
+    float s = 0.0f;
+    for (int i = 0; i < n; ++i) { x[i] = agzo_expf(x[i] - m); s += x[i]; }
+    for (int i = 0; i < n; ++i) x[i] = x[i] / s;
+}
+
+/* ============================================================================================
+ * Batched search — mcts_gpu.jl
+ * ========================================================================================== */
+struct agzo_tree {
+    agzo_game g; int Lmax, V, L;
+    /* vnodesStats (mcts_gpu.jl:35-39), column-major [A][V][L] */
+    float *prior, *policy, *q, *visits;
+    int *Achild;            /* [A][V][L] 1-based child slot, 0 = none */
+    int *childID;           /* [V][V][L] slot -> node (0-based) */
+    int *childnbr;          /* [V][L] */
+    float *policy_final;    /* [A][L] */
+    float *batch;           /* [2VS][L] */
+    /* vnodes (:42-53) */
+    int *parent, *actionFromParent;   /* [V][L]; parent -1 = none */
+    agzo_pos *state;                  /* [V][L] */
+    int8_t *expanded, *uptodate;      /* [V][L] */
+    int *leaf, *newindex;             /* [L]; newindex = number of nodes in use */
+    uint32_t *game_id;                /* [L] */
+    float *prior_tmp, *v_tmp;         /* [A][L], [L] */
+    long sum_p, sum_new, faults;
+};
+#define ST(t, k, n, i) ((size_t)(k) + (size_t)(t)->g.A * ((size_t)(n) + (size_t)(t)->V * (size_t)(i)))
+#define ND(t, n, i) ((size_t)(n) + (size_t)(t)->V * (size_t)(i))
+#define CI(t, s, n, i) ((size_t)(s) + (size_t)(t)->V * ((size_t)(n) + (size_t)(t)->V * (size_t)(i)))
+
+agzo_tree *agzo_tree_create(const agzo_game *g, int Lmax, int V) {
+    agzo_tree *t = (agzo_tree *)calloc(1, sizeof(*t));
+    t->g = *g; t->Lmax = Lmax; t->V = V; t->L = 0;
+    size_t s = (size_t)g->A * V * Lmax, n = (size_t)V * Lmax;
+    t->prior = calloc(s, 4); t->policy = calloc(s, 4); t->q = calloc(s, 4); t->visits = calloc(s, 4);
+    t->Achild = calloc(s, sizeof(int)); t->childID = calloc((size_t)V * V * Lmax, sizeof(int));
+    t->childnbr = calloc(n, sizeof(int));
+    t->policy_final = calloc((size_t)g->A * Lmax, 4); t->batch = calloc((size_t)2 * g->VS * Lmax, 4);
+    t->parent = malloc(n * sizeof(int)); t->actionFromParent = calloc(n, sizeof(int));
+    for (size_t i = 0; i < n; ++i) t->parent[i] = -1;                     /* :48 zeros == "no parent" */
+    t->state = calloc(n, sizeof(agzo_pos));
+    t->expanded = calloc(n, 1); t->uptodate = malloc(n); memset(t->uptodate, 1, n); /* :51 */
+    t->leaf = calloc(Lmax, sizeof(int)); t->newindex = malloc(Lmax * sizeof(int));
+    for (int i = 0; i < Lmax; ++i) t->newindex[i] = 1;
+    t->game_id = calloc(Lmax, sizeof(uint32_t));
+    t->prior_tmp = calloc((size_t)g->A * Lmax, 4); t->v_tmp = calloc(Lmax, 4);
+    return t;
+}
+void agzo_tree_destroy(agzo_tree *t) {
+    if (!t) return;
+    free(t->prior); free(t->policy); free(t->q); free(t->visits); free(t->Achild); free(t->childID);
+    free(t->childnbr); free(t->policy_final); free(t->batch); free(t->parent); free(t->actionFromParent);
+    free(t->state); free(t->expanded); free(t->uptodate); free(t->leaf); free(t->newindex);
+    free(t->game_id); free(t->prior_tmp); free(t->v_tmp); free(t);
+}
+void agzo_tree_set_roots(agzo_tree *t, const agzo_pos *positions, const uint32_t *game_ids, int L) { /* :359-373 */
+    t->L = L;
+    for (int i = 0; i < L; ++i) {
+        t->state[ND(t, 0, i)] = positions[i];
+        t->game_id[i] = game_ids ? game_ids[i] : (uint32_t)i;
+    }
+    memset(t->expanded, 0, (size_t)t->V * t->Lmax);
+    memset(t->uptodate, 1, (size_t)t->V * t->Lmax);
+}
+void agzo_search_reset(agzo_tree *t) {                                    /* :380-387 */
+    size_t s = (size_t)t->g.A * t->V * t->Lmax;
+    memset(t->q, 0, s * 4); memset(t->Achild, 0, s * sizeof(int));
+    memset(t->childID, 0, (size_t)t->V * t->V * t->Lmax * sizeof(int));
+    memset(t->visits, 0, s * 4); memset(t->prior, 0, s * 4); memset(t->policy, 0, s * 4);
+    memset(t->childnbr, 0, (size_t)t->V * t->Lmax * sizeof(int));
+    for (int i = 0; i < t->Lmax; ++i) t->newindex[i] = 1;
+}
+
+void agzo_select(agzo_tree *t, uint64_t seed, uint32_t step, uint32_t rollout, float cpuct) { /* kdescendTree! :100-199 */
+    const int A_ = t->g.A;
+    for (int i = 0; i < t->L; ++i) {
+        int nindex = 0, cpt = 0;
+        while (t->expanded[ND(t, nindex, i)] == 1) {
+            int bestmove = -1;
+            float pr = 0.0f;
+            t->sum_p++;
+            if (t->uptodate[ND(t, nindex, i)] != 1) {                     /* :114 */
+                float A = 0.0f, n = 1.0f, prior_rem = 0.0f;
+                int childnbr = t->childnbr[ND(t, nindex, i)];
+                for (int k = 0; k < A_; ++k) {                            /* :120-131 */
+                    n += t->visits[ST(t, k, nindex, i)];
+                    if (t->Achild[ST(t, k, nindex, i)] == 0) prior_rem += t->prior[ST(t, k, nindex, i)];
+                    if (t->prior[ST(t, k, nindex, i)] > 0) A += 1.0f;
+                }
+                float lambda = cpuct * sqrtf(n) / (A + n);                /* :132 */
+                float alpha = 0.0f;
+                prior_rem *= lambda;
+                for (int k = 0; k < A_; ++k) {                            /* :135-138 */
+                    float lp = lambda * t->prior[ST(t, k, nindex, i)];
+                    float gap = lp > 1e-4f ? lp : 1e-4f;
+                    float cand = t->q[ST(t, k, nindex, i)] + gap;
+                    alpha = cand > alpha ? cand : alpha;
+                }
+                float err = INFINITY, newerr = INFINITY;
+                for (int j = 0; j < 100; ++j) {                           /* :141-162 */
+                    float S = prior_rem / alpha;
+                    float g = -prior_rem / (alpha * alpha);
+                    for (int k = 0; k < childnbr; ++k) {
+                        int CID = t->childID[CI(t, k, nindex, i)];
+                        int action = t->actionFromParent[ND(t, CID, i)];
+                        float top = lambda * t->prior[ST(t, action, nindex, i)];
+                        float bot = alpha - t->q[ST(t, action, nindex, i)];
+                        S += top / bot;
+                        g += -top / (bot * bot);
+                    }
+                    newerr = S - 1.0f;
+                    if (newerr < 0.001f || newerr == err) break;
+                    alpha -= newerr / g;
+                    err = newerr;
+                }
+                for (int k = 0; k < A_; ++k)                              /* :165-169 */
+                    t->policy[ST(t, k, nindex, i)] =
+                        lambda * t->prior[ST(t, k, nindex, i)] / (alpha - t->q[ST(t, k, nindex, i)]);
+            }
+            float u = agzo_uniform_search(seed, t->game_id[i], step, rollout, (uint32_t)cpt);
+            for (int k = 0; k < A_; ++k) {                                /* :172-182 */
+                float d = t->policy[ST(t, k, nindex, i)];
+                pr += d;
+                if (d > 0) bestmove = k;
+                if (pr >= u) break;
+            }
+            if (bestmove < 0) { t->faults++; break; }                     /* reference would index [-1] */
+            if (t->Achild[ST(t, bestmove, nindex, i)] == 0) {             /* :183-191 */
+                int nn = t->newindex[i];                                  /* new node id (0-based) */
+                t->newindex[i] += 1;
+                t->childnbr[ND(t, nindex, i)] += 1;
+                int slot = t->childnbr[ND(t, nindex, i)];
+                t->childID[CI(t, slot - 1, nindex, i)] = nn;
+                t->Achild[ST(t, bestmove, nindex, i)] = slot;
+                t->parent[ND(t, nn, i)] = nindex;
+                t->actionFromParent[ND(t, nn, i)] = bestmove;
+                agzo_play(&t->g, &t->state[ND(t, nindex, i)], bestmove, &t->state[ND(t, nn, i)]);
+                t->sum_new++;
+            }
+            nindex = t->childID[CI(t, t->Achild[ST(t, bestmove, nindex, i)] - 1, nindex, i)]; /* :192 */
+            cpt += 1;
+        }
+        t->leaf[i] = nindex;
+    }
+}
+
+void agzo_encode_leaves(agzo_tree *t, float *batch) {                     /* decoder :202-223, out [L][2VS] */
+    for (int i = 0; i < t->L; ++i)
+        agzo_encode(&t->g, &t->state[ND(t, t->leaf[i], i)], batch + (size_t)i * 2 * t->g.VS);
+}
+
+void agzo_expand(agzo_tree *t, const float *prior, int training) {        /* expand :250-302; prior [L][A] */
+    const int A_ = t->g.A;
+    for (int i = 0; i < t->L; ++i) {
+        int nindex = t->leaf[i], r;
+        const agzo_pos *st = &t->state[ND(t, nindex, i)];
+        int f = agzo_is_over(&t->g, st, &r);
+        t->expanded[ND(t, nindex, i)] = (int8_t)(1 - f);                  /* :256 */
+        const float *pin = prior + (size_t)i * A_;
+        if (!f) {
+            float normalize = 0.0f;
+            if (nindex == 0) {                                            /* :259-280 */
+                float A = 0.0f;
+                for (int j = 0; j < A_; ++j)
+                    if (agzo_can_play(&t->g, st, j)) {
+                        t->prior[ST(t, j, nindex, i)] = pin[j];
+                        normalize += t->prior[ST(t, j, nindex, i)];
+                        A += 1.0f;
+                    }
+                if (training) {
+                    for (int j = 0; j < A_; ++j)
+                        if (agzo_can_play(&t->g, st, j))
+                            t->prior[ST(t, j, nindex, i)] =
+                                0.75f * t->prior[ST(t, j, nindex, i)] / normalize + 0.25f / A;
+                } else {
+                    for (int j = 0; j < A_; ++j) t->prior[ST(t, j, nindex, i)] /= normalize;
+                }
+            } else {                                                      /* :283-294 */
+                for (int j = 0; j < A_; ++j)
+                    if (agzo_can_play(&t->g, st, j)) {
+                        t->prior[ST(t, j, nindex, i)] = pin[j];
+                        normalize += t->prior[ST(t, j, nindex, i)];
+                    }
+                for (int j = 0; j < A_; ++j) t->prior[ST(t, j, nindex, i)] /= normalize;
+            }
+        }
+        for (int k = 0; k < A_; ++k)                                      /* :297-299 */
+            t->policy[ST(t, k, nindex, i)] = t->prior[ST(t, k, nindex, i)];
+    }
+}
+
+void agzo_backup(agzo_tree *t, const float *v) {                          /* backUp :306-328 */
+    for (int i = 0; i < t->L; ++i) {
+        int lf = t->leaf[i], r;
+        int nindex = t->parent[ND(t, lf, i)];
+        int move = t->actionFromParent[ND(t, lf, i)];
+        const agzo_pos *st = &t->state[ND(t, lf, i)];
+        int f = agzo_is_over(&t->g, st, &r);
+        /* value is Float64 for a terminal leaf (Int8*Int8 -> 1+Int -> /2, :314) and Float32 otherwise (:316);
+         * the type sticks while climbing (:319, :324). */
+        if (f) {
+            double value = (double)(1 + (int8_t)(st->player * r)) / 2.0;
+            while (nindex != -1) {
+                size_t e = ST(t, move, nindex, i);
+                float vq = t->visits[e] * t->q[e];                        /* f32 * f32 */
+                t->q[e] = (float)(((double)vq + (1.0 - value)) / (double)(t->visits[e] + 1.0f));
+                t->visits[e] += 1.0f;
+                t->uptodate[ND(t, nindex, i)] = 0;
+                move = t->actionFromParent[ND(t, nindex, i)];
+                nindex = t->parent[ND(t, nindex, i)];
+                value = 1.0 - value;
+            }
+        } else {
+            float value = v[i];
+            while (nindex != -1) {
+                size_t e = ST(t, move, nindex, i);
+                t->q[e] = (t->visits[e] * t->q[e] + (1.0f - value)) / (t->visits[e] + 1.0f);
+                t->visits[e] += 1.0f;
+                t->uptodate[ND(t, nindex, i)] = 0;
+                move = t->actionFromParent[ND(t, nindex, i)];
+                nindex = t->parent[ND(t, nindex, i)];
+                value = 1.0f - value;
+            }
+        }
+    }
+}
+
+void agzo_search(agzo_tree *t, const agzo_net *net, int V, float cpuct, int training,
+                 uint64_t seed, uint32_t step,
+                 const float *prior_inject, const float *v_inject,
+                 float *prior_capture, float *v_capture) {                /* mcts_single :376-462 */
+    const int A_ = t->g.A, L = t->L, IN = 2 * t->g.VS;
+    agzo_search_reset(t);
+    for (int k = 0; k < V; ++k) {
+        agzo_select(t, seed, step, (uint32_t)k, cpuct);
+        agzo_encode_leaves(t, t->batch);
+        const float *pr, *vv;
+        if (prior_inject) {
+            pr = prior_inject + (size_t)k * L * A_; vv = v_inject + (size_t)k * L;
+        } else {
+            for (int i = 0; i < L; ++i) {
+                agzo_forward(net, t->batch + (size_t)i * IN, t->prior_tmp + (size_t)i * A_, &t->v_tmp[i]);
+                agzo_softmax(t->prior_tmp + (size_t)i * A_, A_);
+            }
+            pr = t->prior_tmp; vv = t->v_tmp;
+        }
+        if (prior_capture) memcpy(prior_capture + (size_t)k * L * A_, pr, (size_t)L * A_ * 4);
+        if (v_capture) memcpy(v_capture + (size_t)k * L, vv, (size_t)L * 4);
+        agzo_expand(t, pr, training);
+        agzo_backup(t, vv);
+    }
+    for (int i = 0; i < L; ++i) {                                         /* decoder_roots :441, copy_pol :443 */
+        agzo_encode(&t->g, &t->state[ND(t, 0, i)], t->batch + (size_t)i * IN);
+        for (int k = 0; k < A_; ++k) t->policy_final[(size_t)k + (size_t)A_ * i] = t->policy[ST(t, k, 0, i)];
+    }
+}
+
+void agzo_get_policy(const agzo_tree *t, float *out) { memcpy(out, t->policy_final, (size_t)t->g.A * t->L * 4); }
+void agzo_get_root_planes(const agzo_tree *t, float *out) { memcpy(out, t->batch, (size_t)2 * t->g.VS * t->L * 4); }
+void agzo_get_root_visits(const agzo_tree *t, float *out) {
+    for (int i = 0; i < t->L; ++i) for (int k = 0; k < t->g.A; ++k) out[(size_t)i * t->g.A + k] = t->visits[ST(t, k, 0, i)];
+}
+void agzo_get_root_q(const agzo_tree *t, float *out) {
+    for (int i = 0; i < t->L; ++i) for (int k = 0; k < t->g.A; ++k) out[(size_t)i * t->g.A + k] = t->q[ST(t, k, 0, i)];
+}
+void agzo_get_root_policy_row(const agzo_tree *t, float *out) {
+    for (int i = 0; i < t->L; ++i) for (int k = 0; k < t->g.A; ++k) out[(size_t)i * t->g.A + k] = t->policy[ST(t, k, 0, i)];
+}
+void agzo_get_leaf(const agzo_tree *t, int *out) { memcpy(out, t->leaf, (size_t)t->L * sizeof(int)); }
+void agzo_get_newindex(const agzo_tree *t, int *out) { memcpy(out, t->newindex, (size_t)t->L * sizeof(int)); }
+long agzo_get_counters(const agzo_tree *t, long *sum_p, long *sum_new) {
+    if (sum_p) *sum_p = t->sum_p;
+    if (sum_new) *sum_new = t->sum_new;
+    return t->faults;
+}
+
+/* ============================================================================================
+ * Self-play — mcts_gpu.jl:477-579, PoolSample mainGobang.jl:34-82
+ * ========================================================================================== */
+agzo_samples *agzo_samples_create(const agzo_game *g, long capacity) {
+    agzo_samples *s = (agzo_samples *)calloc(1, sizeof(*s));
+    s->capacity = capacity; s->A = g->A; s->VS = g->VS; s->FS = g->FS;
+    s->state = calloc((size_t)capacity * 2 * g->VS, 1); s->policy = calloc((size_t)capacity * g->A, 4);
+    s->player = calloc(capacity, 1); s->value = calloc(capacity, 4); s->fstate = calloc((size_t)capacity * g->FS, 1);
+    s->game_id = calloc(capacity, 4); s->ply = calloc(capacity, 4); s->move = calloc(capacity, 4);
+    return s;
+}
+void agzo_samples_destroy(agzo_samples *s) {
+    if (!s) return;
+    free(s->state); free(s->policy); free(s->player); free(s->value); free(s->fstate);
+    free(s->game_id); free(s->ply); free(s->move); free(s);
+}
+
+/* move rule mcts_gpu.jl:518-524; sample() restated as StatsBase's cumulative walk with our uniform */
+static int choose_move(const float *pol, int A, int sample, float u) {
+    if (sample) {
+        float total = 0.0f;
+        int n = 0, last = -1;
+        for (int c = 0; c < A; ++c) if (pol[c] != 0) { total += pol[c]; n++; last = c; }
+        if (n == 0) return -1;
+        float tt = u * total, cw = 0.0f;
+        int first = 1;
+        for (int c = 0; c < A; ++c) {
+            if (pol[c] == 0) continue;
+            if (first) { cw = pol[c]; first = 0; } else cw += pol[c];
+            if (!(cw < tt) || c == last) return c;
+        }
+        return last;
+    }
+    int best = 0;
+    for (int c = 1; c < A; ++c) if (pol[c] > pol[best]) best = c;
+    return best;
+}
+
+int agzo_selfplay(const agzo_game *g, const agzo_net *net, int ngames, int V, float cpuct,
+                  int tau_plies, uint64_t seed, uint32_t game_id_base, agzo_samples *out) {
+    agzo_tree *t = agzo_tree_create(g, ngames, V);
+    agzo_pos *positions = malloc((size_t)ngames * sizeof(agzo_pos));
+    uint32_t *ids = malloc((size_t)ngames * 4);
+    long **rtemp = malloc((size_t)ngames * sizeof(long *));               /* sample indices per game :482 */
+    int *rlen = calloc(ngames, sizeof(int));
+    int cap_plies = 2 * g->len + 8;
+    for (int k = 0; k < ngames; ++k) {
+        agzo_pos_init(g, &positions[k]); ids[k] = game_id_base + (uint32_t)k;
+        rtemp[k] = malloc((size_t)cap_plies * sizeof(long));
+    }
+    float *policy = malloc((size_t)ngames * g->A * 4), *batch = malloc((size_t)ngames * 2 * g->VS * 4);
+    int L = ngames, round = 0, rc = 0;
+    agzo_tree_set_roots(t, positions, ids, L);
+    out->nsamples = 0; out->wins = out->draws = out->losses = out->total_plies = out->faults = 0;
+    while (L > 0) {                                                       /* :494 */
+        agzo_search(t, net, V, cpuct, 1, seed, (uint32_t)round, NULL, NULL, NULL, NULL); /* :503 */
+        agzo_get_policy(t, policy); agzo_get_root_planes(t, batch);       /* :506 */
+        int nfin = 0;
+        for (int i = 0; i < L; ++i) {                                     /* :513-549 */
+            long idx = out->nsamples;                                     /* push_buffer mainGobang.jl:54-68 */
+            if (idx >= out->capacity) { rc = -2; goto done; }
+            out->nsamples++;
+            for (int j = 0; j < 2 * g->VS; ++j) out->state[(size_t)idx * 2 * g->VS + j] = (int8_t)batch[(size_t)i * 2 * g->VS + j];
+            memcpy(out->policy + (size_t)idx * g->A, policy + (size_t)i * g->A, (size_t)g->A * 4);
+            out->player[idx] = positions[i].player;
+            out->game_id[idx] = ids[i]; out->ply[idx] = round;
+            rtemp[i][rlen[i]++] = idx;
+            const float *pol = out->policy + (size_t)idx * g->A;
+            int c = choose_move(pol, g->A, round < tau_plies, agzo_uniform_move(seed, ids[i], (uint32_t)round));
+            out->move[idx] = c;
+            if (c < 0 || !agzo_can_play(g, &positions[i], c)) { out->faults++; rc = -1; goto done; } /* "faute" :526-529 */
+            agzo_pos np; agzo_play(g, &positions[i], c, &np); positions[i] = np;
+            int res, f = agzo_is_over(g, &positions[i], &res);
+            if (f) {
+                out->total_plies += round;
+                for (int k = 0; k < rlen[i]; ++k) {                       /* update_buffer mainGobang.jl:70-80 */
+                    long id = rtemp[i][k];
+                    int player = out->player[id];
+                    out->value[id] = (float)((1 + res * player) / 2.0);
+                    for (int j = 0; j < g->VS; ++j) {                     /* decode :464-474 */
+                        int fs = bb_get(positions[i].bplayer, j) ? positions[i].player : -positions[i].player;
+                        out->fstate[(size_t)id * g->FS + j] = (int8_t)(fs * player);
+                    }
+                }
+                if (res == 1) out->wins++; else if (res == 0) out->draws++; else out->losses++;
+                rlen[i] = -1;                                             /* mark finished */
+                nfin++;
+            }
+        }
+        int w = 0;                                                        /* compaction :550-553 */
+        for (int i = 0; i < L; ++i) {
+            if (rlen[i] < 0) { free(rtemp[i]); continue; }
+            positions[w] = positions[i]; ids[w] = ids[i]; rtemp[w] = rtemp[i]; rlen[w] = rlen[i]; ++w;
+        }
+        L = w; round += 1;
+        if (L > 0) agzo_tree_set_roots(t, positions, ids, L);             /* re_init :557-561 */
+    }
+done:
+    if (rc != 0) for (int i = 0; i < L; ++i) if (rlen[i] >= 0) free(rtemp[i]);
+    free(rtemp); free(rlen); free(policy); free(batch); free(positions); free(ids);
+    agzo_tree_destroy(t);
+    return rc;
+}
+
+/* ============================================================================================
+ * CPU baseline — fast_mcts.jl (FMCTS).  Timing baseline only (cpu_baseline.kind = "port");
+ * its semantics differ from the GPU path and it is NOT the parity oracle.
+ * Julia's promotions (Float64 λ/α because sqrt(::Int)) are kept.
+ * ========================================================================================== */
+typedef struct fnode {
+    struct fnode *parent; int actionFromParent; agzo_pos state; int expanded; int visits;
+    float *w, *n, *prior; struct fnode **child;
+} fnode;
+static fnode *fnode_new(const agzo_game *g, fnode *parent, int afp, const agzo_pos *st) { /* nodeInit :72-75 */
+    fnode *x = calloc(1, sizeof(*x));
+    x->parent = parent; x->actionFromParent = afp; x->state = *st;
+    x->w = calloc(g->A, 4); x->n = calloc(g->A, 4); x->prior = calloc(g->A, 4);
+    x->child = calloc(g->A, sizeof(fnode *));
+    return x;
+}
+static void fnode_free(const agzo_game *g, fnode *x) {
+    if (!x) return;
+    for (int a = 0; a < g->A; ++a) fnode_free(g, x->child[a]);
+    free(x->w); free(x->n); free(x->prior); free(x->child); free(x);
+}
+static int f_action_number(const agzo_game *g, const agzo_pos *p) {      /* :32-40 */
+    int A = 0; for (int k = 0; k < g->A; ++k) if (agzo_can_play(g, p, k)) A++; return A;
+}
+static double f_newton(const agzo_game *g, const fnode *x, double lambda) { /* :42-70 */
+    double alpha = 0.0;
+    for (int k = 0; k < g->A; ++k) {
+        double gap = lambda * x->prior[k]; if (!(gap > 1e-4f)) gap = 1e-4f;
+        double c = x->n[k] == 0 ? gap : (double)(x->w[k] / x->n[k]) + gap;
+        if (c > alpha) alpha = c;
+    }
+    double err = INFINITY, newerr = INFINITY;
+    for (int j = 0; j < 100; ++j) {
+        double S = 0, gg = 0;
+        for (int k = 0; k < g->A; ++k) {
+            double top = lambda * x->prior[k];
+            double bot = x->n[k] == 0 ? alpha : alpha - (double)(x->w[k] / x->n[k]);
+            S += top / bot; gg += -top / (bot * bot);
+        }
+        newerr = S - 1.0;
+        if (newerr < 0.001f || newerr == err) break;
+        alpha -= newerr / gg; err = newerr;
+    }
+    return alpha;
+}
+static void f_policy(const agzo_game *g, const fnode *x, float c, double *pi) { /* bestChild :215-218, extractRoot :299-306 */
+    double lambda = (double)c * sqrt((double)x->visits) / (double)(f_action_number(g, &x->state) + x->visits);
+    double alpha = f_newton(g, x, lambda);
+    for (int k = 0; k < g->A; ++k)
+        pi[k] = x->n[k] == 0 ? lambda * x->prior[k] / alpha : lambda * x->prior[k] / (alpha - (double)(x->w[k] / x->n[k]));
+}
+static int f_sample(const double *pi, int A, double u) {                  /* sample(1:A, Weights(π)) :219 */
+    double total = 0; for (int k = 0; k < A; ++k) total += pi[k];
+    double tt = u * total, cw = pi[0]; int i = 0;
+    while (cw < tt && i < A - 1) { ++i; cw += pi[i]; }
+    return i;
+}
+void agzo_fmcts(const agzo_game *g, const agzo_net *net, const agzo_pos *pos, int readout, float c,
+                uint64_t seed, uint32_t game_id, float *policy_out, float *value_out) { /* MctsContext :275-295 */
+    fnode *root = fnode_new(g, NULL, -1, pos);
+    double *pi = malloc((size_t)g->A * sizeof(double));
+    float *planes = malloc((size_t)2 * g->VS * 4), *p = malloc((size_t)g->A * 4);
+    uint32_t draw = 0;
+    for (int cpt = 0; cpt < readout; ++cpt) {
+        fnode *cur = root;                                                /* descendTree :78-95 */
+        while (cur->expanded) {
+            cur->visits += 1;
+            f_policy(g, cur, c, pi);
+            int best = f_sample(pi, g->A, (double)agzo_uniform_move(seed ^ 0xF00DULL, game_id, draw++));
+            cur->n[best] += 1;
+            if (!cur->child[best]) {                                      /* maybeAddChild :232-243 */
+                agzo_pos ns; agzo_play(g, &cur->state, best, &ns);
+                cur->child[best] = fnode_new(g, cur, best, &ns);
+            }
+            cur = cur->child[best];
+        }
+        cur->visits += 1;
+        int r, f = agzo_is_over(g, &cur->state, &r);                      /* evaluate :141-157 */
+        float v;
+        if (f) v = (float)((1 + r * cur->state.player) / 2.0);            /* :282 Float32(v) */
+        else {
+            agzo_encode(g, &cur->state, planes);
+            agzo_forward(net, planes, p, &v);
+            agzo_softmax(p, g->A);                                        /* DenseNet.jl:313 */
+            cur->expanded = 1;                                            /* expand :97-109 */
+            float normalize = 0;
+            for (int j = 0; j < g->A; ++j) if (agzo_can_play(g, &cur->state, j)) { cur->prior[j] = p[j]; normalize += p[j]; }
+            for (int j = 0; j < g->A; ++j) cur->prior[j] /= normalize;
+        }
+        fnode *up = cur->parent; int move = cur->actionFromParent;       /* backUp :160-172 */
+        while (up) { up->w[move] += (1 - v); move = up->actionFromParent; up = up->parent; v = 1 - v; }
+    }
+    if (root->visits > 0 && root->expanded) {                             /* extractRoot :299-308 */
+        f_policy(g, root, c, pi);
+        double sw = 0; for (int k = 0; k < g->A; ++k) { policy_out[k] = (float)pi[k]; sw += root->w[k]; }
+        *value_out = (float)(sw / root->visits);
+    } else { for (int k = 0; k < g->A; ++k) policy_out[k] = 0; *value_out = 0; }
+    free(pi); free(planes); free(p); fnode_free(g, root);
+}
+
+long agzo_fmcts_selfplay(const agzo_game *g, const agzo_net *net, int ngames, int readout, float c,
+                         int tau_plies, uint64_t seed, int threads, int max_plies) {
+    long total = 0;
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#endif
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : total)
+    for (int gi = 0; gi < ngames; ++gi) {
+        agzo_pos pos; agzo_pos_init(g, &pos);
+        float *pol = malloc((size_t)g->A * 4), val;
+        for (int ply = 0; max_plies <= 0 || ply < max_plies; ++ply) {
+            int r; if (agzo_is_over(g, &pos, &r)) break;
+            agzo_fmcts(g, net, &pos, readout, c, seed, (uint32_t)gi * 1024u + (uint32_t)ply, pol, &val);
+            total += readout;
+            int mv = choose_move(pol, g->A, ply < tau_plies, agzo_uniform_move(seed, (uint32_t)gi, (uint32_t)ply));
+            if (mv < 0 || !agzo_can_play(g, &pos, mv)) {                  /* fall back to first legal move */
+                mv = -1; for (int k = 0; k < g->A; ++k) if (agzo_can_play(g, &pos, k)) { mv = k; break; }
+                if (mv < 0) break;
+            }
+            agzo_pos np; agzo_play(g, &pos, mv, &np); pos = np;
+        }
+        free(pol);
+    }
+    return total;
+}
