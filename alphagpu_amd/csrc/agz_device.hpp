@@ -109,6 +109,7 @@ struct TreePar {
     float cpuct;
     int32_t training;
     int32_t do_reset, do_expand, do_select, last, exact, inject, capture;
+    unsigned long long* dbg;      // diagnostic builds (-DAGZ_STAMPS): per-phase cycle sums; unused otherwise
 };
 
 // ---------------------------------------------------------------------------------------------------

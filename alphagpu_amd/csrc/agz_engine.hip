@@ -16,6 +16,7 @@
 #include "agz_games.hpp"
 #include "agz_device.hpp"
 #include "agz_tree.hpp"
+#include "agz_tree_grp.hpp"
 #include "agz_nn.hpp"
 #include "agz_nn_fused.hpp"
 #include "agz_selfplay.hpp"
@@ -80,6 +81,7 @@ struct agz_engine {
     size_t ev_tree_used = 0, ev_nn_used = 0;
     double tree_ms = 0, nn_ms = 0; int64_t tree_launches = 0;
     rollout_fn k_roll = nullptr; advance_fn k_adv = nullptr; softmax_fn k_soft = nullptr;
+    rollout_fn k_lpg = nullptr; size_t lpg_lds = 0; int grp_g = 16;   // group kernel (agz_tree_grp.hpp): G lanes per tree; lpg_lds == 0 -> wave-per-tree kernel
 
     int fail(const char* fmt, ...) {
         char buf[512]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
@@ -106,6 +108,10 @@ static bool bind_kernels(agz_engine* h) {
     if (P.fam == F && P.NR == R && P.NC == C) { h->k_roll = pick_rollout<F, R, C>(h->NRV); h->k_adv = k_advance<F, R, C>; }
     AGZ_COMBOS(X)
 #undef X
+    { const char* eg = getenv("AGZ_TREE_G"); if (eg) h->grp_g = atoi(eg); if (h->grp_g != 4 && h->grp_g != 8) h->grp_g = 16; }
+#define Y(F, C) if (P.fam == F && P.NC == C) h->k_lpg = h->grp_g == 4 ? k_rollout_grp<F, C, 4> : (h->grp_g == 16 ? k_rollout_grp<F, C, 16> : k_rollout_grp<F, C, 8>);
+    Y(F_LINE, 1) Y(F_LINE, 2) Y(F_LINE, 3) Y(F_C4, 1) Y(F_HEX, 1) Y(F_HEX, 2) Y(F_HEX, 3) Y(F_REV, 1)
+#undef Y
     if (P.NR == 1) h->k_soft = k_softmax<1>; else if (P.NR == 2) h->k_soft = k_softmax<2>; else h->k_soft = k_softmax<3>;
     return h->k_roll != nullptr;
 }
@@ -197,8 +203,16 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     hipFuncSetAttribute((const void*)k_layer_exact<EX_VALUE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)k_mlp_fused2<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)k_mlp_fused2<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    const uint32_t A2 = (uint32_t)round_up(P.A, 2);
-    const uint32_t rec_bytes = (uint32_t)round_up((int)(A2 * 10), 64);
+    // node record: [prior f32 x A2][q f32 x A2][vc u16 x A2], A2 = A rounded up to 4 (16-B aligned sub-arrays);
+    // the record size is an ODD multiple of 16 B so that the LDS image of 64 records is bank-conflict free for
+    // per-lane 16-B reads (agz_tree_lpg.hpp)
+    const uint32_t A2 = (uint32_t)round_up(P.A, 4);
+    uint32_t rec_bytes = (uint32_t)round_up((int)(A2 * 10), 16);
+    if (((rec_bytes / 16) & 1u) == 0) rec_bytes += 16;
+    h->lpg_lds = (size_t)(64 / h->grp_g) * grp_lds_layout((int)rec_bytes, (int)A2, h->V).stride;
+    const char* tk = getenv("AGZ_TREE_KERNEL");
+    if (!h->k_lpg || h->lpg_lds > 64 * 1024 /* LDS-DMA destination offsets are 16 bit */ || (tk && !strcmp(tk, "v1"))) h->lpg_lds = 0;
+    if (h->lpg_lds) hipFuncSetAttribute((const void*)h->k_lpg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lpg_lds);
     const size_t Lm = (size_t)h->Lmax, V = (size_t)h->V;
     h->INP = round_up(2 * P.VS, 32);
     h->LGS = round_up(P.A + 1, 32);
@@ -212,7 +226,7 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     if (cfg->nn_mode == AGZ_NN_BF16) { uint16_t* p = nullptr; A_(dmalloc(&p, Lm * h->INP)); h->planes = p; }
     else { float* p = nullptr; A_(dmalloc(&p, Lm * h->INP)); h->planes = p; }
     A_(dmalloc(&h->logits, Lm * h->LGS));
-    A_(dmalloc(&h->prior_eval, Lm * P.A)); A_(dmalloc(&h->v_eval, Lm)); A_(dmalloc(&h->policy_final, Lm * P.A));
+    A_(dmalloc(&h->prior_eval, Lm * P.A + 64)); A_(dmalloc(&h->v_eval, Lm)); A_(dmalloc(&h->policy_final, Lm * P.A));
     A_(dmalloc(&h->newpos, Lm)); A_(dmalloc(&h->alive, Lm)); A_(dmalloc(&h->newslot, Lm)); A_(dmalloc(&h->d_count, 4));
     A_(dmalloc(&h->d_stats, 8));
     A_(dmalloc(&h->scratch_f, Lm * (size_t)((P.A > 2 * P.VS) ? P.A : 2 * P.VS)));
@@ -237,6 +251,9 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     T.cnt_p = h->cnt_p; T.cnt_new = h->cnt_new; T.planes = h->planes; T.INP = h->INP; T.planes_f32 = cfg->nn_mode == AGZ_NN_EXACT;
     T.logits = h->logits; T.LGS = h->LGS; T.prior_eval = h->prior_eval; T.v_eval = h->v_eval; T.policy_final = h->policy_final;
     T.seed = cfg->seed; T.exact = cfg->nn_mode == AGZ_NN_EXACT;
+#ifdef AGZ_STAMPS
+    { unsigned long long* d = nullptr; hipMalloc((void**)&d, (size_t)65536 * 16 * 8); hipMemset(d, 0, (size_t)65536 * 16 * 8); T.dbg = d; }
+#endif
     if (hipStreamSynchronize(h->stream) != hipSuccess) { h->fail("device init failed"); return bail(AGZ_ERR_HIP); }
     *out = h;
     return AGZ_OK;
@@ -247,6 +264,17 @@ int agz_get_info(const agz_engine* h, agz_game_info* out) {
     *out = h->info; return AGZ_OK;
 }
 void* agz_stream(agz_engine* h) { return h ? (void*)h->stream : nullptr; }
+#ifdef AGZ_STAMPS
+extern "C" int agz_debug_stamps(agz_engine* h, unsigned long long* out, int reset) {
+    hipStreamSynchronize(h->stream);
+    std::vector<unsigned long long> all((size_t)65536 * 16);
+    hipMemcpy(all.data(), h->tp.dbg, all.size() * 8, hipMemcpyDeviceToHost);
+    for (int i = 0; i < 16; ++i) out[i] = 0;
+    for (size_t b = 0; b < 65536; ++b) for (int i = 0; i < 16; ++i) out[i] += all[b * 16 + i];
+    if (reset) hipMemset(h->tp.dbg, 0, all.size() * 8);
+    return 0;
+}
+#endif
 int agz_synchronize(agz_engine* h) {
     if (!h) return AGZ_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device));
@@ -394,10 +422,12 @@ static int launch_rollout(agz_engine* h, uint32_t rollout, int do_reset, int do_
     TreePar T = h->tp;
     T.L = h->L; T.step = h->step; T.rollout = rollout; T.cpuct = h->cpuct; T.training = h->training;
     T.do_reset = do_reset; T.do_expand = do_expand; T.do_select = do_select; T.last = last; T.inject = inject; T.capture = capture;
-    dim3 grid((unsigned)((h->L + 3) / 4)), block(256);
+    const bool lpg = h->lpg_lds != 0;
+    const int ng = 64 / h->grp_g;
+    dim3 grid((unsigned)(lpg ? (h->L + ng - 1) / ng : (h->L + 3) / 4)), block(lpg ? 64 : 256);
     std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
     if (h->profiling) { ev = next_events(h, h->ev_tree, h->ev_tree_used); hipEventRecord(ev->first, h->stream); }
-    hipLaunchKernelGGL(h->k_roll, grid, block, 0, h->stream, T);
+    hipLaunchKernelGGL(lpg ? h->k_lpg : h->k_roll, grid, block, lpg ? h->lpg_lds : 0, h->stream, T);
     if (ev) hipEventRecord(ev->second, h->stream);
     h->cnt_live = true;
     HIPCHK(h, hipGetLastError());

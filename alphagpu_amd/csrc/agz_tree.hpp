@@ -56,25 +56,17 @@ template <int NR> __device__ __forceinline__ void softmax_row(float (&x)[NR], in
     float m = -__builtin_inff();
     for (int r = 0; r < NR; ++r) { int k = 64 * r + lane; m = (k < A && x[r] > m) ? x[r] : m; }
     m = ufirst(wave_max(m));
-    float s;
-    if (exact) {
-        float carry = 0.0f; bool st = false;
-        for (int r = 0; r < NR; ++r) {
-            int k = 64 * r + lane;
-            x[r] = k < A ? exp_spec(x[r] - m) : 0.0f;
-            int nr = A - 64 * r; uint64_t full = nr >= 64 ? ~0ull : ((1ull << nr) - 1ull);
-            (void)chain64(x[r], full, carry, false, 0.0f, st);
-        }
-        s = carry;
-    } else {
-        float part = 0.0f;
-        for (int r = 0; r < NR; ++r) {
-            int k = 64 * r + lane;
-            x[r] = k < A ? __expf(x[r] - m) : 0.0f;
-            part += x[r];
-        }
-        s = ufirst(wave_sum_f(part));
+    // the sum is taken in source order in both modes (the lane-per-tree kernel sums sequentially anyway);
+    // the modes differ only in the exponential: exp_spec (bit-identical to the oracle) or the hardware v_exp_f32.
+    float carry = 0.0f; bool st = false;
+    for (int r = 0; r < NR; ++r) {
+        int k = 64 * r + lane;
+        float e = exact ? exp_spec(x[r] - m) : __expf(x[r] - m);
+        x[r] = k < A ? e : 0.0f;
+        int nr = A - 64 * r; uint64_t full = nr >= 64 ? ~0ull : ((1ull << nr) - 1ull);
+        (void)chain64(x[r], full, carry, false, 0.0f, st);
     }
+    const float s = carry;
     for (int r = 0; r < NR; ++r) x[r] = x[r] / s;
 }
 

@@ -1,0 +1,21 @@
+import sys, os, ctypes as C
+sys.path.insert(0, os.getcwd())
+import alphagpu_amd.lib as aglib
+aglib.LIB_PATH = os.path.join(os.getcwd(), 'scratch', 'libagz_dbg.so')
+import alphagpu_amd as ag
+from alphagpu_amd import mcts_gpu as M
+V, L = 64, 32768
+g = ag.GameSpec('gobang', 9, 5); net = ag.SNetwork2.random(g, 128, 6)
+e = M.Engine(g, L, V, seed=1, nn_mode=M.NN_BF16); e.set_network(net)
+e.set_roots(None, L=L); e.search(V, cpuct=1.5, training=True, step=0); e.synchronize()
+out = (C.c_ulonglong * 16)()
+e.L.agz_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+e.L.agz_debug_stamps(e.h, out, 1)
+e.set_roots(None, L=L); e.search(V, cpuct=1.5, training=True, step=0); e.synchronize()
+e.L.agz_debug_stamps(e.h, out, 1)
+names = ['meta stage', 'logits gather', 'expand compute', 'scatter', 'backup', 'fence', 'round: philox', 'round: gather', 'round: stats/prior_rem/alpha0', 'round: child scan', 'round: newton', 'round: policy', 'round: sampling', 'tail: create+planes', 'writeback', '-']
+tot = sum(out)
+G = int(os.environ.get('AGZ_TREE_G', '8')); waves = (L * G // 64) * 65
+for n, v in zip(names, out):
+    print(f"{n:32s} {v/waves:10.0f} cyc/wave  {100*v/tot:5.1f}%")
+print('total cyc/wave', tot / waves)
