@@ -1,0 +1,104 @@
+# AlphaGPUAMD.jl — `ccall` binding of libagz for the reference's Julia host code.
+#
+# Drop-in for `module mcts_gpu` (mcts_gpu.jl) on AMD MI355X: same entry points, same argument meaning.
+# NOT EXECUTED in this repository's CI (there is no Julia toolchain in the build image); it is the binding a
+# maintainer of fabricerosay/AlphaGPU would add.  See INTEGRATION.md.
+module mcts_gpu
+
+export mcts, duelnetwork, mcts_single, init, re_init
+
+using ..Game            # Position, canPlay, play, isOver, VectorizedState, FeatureSize, maxActions, maxLengthGame, PoolSample
+
+const libagz = get(ENV, "LIBAGZ", "libagz.so")
+
+struct AgzConfig
+    game::Int32; n::Int32; nvict::Int32; max_games::Int32; max_visits::Int32; device::Int32
+    seed::UInt64; game_id_base::UInt32; nn_mode::Int32; sample_capacity_games::Int32
+    reserved::NTuple{3,Int32}
+end
+struct AgzStats
+    nsamples::Int64; total_plies::Int64; wins::Int64; draws::Int64; losses::Int64; rollouts::Int64
+    plies::Int32; faults::Int32; search_seconds::Float64; total_seconds::Float64
+end
+
+mutable struct Engine
+    h::Ptr{Cvoid}
+    L::Int
+end
+check(e::Engine, rc) = rc == 0 ? nothing : error(unsafe_string(ccall((:agz_last_error, libagz), Cstring, (Ptr{Cvoid},), e.h)))
+
+# game ids: 0 Gobang, 1 Connect4, 2 Hex, 3 Reversi 8x8, 4 Reversi 6x6 — set by the main*.jl that includes the plugin
+function init(positions::Vector{Position}, visits; game::Integer, N::Integer=0, Nvict::Integer=0, device=0, seed=1, nn_mode=0)
+    cfg = Ref(AgzConfig(game, N, Nvict, length(positions), visits, device, seed, 0, nn_mode, 0, (0, 0, 0)))
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = ccall((:agz_create, libagz), Cint, (Ref{AgzConfig}, Ref{Ptr{Cvoid}}), cfg, h)
+    rc == 0 || error(unsafe_string(ccall((:agz_last_error, libagz), Cstring, (Ptr{Cvoid},), C_NULL)))
+    e = Engine(h[], 0)
+    finalizer(x -> ccall((:agz_destroy, libagz), Cvoid, (Ptr{Cvoid},), x.h), e)
+    re_init(positions, e)
+    e
+end
+init(L::Int, visits; kw...) = init([Position() for _ in 1:L], visits; kw...)
+
+# re_init(cu(positions), vnodes, L, ...) — the Vector{Position} memory image is passed as is (format 0 = Julia)
+function re_init(positions::Vector{Position}, e::Engine)
+    check(e, ccall((:agz_set_roots, libagz), Cint, (Ptr{Cvoid}, Ptr{Position}, Cint, Ptr{UInt32}, Cint),
+                   e.h, positions, 0, C_NULL, length(positions)))
+    e.L = length(positions)
+end
+
+# actor = convert_back(net)::snetwork2 (DenseNet.jl:331-333); weights are CPU Arrays in Flux (out,in) layout
+function set_network!(e::Engine, actor; slot=0)
+    res = isempty(actor.res) ? Float32[] : reduce(vcat, vec.(Array.(actor.res)))
+    H = size(actor.base, 1)
+    check(e, ccall((:agz_set_network_slot, libagz), Cint,
+                   (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}),
+                   e.h, slot, H, length(actor.res), Array(actor.base), res, Array(actor.policy), Array(actor.policy_bias),
+                   Array(actor.value), Array(actor.value_bias)))
+end
+
+function mcts_single(actor, visits, e::Engine; training=true, cpuct=2f0, step=0)
+    actor === nothing || set_network!(e, actor)
+    check(e, ccall((:agz_search, libagz), Cint, (Ptr{Cvoid}, Cint, Cfloat, Cint, UInt32), e.h, visits, cpuct, training, step))
+    policy = Matrix{Float32}(undef, maxActions, e.L); batch = Matrix{Float32}(undef, 2VectorizedState, e.L)
+    check(e, ccall((:agz_get_policy, libagz), Cint, (Ptr{Cvoid}, Ptr{Float32}), e.h, policy))
+    check(e, ccall((:agz_get_batch, libagz), Cint, (Ptr{Cvoid}, Ptr{Float32}), e.h, batch))
+    policy, batch                                  # == Array(vnodesStats.policy_final), Array(vnodesStats.batch)
+end
+
+function mcts(actor, visits, ngames, buffer::PoolSample; θ=1, cpuct=2.0, noise=Float32(1 / maxActions), game, N=0, Nvict=0)
+    e = init(ngames, visits; game=game, N=N, Nvict=Nvict)
+    set_network!(e, actor)
+    st = Ref{AgzStats}()
+    rc = ccall((:agz_selfplay, libagz), Cint, (Ptr{Cvoid}, Cint, Cint, Cfloat, Cint, Ref{AgzStats}), e.h, ngames, visits, cpuct, 25, st)
+    rc == -5 && return (data=[], valid=false)      # "faute"
+    check(e, rc)
+    n = st[].nsamples
+    state = Matrix{Int8}(undef, 2VectorizedState, n); policy = Matrix{Float32}(undef, maxActions, n)
+    player = Vector{Int8}(undef, n); value = Vector{Float32}(undef, n); fstate = Matrix{Int8}(undef, FeatureSize, n)
+    check(e, ccall((:agz_get_samples, libagz), Cint,
+                   (Ptr{Cvoid}, Ptr{Int8}, Ptr{Float32}, Ptr{Int8}, Ptr{Float32}, Ptr{Int8}, Ptr{UInt32}, Ptr{Int32}, Ptr{Int32}),
+                   e.h, state, policy, player, value, fstate, C_NULL, C_NULL, C_NULL))
+    for i in 1:n                                   # same order the reference pushes them (ply-major, slot order)
+        idx = Main.push_buffer(buffer, state, policy, player[i], i)
+        buffer.pool[idx].value = value[i]; buffer.pool[idx].fstate .= @view fstate[:, i]
+    end
+    println("victoires,nul,défaites", [st[].wins, st[].draws, st[].losses])
+    (data=[], valid=true)
+end
+
+function duelnetwork(actor1, actor2, visits, ngames, conv=2; game, N=0, Nvict=0)
+    half = div(ngames, 2)
+    function half_duel(a, b)
+        e = init(half, visits; game=game, N=N, Nvict=Nvict)
+        set_network!(e, a; slot=0); set_network!(e, b; slot=1)
+        wdl = zeros(Int64, 3)
+        check(e, ccall((:agz_duel, libagz), Cint, (Ptr{Cvoid}, Cint, Cint, Cfloat, Cint, Cint, Ptr{Int64}), e.h, half, visits, 2f0, 15, 0, wdl))
+        wdl
+    end
+    v1, n1, d1 = half_duel(actor1, actor2)
+    d2, n2, v2 = half_duel(actor2, actor1)
+    v1 + v2, n1 + n2, d1 + d2
+end
+
+end # module
