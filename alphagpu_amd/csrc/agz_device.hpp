@@ -21,11 +21,18 @@ AGZ_HD void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, ui
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
-// uniform in (0,1] standing for prob[cpt,i] (mcts_gpu.jl:178)
-AGZ_HD float uniform_search(uint64_t seed, uint32_t game, uint32_t step, uint32_t rollout, uint32_t depth) {
+// uniforms in (0,1] standing for prob[cpt,i] (mcts_gpu.jl:178): one Philox block serves four consecutive depths,
+// counter = (game, step, rollout, depth >> 2), word = depth & 3
+AGZ_HD void uniform_search4(uint64_t seed, uint32_t game, uint32_t step, uint32_t rollout, uint32_t dquad, float u[4]) {
     uint32_t o[4];
-    philox4x32_10(game, step, rollout, depth, (uint32_t)seed, (uint32_t)(seed >> 32), o);
-    return (float)((o[0] >> 8) + 1u) * 5.9604644775390625e-8f;
+    philox4x32_10(game, step, rollout, dquad, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+    for (int i = 0; i < 4; ++i) u[i] = (float)((o[i] >> 8) + 1u) * 5.9604644775390625e-8f;
+}
+AGZ_HD float uniform_search(uint64_t seed, uint32_t game, uint32_t step, uint32_t rollout, uint32_t depth) {
+    float u[4];
+    uniform_search4(seed, game, step, rollout, depth >> 2, u);
+    const uint32_t w = depth & 3u;
+    return w == 0 ? u[0] : (w == 1 ? u[1] : (w == 2 ? u[2] : u[3]));
 }
 // uniform in [0,1) standing for rand() inside StatsBase.sample (mcts_gpu.jl:520)
 AGZ_HD float uniform_move(uint64_t seed, uint32_t game, uint32_t step) {

@@ -42,19 +42,18 @@ template <int NC, bool REV> __device__ __forceinline__ WPos<NC> grp_load_pos(con
 }
 
 struct GrpLds {                     // byte offsets inside one game's LDS image
-    int row, pol, meta, ctop, cq, ct, cu, clist, stride;
+    int row, meta, cbuf, cu, clist, stride;
 };
 __host__ __device__ inline GrpLds grp_lds_layout(int rec_bytes, int A4, int V) {
     GrpLds o;
     auto up16 = [](int x) { return (x + 15) & ~15; };
-    o.row = 0;
-    o.pol = up16(rec_bytes);
-    o.meta = o.pol + up16(A4 * 4);
-    o.ctop = o.meta + up16((V + 1) * 4);
-    o.cq = o.ctop + up16(V * 4);
-    o.ct = o.cq + up16(V * 4);
-    o.cu = o.ct + up16(V * 4);
-    o.clist = o.cu + up16(V * 4);
+    o.row = 0;                                                  // node record: prior | q (later: policy) | vc
+    o.meta = up16(rec_bytes);
+    o.cbuf = o.meta + up16((V + 1) * 4);                        // masked priors [A4], then Newton terms ct[V+1]
+    const int cb = up16((V + 1) * 4);
+    o.cu = o.cbuf + cb;                                         //                                  and cu[V+1]
+    const int both = 2 * cb > up16(A4 * 4) ? 2 * cb : up16(A4 * 4);
+    o.clist = o.cbuf + both;                                    // child actions in creation order [V]
     o.stride = o.clist + up16(V);
     if (((o.stride / 16) & 1) == 0) o.stride += 16;
     return o;
@@ -147,12 +146,12 @@ __global__ __launch_bounds__(64, G >= 16 ? 4 : 2) void k_rollout_grp(const TreeP
     float* const rp = reinterpret_cast<float*>(mine + LO.row);
     float* const rq = reinterpret_cast<float*>(mine + LO.row + T.off_q);
     uint16_t* const rvc = reinterpret_cast<uint16_t*>(mine + LO.row + T.off_vc);
-    float* const pol = reinterpret_cast<float*>(mine + LO.pol);
+    float* const pol = rq;                                                   // the policy row overwrites q in place
     uint32_t* const mymeta = reinterpret_cast<uint32_t*>(mine + LO.meta);
-    float* const ctop = reinterpret_cast<float*>(mine + LO.ctop);
-    float* const cq = reinterpret_cast<float*>(mine + LO.cq);
-    float* const ct = reinterpret_cast<float*>(mine + LO.ct);
+    float* const mrow = reinterpret_cast<float*>(mine + LO.cbuf);            // masked priors (prior_rem), legal flags
+    float* const ct = reinterpret_cast<float*>(mine + LO.cbuf);
     float* const cu = reinterpret_cast<float*>(mine + LO.cu);
+    uint8_t* const clist = mine + LO.clist;
     const int sl = live ? slot : 0;
     uint8_t* const myrecs = T.recs + (size_t)sl * V * ROWS;
     Pos* const mystates = T.states + (size_t)sl * V;
@@ -215,7 +214,7 @@ __global__ __launch_bounds__(64, G >= 16 ? 4 : 2) void k_rollout_grp(const TreeP
             for (int k = sub; k < A4; k += G) {                         // pad entries A..A4-1 become +0 (exact in the ordered sum)
                 const bool lg = k < A && GM::canPlay(P, st, k);
                 rp[k] = lg ? rp[k] : 0.0f;
-                pol[k] = lg ? 1.0f : 0.0f;
+                mrow[k] = lg ? 1.0f : 0.0f;
                 nl += lg ? 1 : 0;
             }
             nl = grp_sum<G>(nl);
@@ -227,7 +226,7 @@ __global__ __launch_bounds__(64, G >= 16 ? 4 : 2) void k_rollout_grp(const TreeP
             const float Af = (float)nl;
             for (int k = sub; k < A4; k += G) {
                 float pr = 0.0f;
-                if (k < A) pr = rootmix ? (pol[k] != 0.0f ? 0.75f * rp[k] / normalize + 0.25f / Af : 0.0f) : rp[k] / normalize;
+                if (k < A) pr = rootmix ? (mrow[k] != 0.0f ? 0.75f * rp[k] / normalize + 0.25f / Af : 0.0f) : rp[k] / normalize;
                 rp[k] = pr; rq[k] = 0.0f; rvc[k] = 0;
                 if (lf == 0 && k < A) T.policy_final[(size_t)slot * A + k] = pr;
             }
@@ -284,9 +283,12 @@ __global__ __launch_bounds__(64, G >= 16 ? 4 : 2) void k_rollout_grp(const TreeP
         lst.player = 1; lst.aux = 0;
         bool descending = live && (mn & M_EXPANDED);
         int create_from = -1, create_move = 0; uint32_t create_vc = 0;
+        float uq[4] = {1.0f, 1.0f, 1.0f, 1.0f};
         uint64_t dmask = __ballot(descending && lead);
         while (dmask) {
-            const float u = uniform_search(T.seed, gid, T.step, T.rollout, (uint32_t)depth);   // independent of the rows: overlaps the DMA
+            if ((depth & 3) == 0) uniform_search4(T.seed, gid, T.step, T.rollout, (uint32_t)depth >> 2, uq);   // independent of the rows: overlaps the DMA
+            const int uw = depth & 3;
+            const float u = uw == 0 ? uq[0] : (uw == 1 ? uq[1] : (uw == 2 ? uq[2] : uq[3]));
             STAMP(6);
             grp_gather<G>(dmask, myrecs + (size_t)node * ROWS, lds, LO.stride, LO.row, ROWS);
             STAMP(7);
@@ -304,13 +306,13 @@ __global__ __launch_bounds__(64, G >= 16 ? 4 : 2) void k_rollout_grp(const TreeP
                         float4 m4;                                         // prior of childless actions, +0 otherwise (adding +0 is exact)
                         m4.x = (v4.x & 0xff00u) == 0 ? p4.x : 0.0f; m4.y = (v4.x >> 24) == 0 ? p4.y : 0.0f;
                         m4.z = (v4.y & 0xff00u) == 0 ? p4.z : 0.0f; m4.w = (v4.y >> 24) == 0 ? p4.w : 0.0f;
-                        *reinterpret_cast<float4*>(pol + k) = m4;
+                        *reinterpret_cast<float4*>(mrow + k) = m4;
                     }
                     vs = grp_sum<G>(vs); ac = grp_sum<G>(ac);
                     const float nf = 1.0f + (float)vs, Af = (float)ac;
                     AGZ_WSYNC();
                     float prior_rem = 0.0f;                                // ordered: childless priors in k order (:122-124)
-                    if (lead) prior_rem = lds_ordered_sum(pol, A4, 0.0f);
+                    if (lead) prior_rem = lds_ordered_sum(mrow, A4, 0.0f);
                     AGZ_WSYNC();
                     prior_rem = grp_bcast<G>(prior_rem);
                     lambda = T.cpuct * __builtin_sqrtf(nf) / (Af + nf);   // :132
@@ -341,8 +343,7 @@ __global__ __launch_bounds__(64, G >= 16 ? 4 : 2) void k_rollout_grp(const TreeP
                             if (isc) {
                                 const int pos = nch + __popc(bits & ((1u << sub) - 1u));
                                 const int a = (int)((mi[j] >> 8) & 0xffu);
-                                ctop[pos] = lambda * rp[a];                // :147 top
-                                cq[pos] = rq[a];
+                                clist[pos] = (uint8_t)a;
                             }
                             nch += __popc(bits);
                         }
@@ -351,22 +352,25 @@ __global__ __launch_bounds__(64, G >= 16 ? 4 : 2) void k_rollout_grp(const TreeP
                     STAMP(9);
                     float err = __builtin_inff();
                     for (int j = 0; j < 100; ++j) {                        // :141-162
-                        for (int c = sub; c < nch; c += G) {
-                            const float bot = alpha - cq[c];
-                            ct[c] = ctop[c] / bot;
-                            cu[c] = -ctop[c] / (bot * bot);
+                        for (int c = sub; c <= nch; c += G) {
+                            float top = prior_rem, qv = 0.0f;              // c == 0: S = prior_rem/alpha, g = -prior_rem/alpha^2 (:142-143)
+                            if (c > 0) { const int a = clist[c - 1]; top = lambda * rp[a]; qv = rq[a]; }   // :147-148
+                            const float bot = alpha - qv;
+                            ct[c] = top / bot;
+                            cu[c] = -top / (bot * bot);
                         }
                         AGZ_WSYNC();
-                        float S = prior_rem / alpha;
-                        float gg = -prior_rem / (alpha * alpha);
-                        if (lead)
-                            for (int c0 = 0; c0 < nch; c0 += 8) {
+                        float S = 0.0f, gg = 0.0f;
+                        if (lead) {
+                            S = ct[0]; gg = cu[0];
+                            for (int c0 = 1; c0 <= nch; c0 += 8) {
                                 float tv[8], uv[8];
 #pragma unroll
-                                for (int j = 0; j < 8; ++j) { tv[j] = c0 + j < nch ? ct[c0 + j] : 0.0f; uv[j] = c0 + j < nch ? cu[c0 + j] : 0.0f; }
+                                for (int j = 0; j < 8; ++j) { tv[j] = c0 + j <= nch ? ct[c0 + j] : 0.0f; uv[j] = c0 + j <= nch ? cu[c0 + j] : 0.0f; }
 #pragma unroll
                                 for (int j = 0; j < 8; ++j) { S += tv[j]; gg += uv[j]; }
                             }
+                        }
                         S = grp_bcast<G>(S); gg = grp_bcast<G>(gg);
                         AGZ_WSYNC();
                         const float newerr = S - 1.0f;

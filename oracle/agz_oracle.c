@@ -344,11 +344,12 @@ void agzo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t o
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
-/* search uniform in (0,1]: stands for prob[cpt,i] (mcts_gpu.jl:178, 397); keyed by GAME id, not slot */
+/* search uniform in (0,1]: stands for prob[cpt,i] (mcts_gpu.jl:178, 397); keyed by GAME id, not slot.
+ * One Philox block serves four consecutive depths: counter = (game, step, rollout, depth >> 2), word = depth & 3. */
 float agzo_uniform_search(uint64_t seed, uint32_t game_id, uint32_t step, uint32_t rollout, uint32_t depth) {
-    uint32_t ctr[4] = { game_id, step, rollout, depth }, key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) }, o[4];
+    uint32_t ctr[4] = { game_id, step, rollout, depth >> 2 }, key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) }, o[4];
     agzo_philox4x32_10(ctr, key, o);
-    return (float)((o[0] >> 8) + 1u) * 5.9604644775390625e-8f;           /* 2^-24 */
+    return (float)((o[depth & 3u] >> 8) + 1u) * 5.9604644775390625e-8f;           /* 2^-24 */
 }
 /* move uniform in [0,1): stands for rand() inside StatsBase.sample (mcts_gpu.jl:520) */
 float agzo_uniform_move(uint64_t seed, uint32_t game_id, uint32_t step) {
