@@ -108,8 +108,8 @@ static bool bind_kernels(agz_engine* h) {
     if (P.fam == F && P.NR == R && P.NC == C) { h->k_roll = pick_rollout<F, R, C>(h->NRV); h->k_adv = k_advance<F, R, C>; }
     AGZ_COMBOS(X)
 #undef X
-    { const char* eg = getenv("AGZ_TREE_G"); if (eg) h->grp_g = atoi(eg); if (h->grp_g != 4 && h->grp_g != 8) h->grp_g = 16; }
-#define Y(F, C) if (P.fam == F && P.NC == C) h->k_lpg = h->grp_g == 4 ? k_rollout_grp<F, C, 4> : (h->grp_g == 16 ? k_rollout_grp<F, C, 16> : k_rollout_grp<F, C, 8>);
+    { const char* eg = getenv("AGZ_TREE_G"); if (eg) h->grp_g = atoi(eg); if (h->grp_g != 2 && h->grp_g != 4 && h->grp_g != 8) h->grp_g = 16; }
+#define Y(F, C) if (P.fam == F && P.NC == C) h->k_lpg = h->grp_g == 2 ? k_rollout_grp<F, C, 2> : (h->grp_g == 4 ? k_rollout_grp<F, C, 4> : (h->grp_g == 16 ? k_rollout_grp<F, C, 16> : k_rollout_grp<F, C, 8>));
     Y(F_LINE, 1) Y(F_LINE, 2) Y(F_LINE, 3) Y(F_C4, 1) Y(F_HEX, 1) Y(F_HEX, 2) Y(F_HEX, 3) Y(F_REV, 1)
 #undef Y
     if (P.NR == 1) h->k_soft = k_softmax<1>; else if (P.NR == 2) h->k_soft = k_softmax<2>; else h->k_soft = k_softmax<3>;

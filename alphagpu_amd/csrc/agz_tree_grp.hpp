@@ -94,7 +94,8 @@ template <int CTRL, int BANK> __device__ __forceinline__ int dpp_mov(int old, in
 }
 enum { DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140, DPP_QUAD_B0 = 0x00, DPP_SHR4 = 0x114, DPP_SHR8 = 0x118 };
 template <int G> __device__ __forceinline__ int grp_bcast(int x) {          // value of the group's lane 0
-    static_assert(G == 1 || G == 4 || G == 8 || G == 16, "group size");
+    static_assert(G == 1 || G == 2 || G == 4 || G == 8 || G == 16, "group size");
+    if (G == 2) return dpp_mov<0xA0, 0xF>(x, x);                            // quad_perm [0,0,2,2]
     if (G == 16) x = dpp_mov<DPP_SHR8, 0xC>(x, x);                          // lanes 8..15 <- lanes 0..7
     if (G >= 8) x = dpp_mov<DPP_SHR4, 0xA>(x, x);                           // lanes 4..7 (12..15) <- lanes 0..3 (8..11)
     if (G >= 4) x = dpp_mov<DPP_QUAD_B0, 0xF>(x, x);
@@ -102,17 +103,16 @@ template <int G> __device__ __forceinline__ int grp_bcast(int x) {          // v
 }
 template <int G> __device__ __forceinline__ float grp_bcast(float x) { return __int_as_float(grp_bcast<G>(__float_as_int(x))); }
 template <int G> __device__ __forceinline__ int grp_sum(int x) {
-    if (G >= 4) { x += dpp_mov<DPP_XOR1, 0xF>(0, x); x += dpp_mov<DPP_XOR2, 0xF>(0, x); }
+    if (G >= 2) x += dpp_mov<DPP_XOR1, 0xF>(0, x);
+    if (G >= 4) x += dpp_mov<DPP_XOR2, 0xF>(0, x);
     if (G >= 8) x += dpp_mov<DPP_HALF_MIRROR, 0xF>(0, x);
     if (G >= 16) x += dpp_mov<DPP_MIRROR, 0xF>(0, x);
     return x;
 }
 template <int G> __device__ __forceinline__ float grp_max(float x) {
     float y;
-    if (G >= 4) {
-        y = __int_as_float(dpp_mov<DPP_XOR1, 0xF>(0, __float_as_int(x))); x = y > x ? y : x;
-        y = __int_as_float(dpp_mov<DPP_XOR2, 0xF>(0, __float_as_int(x))); x = y > x ? y : x;
-    }
+    if (G >= 2) { y = __int_as_float(dpp_mov<DPP_XOR1, 0xF>(0, __float_as_int(x))); x = y > x ? y : x; }
+    if (G >= 4) { y = __int_as_float(dpp_mov<DPP_XOR2, 0xF>(0, __float_as_int(x))); x = y > x ? y : x; }
     if (G >= 8) { y = __int_as_float(dpp_mov<DPP_HALF_MIRROR, 0xF>(0, __float_as_int(x))); x = y > x ? y : x; }
     if (G >= 16) { y = __int_as_float(dpp_mov<DPP_MIRROR, 0xF>(0, __float_as_int(x))); x = y > x ? y : x; }
     return x;
@@ -130,7 +130,7 @@ __device__ __forceinline__ float lds_ordered_sum(const float* p, int n, float ac
 }
 
 template <int FAM, int NC, int G>
-__global__ __launch_bounds__(64, G >= 16 ? 4 : 2) void k_rollout_grp(const TreePar T) {
+__global__ __launch_bounds__(64, G >= 16 ? 4 : (G >= 8 ? 2 : 1)) void k_rollout_grp(const TreePar T) {
     using GM = Game<FAM, NC>;
     constexpr bool REV = FAM == F_REV;
     constexpr int NG = 64 / G;
@@ -363,12 +363,12 @@ __global__ __launch_bounds__(64, G >= 16 ? 4 : 2) void k_rollout_grp(const TreeP
                         float S = 0.0f, gg = 0.0f;
                         if (lead) {
                             S = ct[0]; gg = cu[0];
-                            for (int c0 = 1; c0 <= nch; c0 += 8) {
-                                float tv[8], uv[8];
+                            for (int c0 = 1; c0 <= nch; c0 += 4) {
+                                float tv[4], uv[4];
 #pragma unroll
-                                for (int j = 0; j < 8; ++j) { tv[j] = c0 + j <= nch ? ct[c0 + j] : 0.0f; uv[j] = c0 + j <= nch ? cu[c0 + j] : 0.0f; }
+                                for (int j = 0; j < 4; ++j) { tv[j] = c0 + j <= nch ? ct[c0 + j] : 0.0f; uv[j] = c0 + j <= nch ? cu[c0 + j] : 0.0f; }
 #pragma unroll
-                                for (int j = 0; j < 8; ++j) { S += tv[j]; gg += uv[j]; }
+                                for (int j = 0; j < 4; ++j) { S += tv[j]; gg += uv[j]; }
                             }
                         }
                         S = grp_bcast<G>(S); gg = grp_bcast<G>(gg);
@@ -404,25 +404,21 @@ __global__ __launch_bounds__(64, G >= 16 ? 4 : 2) void k_rollout_grp(const TreeP
                 int bestmove = -1;
                 if (lead) {
                     float pr = 0.0f; int kb = A4;                           // kb = first k with running sum >= u (A4: none)
-                    for (int k0 = 0; k0 < A4 && kb == A4; k0 += 32) {
-                        float sp[32];
+                    for (int k0 = 0; k0 < A4 && kb == A4; k0 += 16) {
+                        float sp[16];
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) {
+                        for (int j = 0; j < 4; ++j) {
                             const float4 d = (k0 + 4 * j < A4) ? *reinterpret_cast<const float4*>(pol + k0 + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
                             sp[4 * j] = d.x; sp[4 * j + 1] = d.y; sp[4 * j + 2] = d.z; sp[4 * j + 3] = d.w;
                         }
+                        float mx = -__builtin_inff();
 #pragma unroll
-                        for (int j = 0; j < 32; ++j) { pr += sp[j]; sp[j] = pr; }
-                        if (pr >= u || sp[15] >= u || sp[7] >= u || sp[23] >= u) {       // cheap filter; exact search below
-                            int f = 32;
+                        for (int j = 0; j < 16; ++j) { pr += sp[j]; sp[j] = pr; mx = pr > mx ? pr : mx; }
+                        if (mx >= u) {                                      // some prefix of this batch reaches u: find the first
+                            int f = 15;
 #pragma unroll
-                            for (int j = 31; j >= 0; --j) f = sp[j] >= u ? j : f;
-                            if (f < 32) kb = k0 + f;
-                        } else {
-                            int f = 32;
-#pragma unroll
-                            for (int j = 31; j >= 0; --j) f = sp[j] >= u ? j : f;
-                            if (f < 32) kb = k0 + f;
+                            for (int j = 14; j >= 0; --j) f = sp[j] >= u ? j : f;
+                            kb = k0 + f;
                         }
                     }
                     STAMP(15);
