@@ -76,7 +76,7 @@ struct agz_engine {
     float cpuct = 1.5f; int training = 1; uint32_t step = 0; bool need_reset = true; bool injected = false;
     uint64_t total_rollouts = 0, acc_p = 0, acc_new = 0;
     // profiling
-    bool profiling = false;
+    int profiling = 0;         // bit 0: HIP events around every tree-kernel launch, bit 1: around every network launch
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_tree, ev_nn;
     size_t ev_tree_used = 0, ev_nn_used = 0;
     double tree_ms = 0, nn_ms = 0; int64_t tree_launches = 0;
@@ -426,7 +426,7 @@ static int launch_rollout(agz_engine* h, uint32_t rollout, int do_reset, int do_
     const int ng = 64 / h->grp_g;
     dim3 grid((unsigned)(lpg ? (h->L + ng - 1) / ng : (h->L + 3) / 4)), block(lpg ? 64 : 256);
     std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
-    if (h->profiling) { ev = next_events(h, h->ev_tree, h->ev_tree_used); hipEventRecord(ev->first, h->stream); }
+    if (h->profiling & 1) { ev = next_events(h, h->ev_tree, h->ev_tree_used); hipEventRecord(ev->first, h->stream); }
     hipLaunchKernelGGL(lpg ? h->k_lpg : h->k_roll, grid, block, lpg ? h->lpg_lds : 0, h->stream, T);
     if (ev) hipEventRecord(ev->second, h->stream);
     h->cnt_live = true;
@@ -440,7 +440,7 @@ static int launch_network(agz_engine* h, int which) {
     if (!n.loaded) { h->fail("no network loaded in slot %d (call agz_set_network)", which); return AGZ_ERR_STATE; }
     const int L = h->L;
     std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
-    if (h->profiling) { ev = next_events(h, h->ev_nn, h->ev_nn_used); hipEventRecord(ev->first, h->stream); }
+    if (h->profiling & 2) { ev = next_events(h, h->ev_nn, h->ev_nn_used); hipEventRecord(ev->first, h->stream); }
     size_t fused_lds = 0;
     if (h->cfg.nn_mode == AGZ_NN_BF16 && (n.H == 64 || n.H == 128) && n.AOP / 32 <= n.H / 32 && !getenv("AGZ_NO_FUSED_NN"))
         fused_lds = (size_t)F2_M * (n.H * 2 + 16) + F2_WCHUNK;
@@ -638,7 +638,7 @@ int agz_get_counters(agz_engine* h, uint64_t* sum_p, uint64_t* sum_new, uint64_t
 
 int agz_set_profiling(agz_engine* h, int enable) {
     if (!h) return AGZ_ERR_ARG;
-    h->profiling = enable != 0;
+    h->profiling = enable;
     return AGZ_OK;
 }
 int agz_get_kernel_times(agz_engine* h, double* tree_ms, double* nn_ms, int64_t* tree_launches, int reset) {

@@ -15,6 +15,9 @@
 
 namespace agz {
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#define AGZ_GLOBAL __attribute__((address_space(1)))
+
 constexpr int F2_M = 128;                 // leaves per workgroup
 constexpr int F2_WCHUNK = 32 * 1024;      // bytes of weight fragments staged at a time
 
@@ -32,6 +35,7 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return r;
 }
 __device__ __forceinline__ float relu(float x) { return x > 0.0f ? x : 0.0f; }
+__device__ __attribute__((noinline)) float sigmoid_call(float x) { return sigmoid_spec(x); }
 
 template <int H>
 __global__ __launch_bounds__(256, 2) void k_mlp_fused2(const Fused2Par P) {
@@ -48,7 +52,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fused2(const Fused2Par P) {
     const int nlayers = P.T + 2;
 
     f32x16 acc[NTH];
-    uint4 pf0, pf1, pf2, pf3, pf4, pf5, pf6, pf7;               // next weight chunk in flight (32 KiB / 256 threads)
+    u32x4 pf0, pf1, pf2, pf3, pf4, pf5, pf6, pf7;               // next weight chunk in flight (32 KiB / 256 threads)
 
 #define AGZ_LAYER_DIMS(ll, KT, NT, w)                                                       \
     do {                                                                                    \
@@ -63,9 +67,9 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fused2(const Fused2Par P) {
     do {                                                                                    \
         int KT_, NT_; const uint16_t* w_; AGZ_LAYER_DIMS(ll, KT_, NT_, w_);                 \
         int kc_ = F2_WCHUNK / (NT_ * 1024); if ((k0) + kc_ > KT_) kc_ = KT_ - (k0);         \
-        const uint4* src_ = reinterpret_cast<const uint4*>(w_ + (size_t)(k0) * NT_ * 512);  \
+        const AGZ_GLOBAL u32x4* src_ = (const AGZ_GLOBAL u32x4*)(w_ + (size_t)(k0) * NT_ * 512);  \
         const int n16_ = kc_ * NT_ * 64;                                                    \
-        const uint4 z_ = make_uint4(0, 0, 0, 0);                                            \
+        const u32x4 z_ = {0u, 0u, 0u, 0u};                                                  \
         pf0 = tid < n16_ ? src_[tid] : z_;               pf1 = tid + 256 < n16_ ? src_[tid + 256] : z_;   \
         pf2 = tid + 512 < n16_ ? src_[tid + 512] : z_;   pf3 = tid + 768 < n16_ ? src_[tid + 768] : z_;   \
         pf4 = tid + 1024 < n16_ ? src_[tid + 1024] : z_; pf5 = tid + 1280 < n16_ ? src_[tid + 1280] : z_; \
@@ -73,7 +77,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fused2(const Fused2Par P) {
     } while (0)
 #define AGZ_COMMIT()                                                                        \
     do {                                                                                    \
-        uint4* d_ = reinterpret_cast<uint4*>(wl);                                           \
+        u32x4* d_ = reinterpret_cast<u32x4*>(wl);                                           \
         d_[tid] = pf0; d_[tid + 256] = pf1; d_[tid + 512] = pf2; d_[tid + 768] = pf3;       \
         d_[tid + 1024] = pf4; d_[tid + 1280] = pf5; d_[tid + 1536] = pf6; d_[tid + 1792] = pf7; \
     } while (0)
@@ -100,9 +104,9 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fused2(const Fused2Par P) {
         // ---- MFMAs of this chunk: acc[t] += Wfrag(c, t) * Xfrag(c); fragments of step c+1 are read while step c computes
         const uint8_t* wlane = wl + lane * 16;
         if (l == 0 || l < nlayers - 1) {                           // input / hidden layers: NT == NTH, D = W * X^T
-            const uint16_t* prow = P.planes + (size_t)(m < P.L ? m : 0) * P.INP + half * 8;
+            const __attribute__((address_space(1))) uint16_t* prow = (const __attribute__((address_space(1))) uint16_t*)(P.planes + (size_t)(m < P.L ? m : 0) * P.INP + half * 8);
             bf16x8 b, a[NTH];
-            if (l == 0) b = *reinterpret_cast<const bf16x8*>(prow + kt0 * 16);
+            if (l == 0) b = *(const __attribute__((address_space(1))) bf16x8*)(prow + kt0 * 16);
             else b = *reinterpret_cast<const bf16x8*>(myrow + kt0 * 32 + half * 16);
 #pragma unroll
             for (int t = 0; t < NTH; ++t) a[t] = *reinterpret_cast<const bf16x8*>(wlane + (size_t)t * 1024);
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fused2(const Fused2Par P) {
 #pragma unroll
                 for (int t = 0; t < NTH; ++t) an[t] = a[t];
                 if (c + 1 < kc) {
-                    if (l == 0) bn = *reinterpret_cast<const bf16x8*>(prow + (kt0 + c + 1) * 16);
+                    if (l == 0) bn = *(const __attribute__((address_space(1))) bf16x8*)(prow + (kt0 + c + 1) * 16);
                     else bn = *reinterpret_cast<const bf16x8*>(myrow + (kt0 + c + 1) * 32 + half * 16);
 #pragma unroll
                     for (int t = 0; t < NTH; ++t) an[t] = *reinterpret_cast<const bf16x8*>(wlane + (size_t)((c + 1) * NTH + t) * 1024);
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fused2(const Fused2Par P) {
 #pragma unroll
                             for (int e = 0; e < 16; ++e) {
                                 const int mm = mw + (e & 3) + 8 * (e >> 2) + 4 * half;
-                                if (mm < P.L) P.vout[mm] = sigmoid_spec(acc[t][e] + bias);
+                                if (mm < P.L) P.vout[mm] = sigmoid_call(acc[t][e] + bias);
                             }
                         }
                     }

@@ -156,7 +156,7 @@ class Engine:
         return a.value, b.value, c.value
 
     def set_profiling(self, on):
-        self._chk(self.L.agz_set_profiling(self.h, int(bool(on))))
+        self._chk(self.L.agz_set_profiling(self.h, 3 if on is True else int(on)))
 
     def kernel_times(self, reset=False):
         t, n, k = C.c_double(0), C.c_double(0), C.c_int64(0)

@@ -91,7 +91,7 @@ def main():
     eng = M.Engine(game, G, V, device=local_rank, seed=1, game_id_base=shard.shard_base(rank, G),
                    nn_mode=M.NN_BF16 if args.mode == "bf16" else M.NN_EXACT)
     eng.set_network(net)
-    eng.set_profiling(True)
+    eng.set_profiling(1)          # HIP events around every PUCT-kernel launch (roofline); network time = search - tree
     rb = game.rec_bytes
     sample_buf = torch.empty(G * game.max_plies * rb, dtype=torch.uint8, device="cuda") if world > 1 else None
 
@@ -158,7 +158,7 @@ def main():
                          "algorithmic_bytes_per_launch": alg / max(launches, 1), "avg_launch_ms": tree_ms / max(launches, 1),
                          "launches": launches, "mean_depth_p": sum_p / max(r_cnt, 1)},
             "rank0": {"search_only_rollouts_per_s": rollouts / search_s if search_s > 0 else None,
-                      "tree_kernel_ms": tree_ms, "network_kernel_ms": nn_ms, "plies": plies, "samples": nsamples,
+                      "tree_kernel_ms": tree_ms, "search_ms": search_s * 1e3, "other_search_ms_network_and_gaps": search_s * 1e3 - tree_ms, "plies": plies, "samples": nsamples,
                       "wall_s": dt},
         }
         if not args.no_cpu_baseline and world == 1:

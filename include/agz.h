@@ -138,7 +138,7 @@ void *agz_stream(agz_engine *h);                       /* the engine's hipStream
 int  agz_synchronize(agz_engine *h);
 /* HIP-event timings (ms) accumulated since the last reset: [0] tree kernels, [1] network kernels, [2] launches */
 int  agz_get_kernel_times(agz_engine *h, double *tree_ms, double *nn_ms, int64_t *tree_launches, int reset);
-int  agz_set_profiling(agz_engine *h, int enable);     /* per-kernel HIP events (serialises tree/nn kernels) */
+int  agz_set_profiling(agz_engine *h, int mode);       /* HIP events per launch: bit 0 tree kernel, bit 1 network kernel */
 
 #ifdef __cplusplus
 }

@@ -9,7 +9,7 @@ g = ag.GameSpec('gobang', 9, 5)
 net = ag.SNetwork2.random(g, 128, 6)
 e = M.Engine(g, L, V, seed=1, nn_mode=M.NN_BF16)
 e.set_network(net)
-e.set_profiling(True)
+e.set_profiling(os.environ.get("NOPROF") is None)
 for r in range(reps):
     e.set_roots(None, L=L)
     e.kernel_times(reset=True)
@@ -19,5 +19,5 @@ for r in range(reps):
     dt = time.perf_counter() - t0
     tree, nn, k = e.kernel_times()
     p, n, ro = e.counters()
-    print(f"search {r}: wall {dt*1e3:.2f} ms  tree {tree:.2f} ms ({k} launches, {tree/k*1e3:.1f} us avg)  nn {nn:.2f} ms  p/rollout {p/ro:.2f}  rollouts/s {ro/dt/1e6:.1f}M")
+    print(f"search {r}: wall {dt*1e3:.2f} ms  tree {tree:.2f} ms ({k} launches, {tree/max(k,1)*1e3:.1f} us avg)  nn {nn:.2f} ms  p/rollout {p/ro:.2f}  rollouts/s {ro/dt/1e6:.1f}M")
 e.close()
