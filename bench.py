@@ -141,6 +141,13 @@ def main():
     if rank == 0:
         S = game.pos_image_bytes
         alg = algorithmic_bytes(game, sum_p, sum_new, r_cnt, S)
+        traffic = None          # HBM bytes per launch from the committed PMC passes, scaled by this run's algorithmic bytes
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if args.n == 9 and args.rollouts == 64:
+                traffic = pm["traffic_over_algorithmic"] * alg / max(launches, 1)
+        except Exception:
+            traffic = None
         achieved = alg / (tree_ms * 1e-3) / 1e9 if tree_ms > 0 else 0.0
         out = {
             "metric": "self-play rollouts/sec at 32768 games x 64 rollouts, Gobang 9x9",
@@ -152,9 +159,9 @@ def main():
                        "games_per_gpu": G, "rollouts_per_move": V, "cpuct": args.cpuct, "tau_plies": 25,
                        "tree_arithmetic": "f32 strict IEEE", "network": "bf16 MFMA, fp32 accumulate" if args.mode == "bf16" else "f32 exact",
                        "parallelism": f"game-shard x{world}, RCCL all-gather of samples at generation end" if world > 1 else "single GPU"},
-            "roofline": {"kernel": "k_rollout (expand+backup+select+encode, one wavefront per game tree)",
+            "roofline": {"kernel": "k_rollout_grp (expand+backup+select+encode, 16 lanes per game tree)",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg / max(launches, 1), "avg_launch_ms": tree_ms / max(launches, 1),
                          "launches": launches, "mean_depth_p": sum_p / max(r_cnt, 1)},
             "rank0": {"search_only_rollouts_per_s": rollouts / search_s if search_s > 0 else None,

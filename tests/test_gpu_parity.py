@@ -256,3 +256,71 @@ def test_errors_are_reported_not_swallowed():
         e.set_roots(None, L=0)                                   # empty batch is legal
         e.search(8)
         assert e.policy().shape == (0, 9)
+
+
+# ---- further shapes of BASELINE.json's configs -----------------------------------------------------------
+def test_hex_128_rollouts_exact_parity():
+    """configs[3] family: Hex 9x9 with V = 128 (two meta registers / 128-node trees), irregular-action PUCT stress."""
+    g, og = spec("hex9")
+    net, onet = nets(g, og, 128, 2)
+    L, V = 16, 128
+    roots = common.diverse_roots(og, L, seed=13, max_prefix=30)
+    t = O.OracleTree(og, L, V)
+    t.set_roots(roots)
+    t.search(onet, V, 1.5, True, 5, 9)
+    with M.Engine(g, L, V, seed=5, nn_mode=M.NN_EXACT) as e:
+        e.set_network(net)
+        e.set_roots(common.pos_bytes(roots))
+        e.search(V, cpuct=1.5, training=True, step=9)
+        assert_same_bits(e.root_visits(), t.root_visits(), "visits")
+        assert_same_bits(e.policy(), t.policy(), "policy")
+        assert_same_bits(e.root_q(), t.root_q(), "q")
+        assert_same_bits(e.node_count(), t.newindex(), "newindex")
+
+
+def test_reversi8_generation_with_passes_exact_parity():
+    """configs[4] family: Reversi 8x8 self-play including pass moves (action 64) and game-end by double pass."""
+    g, og = spec("reversi8")
+    net, onet = nets(g, og, 32, 1)
+    ref = O.selfplay(og, onet, 16, 8, 1.5, 25, 9, 0)
+    with M.Engine(g, 16, 8, seed=9, nn_mode=M.NN_EXACT) as e:
+        e.set_network(net)
+        st = e.selfplay(16, 8, cpuct=1.5, tau_plies=25)
+        s = e.samples()
+    assert st["valid"] and st["nsamples"] == ref["n"]
+    for key in ("game_id", "ply", "move", "player", "state", "fstate", "policy", "value"):
+        assert_same_bits(s[key], ref[key], key)
+
+
+@pytest.mark.parametrize("kernel", ["v1", "grp8", "grp4"])
+def test_all_tree_kernels_agree(kernel, monkeypatch):
+    """The wave-per-tree kernel (fallback for large shapes) and the group kernel at other group sizes must
+    produce the same bits as the default."""
+    g, og = spec("gobang9")
+    net, onet = nets(g, og, 64, 2)
+    L, V = 24, 48
+    roots = common.diverse_roots(og, L, seed=21)
+    t = O.OracleTree(og, L, V)
+    t.set_roots(roots)
+    t.search(onet, V, 1.5, True, 3, 1)
+    if kernel == "v1":
+        monkeypatch.setenv("AGZ_TREE_KERNEL", "v1")
+    else:
+        monkeypatch.setenv("AGZ_TREE_G", kernel[3:])
+    with M.Engine(g, L, V, seed=3, nn_mode=M.NN_EXACT) as e:
+        e.set_network(net)
+        e.set_roots(common.pos_bytes(roots))
+        e.search(V, cpuct=1.5, training=True, step=1)
+        assert_same_bits(e.root_visits(), t.root_visits(), "visits")
+        assert_same_bits(e.policy(), t.policy(), "policy")
+        assert_same_bits(e.root_q(), t.root_q(), "q")
+
+
+def test_duel_runs_and_is_consistent():
+    """mcts(actor1, actor2, ...) (mcts_gpu.jl:581-651): same net on both sides, every game ends, W+D+L = ngames."""
+    g, _ = spec("tictactoe")
+    net = ag.SNetwork2.random(g, 32, 1)
+    wdl = M.mcts_duel(net, net, 16, 64, g, cpuct=2.0, seed=5)
+    assert sum(wdl) == 64 and all(x >= 0 for x in wdl)
+    v, n, d = M.duelnetwork(net, net, 16, 64, g, seed=5)
+    assert v + n + d == 64
