@@ -17,6 +17,7 @@
 #include "agz_device.hpp"
 #include "agz_tree.hpp"
 #include "agz_tree_grp.hpp"
+#include "agz_tree_reg.hpp"
 #include "agz_nn.hpp"
 #include "agz_nn_fused.hpp"
 #include "agz_selfplay.hpp"
@@ -81,6 +82,7 @@ struct agz_engine {
     size_t ev_tree_used = 0, ev_nn_used = 0;
     double tree_ms = 0, nn_ms = 0; int64_t tree_launches = 0;
     rollout_fn k_roll = nullptr; advance_fn k_adv = nullptr; softmax_fn k_soft = nullptr;
+    rollout_fn k_reg = nullptr; size_t reg_lds = 0; int reg_kpl = 0;   // register-row kernel (agz_tree_reg.hpp), 8 lanes per tree
     rollout_fn k_lpg = nullptr; size_t lpg_lds = 0; int grp_g = 16;   // group kernel (agz_tree_grp.hpp): G lanes per tree; lpg_lds == 0 -> wave-per-tree kernel
 
     int fail(const char* fmt, ...) {
@@ -112,6 +114,15 @@ static bool bind_kernels(agz_engine* h) {
 #define Y(F, C) if (P.fam == F && P.NC == C) h->k_lpg = h->grp_g == 2 ? k_rollout_grp<F, C, 2> : (h->grp_g == 4 ? k_rollout_grp<F, C, 4> : (h->grp_g == 16 ? k_rollout_grp<F, C, 16> : k_rollout_grp<F, C, 8>));
     Y(F_LINE, 1) Y(F_LINE, 2) Y(F_LINE, 3) Y(F_C4, 1) Y(F_HEX, 1) Y(F_HEX, 2) Y(F_HEX, 3) Y(F_REV, 1)
 #undef Y
+    {   // register-row kernel: smallest block length KPL with 8*KPL >= A among the instantiated shapes
+        const int kpl = P.A <= 32 ? 4 : (P.A <= 64 ? 8 : (P.A <= 96 ? 12 : (P.A <= 128 ? 16 : (P.A <= 192 ? 24 : 0))));
+#define Z(F, C, K) if (P.fam == F && P.NC == C && kpl == K) { h->k_reg = k_rollout_reg<F, C, 8, K>; h->reg_kpl = K; }
+        Z(F_LINE, 1, 4) Z(F_LINE, 1, 8) Z(F_LINE, 2, 12) Z(F_LINE, 2, 16) Z(F_LINE, 3, 24)
+        Z(F_C4, 1, 4)
+        Z(F_HEX, 1, 4) Z(F_HEX, 1, 8) Z(F_HEX, 2, 8) Z(F_HEX, 2, 12) Z(F_HEX, 2, 16) Z(F_HEX, 3, 16) Z(F_HEX, 3, 24)
+        Z(F_REV, 1, 12) Z(F_REV, 1, 8)
+#undef Z
+    }
     if (P.NR == 1) h->k_soft = k_softmax<1>; else if (P.NR == 2) h->k_soft = k_softmax<2>; else h->k_soft = k_softmax<3>;
     return h->k_roll != nullptr;
 }
@@ -206,12 +217,17 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     // node record: [prior f32 x A2][q f32 x A2][vc u16 x A2], A2 = A rounded up to 4 (16-B aligned sub-arrays);
     // the record size is an ODD multiple of 16 B so that the LDS image of 64 records is bank-conflict free for
     // per-lane 16-B reads (agz_tree_lpg.hpp)
-    const uint32_t A2 = (uint32_t)round_up(P.A, 4);
+    const char* tk = getenv("AGZ_TREE_KERNEL");
+    const bool want_reg = h->k_reg && !(tk && (!strcmp(tk, "v1") || !strcmp(tk, "grp")));
+    h->reg_lds = want_reg ? (size_t)8 * reg_lds_layout(h->V).stride : 0;
+    if (h->reg_lds > 160 * 1024) h->reg_lds = 0;
+    // row length: the register-row kernel gives each of its 8 lanes a block of KPL actions
+    const uint32_t A2 = h->reg_lds ? (uint32_t)(8 * h->reg_kpl) : (uint32_t)round_up(P.A, 4);
     uint32_t rec_bytes = (uint32_t)round_up((int)(A2 * 10), 16);
     if (((rec_bytes / 16) & 1u) == 0) rec_bytes += 16;
     h->lpg_lds = (size_t)(64 / h->grp_g) * grp_lds_layout((int)rec_bytes, (int)A2, h->V).stride;
-    const char* tk = getenv("AGZ_TREE_KERNEL");
-    if (!h->k_lpg || h->lpg_lds > 64 * 1024 /* LDS-DMA destination offsets are 16 bit */ || (tk && !strcmp(tk, "v1"))) h->lpg_lds = 0;
+    if (h->reg_lds) hipFuncSetAttribute((const void*)h->k_reg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->reg_lds);
+    if (h->reg_lds || !h->k_lpg || h->lpg_lds > 64 * 1024 /* LDS-DMA destination offsets are 16 bit */ || (tk && !strcmp(tk, "v1"))) h->lpg_lds = 0;
     if (h->lpg_lds) hipFuncSetAttribute((const void*)h->k_lpg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lpg_lds);
     const size_t Lm = (size_t)h->Lmax, V = (size_t)h->V;
     h->INP = round_up(2 * P.VS, 32);
@@ -422,12 +438,12 @@ static int launch_rollout(agz_engine* h, uint32_t rollout, int do_reset, int do_
     TreePar T = h->tp;
     T.L = h->L; T.step = h->step; T.rollout = rollout; T.cpuct = h->cpuct; T.training = h->training;
     T.do_reset = do_reset; T.do_expand = do_expand; T.do_select = do_select; T.last = last; T.inject = inject; T.capture = capture;
-    const bool lpg = h->lpg_lds != 0;
-    const int ng = 64 / h->grp_g;
-    dim3 grid((unsigned)(lpg ? (h->L + ng - 1) / ng : (h->L + 3) / 4)), block(lpg ? 64 : 256);
+    const bool reg = h->reg_lds != 0, lpg = !reg && h->lpg_lds != 0;
+    const int ng = reg ? 8 : 64 / h->grp_g;
+    dim3 grid((unsigned)((reg || lpg) ? (h->L + ng - 1) / ng : (h->L + 3) / 4)), block((reg || lpg) ? 64 : 256);
     std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
     if (h->profiling & 1) { ev = next_events(h, h->ev_tree, h->ev_tree_used); hipEventRecord(ev->first, h->stream); }
-    hipLaunchKernelGGL(lpg ? h->k_lpg : h->k_roll, grid, block, lpg ? h->lpg_lds : 0, h->stream, T);
+    hipLaunchKernelGGL(reg ? h->k_reg : (lpg ? h->k_lpg : h->k_roll), grid, block, reg ? h->reg_lds : (lpg ? h->lpg_lds : 0), h->stream, T);
     if (ev) hipEventRecord(ev->second, h->stream);
     h->cnt_live = true;
     HIPCHK(h, hipGetLastError());

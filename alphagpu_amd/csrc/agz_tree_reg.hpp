@@ -1,0 +1,467 @@
+// agz_tree_reg.hpp — PUCT tree kernel, fourth generation: node rows live in REGISTERS.
+//
+// G lanes per game tree (64/G trees per wavefront); lane `sub` of a group owns the contiguous block of KPL actions
+// k = sub*KPL .. sub*KPL+KPL-1 of the node row (prior, q, visits|child), loaded straight from HBM with 16-B loads.
+// KPL is a compile-time constant, so every O(A) loop is fully unrolled register arithmetic:
+//   * order-free work (lambda*P/(alpha-Q), alpha0 max, counts, exp, legality) runs on all lanes at once;
+//   * an ordered fp32 sum (prior_rem, sampling prefix, softmax denominator, normalize: mcts_gpu.jl:120-131, 172-181,
+//     260-268) is walked by the lanes TAKING TURNS: lane t adds its KPL values to the carry handed over by lane t-1
+//     (one DPP row_shr:1 per turn) — G*(KPL+2) instructions for the whole group, bit-identical to the source-order
+//     loop.  The sampling prefix is then re-derived by all lanes in parallel from their now-known starting sums.
+//   * Newton's child terms (:142-151) go through a small LDS table indexed by child node id (written while the row is
+//     scanned), are compacted in creation order and summed by the group's lane 0.
+// LDS per game: meta (V words) + child table (2 V floats) + Newton terms (2 V floats) = 1280 B at V = 64, i.e. 10 KiB
+// per wave at G = 8 -> 16 waves per CU, all 4096 waves of a 32768-game launch resident at once.
+#pragma once
+#include "agz_tree_grp.hpp"
+
+namespace agz {
+
+enum { DPP_SHR1 = 0x111, DPP_SHL4 = 0x104, DPP_SHL8 = 0x108, DPP_QUAD_B3 = 0xFF, DPP_QUAD_B13 = 0xF5 };
+
+// value held by the LAST lane of the group, in every lane
+template <int G> __device__ __forceinline__ float grp_bcast_last(float xf) {
+    int x = __float_as_int(xf);
+    if (G == 2) x = dpp_mov<DPP_QUAD_B13, 0xF>(x, x);
+    if (G == 16) x = dpp_mov<DPP_SHL8, 0x3>(x, x);            // lanes 0..7 <- lanes 8..15
+    if (G >= 8) x = dpp_mov<DPP_SHL4, 0x5>(x, x);             // lanes 0..3 (8..11) <- lanes 4..7 (12..15)
+    if (G >= 4) x = dpp_mov<DPP_QUAD_B3, 0xF>(x, x);
+    return __int_as_float(x);
+}
+__device__ __forceinline__ float lane_shr1(float x) { return __int_as_float(dpp_mov<DPP_SHR1, 0xF>(__float_as_int(x), __float_as_int(x))); }
+
+// Source-order sum of the group's G*KPL values (lane sub holds block sub).  Returns the total in every lane and
+// leaves in `start` the running sum BEFORE the lane's own block (its correct starting value).
+template <int G, int KPL>
+__device__ __forceinline__ float grp_ordered_sum(const float (&x)[KPL], int sub, float& start) {
+    float a = 0.0f, st = 0.0f;
+#pragma unroll
+    for (int t = 0; t < G; ++t) {
+        const float carry = lane_shr1(a);                       // what the previous lane ended with
+        const float s0 = sub == 0 ? 0.0f : carry;
+        if (sub == t) st = s0;
+        a = s0;
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) a += x[j];                // only lane t's result is final in turn t
+    }
+    start = st;
+    return grp_bcast_last<G>(a);
+}
+
+struct RegLds { int meta, tabp, tabq, ct, cu, stride; };
+__host__ __device__ inline RegLds reg_lds_layout(int V) {
+    RegLds o;
+    auto up16 = [](int x) { return (x + 15) & ~15; };
+    o.meta = 0;
+    o.tabp = up16(V * 4);                                       // child table: prior / q by child node id; compacted in place
+    o.tabq = o.tabp + up16(V * 4);
+    o.ct = o.tabq + up16(V * 4);                                // Newton terms (index 0 = the prior_rem term)
+    o.cu = o.ct + up16(V * 4);
+    o.stride = o.cu + up16(V * 4);
+    return o;
+}
+
+template <int FAM, int NC, int G, int KPL>
+__global__ __launch_bounds__(64, 4) void k_rollout_reg(const TreePar T) {
+    using GM = Game<FAM, NC>;
+    constexpr bool REV = FAM == F_REV;
+    constexpr int NG = 64 / G;
+    constexpr int AP = G * KPL;                                  // padded row length (== T.A2)
+    static_assert(KPL % 4 == 0, "block of actions per lane must be a multiple of 4");
+    const GamePar& P = T.G;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int lane = lane_id(), g = lane / G, sub = lane % G;
+    const int slot = (int)blockIdx.x * NG + g;
+    const bool live = slot < T.L;
+    const bool lead = sub == 0;
+    const int A = P.A, V = T.V, ROWS = (int)T.rec_bytes;
+    const RegLds LO = reg_lds_layout(V);
+    uint8_t* const mine = lds + (size_t)g * LO.stride;
+    uint32_t* const mymeta = reinterpret_cast<uint32_t*>(mine + LO.meta);
+    float* const tabp = reinterpret_cast<float*>(mine + LO.tabp);
+    float* const tabq = reinterpret_cast<float*>(mine + LO.tabq);
+    float* const ct = reinterpret_cast<float*>(mine + LO.ct);
+    float* const cu = reinterpret_cast<float*>(mine + LO.cu);
+    const int sl = live ? slot : 0;
+    uint8_t* const myrecs = T.recs + (size_t)sl * V * ROWS;
+    Pos* const mystates = T.states + (size_t)sl * V;
+    const uint32_t gbits_shift = (uint32_t)(g * G);
+    const uint64_t gmask = G == 64 ? ~0ull : (((1ull << G) - 1ull) << gbits_shift);
+    const int k0 = sub * KPL;                                    // first action of this lane's block
+#ifdef AGZ_STAMPS
+    unsigned long long stamp_acc[16]; for (int i = 0; i < 16; ++i) stamp_acc[i] = 0;
+    unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
+#endif
+
+    // ---- stage the meta rows of the wave's games (coalesced) ------------------------------------------
+    uint32_t ncount = 1, leafn = 0;
+    if (T.do_reset) {
+        if (lead) mymeta[0] = M_EXISTS;
+    } else {
+        for (int j = 0; j < NG; ++j) {
+            const int sj = (int)blockIdx.x * NG + j;
+            if (sj >= T.L) break;
+            uint32_t* dm = reinterpret_cast<uint32_t*>(lds + (size_t)j * LO.stride + LO.meta);
+            for (int c = lane; c < V; c += 64) dm[c] = T.meta[(size_t)sj * V + c];
+        }
+        if (live) { ncount = T.ncount[slot]; leafn = T.leaf[slot]; }
+    }
+    AGZ_WSYNC();
+    STAMP(0);
+    uint32_t add_p = 0, add_new = 0;
+
+    // =============================================================================================
+    // expand (mcts_gpu.jl:250-302) + backUp (:306-328) of the previous rollout's leaf
+    // =============================================================================================
+    if (T.do_expand) {
+        const int lf = (int)leafn;
+        uint32_t ml = live ? mymeta[lf] : (uint32_t)M_TERM;
+        const bool term = (ml & M_TERM) != 0;
+        const bool doexp = live && !term;
+        float vleaf = 0.0f;
+        if (doexp) {
+            vleaf = T.v_eval[slot];
+            const WPos<NC> st = grp_load_pos<NC, REV>(mystates + lf);
+            float x[KPL];
+            const float* src = T.inject ? T.prior_eval + (size_t)slot * A : T.logits + (size_t)slot * T.LGS;
+#pragma unroll
+            for (int j = 0; j < KPL; ++j) x[j] = (k0 + j < A) ? src[k0 + j] : (T.inject ? 0.0f : -__builtin_inff());
+            if (!T.inject) {                                          // softmax!(prior) (:417), source-order sum
+                float mx = -__builtin_inff();
+#pragma unroll
+                for (int j = 0; j < KPL; ++j) mx = x[j] > mx ? x[j] : mx;
+                mx = grp_max<G>(mx);
+#pragma unroll
+                for (int j = 0; j < KPL; ++j) x[j] = (k0 + j < A) ? (T.exact ? exp_spec(x[j] - mx) : __expf(x[j] - mx)) : 0.0f;
+                float st0;
+                const float s = grp_ordered_sum<G, KPL>(x, sub, st0);
+#pragma unroll
+                for (int j = 0; j < KPL; ++j) {
+                    x[j] = x[j] / s;
+                    if (T.capture && k0 + j < A) T.prior_eval[(size_t)slot * A + k0 + j] = x[j];
+                }
+            }
+            bool lg[KPL]; int nl = 0;                                 // legal mask; masked priors (:260-268 / :284-290)
+#pragma unroll
+            for (int j = 0; j < KPL; ++j) {
+                lg[j] = (k0 + j < A) && GM::canPlay(P, st, k0 + j);
+                x[j] = lg[j] ? x[j] : 0.0f;
+                nl += lg[j] ? 1 : 0;
+            }
+            nl = grp_sum<G>(nl);
+            float st1;
+            const float normalize = grp_ordered_sum<G, KPL>(x, sub, st1);
+            const bool rootmix = lf == 0 && T.training;               // :270-275 vs :277-279, :292-294
+            const float Af = (float)nl;
+            uint8_t* rec = myrecs + (size_t)lf * ROWS;
+#pragma unroll
+            for (int j = 0; j < KPL; ++j) {
+                float pr = rootmix ? (lg[j] ? 0.75f * x[j] / normalize + 0.25f / Af : 0.0f) : x[j] / normalize;
+                if (k0 + j >= A) pr = 0.0f;
+                x[j] = pr;
+                if (lf == 0 && k0 + j < A) T.policy_final[(size_t)slot * A + k0 + j] = pr;
+            }
+#pragma unroll
+            for (int j = 0; j < KPL; j += 4) {
+                *reinterpret_cast<float4*>(rec + (size_t)(k0 + j) * 4) = make_float4(x[j], x[j + 1], x[j + 2], x[j + 3]);
+                *reinterpret_cast<float4*>(rec + T.off_q + (size_t)(k0 + j) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<uint2*>(rec + T.off_vc + (size_t)(k0 + j) * 2) = make_uint2(0u, 0u);
+            }
+            ml |= M_EXPANDED;                                         // :256
+            if (lead) mymeta[lf] = ml;
+        } else if (live && lf == 0) {
+#pragma unroll
+            for (int j = 0; j < KPL; ++j) if (k0 + j < A) T.policy_final[(size_t)slot * A + k0 + j] = 0.0f;   // terminal root
+        }
+        STAMP(2);
+        // ---- backUp (:306-328): the group walks the path together, lane (i mod G) updates ancestor i
+        if (live) {
+            const int tv2 = (int)((ml >> M_TV_SHIFT) & 3u);
+            float valf = vleaf; double vald = 0.5 * (double)tv2;
+            int cur = lf; uint32_t mcur = ml; int i = 0;
+            while (cur != 0) {
+                const int par = (int)(mcur & 0xffu), mv = (int)((mcur >> 8) & 0xffu);
+                if ((i % G) == sub) {
+                    uint8_t* rec = myrecs + (size_t)par * ROWS;
+                    float* qp = reinterpret_cast<float*>(rec + T.off_q) + mv;
+                    uint16_t* vp = reinterpret_cast<uint16_t*>(rec + T.off_vc) + mv;
+                    const float q = *qp; const uint32_t vc = *vp;
+                    const float vis = (float)(vc & 0xffu);
+                    float nq;
+                    if (term) nq = (float)(((double)(vis * q) + (1.0 - vald)) / (double)(vis + 1.0f));
+                    else nq = (vis * q + (1.0f - valf)) / (vis + 1.0f);                  // :319
+                    *qp = nq;
+                    *vp = (uint16_t)(vc + 1u);                                           // :320
+                }
+                valf = 1.0f - valf; vald = 1.0 - vald;                                   // :324
+                mcur = mymeta[par];
+                if (lead) mymeta[par] = mcur | M_STALE;                                  // :321 uptodate = 0
+                cur = par; ++i;
+            }
+        }
+        STAMP(4);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        AGZ_WSYNC();
+        STAMP(5);
+    }
+
+    // =============================================================================================
+    // kdescendTree! (mcts_gpu.jl:100-199) + decoder (:202-223)
+    // =============================================================================================
+    if (T.do_select) {
+        const uint32_t gid = live ? T.game_id[slot] : 0u;
+        int node = 0, depth = 0;
+        uint32_t mn = live ? mymeta[0] : 0u;
+        WPos<NC> lst; bool have_state = false;
+        for (int i = 0; i < NC; ++i) { lst.p.c[i] = 0; lst.o.c[i] = 0; lst.lg.c[i] = 0; }
+        lst.player = 1; lst.aux = 0;
+        bool descending = live && (mn & M_EXPANDED);
+        int create_from = -1, create_move = 0; uint32_t create_vc = 0;
+        float uq[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+        while (__ballot(descending)) {
+            if (descending) {
+                if (lead) ++add_p;
+                // ---- this lane's block of the node row, straight from HBM
+                const uint8_t* rec = myrecs + (size_t)node * ROWS;
+                float p[KPL], q[KPL]; uint32_t vw[KPL / 2];                // vw[j] = vc[2j] | vc[2j+1] << 16
+#pragma unroll
+                for (int j = 0; j < KPL; j += 4) {
+                    const float4 a = *reinterpret_cast<const float4*>(rec + (size_t)(k0 + j) * 4);
+                    p[j] = a.x; p[j + 1] = a.y; p[j + 2] = a.z; p[j + 3] = a.w;
+                    const uint2 c = *reinterpret_cast<const uint2*>(rec + T.off_vc + (size_t)(k0 + j) * 2);
+                    vw[j / 2] = c.x; vw[j / 2 + 1] = c.y;
+                }
+                const bool stale = (mn & M_STALE) != 0;
+                if (stale) {
+#pragma unroll
+                    for (int j = 0; j < KPL; j += 4) {
+                        const float4 b = *reinterpret_cast<const float4*>(rec + T.off_q + (size_t)(k0 + j) * 4);
+                        q[j] = b.x; q[j + 1] = b.y; q[j + 2] = b.z; q[j + 3] = b.w;
+                    }
+                }
+                if ((depth & 3) == 0) uniform_search4(T.seed, gid, T.step, T.rollout, (uint32_t)depth >> 2, uq);   // overlaps the loads
+                const int uw = depth & 3;
+                const float u = uw == 0 ? uq[0] : (uw == 1 ? uq[1] : (uw == 2 ? uq[2] : uq[3]));
+                STAMP(7);
+                float alpha = 0.0f, lambda = 0.0f;
+                float pol[KPL];
+                if (stale) {                                               // :114
+                    int vs = 0, ac = 0; float m[KPL];                      // :120-131
+#pragma unroll
+                    for (int j = 0; j < KPL; ++j) {
+                        const uint32_t c = (j & 1) ? (vw[j / 2] >> 16) : (vw[j / 2] & 0xffffu);
+                        vs += (int)(c & 0xffu);
+                        ac += p[j] > 0.0f ? 1 : 0;
+                        const uint32_t ch = c >> 8;
+                        m[j] = ch == 0 ? p[j] : 0.0f;                      // prior of childless actions, +0 otherwise (exact)
+                        if (ch != 0) { tabp[ch] = p[j]; tabq[ch] = q[j]; } // child table by child node id
+                    }
+                    vs = grp_sum<G>(vs); ac = grp_sum<G>(ac);
+                    const float nf = 1.0f + (float)vs, Af = (float)ac;
+                    float st0;
+                    float prior_rem = grp_ordered_sum<G, KPL>(m, sub, st0);   // ordered (:122-124)
+                    lambda = T.cpuct * __builtin_sqrtf(nf) / (Af + nf);    // :132
+                    prior_rem *= lambda;                                    // :134
+                    float am = 0.0f;                                        // :133-138
+#pragma unroll
+                    for (int j = 0; j < KPL; ++j) {
+                        const float lp = lambda * p[j];
+                        const float gap = lp > 1e-4f ? lp : 1e-4f;
+                        const float c = q[j] + gap;
+                        am = c > am ? c : am;
+                    }
+                    alpha = grp_max<G>(am);
+                    STAMP(8);
+                    // children in creation order = nodes i with parent(i) == node, ascending i (:144-146); compact the table in place
+                    AGZ_WSYNC();
+                    int nch = 0;
+                    for (int base = 1; base < (int)ncount; base += 8 * G) {
+                        uint32_t mi[8]; float tp[8], tq[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int i = base + G * j + sub;
+                            mi[j] = i < (int)ncount ? mymeta[i] : 0xffffffffu;
+                            tp[j] = i < (int)ncount ? tabp[i] : 0.0f; tq[j] = i < (int)ncount ? tabq[i] : 0.0f;
+                        }
+                        AGZ_WSYNC();                                       // all reads of this batch precede its writes
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int i = base + G * j + sub;
+                            const bool isc = i < (int)ncount && (int)(mi[j] & 0xffu) == node;
+                            const uint32_t bits = (uint32_t)((__ballot(isc) & gmask) >> gbits_shift);
+                            if (isc) {
+                                const int pos = nch + __popc(bits & ((1u << sub) - 1u));   // pos < i: never an unread entry
+                                tabp[pos] = tp[j]; tabq[pos] = tq[j];
+                            }
+                            nch += __popc(bits);
+                        }
+                        AGZ_WSYNC();
+                    }
+                    STAMP(9);
+                    float err = __builtin_inff();
+                    for (int it = 0; it < 100; ++it) {                     // :141-162
+                        for (int c = sub; c <= nch; c += G) {
+                            float top = prior_rem, qv = 0.0f;              // c == 0: S = prior_rem/alpha, g = -prior_rem/alpha^2
+                            if (c > 0) { top = lambda * tabp[c - 1]; qv = tabq[c - 1]; }   // :147-148
+                            const float bot = alpha - qv;
+                            ct[c] = top / bot;
+                            cu[c] = -top / (bot * bot);
+                        }
+                        AGZ_WSYNC();
+                        float S = 0.0f, gg = 0.0f;
+                        if (lead) {
+                            S = ct[0]; gg = cu[0];
+                            for (int c0 = 1; c0 <= nch; c0 += 4) {
+                                float tv[4], uv[4];
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) { tv[j] = c0 + j <= nch ? ct[c0 + j] : 0.0f; uv[j] = c0 + j <= nch ? cu[c0 + j] : 0.0f; }
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) { S += tv[j]; gg += uv[j]; }
+                            }
+                        }
+                        S = grp_bcast<G>(S); gg = grp_bcast<G>(gg);
+                        AGZ_WSYNC();
+                        const float newerr = S - 1.0f;
+                        if (newerr < 0.001f || newerr == err) break;
+                        alpha -= newerr / gg;
+                        err = newerr;
+                    }
+                    STAMP(10);
+#pragma unroll
+                    for (int j = 0; j < KPL; ++j) pol[j] = lambda * p[j] / (alpha - q[j]);   // :165-169
+                } else {
+#pragma unroll
+                    for (int j = 0; j < KPL; ++j) pol[j] = p[j];           // policy == prior since expand (:297-299)
+                }
+                if (node == 0 && T.last) {                                 // copy_pol (:330-339) of the last descent
+#pragma unroll
+                    for (int j = 0; j < KPL; ++j) if (k0 + j < A) T.policy_final[(size_t)slot * A + k0 + j] = pol[j];
+                }
+                STAMP(11);
+                // ---- sample (:172-182): ordered prefix by turns, then every lane re-derives its own prefixes
+                float st0;
+                (void)grp_ordered_sum<G, KPL>(pol, sub, st0);
+                int jhit = KPL, jpos = -1;                                 // first j with prefix >= u ; last j <= jhit with policy > 0
+                {
+                    float a = st0;
+#pragma unroll
+                    for (int j = 0; j < KPL; ++j) {
+                        a += pol[j];
+                        if (jhit == KPL) { if (pol[j] > 0.0f) jpos = j; if (a >= u) jhit = j; }
+                    }
+                }
+                const uint32_t hitbits = (uint32_t)((__ballot(jhit < KPL) & gmask) >> gbits_shift);
+                const int hl = hitbits ? __builtin_ctz(hitbits) : G;       // first lane of the group whose block crosses u
+                // bestmove = last positive action at or before the crossing (whole row if there is no crossing)
+                int cand = (sub <= hl && jpos >= 0) ? k0 + jpos : -1;
+                if (G > 1) {
+                    int y;
+                    if (G >= 2) { y = dpp_mov<DPP_XOR1, 0xF>(-1, cand); cand = y > cand ? y : cand; }
+                    if (G >= 4) { y = dpp_mov<DPP_XOR2, 0xF>(-1, cand); cand = y > cand ? y : cand; }
+                    if (G >= 8) { y = dpp_mov<DPP_HALF_MIRROR, 0xF>(-1, cand); cand = y > cand ? y : cand; }
+                    if (G >= 16) { y = dpp_mov<DPP_MIRROR, 0xF>(-1, cand); cand = y > cand ? y : cand; }
+                }
+                const int bestmove = cand;
+                STAMP(13);
+                if (bestmove < 0) {
+                    descending = false;                                    // reference would index [-1]; leaf = node
+                } else {
+                    // child id of bestmove: the owning lane looks it up in its block
+                    int cv = 0;
+#pragma unroll
+                    for (int j = 0; j < KPL; ++j) {
+                        const uint32_t c = (j & 1) ? (vw[j / 2] >> 16) : (vw[j / 2] & 0xffffu);
+                        cv = (k0 + j == bestmove) ? (int)c : cv;
+                    }
+                    cv = grp_sum<G>(cv);
+                    const uint32_t child = (uint32_t)cv >> 8;
+                    if (child == 0) {                                      // :183-191: a new child is never expanded -> descent ends
+                        create_from = node; create_move = bestmove; create_vc = (uint32_t)cv;
+                        descending = false;
+                    } else {
+                        mn = mymeta[child];
+                        node = (int)child;                                 // :192
+                        descending = (mn & M_EXPANDED) != 0;
+                    }
+                    ++depth;
+                }
+            }
+            AGZ_WSYNC();
+            STAMP(12);
+        }
+        if (live && create_from >= 0) {                                    // :183-191 node creation (at most one per rollout)
+            const uint32_t child = ncount; ncount += 1;
+            const WPos<NC> ps = grp_load_pos<NC, REV>(mystates + create_from);
+            lst = GM::play(P, ps, create_move);
+            have_state = true;
+            int rr; const bool f = GM::isOver(P, lst, rr);
+            uint32_t mc = (uint32_t)create_from | ((uint32_t)create_move << 8) | M_EXISTS | M_EVAL;
+            if (f) mc |= M_TERM | ((uint32_t)(1 + lst.player * rr) << M_TV_SHIFT);
+            if (lead) {
+                ++add_new;
+                reinterpret_cast<uint16_t*>(myrecs + (size_t)create_from * ROWS + T.off_vc)[create_move] = (uint16_t)(create_vc | (child << 8));
+                mystates[child] = pack(lst);
+                mymeta[child] = mc;
+            }
+            mn = mc; node = (int)child;
+        }
+        if (live) {
+            if (!(mn & M_EVAL)) {                                           // root on the first rollout
+                lst = grp_load_pos<NC, REV>(mystates + node); have_state = true;
+                int rr; const bool f = GM::isOver(P, lst, rr);
+                mn |= M_EVAL;
+                if (f) mn |= M_TERM | ((uint32_t)(1 + lst.player * rr) << M_TV_SHIFT);
+                if (lead) mymeta[node] = mn;
+            }
+            if (!have_state) lst = grp_load_pos<NC, REV>(mystates + node);
+            // decoder (:202-223): 8 planes (16 bytes of bf16, or 32 of fp32) per store, chunks dealt round-robin to the group
+            for (int j0 = 8 * sub; j0 < T.INP; j0 += 8 * G) {
+                uint32_t w[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int j = j0 + e;
+                    bool bit = false;
+                    if (j < P.VS) bit = bb_get(lst.p, j);
+                    else if (j < 2 * P.VS) bit = bb_get(lst.o, j - P.VS);
+                    w[e] = bit ? 1u : 0u;
+                }
+                if (T.planes_f32) {
+                    float4* d = reinterpret_cast<float4*>(reinterpret_cast<float*>(T.planes) + (size_t)slot * T.INP + j0);
+                    d[0] = make_float4((float)w[0], (float)w[1], (float)w[2], (float)w[3]);
+                    d[1] = make_float4((float)w[4], (float)w[5], (float)w[6], (float)w[7]);
+                } else {
+                    uint4 o;
+                    o.x = (w[0] ? 0x3F80u : 0u) | (w[1] ? 0x3F800000u : 0u); o.y = (w[2] ? 0x3F80u : 0u) | (w[3] ? 0x3F800000u : 0u);
+                    o.z = (w[4] ? 0x3F80u : 0u) | (w[5] ? 0x3F800000u : 0u); o.w = (w[6] ? 0x3F80u : 0u) | (w[7] ? 0x3F800000u : 0u);
+                    *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(T.planes) + (size_t)slot * T.INP + j0) = o;
+                }
+            }
+            leafn = (uint32_t)node;
+        }
+    }
+
+    STAMP(14);
+    // ---- write back bookkeeping ---------------------------------------------------------------------
+    AGZ_WSYNC();
+    for (int j = 0; j < NG; ++j) {
+        const int sj = (int)blockIdx.x * NG + j;
+        if (sj >= T.L) break;
+        const int nj = (int)rdlane(ncount, j * G);
+        const uint32_t* sm = reinterpret_cast<const uint32_t*>(lds + (size_t)j * LO.stride + LO.meta);
+        for (int c = lane; c < nj; c += 64) T.meta[(size_t)sj * V + c] = sm[c];
+    }
+    if (live && lead) {
+        T.ncount[slot] = ncount;
+        T.leaf[slot] = leafn;
+        if (T.do_reset) { T.cnt_p[slot] = add_p; T.cnt_new[slot] = add_new; }
+        else { T.cnt_p[slot] += add_p; T.cnt_new[slot] += add_new; }
+    }
+#ifdef AGZ_STAMPS
+    STAMP(15);
+    if (lane == 0 && T.dbg) for (int i = 0; i < 16; ++i) T.dbg[(size_t)blockIdx.x * 16 + i] += stamp_acc[i];
+#endif
+    (void)AP;
+}
+
+}  // namespace agz
