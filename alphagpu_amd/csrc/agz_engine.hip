@@ -82,7 +82,7 @@ struct agz_engine {
     size_t ev_tree_used = 0, ev_nn_used = 0;
     double tree_ms = 0, nn_ms = 0; int64_t tree_launches = 0;
     rollout_fn k_roll = nullptr; advance_fn k_adv = nullptr; softmax_fn k_soft = nullptr;
-    rollout_fn k_reg = nullptr; size_t reg_lds = 0; int reg_kpl = 0;   // register-row kernel (agz_tree_reg.hpp), 8 lanes per tree
+    rollout_fn k_reg = nullptr; size_t reg_lds = 0; int reg_kpl = 0, reg_g = 8;   // register-row kernel (agz_tree_reg.hpp), 8 lanes per tree
     rollout_fn k_lpg = nullptr; size_t lpg_lds = 0; int grp_g = 16;   // group kernel (agz_tree_grp.hpp): G lanes per tree; lpg_lds == 0 -> wave-per-tree kernel
 
     int fail(const char* fmt, ...) {
@@ -122,6 +122,9 @@ static bool bind_kernels(agz_engine* h) {
         Z(F_HEX, 1, 4) Z(F_HEX, 1, 8) Z(F_HEX, 2, 8) Z(F_HEX, 2, 12) Z(F_HEX, 2, 16) Z(F_HEX, 3, 16) Z(F_HEX, 3, 24)
         Z(F_REV, 1, 12) Z(F_REV, 1, 8)
 #undef Z
+        { const char* eg = getenv("AGZ_REG_G");     // experiment: 4 lanes per tree (Gobang 9x9 / Hex 9x9 shapes only)
+          if (eg && atoi(eg) == 4 && P.fam == F_LINE && P.NC == 2 && kpl == 12) { h->k_reg = k_rollout_reg<F_LINE, 2, 4, 24>; h->reg_kpl = 24; h->reg_g = 4; }
+          if (eg && atoi(eg) == 16 && P.fam == F_LINE && P.NC == 2 && kpl == 12) { h->k_reg = k_rollout_reg<F_LINE, 2, 16, 8>; h->reg_kpl = 8; h->reg_g = 16; } }
     }
     if (P.NR == 1) h->k_soft = k_softmax<1>; else if (P.NR == 2) h->k_soft = k_softmax<2>; else h->k_soft = k_softmax<3>;
     return h->k_roll != nullptr;
@@ -219,10 +222,13 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     // per-lane 16-B reads (agz_tree_lpg.hpp)
     const char* tk = getenv("AGZ_TREE_KERNEL");
     const bool want_reg = h->k_reg && !(tk && (!strcmp(tk, "v1") || !strcmp(tk, "grp")));
-    h->reg_lds = want_reg ? (size_t)8 * reg_lds_layout(h->V).stride : 0;
+    h->reg_lds = want_reg ? (size_t)(64 / h->reg_g) * reg_lds_layout(h->V).stride : 0;
+#ifdef AGZ_STAMPS
+    if (h->reg_lds) h->reg_lds += 256;
+#endif
     if (h->reg_lds > 160 * 1024) h->reg_lds = 0;
     // row length: the register-row kernel gives each of its 8 lanes a block of KPL actions
-    const uint32_t A2 = h->reg_lds ? (uint32_t)(8 * h->reg_kpl) : (uint32_t)round_up(P.A, 4);
+    const uint32_t A2 = h->reg_lds ? (uint32_t)(h->reg_g * h->reg_kpl) : (uint32_t)round_up(P.A, 4);
     uint32_t rec_bytes = (uint32_t)round_up((int)(A2 * 10), 16);
     if (((rec_bytes / 16) & 1u) == 0) rec_bytes += 16;
     h->lpg_lds = (size_t)(64 / h->grp_g) * grp_lds_layout((int)rec_bytes, (int)A2, h->V).stride;
@@ -439,7 +445,7 @@ static int launch_rollout(agz_engine* h, uint32_t rollout, int do_reset, int do_
     T.L = h->L; T.step = h->step; T.rollout = rollout; T.cpuct = h->cpuct; T.training = h->training;
     T.do_reset = do_reset; T.do_expand = do_expand; T.do_select = do_select; T.last = last; T.inject = inject; T.capture = capture;
     const bool reg = h->reg_lds != 0, lpg = !reg && h->lpg_lds != 0;
-    const int ng = reg ? 8 : 64 / h->grp_g;
+    const int ng = reg ? 64 / h->reg_g : 64 / h->grp_g;
     dim3 grid((unsigned)((reg || lpg) ? (h->L + ng - 1) / ng : (h->L + 3) / 4)), block((reg || lpg) ? 64 : 256);
     std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
     if (h->profiling & 1) { ev = next_events(h, h->ev_tree, h->ev_tree_used); hipEventRecord(ev->first, h->stream); }

@@ -18,7 +18,10 @@
 namespace agz {
 
 #ifdef AGZ_STAMPS
-#define STAMP(i) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp_acc[i] += t_ - stamp_last; stamp_last = t_; } while (0)
+// diagnostic builds only: per-phase cycle sums kept in LDS (stamp_lds[0..15] sums, [16] last time stamp) and updated by the
+// first ACTIVE lane, so that the attribution is right inside divergent code as well
+#define STAMP(i) do { unsigned long long t_ = __builtin_amdgcn_s_memtime();                                   \
+                      if (lane_id() == (int)__builtin_ctzll(__ballot(1))) { stamp_lds[i] += t_ - stamp_lds[16]; stamp_lds[16] = t_; } } while (0)
 #else
 #define STAMP(i) do { } while (0)
 #endif
@@ -158,10 +161,6 @@ __global__ __launch_bounds__(64, G >= 16 ? 4 : (G >= 8 ? 2 : 1)) void k_rollout_
     const uint32_t gbits_shift = (uint32_t)(g * G);
     const uint64_t gmask = G == 64 ? ~0ull : (((1ull << G) - 1ull) << gbits_shift);
 
-#ifdef AGZ_STAMPS
-    unsigned long long stamp_acc[16]; for (int i = 0; i < 16; ++i) stamp_acc[i] = 0;
-    unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
-#endif
     // ---- stage the meta rows of the wave's games (coalesced) ------------------------------------------
     uint32_t ncount = 1, leafn = 0;
     if (T.do_reset) {
@@ -176,7 +175,6 @@ __global__ __launch_bounds__(64, G >= 16 ? 4 : (G >= 8 ? 2 : 1)) void k_rollout_
         if (live) { ncount = T.ncount[slot]; leafn = T.leaf[slot]; }
     }
     AGZ_WSYNC();
-    STAMP(0);
     uint32_t add_p = 0, add_new = 0;
 
     // =============================================================================================
@@ -190,7 +188,6 @@ __global__ __launch_bounds__(64, G >= 16 ? 4 : (G >= 8 ? 2 : 1)) void k_rollout_
         const int inbytes = (A * 4 + 15) & ~15;
         if (T.inject) grp_gather<G>(__ballot(doexp && lead), reinterpret_cast<const uint8_t*>(T.prior_eval + (size_t)sl * A), lds, LO.stride, LO.row, inbytes);
         else grp_gather<G>(__ballot(doexp && lead), reinterpret_cast<const uint8_t*>(T.logits + (size_t)sl * T.LGS), lds, LO.stride, LO.row, inbytes);
-        STAMP(1);
         float vleaf = 0.0f;
         if (doexp) {
             vleaf = T.v_eval[slot];
@@ -236,9 +233,7 @@ __global__ __launch_bounds__(64, G >= 16 ? 4 : (G >= 8 ? 2 : 1)) void k_rollout_
             for (int k = sub; k < A; k += G) T.policy_final[(size_t)slot * A + k] = 0.0f;   // terminal root
         }
         AGZ_WSYNC();
-        STAMP(2);
         grp_scatter<G>(__ballot(doexp && lead), myrecs + (size_t)lf * ROWS, lds, LO.stride, LO.row, ROWS);
-        STAMP(3);
         // ---- backUp (:306-328): the group walks the path together, lane (i mod G) updates ancestor i
         if (live) {
             const int tv2 = (int)((ml >> M_TV_SHIFT) & 3u);
@@ -264,11 +259,9 @@ __global__ __launch_bounds__(64, G >= 16 ? 4 : (G >= 8 ? 2 : 1)) void k_rollout_
                 cur = par; ++i;
             }
         }
-        STAMP(4);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         AGZ_WSYNC();
-        STAMP(5);
     }
 
     // =============================================================================================
@@ -289,9 +282,7 @@ __global__ __launch_bounds__(64, G >= 16 ? 4 : (G >= 8 ? 2 : 1)) void k_rollout_
             if ((depth & 3) == 0) uniform_search4(T.seed, gid, T.step, T.rollout, (uint32_t)depth >> 2, uq);   // independent of the rows: overlaps the DMA
             const int uw = depth & 3;
             const float u = uw == 0 ? uq[0] : (uw == 1 ? uq[1] : (uw == 2 ? uq[2] : uq[3]));
-            STAMP(6);
             grp_gather<G>(dmask, myrecs + (size_t)node * ROWS, lds, LO.stride, LO.row, ROWS);
-            STAMP(7);
             if (descending) {
                 if (lead) ++add_p;
                 float alpha = 0.0f, lambda = 0.0f;
@@ -328,7 +319,6 @@ __global__ __launch_bounds__(64, G >= 16 ? 4 : (G >= 8 ? 2 : 1)) void k_rollout_
                         lp = lambda * p4.w; gap = lp > 1e-4f ? lp : 1e-4f; c = q4.w + gap; am = c > am ? c : am;
                     }
                     alpha = grp_max<G>(am);
-                    STAMP(8);
                     // children in creation order = nodes i with parent(i) == node, ascending i (:144-146)
                     int nch = 0;
                     for (int base = 1; base < (int)ncount; base += 8 * G) {
@@ -349,7 +339,6 @@ __global__ __launch_bounds__(64, G >= 16 ? 4 : (G >= 8 ? 2 : 1)) void k_rollout_
                         }
                     }
                     AGZ_WSYNC();
-                    STAMP(9);
                     float err = __builtin_inff();
                     for (int j = 0; j < 100; ++j) {                        // :141-162
                         for (int c = sub; c <= nch; c += G) {
@@ -379,7 +368,6 @@ __global__ __launch_bounds__(64, G >= 16 ? 4 : (G >= 8 ? 2 : 1)) void k_rollout_
                         err = newerr;
                     }
                 }
-                STAMP(10);
                 // policy row (:165-169, or the prior while the node is up to date)
                 const bool wr_final = node == 0 && T.last;                 // copy_pol (:330-339) of the last descent
                 for (int k = 4 * sub; k < A4; k += 4 * G) {
@@ -399,7 +387,6 @@ __global__ __launch_bounds__(64, G >= 16 ? 4 : (G >= 8 ? 2 : 1)) void k_rollout_
                     }
                 }
                 AGZ_WSYNC();
-                STAMP(11);
                 // ---- sample (:172-182), ordered prefix on the group's lane 0
                 int bestmove = -1;
                 if (lead) {
@@ -421,12 +408,10 @@ __global__ __launch_bounds__(64, G >= 16 ? 4 : (G >= 8 ? 2 : 1)) void k_rollout_
                             kb = k0 + f;
                         }
                     }
-                    STAMP(15);
                     if (kb > A4 - 1) kb = A4 - 1;
                     int k = kb;                                             // bestmove = last k' <= kb with policy > 0
                     for (; k >= 0; --k) if (pol[k] > 0.0f) { bestmove = k; break; }
                 }
-                STAMP(13);
                 bestmove = grp_bcast<G>(bestmove);
                 if (bestmove < 0) {
                     descending = false;                                    // reference would index [-1]; leaf = node
@@ -445,7 +430,6 @@ __global__ __launch_bounds__(64, G >= 16 ? 4 : (G >= 8 ? 2 : 1)) void k_rollout_
                 }
             }
             AGZ_WSYNC();
-            STAMP(12);
             dmask = __ballot(descending && lead);
         }
         if (live && create_from >= 0) {                                    // :183-191 node creation (at most one per rollout)
@@ -498,8 +482,6 @@ __global__ __launch_bounds__(64, G >= 16 ? 4 : (G >= 8 ? 2 : 1)) void k_rollout_
             leafn = (uint32_t)node;
         }
     }
-
-    STAMP(13);
     // ---- write back bookkeeping ---------------------------------------------------------------------
     AGZ_WSYNC();
     for (int j = 0; j < NG; ++j) {
@@ -515,10 +497,6 @@ __global__ __launch_bounds__(64, G >= 16 ? 4 : (G >= 8 ? 2 : 1)) void k_rollout_
         if (T.do_reset) { T.cnt_p[slot] = add_p; T.cnt_new[slot] = add_new; }
         else { T.cnt_p[slot] += add_p; T.cnt_new[slot] += add_new; }
     }
-#ifdef AGZ_STAMPS
-    STAMP(14);
-    if (lane == 0 && T.dbg) for (int i = 0; i < 16; ++i) T.dbg[(size_t)blockIdx.x * 16 + i] += stamp_acc[i];   // one private row per workgroup
-#endif
 }
 
 }  // namespace agz

@@ -17,6 +17,9 @@
 
 namespace agz {
 
+#ifndef AGZ_REG_WAVES
+#define AGZ_REG_WAVES 4
+#endif
 enum { DPP_SHR1 = 0x111, DPP_SHL4 = 0x104, DPP_SHL8 = 0x108, DPP_QUAD_B3 = 0xFF, DPP_QUAD_B13 = 0xF5 };
 
 // value held by the LAST lane of the group, in every lane
@@ -62,7 +65,7 @@ __host__ __device__ inline RegLds reg_lds_layout(int V) {
 }
 
 template <int FAM, int NC, int G, int KPL>
-__global__ __launch_bounds__(64, 4) void k_rollout_reg(const TreePar T) {
+__global__ __launch_bounds__(64, G <= 4 ? 2 : AGZ_REG_WAVES) void k_rollout_reg(const TreePar T) {
     using GM = Game<FAM, NC>;
     constexpr bool REV = FAM == F_REV;
     constexpr int NG = 64 / G;
@@ -89,8 +92,8 @@ __global__ __launch_bounds__(64, 4) void k_rollout_reg(const TreePar T) {
     const uint64_t gmask = G == 64 ? ~0ull : (((1ull << G) - 1ull) << gbits_shift);
     const int k0 = sub * KPL;                                    // first action of this lane's block
 #ifdef AGZ_STAMPS
-    unsigned long long stamp_acc[16]; for (int i = 0; i < 16; ++i) stamp_acc[i] = 0;
-    unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
+    unsigned long long* const stamp_lds = reinterpret_cast<unsigned long long*>(lds + (size_t)NG * LO.stride);
+    if (lane < 17) stamp_lds[lane] = lane == 16 ? __builtin_amdgcn_s_memtime() : 0ull;
 #endif
 
     // ---- stage the meta rows of the wave's games (coalesced) ------------------------------------------
@@ -174,29 +177,34 @@ __global__ __launch_bounds__(64, 4) void k_rollout_reg(const TreePar T) {
             for (int j = 0; j < KPL; ++j) if (k0 + j < A) T.policy_final[(size_t)slot * A + k0 + j] = 0.0f;   // terminal root
         }
         STAMP(2);
-        // ---- backUp (:306-328): the group walks the path together, lane (i mod G) updates ancestor i
+        // ---- backUp (:306-328): the group walks the path together (meta words are in LDS) and lane (i mod G) takes
+        // ancestor i; the read-modify-writes of all ancestors are then issued at once, one memory latency per G levels.
         if (live) {
             const int tv2 = (int)((ml >> M_TV_SHIFT) & 3u);
             float valf = vleaf; double vald = 0.5 * (double)tv2;
-            int cur = lf; uint32_t mcur = ml; int i = 0;
+            int cur = lf; uint32_t mcur = ml;
             while (cur != 0) {
-                const int par = (int)(mcur & 0xffu), mv = (int)((mcur >> 8) & 0xffu);
-                if ((i % G) == sub) {
-                    uint8_t* rec = myrecs + (size_t)par * ROWS;
-                    float* qp = reinterpret_cast<float*>(rec + T.off_q) + mv;
-                    uint16_t* vp = reinterpret_cast<uint16_t*>(rec + T.off_vc) + mv;
+                int mypar = -1, mymv = 0; float myvf = 0.0f; double myvd = 0.0;
+                for (int i = 0; i < G && cur != 0; ++i) {
+                    const int par = (int)(mcur & 0xffu), mv = (int)((mcur >> 8) & 0xffu);
+                    if (i == sub) { mypar = par; mymv = mv; myvf = valf; myvd = vald; }
+                    valf = 1.0f - valf; vald = 1.0 - vald;                               // :324
+                    mcur = mymeta[par];
+                    if (lead) mymeta[par] = mcur | M_STALE;                              // :321 uptodate = 0
+                    cur = par;
+                }
+                if (mypar >= 0) {
+                    uint8_t* rec = myrecs + (size_t)mypar * ROWS;
+                    float* qp = reinterpret_cast<float*>(rec + T.off_q) + mymv;
+                    uint16_t* vp = reinterpret_cast<uint16_t*>(rec + T.off_vc) + mymv;
                     const float q = *qp; const uint32_t vc = *vp;
                     const float vis = (float)(vc & 0xffu);
                     float nq;
-                    if (term) nq = (float)(((double)(vis * q) + (1.0 - vald)) / (double)(vis + 1.0f));
-                    else nq = (vis * q + (1.0f - valf)) / (vis + 1.0f);                  // :319
+                    if (term) nq = (float)(((double)(vis * q) + (1.0 - myvd)) / (double)(vis + 1.0f));
+                    else nq = (vis * q + (1.0f - myvf)) / (vis + 1.0f);                  // :319
                     *qp = nq;
                     *vp = (uint16_t)(vc + 1u);                                           // :320
                 }
-                valf = 1.0f - valf; vald = 1.0 - vald;                                   // :324
-                mcur = mymeta[par];
-                if (lead) mymeta[par] = mcur | M_STALE;                                  // :321 uptodate = 0
-                cur = par; ++i;
             }
         }
         STAMP(4);
@@ -300,28 +308,47 @@ __global__ __launch_bounds__(64, 4) void k_rollout_reg(const TreePar T) {
                     }
                     STAMP(9);
                     float err = __builtin_inff();
+                    // element c of the Newton sums: c == 0 is the prior_rem term (S = prior_rem/alpha, g = -prior_rem/alpha^2,
+                    // :142-143), c = 1..nch the children in creation order (:144-151).  With nch < G there is one element per
+                    // lane and the ordered sums run lane to lane through DPP; otherwise through the LDS arrays ct / cu.
+                    const bool fast = nch < G;
+                    float top_l = 0.0f, qv_l = 0.0f;
+                    if (sub == 0) top_l = prior_rem;
+                    else if (sub <= nch && fast) { top_l = lambda * tabp[sub - 1]; qv_l = tabq[sub - 1]; }   // :147-148
                     for (int it = 0; it < 100; ++it) {                     // :141-162
-                        for (int c = sub; c <= nch; c += G) {
-                            float top = prior_rem, qv = 0.0f;              // c == 0: S = prior_rem/alpha, g = -prior_rem/alpha^2
-                            if (c > 0) { top = lambda * tabp[c - 1]; qv = tabq[c - 1]; }   // :147-148
-                            const float bot = alpha - qv;
-                            ct[c] = top / bot;
-                            cu[c] = -top / (bot * bot);
-                        }
-                        AGZ_WSYNC();
                         float S = 0.0f, gg = 0.0f;
-                        if (lead) {
-                            S = ct[0]; gg = cu[0];
-                            for (int c0 = 1; c0 <= nch; c0 += 4) {
-                                float tv[4], uv[4];
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) { tv[j] = c0 + j <= nch ? ct[c0 + j] : 0.0f; uv[j] = c0 + j <= nch ? cu[c0 + j] : 0.0f; }
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) { S += tv[j]; gg += uv[j]; }
+                        if (fast) {
+                            float t = 0.0f, uu = 0.0f;
+                            if (sub <= nch) { const float bot = alpha - qv_l; t = top_l / bot; uu = -top_l / (bot * bot); }
+                            float a = 0.0f, b = 0.0f;
+                            for (int tn = 0; tn <= nch; ++tn) {            // lane tn continues the sums of lane tn-1
+                                const float ca = lane_shr1(a), cb = lane_shr1(b);
+                                a = (sub == 0 ? 0.0f : ca) + t;
+                                b = (sub == 0 ? 0.0f : cb) + uu;
                             }
+                            S = __shfl(a, nch, G); gg = __shfl(b, nch, G);
+                        } else {
+                            for (int c = sub; c <= nch; c += G) {
+                                float top = prior_rem, qv = 0.0f;
+                                if (c > 0) { top = lambda * tabp[c - 1]; qv = tabq[c - 1]; }
+                                const float bot = alpha - qv;
+                                ct[c] = top / bot;
+                                cu[c] = -top / (bot * bot);
+                            }
+                            AGZ_WSYNC();
+                            if (lead) {
+                                S = ct[0]; gg = cu[0];
+                                for (int c0 = 1; c0 <= nch; c0 += 4) {
+                                    float tv[4], uv[4];
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) { tv[j] = c0 + j <= nch ? ct[c0 + j] : 0.0f; uv[j] = c0 + j <= nch ? cu[c0 + j] : 0.0f; }
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) { S += tv[j]; gg += uv[j]; }
+                                }
+                            }
+                            S = grp_bcast<G>(S); gg = grp_bcast<G>(gg);
+                            AGZ_WSYNC();
                         }
-                        S = grp_bcast<G>(S); gg = grp_bcast<G>(gg);
-                        AGZ_WSYNC();
                         const float newerr = S - 1.0f;
                         if (newerr < 0.001f || newerr == err) break;
                         alpha -= newerr / gg;
@@ -459,7 +486,7 @@ __global__ __launch_bounds__(64, 4) void k_rollout_reg(const TreePar T) {
     }
 #ifdef AGZ_STAMPS
     STAMP(15);
-    if (lane == 0 && T.dbg) for (int i = 0; i < 16; ++i) T.dbg[(size_t)blockIdx.x * 16 + i] += stamp_acc[i];
+    if (lane < 16 && T.dbg) T.dbg[(size_t)blockIdx.x * 16 + lane] += stamp_lds[lane];
 #endif
     (void)AP;
 }

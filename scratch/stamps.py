@@ -13,9 +13,9 @@ e.L.agz_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 e.L.agz_debug_stamps(e.h, out, 1)
 e.set_roots(None, L=L); e.search(V, cpuct=1.5, training=True, step=0); e.synchronize()
 e.L.agz_debug_stamps(e.h, out, 1)
-names = ['meta stage', 'logits gather', 'expand compute', 'scatter', 'backup', 'fence', 'round: philox', 'round: gather', 'round: stats/prior_rem/alpha0', 'round: child scan', 'round: newton', 'round: policy', 'round: sampling', 'tail: create+planes', 'writeback', '-']
+names = ['0 meta stage', '1 -', '2 expand', '3 -', '4 backup', '5 fence', '6 -', '7 round: row load+philox', '8 round: stats/prior_rem/alpha0', '9 round: child table compaction', '10 round: newton', '11 round: policy', '12 round: child lookup/end', '13 round: sampling', '14 tail: create+planes', '15 writeback']
 tot = sum(out)
-G = int(os.environ.get('AGZ_TREE_G', '8')); waves = (L * G // 64) * 65
+G = 8; waves = (L * G // 64) * 65
 for n, v in zip(names, out):
     print(f"{n:32s} {v/waves:10.0f} cyc/wave  {100*v/tot:5.1f}%")
 print('total cyc/wave', tot / waves)
