@@ -20,6 +20,7 @@
 #include "agz_tree_reg.hpp"
 #include "agz_nn.hpp"
 #include "agz_nn_fused.hpp"
+#include "agz_nn_fused3.hpp"
 #include "agz_selfplay.hpp"
 
 using namespace agz;
@@ -39,6 +40,7 @@ struct DevNet {
     float *W0 = nullptr, *Wres = nullptr, *Wp = nullptr, *bp = nullptr, *Wv = nullptr, *bv = nullptr;
     // bf16 mode: pre-tiled B fragments
     uint16_t *t0 = nullptr, *tres = nullptr, *thead = nullptr;
+    uint16_t* w16 = nullptr;       // the same three sections tiled for v_mfma_f32_16x16x32_bf16 (agz_nn_fused3.hpp)
     float* bias_head = nullptr;
     int NT_h = 0, NT_head = 0;
 };
@@ -150,11 +152,24 @@ static void tile_weights(const float* W, int N, int K, int NT, int KT, std::vect
                 }
 }
 
+// tile W (N x K, Flux layout) for the 16x16x32 MFMA: tile (kt, nt), lane l, element j = W[16 nt + (l & 15)][32 kt + 8 (l >> 4) + j]
+static void tile_weights16(const float* W, int N, int K, int NT, int KT, uint16_t* out, int row_off = 0, int ldn = -1) {
+    if (ldn < 0) ldn = N;
+    for (int kt = 0; kt < KT; ++kt)
+        for (int nt = 0; nt < NT; ++nt)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    int n = 16 * nt + (l & 15) - row_off, k = 32 * kt + 8 * (l >> 4) + j;
+                    size_t o = (((size_t)kt * NT + nt) * 64 + l) * 8 + j;
+                    if (n >= 0 && n < N && k < K) out[o] = host_f2bf(W[(size_t)n + (size_t)ldn * k]);
+                }
+}
+
 template <typename T> static hipError_t dmalloc(T** p, size_t n) { return hipMalloc((void**)p, n * sizeof(T)); }
 
 static void free_net(DevNet& n) {
     hipFree(n.W0); hipFree(n.Wres); hipFree(n.Wp); hipFree(n.bp); hipFree(n.Wv); hipFree(n.bv);
-    hipFree(n.t0); hipFree(n.bias_head);          // tres / thead point into t0's allocation
+    hipFree(n.t0); hipFree(n.w16); hipFree(n.bias_head);          // tres / thead point into t0's allocation
     n = DevNet();
 }
 
@@ -215,6 +230,8 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     hipFuncSetAttribute((const void*)k_layer_exact<EX_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)k_layer_exact<EX_POLICY>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)k_layer_exact<EX_VALUE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)k_mlp_fused3<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)k_mlp_fused3<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)k_mlp_fused2<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)k_mlp_fused2<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     // node record: [prior f32 x A2][q f32 x A2][vc u16 x A2], A2 = A rounded up to 4 (16-B aligned sub-arrays);
@@ -287,6 +304,15 @@ int agz_get_info(const agz_engine* h, agz_game_info* out) {
 }
 void* agz_stream(agz_engine* h) { return h ? (void*)h->stream : nullptr; }
 #ifdef AGZ_STAMPS
+extern "C" int agz_debug_nn_stamps(agz_engine* h, unsigned long long* out) {
+    hipStreamSynchronize(h->stream);
+    std::vector<unsigned long long> all((size_t)4096 * 8);
+    hipMemcpy(all.data(), h->tp.dbg + (size_t)32768 * 16, all.size() * 8, hipMemcpyDeviceToHost);
+    for (int i = 0; i < 8; ++i) out[i] = 0;
+    for (size_t b = 0; b < 4096; ++b) for (int i = 0; i < 8; ++i) out[i] += all[b * 8 + i];
+    hipMemset(h->tp.dbg + (size_t)32768 * 16, 0, all.size() * 8);
+    return 0;
+}
 extern "C" int agz_debug_stamps(agz_engine* h, unsigned long long* out, int reset) {
     hipStreamSynchronize(h->stream);
     std::vector<unsigned long long> all((size_t)65536 * 16);
@@ -373,6 +399,17 @@ int agz_set_network_slot(agz_engine* h, int which, int H, int T, const float* W0
         tile_weights(Wp, P.A, H, NThead, KTh, buf);                 // rows 0..A-1: policy head
         tile_weights(Wv, 1, H, NThead, KTh, buf, P.A, 1);           // row A: value head
         HIPCHK(h, hipMemcpy(n.thead, buf.data(), buf.size() * 2, hipMemcpyHostToDevice));
+        if (H % 16 == 0 && n.INP % 32 == 0 && H % 32 == 0) {       // 16x16x32 tiling of the same sections
+            const int KT0b = n.INP / 32, KThb = H / 32, NTb = H / 16, NTheadb = n.AOP / 16;
+            const size_t s0 = (size_t)KT0b * NTb * 512, sr = (size_t)KThb * NTb * 512, sh = (size_t)KThb * NTheadb * 512;
+            std::vector<uint16_t> b16(s0 + sr * T + sh, 0);
+            tile_weights16(W0, H, n.in, NTb, KT0b, b16.data());
+            for (int t = 0; t < T; ++t) tile_weights16(Wres + (size_t)t * H * H, H, H, NTb, KThb, b16.data() + s0 + sr * t);
+            tile_weights16(Wp, P.A, H, NTheadb, KThb, b16.data() + s0 + sr * T);
+            tile_weights16(Wv, 1, H, NTheadb, KThb, b16.data() + s0 + sr * T, P.A, 1);
+            HIPCHK(h, dmalloc(&n.w16, b16.size()));
+            HIPCHK(h, hipMemcpy(n.w16, b16.data(), b16.size() * 2, hipMemcpyHostToDevice));
+        }
         std::vector<float> bh((size_t)n.AOP, 0.0f);
         for (int a = 0; a < P.A; ++a) bh[a] = bp[a];
         bh[P.A] = bv[0];
@@ -465,11 +502,27 @@ static int launch_network(agz_engine* h, int which) {
     if (h->profiling & 2) { ev = next_events(h, h->ev_nn, h->ev_nn_used); hipEventRecord(ev->first, h->stream); }
     size_t fused_lds = 0;
     if (h->cfg.nn_mode == AGZ_NN_BF16 && (n.H == 64 || n.H == 128) && n.AOP / 32 <= n.H / 32 && !getenv("AGZ_NO_FUSED_NN"))
-        fused_lds = (size_t)F2_M * (n.H * 2 + 16) + F2_WCHUNK;
-    if (fused_lds) {                    // the whole forward in one launch, activations never leave LDS
+        fused_lds = (size_t)F2_M * (n.H * 2 + 16) + F2_WCHUNK + (size_t)F2_M * (n.INP * 2 + 16);
+    if (fused_lds > 160 * 1024) fused_lds = 0;
+    size_t f3_lds = 0;
+    if (h->cfg.nn_mode == AGZ_NN_BF16 && (n.H == 64 || n.H == 128) && n.w16 && n.AOP / 16 <= n.H / 16 && !getenv("AGZ_NO_FUSED_NN") && !getenv("AGZ_NN_FUSED2")) {
+        f3_lds = (size_t)F3_M * (n.H * 2 + 16) + F3_WCHUNK + (size_t)F3_M * (n.INP * 2 + 16);
+        if (f3_lds > 160 * 1024) f3_lds = 0;
+    }
+    if (f3_lds) {                       // 16x16x32 tiles, 8 waves per workgroup
+        Fused3Par F;
+        F.planes = (const uint16_t*)h->planes; F.INP = n.INP; F.w16 = n.w16; F.bias_head = n.bias_head;
+        F.logits = h->logits; F.LGS = h->LGS; F.vout = h->v_eval; F.L = L; F.T = n.T; F.A = h->G.A; F.AOP = n.AOP;
+        dim3 grid((unsigned)((L + F3_M - 1) / F3_M)), block(F3_THREADS);
+        if (n.H == 128) hipLaunchKernelGGL(k_mlp_fused3<128>, grid, block, f3_lds, h->stream, F);
+        else hipLaunchKernelGGL(k_mlp_fused3<64>, grid, block, f3_lds, h->stream, F);
+    } else if (fused_lds) {             // the whole forward in one launch, activations never leave LDS
         Fused2Par F;
         F.planes = (const uint16_t*)h->planes; F.INP = n.INP; F.t0 = n.t0; F.tres = n.tres; F.thead = n.thead; F.bias_head = n.bias_head;
-        F.logits = h->logits; F.LGS = h->LGS; F.vout = h->v_eval; F.L = L; F.T = n.T; F.A = h->G.A; F.AOP = n.AOP;
+        F.logits = h->logits; F.LGS = h->LGS; F.vout = h->v_eval; F.L = L; F.T = n.T; F.A = h->G.A; F.AOP = n.AOP; F.dbg = nullptr;
+#ifdef AGZ_STAMPS
+        F.dbg = h->tp.dbg + (size_t)32768 * 16;
+#endif
         dim3 grid((unsigned)((L + F2_M - 1) / F2_M)), block(256);
         if (n.H == 128) hipLaunchKernelGGL(k_mlp_fused2<128>, grid, block, fused_lds, h->stream, F);
         else hipLaunchKernelGGL(k_mlp_fused2<64>, grid, block, fused_lds, h->stream, F);

@@ -21,12 +21,19 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int F2_M = 128;                 // leaves per workgroup
 constexpr int F2_WCHUNK = 32 * 1024;      // bytes of weight fragments staged at a time
 
+#ifdef AGZ_STAMPS
+#define NSTAMP(i) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); nacc[i] += t_ - nlast; nlast = t_; } while (0)
+#else
+#define NSTAMP(i) do { } while (0)
+#endif
+
 struct Fused2Par {
     const uint16_t* planes; int INP;      // [L][INP] bf16, INP % 32 == 0
     const uint16_t* t0; const uint16_t* tres; const uint16_t* thead;
     const float* bias_head;
     float* logits; int LGS; float* vout;
     int L, T, A, AOP;
+    unsigned long long* dbg;
 };
 
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
@@ -52,6 +59,9 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fused2(const Fused2Par P) {
     const int nlayers = P.T + 2;
 
     f32x16 acc[NTH];
+#ifdef AGZ_STAMPS
+    unsigned long long nacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nlast = __builtin_amdgcn_s_memtime();
+#endif
     u32x4 pf0, pf1, pf2, pf3, pf4, pf5, pf6, pf7;               // next weight chunk in flight (32 KiB / 256 threads)
 
 #define AGZ_LAYER_DIMS(ll, KT, NT, w)                                                       \
@@ -82,9 +92,25 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fused2(const Fused2Par P) {
         d_[tid + 1024] = pf4; d_[tid + 1280] = pf5; d_[tid + 1536] = pf6; d_[tid + 1792] = pf7; \
     } while (0)
 
+    // the input planes of the tile go to LDS once (coalesced 16-B loads, all in flight together); layer 0 then reads its
+    // B fragments from there exactly like the hidden layers read theirs
+    uint8_t* const pl = wl + F2_WCHUNK;                         // [128][PROWB]
+    const int PROWB = P.INP * 2 + 16;
+    {
+        const int segs = P.INP / 8;
+        const AGZ_GLOBAL uint16_t* gp = (const AGZ_GLOBAL uint16_t*)P.planes;
+        for (int c = tid; c < F2_M * segs; c += 256) {
+            const int row = c / segs, seg = c - row * segs, mm = blockIdx.x * F2_M + row;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (mm < P.L) v = *(const AGZ_GLOBAL u32x4*)(gp + (size_t)mm * P.INP + seg * 8);
+            *reinterpret_cast<u32x4*>(pl + (size_t)row * PROWB + seg * 16) = v;
+        }
+    }
+    const uint8_t* const myprow = pl + (size_t)lrow * PROWB;
     AGZ_PREFETCH(0, 0);
     AGZ_COMMIT();
     __syncthreads();
+    NSTAMP(0);
 
     int l = 0, kt0 = 0;
     while (l < nlayers) {
@@ -100,14 +126,14 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fused2(const Fused2Par P) {
                 for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
         }
         if (nl < nlayers) AGZ_PREFETCH(nl, nk);
+        NSTAMP(1);
 
         // ---- MFMAs of this chunk: acc[t] += Wfrag(c, t) * Xfrag(c); fragments of step c+1 are read while step c computes
         const uint8_t* wlane = wl + lane * 16;
         if (l == 0 || l < nlayers - 1) {                           // input / hidden layers: NT == NTH, D = W * X^T
-            const __attribute__((address_space(1))) uint16_t* prow = (const __attribute__((address_space(1))) uint16_t*)(P.planes + (size_t)(m < P.L ? m : 0) * P.INP + half * 8);
+            const uint8_t* const inrow = l == 0 ? myprow : myrow;
             bf16x8 b, a[NTH];
-            if (l == 0) b = *(const __attribute__((address_space(1))) bf16x8*)(prow + kt0 * 16);
-            else b = *reinterpret_cast<const bf16x8*>(myrow + kt0 * 32 + half * 16);
+            b = *reinterpret_cast<const bf16x8*>(inrow + kt0 * 32 + half * 16);
 #pragma unroll
             for (int t = 0; t < NTH; ++t) a[t] = *reinterpret_cast<const bf16x8*>(wlane + (size_t)t * 1024);
 #pragma unroll 1
@@ -116,8 +142,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fused2(const Fused2Par P) {
 #pragma unroll
                 for (int t = 0; t < NTH; ++t) an[t] = a[t];
                 if (c + 1 < kc) {
-                    if (l == 0) bn = *(const __attribute__((address_space(1))) bf16x8*)(prow + (kt0 + c + 1) * 16);
-                    else bn = *reinterpret_cast<const bf16x8*>(myrow + (kt0 + c + 1) * 32 + half * 16);
+                    bn = *reinterpret_cast<const bf16x8*>(inrow + (kt0 + c + 1) * 32 + half * 16);
 #pragma unroll
                     for (int t = 0; t < NTH; ++t) an[t] = *reinterpret_cast<const bf16x8*>(wlane + (size_t)((c + 1) * NTH + t) * 1024);
                 }
@@ -140,6 +165,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fused2(const Fused2Par P) {
                 }
             }
         }
+        NSTAMP(2);
         // ---- epilogue when the layer's K range is complete (only this wave's own rows are touched)
         if (kt0 + kc >= KT) {
             if (l < nlayers - 1) {
@@ -184,12 +210,19 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fused2(const Fused2Par P) {
                 }
             }
         }
+        NSTAMP(3);
         // ---- rotate the weight chunk
-        __syncthreads();                                                   // all waves finished reading wl
-        if (nl < nlayers) AGZ_COMMIT();
         __syncthreads();
+        NSTAMP(4);                                                   // all waves finished reading wl
+        if (nl < nlayers) AGZ_COMMIT();
+        NSTAMP(5);
+        __syncthreads();
+        NSTAMP(6);
         l = nl; kt0 = nk;
     }
+#ifdef AGZ_STAMPS
+    if (tid == 0 && P.dbg) for (int i = 0; i < 8; ++i) P.dbg[(size_t)blockIdx.x * 8 + i] += nacc[i];
+#endif
 #undef AGZ_LAYER_DIMS
 #undef AGZ_PREFETCH
 #undef AGZ_COMMIT
