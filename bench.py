@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--mode", choices=["bf16", "exact"], default="bf16")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI); gloo only for single-GPU smoke tests of the N>1 path")
     args = ap.parse_args()
 
     import torch
@@ -79,16 +80,21 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libagz has no CPU path)")
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    dev = local_rank % max(ndev, 1)             # (several ranks on one GPU only with --backend gloo)
+    torch.cuda.set_device(dev)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     game = ag.GameSpec("gobang", args.n, args.nvict)
     net = ag.SNetwork2.random(game, args.filters, args.towers)
     G, V = args.games, args.rollouts
-    eng = M.Engine(game, G, V, device=local_rank, seed=1, game_id_base=shard.shard_base(rank, G),
+    eng = M.Engine(game, G, V, device=dev, seed=1, game_id_base=shard.shard_base(rank, G),
                    nn_mode=M.NN_BF16 if args.mode == "bf16" else M.NN_EXACT)
     eng.set_network(net)
     eng.set_profiling(1)          # HIP events around every PUCT-kernel launch (roofline); network time = search - tree
@@ -101,7 +107,10 @@ def main():
             raise SystemExit("illegal move sampled ('faute')")
         if world > 1:                       # the one exchange step: all-gather of the generated samples
             n = eng.samples_packed_into(sample_buf.data_ptr(), G * game.max_plies)
-            shard.allgather_records(sample_buf, n, rb)
+            if args.backend == "nccl":
+                shard.allgather_records(sample_buf, n, rb)
+            else:                               # gloo smoke path: stage through host memory
+                shard.allgather_records(sample_buf[: n * rb].cpu(), n, rb)
         return st
 
     def fence():
@@ -131,8 +140,9 @@ def main():
     tree_ms, nn_ms, launches = eng.kernel_times()
     sum_p, sum_new, r_cnt = eng.counters()
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    tot = torch.tensor([float(rollouts)], dtype=torch.float64, device="cuda")
+    cdev = "cuda" if args.backend == "nccl" else "cpu"
+    tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
+    tot = torch.tensor([float(rollouts)], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -159,7 +169,7 @@ def main():
                        "games_per_gpu": G, "rollouts_per_move": V, "cpuct": args.cpuct, "tau_plies": 25,
                        "tree_arithmetic": "f32 strict IEEE", "network": "bf16 MFMA, fp32 accumulate" if args.mode == "bf16" else "f32 exact",
                        "parallelism": f"game-shard x{world}, RCCL all-gather of samples at generation end" if world > 1 else "single GPU"},
-            "roofline": {"kernel": "k_rollout_grp (expand+backup+select+encode, 16 lanes per game tree)",
+            "roofline": {"kernel": "k_rollout_reg (expand+backup+select+encode, 8 lanes per game tree, rows in registers)",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg / max(launches, 1), "avg_launch_ms": tree_ms / max(launches, 1),
