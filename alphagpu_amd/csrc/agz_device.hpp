@@ -97,7 +97,8 @@ enum : uint32_t {
 
 struct TreePar {
     GamePar G;
-    int32_t L, V;
+    int32_t L, V;            // L = END of the slot range [slot0, L) of this launch
+    int32_t slot0;           // first slot (register-row kernel only: sub-batches on parallel streams)
     uint32_t rec_bytes, off_q, off_vc, A2;
     uint8_t* recs;
     Pos* states;

@@ -55,6 +55,10 @@ struct agz_engine {
     agz_game_info info;
     std::string err;
     hipStream_t stream = nullptr;
+    static constexpr int KCH = 4;       // sub-batches of a search run as independent chains on parallel streams
+    hipStream_t aux[KCH - 1] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[KCH - 1] = {nullptr, nullptr, nullptr};
+    int chains = 0;                     // 0 = automatic (AGZ_CHAINS overrides)
     int L = 0;                 // active slots
     int Lmax = 0, V = 0, NRV = 1;
     TreePar tp;                // template of kernel arguments
@@ -202,6 +206,8 @@ void agz_destroy(agz_engine* h) {
     free_net(h->net[0]); free_net(h->net[1]);
     for (auto& e : h->ev_tree) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto& e : h->ev_nn) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    for (int c = 0; c < agz_engine::KCH - 1; ++c) { if (h->aux[c]) hipStreamDestroy(h->aux[c]); if (h->ev_join[c]) hipEventDestroy(h->ev_join[c]); }
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -221,6 +227,15 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     if (cfg->device < 0 || cfg->device >= ndev) { h->fail("device %d out of range (%d devices)", cfg->device, ndev); return bail(AGZ_ERR_ARG); }
     if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
         h->fail("cannot initialise device %d", cfg->device); return bail(AGZ_ERR_HIP);
+    }
+    {
+        const char* e = getenv("AGZ_CHAINS");
+        h->chains = e ? atoi(e) : 0;
+        bool ok = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
+        for (int c = 0; ok && c < agz_engine::KCH - 1; ++c)
+            ok = hipStreamCreateWithFlags(&h->aux[c], hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&h->ev_join[c], hipEventDisableTiming) == hipSuccess;
+        if (!ok) { h->fail("cannot create the sub-batch streams"); return bail(AGZ_ERR_HIP); }
     }
     const GamePar& P = h->G;
     h->Lmax = cfg->max_games; h->V = cfg->max_visits;
@@ -476,30 +491,40 @@ static void drain_events(agz_engine* h) {     // stream must be idle
     h->ev_tree_used = h->ev_nn_used = 0;
 }
 
-static int launch_rollout(agz_engine* h, uint32_t rollout, int do_reset, int do_expand, int do_select, int last, int inject, int capture) {
+static int launch_rollout(agz_engine* h, uint32_t rollout, int do_reset, int do_expand, int do_select, int last, int inject, int capture,
+                          int s0 = 0, int s1 = -1, hipStream_t stream = nullptr) {
     if (h->L == 0) return AGZ_OK;
+    if (s1 < 0) s1 = h->L;
+    if (!stream) stream = h->stream;
+    const int n = s1 - s0;
     TreePar T = h->tp;
-    T.L = h->L; T.step = h->step; T.rollout = rollout; T.cpuct = h->cpuct; T.training = h->training;
+    T.L = s1; T.slot0 = s0; T.step = h->step; T.rollout = rollout; T.cpuct = h->cpuct; T.training = h->training;
     T.do_reset = do_reset; T.do_expand = do_expand; T.do_select = do_select; T.last = last; T.inject = inject; T.capture = capture;
     const bool reg = h->reg_lds != 0, lpg = !reg && h->lpg_lds != 0;
     const int ng = reg ? 64 / h->reg_g : 64 / h->grp_g;
-    dim3 grid((unsigned)((reg || lpg) ? (h->L + ng - 1) / ng : (h->L + 3) / 4)), block((reg || lpg) ? 64 : 256);
+    if (!reg && s0 != 0) { h->fail("sub-batches need the register-row kernel"); return AGZ_ERR_STATE; }
+    dim3 grid((unsigned)((reg || lpg) ? (n + ng - 1) / ng : (n + 3) / 4)), block((reg || lpg) ? 64 : 256);
     std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
-    if (h->profiling & 1) { ev = next_events(h, h->ev_tree, h->ev_tree_used); hipEventRecord(ev->first, h->stream); }
-    hipLaunchKernelGGL(reg ? h->k_reg : (lpg ? h->k_lpg : h->k_roll), grid, block, reg ? h->reg_lds : (lpg ? h->lpg_lds : 0), h->stream, T);
-    if (ev) hipEventRecord(ev->second, h->stream);
+    if (h->profiling & 1) { ev = next_events(h, h->ev_tree, h->ev_tree_used); hipEventRecord(ev->first, stream); }
+    hipLaunchKernelGGL(reg ? h->k_reg : (lpg ? h->k_lpg : h->k_roll), grid, block, reg ? h->reg_lds : (lpg ? h->lpg_lds : 0), stream, T);
+    if (ev) hipEventRecord(ev->second, stream);
     h->cnt_live = true;
     HIPCHK(h, hipGetLastError());
     return AGZ_OK;
 }
 
-static int launch_network(agz_engine* h, int which) {
+static int launch_network(agz_engine* h, int which, int s0 = 0, int s1 = -1, hipStream_t stream = nullptr) {
     if (h->L == 0) return AGZ_OK;
+    if (s1 < 0) s1 = h->L;
+    if (!stream) stream = h->stream;
     DevNet& n = h->net[which];
     if (!n.loaded) { h->fail("no network loaded in slot %d (call agz_set_network)", which); return AGZ_ERR_STATE; }
-    const int L = h->L;
+    const int L = s1 - s0;                                  // rows [s0, s1) of every per-slot buffer
+    const size_t pe = h->cfg.nn_mode == AGZ_NN_EXACT ? 4 : 2;
+    const uint8_t* const planes = (const uint8_t*)h->planes + (size_t)s0 * h->INP * pe;
+    float* const logits = h->logits + (size_t)s0 * h->LGS; float* const v_eval = h->v_eval + s0;
     std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
-    if (h->profiling & 2) { ev = next_events(h, h->ev_nn, h->ev_nn_used); hipEventRecord(ev->first, h->stream); }
+    if (h->profiling & 2) { ev = next_events(h, h->ev_nn, h->ev_nn_used); hipEventRecord(ev->first, stream); }
     size_t fused_lds = 0;
     if (h->cfg.nn_mode == AGZ_NN_BF16 && (n.H == 64 || n.H == 128) && n.AOP / 32 <= n.H / 32 && !getenv("AGZ_NO_FUSED_NN"))
         fused_lds = (size_t)F2_M * (n.H * 2 + 16) + F2_WCHUNK + (size_t)F2_M * (n.INP * 2 + 16);
@@ -511,55 +536,55 @@ static int launch_network(agz_engine* h, int which) {
     }
     if (f3_lds) {                       // 16x16x32 tiles, 8 waves per workgroup
         Fused3Par F;
-        F.planes = (const uint16_t*)h->planes; F.INP = n.INP; F.w16 = n.w16; F.bias_head = n.bias_head;
-        F.logits = h->logits; F.LGS = h->LGS; F.vout = h->v_eval; F.L = L; F.T = n.T; F.A = h->G.A; F.AOP = n.AOP;
+        F.planes = (const uint16_t*)planes; F.INP = n.INP; F.w16 = n.w16; F.bias_head = n.bias_head;
+        F.logits = logits; F.LGS = h->LGS; F.vout = v_eval; F.L = L; F.T = n.T; F.A = h->G.A; F.AOP = n.AOP;
         dim3 grid((unsigned)((L + F3_M - 1) / F3_M)), block(F3_THREADS);
-        if (n.H == 128) hipLaunchKernelGGL(k_mlp_fused3<128>, grid, block, f3_lds, h->stream, F);
-        else hipLaunchKernelGGL(k_mlp_fused3<64>, grid, block, f3_lds, h->stream, F);
+        if (n.H == 128) hipLaunchKernelGGL(k_mlp_fused3<128>, grid, block, f3_lds, stream, F);
+        else hipLaunchKernelGGL(k_mlp_fused3<64>, grid, block, f3_lds, stream, F);
     } else if (fused_lds) {             // the whole forward in one launch, activations never leave LDS
         Fused2Par F;
-        F.planes = (const uint16_t*)h->planes; F.INP = n.INP; F.t0 = n.t0; F.tres = n.tres; F.thead = n.thead; F.bias_head = n.bias_head;
-        F.logits = h->logits; F.LGS = h->LGS; F.vout = h->v_eval; F.L = L; F.T = n.T; F.A = h->G.A; F.AOP = n.AOP; F.dbg = nullptr;
+        F.planes = (const uint16_t*)planes; F.INP = n.INP; F.t0 = n.t0; F.tres = n.tres; F.thead = n.thead; F.bias_head = n.bias_head;
+        F.logits = logits; F.LGS = h->LGS; F.vout = v_eval; F.L = L; F.T = n.T; F.A = h->G.A; F.AOP = n.AOP; F.dbg = nullptr;
 #ifdef AGZ_STAMPS
         F.dbg = h->tp.dbg + (size_t)32768 * 16;
 #endif
         dim3 grid((unsigned)((L + F2_M - 1) / F2_M)), block(256);
-        if (n.H == 128) hipLaunchKernelGGL(k_mlp_fused2<128>, grid, block, fused_lds, h->stream, F);
-        else hipLaunchKernelGGL(k_mlp_fused2<64>, grid, block, fused_lds, h->stream, F);
+        if (n.H == 128) hipLaunchKernelGGL(k_mlp_fused2<128>, grid, block, fused_lds, stream, F);
+        else hipLaunchKernelGGL(k_mlp_fused2<64>, grid, block, fused_lds, stream, F);
     } else if (h->cfg.nn_mode == AGZ_NN_BF16) {
         dim3 block(256);
         dim3 gh((unsigned)((L + GB_M - 1) / GB_M), (unsigned)((n.H + GB_N - 1) / GB_N));
-        const uint16_t* x = (const uint16_t*)h->planes;
-        hipLaunchKernelGGL(k_layer_bf16<EPI_RELU>, gh, block, 0, h->stream, x, n.INP, n.INP, n.t0, n.NT_h, h->act0, n.H, n.H, L,
+        const uint16_t* x = (const uint16_t*)planes;
+        hipLaunchKernelGGL(k_layer_bf16<EPI_RELU>, gh, block, 0, stream, x, n.INP, n.INP, n.t0, n.NT_h, h->act0 + (size_t)s0 * n.H, n.H, n.H, L,
                            (const float*)nullptr, (float*)nullptr, 0, (float*)nullptr, 0);
-        uint16_t *a = h->act0, *b = h->act1;
+        uint16_t *a = h->act0 + (size_t)s0 * n.H, *b = h->act1 + (size_t)s0 * n.H;
         const size_t per = (size_t)(n.H / 16) * n.NT_h * 512;
         for (int t = 0; t < n.T; ++t) {
-            hipLaunchKernelGGL(k_layer_bf16<EPI_RES>, gh, block, 0, h->stream, (const uint16_t*)a, n.H, n.H, n.tres + per * t, n.NT_h, b, n.H,
+            hipLaunchKernelGGL(k_layer_bf16<EPI_RES>, gh, block, 0, stream, (const uint16_t*)a, n.H, n.H, n.tres + per * t, n.NT_h, b, n.H,
                                n.H, L, (const float*)nullptr, (float*)nullptr, 0, (float*)nullptr, 0);
             uint16_t* s = a; a = b; b = s;
         }
         dim3 gp((unsigned)((L + GB_M - 1) / GB_M), (unsigned)((n.AOP + GB_N - 1) / GB_N));
-        hipLaunchKernelGGL(k_layer_bf16<EPI_HEAD>, gp, block, 0, h->stream, (const uint16_t*)a, n.H, n.H, n.thead, n.NT_head, (uint16_t*)nullptr, 0,
-                           n.AOP, L, (const float*)n.bias_head, h->logits, h->LGS, h->v_eval, h->G.A);
+        hipLaunchKernelGGL(k_layer_bf16<EPI_HEAD>, gp, block, 0, stream, (const uint16_t*)a, n.H, n.H, n.thead, n.NT_head, (uint16_t*)nullptr, 0,
+                           n.AOP, L, (const float*)n.bias_head, logits, h->LGS, v_eval, h->G.A);
     } else {
         dim3 block(64, 4);
         auto grid = [&](int O) { return dim3((unsigned)((L + EX_TL - 1) / EX_TL), (unsigned)((O + 63) / 64)); };
         auto shm = [&](int K) { return (size_t)EX_TL * (size_t)((K + 3) & ~3) * 4; };
-        const float* x = (const float*)h->planes;
-        hipLaunchKernelGGL(k_layer_exact<EX_RELU>, grid(n.H), block, shm(n.in), h->stream, x, h->INP, n.in, (const float*)n.W0, n.H, h->actf0, n.H, L, (const float*)nullptr);
-        float *a = h->actf0, *b = h->actf1;
+        const float* x = (const float*)planes;
+        hipLaunchKernelGGL(k_layer_exact<EX_RELU>, grid(n.H), block, shm(n.in), stream, x, h->INP, n.in, (const float*)n.W0, n.H, h->actf0 + (size_t)s0 * n.H, n.H, L, (const float*)nullptr);
+        float *a = h->actf0 + (size_t)s0 * n.H, *b = h->actf1 + (size_t)s0 * n.H;
         for (int t = 0; t < n.T; ++t) {
-            hipLaunchKernelGGL(k_layer_exact<EX_RES>, grid(n.H), block, shm(n.H), h->stream, (const float*)a, n.H, n.H,
+            hipLaunchKernelGGL(k_layer_exact<EX_RES>, grid(n.H), block, shm(n.H), stream, (const float*)a, n.H, n.H,
                                (const float*)(n.Wres + (size_t)t * n.H * n.H), n.H, b, n.H, L, (const float*)nullptr);
             float* s = a; a = b; b = s;
         }
-        hipLaunchKernelGGL(k_layer_exact<EX_POLICY>, grid(n.A), block, shm(n.H), h->stream, (const float*)a, n.H, n.H, (const float*)n.Wp, n.A,
-                           h->logits, h->LGS, L, (const float*)n.bp);
-        hipLaunchKernelGGL(k_layer_exact<EX_VALUE>, grid(1), block, shm(n.H), h->stream, (const float*)a, n.H, n.H, (const float*)n.Wv, 1,
-                           h->v_eval, 1, L, (const float*)n.bv);
+        hipLaunchKernelGGL(k_layer_exact<EX_POLICY>, grid(n.A), block, shm(n.H), stream, (const float*)a, n.H, n.H, (const float*)n.Wp, n.A,
+                           logits, h->LGS, L, (const float*)n.bp);
+        hipLaunchKernelGGL(k_layer_exact<EX_VALUE>, grid(1), block, shm(n.H), stream, (const float*)a, n.H, n.H, (const float*)n.Wv, 1,
+                           v_eval, 1, L, (const float*)n.bv);
     }
-    if (ev) hipEventRecord(ev->second, h->stream);
+    if (ev) hipEventRecord(ev->second, stream);
     HIPCHK(h, hipGetLastError());
     return AGZ_OK;
 }
@@ -575,11 +600,38 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
     if (which < 0 || which > 1 || !h->net[which].loaded) { h->fail("no network loaded in slot %d", which); return AGZ_ERR_STATE; }
     HIPCHK(h, hipSetDevice(h->cfg.device));
     h->cpuct = cpuct; h->training = training; h->step = step;
-    for (int k = 0; k < V; ++k) {
-        rc = launch_rollout(h, (uint32_t)k, k == 0, k > 0, 1, k == V - 1, 0, 0); if (rc) return rc;
-        rc = launch_network(h, which); if (rc) return rc;
+    // The slots are independent, so the batch is cut into up to KCH sub-batches (multiples of 128 slots = one network
+    // tile) and each runs its own select -> network -> expand/backup chain on its own stream: while one chain's tree
+    // kernel waits on memory latency the other chains' network and tree kernels fill the machine.  Results do not depend
+    // on the cut (every per-game quantity is keyed by game id).
+    int K = 1;
+    if (h->reg_lds != 0 && h->aux[0]) {
+        K = h->chains > 0 ? h->chains : agz_engine::KCH;
+        const int kmax = (h->L + 255) / 256;               // at least 256 games per chain
+        if (K > kmax) K = kmax;
+        if (K > agz_engine::KCH) K = agz_engine::KCH;
+        if (K < 1) K = 1;
     }
-    rc = launch_rollout(h, (uint32_t)V, 0, 1, 0, 0, 0, 0); if (rc) return rc;
+    const int chunk = ((h->L + K - 1) / K + 127) / 128 * 128;
+    if (K > 1) HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
+    for (int c = 1; c < K; ++c) if (c * chunk < h->L) HIPCHK(h, hipStreamWaitEvent(h->aux[c - 1], h->ev_fork, 0));
+    for (int k = 0; k <= V; ++k) {
+        for (int c = 0; c < K; ++c) {
+            const int s0 = c * chunk, s1 = (c + 1) * chunk < h->L ? (c + 1) * chunk : h->L;
+            if (s0 >= s1) break;
+            hipStream_t st = c == 0 ? h->stream : h->aux[c - 1];
+            if (k < V) {
+                rc = launch_rollout(h, (uint32_t)k, k == 0, k > 0, 1, k == V - 1, 0, 0, s0, s1, st); if (rc) return rc;
+                rc = launch_network(h, which, s0, s1, st); if (rc) return rc;
+            } else {
+                rc = launch_rollout(h, (uint32_t)V, 0, 1, 0, 0, 0, 0, s0, s1, st); if (rc) return rc;
+            }
+        }
+    }
+    for (int c = 1; c < K; ++c) if (c * chunk < h->L) {
+        HIPCHK(h, hipEventRecord(h->ev_join[c - 1], h->aux[c - 1]));
+        HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join[c - 1], 0));
+    }
     h->need_reset = true; h->injected = false;
     h->total_rollouts += (uint64_t)h->L * (uint64_t)V;
     return AGZ_OK;

@@ -31,6 +31,14 @@ template <int G> __device__ __forceinline__ float grp_bcast_last(float xf) {
     if (G >= 4) x = dpp_mov<DPP_QUAD_B3, 0xF>(x, x);
     return __int_as_float(x);
 }
+template <int G> __device__ __forceinline__ uint64_t grp_or64(uint64_t v) {
+    int lo = (int)(uint32_t)v, hi = (int)(uint32_t)(v >> 32);
+    if (G >= 2) { lo |= dpp_mov<DPP_XOR1, 0xF>(0, lo); hi |= dpp_mov<DPP_XOR1, 0xF>(0, hi); }
+    if (G >= 4) { lo |= dpp_mov<DPP_XOR2, 0xF>(0, lo); hi |= dpp_mov<DPP_XOR2, 0xF>(0, hi); }
+    if (G >= 8) { lo |= dpp_mov<DPP_HALF_MIRROR, 0xF>(0, lo); hi |= dpp_mov<DPP_HALF_MIRROR, 0xF>(0, hi); }
+    if (G >= 16) { lo |= dpp_mov<DPP_MIRROR, 0xF>(0, lo); hi |= dpp_mov<DPP_MIRROR, 0xF>(0, hi); }
+    return (uint64_t)(uint32_t)lo | ((uint64_t)(uint32_t)hi << 32);
+}
 __device__ __forceinline__ float lane_shr1(float x) { return __int_as_float(dpp_mov<DPP_SHR1, 0xF>(__float_as_int(x), __float_as_int(x))); }
 
 // Source-order sum of the group's G*KPL values (lane sub holds block sub).  Returns the total in every lane and
@@ -74,7 +82,7 @@ __global__ __launch_bounds__(64, G <= 4 ? 2 : AGZ_REG_WAVES) void k_rollout_reg(
     const GamePar& P = T.G;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = lane_id(), g = lane / G, sub = lane % G;
-    const int slot = (int)blockIdx.x * NG + g;
+    const int slot = T.slot0 + (int)blockIdx.x * NG + g;
     const bool live = slot < T.L;
     const bool lead = sub == 0;
     const int A = P.A, V = T.V, ROWS = (int)T.rec_bytes;
@@ -91,6 +99,7 @@ __global__ __launch_bounds__(64, G <= 4 ? 2 : AGZ_REG_WAVES) void k_rollout_reg(
     const uint32_t gbits_shift = (uint32_t)(g * G);
     const uint64_t gmask = G == 64 ? ~0ull : (((1ull << G) - 1ull) << gbits_shift);
     const int k0 = sub * KPL;                                    // first action of this lane's block
+    const bool small = V <= 64;                                  // node ids fit a 64-bit set
 #ifdef AGZ_STAMPS
     unsigned long long* const stamp_lds = reinterpret_cast<unsigned long long*>(lds + (size_t)NG * LO.stride);
     if (lane < 17) stamp_lds[lane] = lane == 16 ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -102,7 +111,7 @@ __global__ __launch_bounds__(64, G <= 4 ? 2 : AGZ_REG_WAVES) void k_rollout_reg(
         if (lead) mymeta[0] = M_EXISTS;
     } else {
         for (int j = 0; j < NG; ++j) {
-            const int sj = (int)blockIdx.x * NG + j;
+            const int sj = T.slot0 + (int)blockIdx.x * NG + j;
             if (sj >= T.L) break;
             uint32_t* dm = reinterpret_cast<uint32_t*>(lds + (size_t)j * LO.stride + LO.meta);
             for (int c = lane; c < V; c += 64) dm[c] = T.meta[(size_t)sj * V + c];
@@ -256,6 +265,7 @@ __global__ __launch_bounds__(64, G <= 4 ? 2 : AGZ_REG_WAVES) void k_rollout_reg(
                 float pol[KPL];
                 if (stale) {                                               // :114
                     int vs = 0, ac = 0; float m[KPL];                      // :120-131
+                    uint64_t cm = 0;
 #pragma unroll
                     for (int j = 0; j < KPL; ++j) {
                         const uint32_t c = (j & 1) ? (vw[j / 2] >> 16) : (vw[j / 2] & 0xffffu);
@@ -263,9 +273,23 @@ __global__ __launch_bounds__(64, G <= 4 ? 2 : AGZ_REG_WAVES) void k_rollout_reg(
                         ac += p[j] > 0.0f ? 1 : 0;
                         const uint32_t ch = c >> 8;
                         m[j] = ch == 0 ? p[j] : 0.0f;                      // prior of childless actions, +0 otherwise (exact)
-                        if (ch != 0) { tabp[ch] = p[j]; tabq[ch] = q[j]; } // child table by child node id
+                        if (small) cm |= ch != 0 ? 1ull << ch : 0ull;      // set of this node's child ids
+                        else if (ch != 0) { tabp[ch] = p[j]; tabq[ch] = q[j]; }   // child table by child node id
                     }
                     vs = grp_sum<G>(vs); ac = grp_sum<G>(ac);
+                    int nch = 0;
+                    if (small) {
+                        // children in creation order = ascending node id (:144-146): the rank of child id c among the set
+                        // bits of the group's id mask IS its creation index -> the table is written already compacted
+                        const uint64_t M = grp_or64<G>(cm);
+                        nch = __popcll(M);
+#pragma unroll
+                        for (int j = 0; j < KPL; ++j) {
+                            const uint32_t c = (j & 1) ? (vw[j / 2] >> 16) : (vw[j / 2] & 0xffffu);
+                            const uint32_t ch = c >> 8;
+                            if (ch != 0) { const int r = __popcll(M & ((1ull << ch) - 1ull)); tabp[r] = p[j]; tabq[r] = q[j]; }
+                        }
+                    }
                     const float nf = 1.0f + (float)vs, Af = (float)ac;
                     float st0;
                     float prior_rem = grp_ordered_sum<G, KPL>(m, sub, st0);   // ordered (:122-124)
@@ -281,10 +305,10 @@ __global__ __launch_bounds__(64, G <= 4 ? 2 : AGZ_REG_WAVES) void k_rollout_reg(
                     }
                     alpha = grp_max<G>(am);
                     STAMP(8);
-                    // children in creation order = nodes i with parent(i) == node, ascending i (:144-146); compact the table in place
+                    // V > 64: children in creation order = nodes i with parent(i) == node, ascending i (:144-146); compact the
+                    // id-indexed table in place
                     AGZ_WSYNC();
-                    int nch = 0;
-                    for (int base = 1; base < (int)ncount; base += 8 * G) {
+                    for (int base = 1; !small && base < (int)ncount; base += 8 * G) {
                         uint32_t mi[8]; float tp[8], tq[8];
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
@@ -472,7 +496,7 @@ __global__ __launch_bounds__(64, G <= 4 ? 2 : AGZ_REG_WAVES) void k_rollout_reg(
     // ---- write back bookkeeping ---------------------------------------------------------------------
     AGZ_WSYNC();
     for (int j = 0; j < NG; ++j) {
-        const int sj = (int)blockIdx.x * NG + j;
+        const int sj = T.slot0 + (int)blockIdx.x * NG + j;
         if (sj >= T.L) break;
         const int nj = (int)rdlane(ncount, j * G);
         const uint32_t* sm = reinterpret_cast<const uint32_t*>(lds + (size_t)j * LO.stride + LO.meta);

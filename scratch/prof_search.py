@@ -15,9 +15,10 @@ for r in range(reps):
     e.kernel_times(reset=True)
     t0 = time.perf_counter()
     e.search(V, cpuct=1.5, training=True, step=0)
+    t_enq = time.perf_counter() - t0
     e.synchronize()
     dt = time.perf_counter() - t0
     tree, nn, k = e.kernel_times()
     p, n, ro = e.counters()
-    print(f"search {r}: wall {dt*1e3:.2f} ms  tree {tree:.2f} ms ({k} launches, {tree/max(k,1)*1e3:.1f} us avg)  nn {nn:.2f} ms  p/rollout {p/ro:.2f}  rollouts/s {ro/dt/1e6:.1f}M")
+    print(f"search {r}: enq {t_enq*1e3:.2f} ms wall {dt*1e3:.2f} ms  tree {tree:.2f} ms ({k} launches, {tree/max(k,1)*1e3:.1f} us avg)  nn {nn:.2f} ms  p/rollout {p/ro:.2f}  rollouts/s {ro/dt/1e6:.1f}M")
 e.close()
