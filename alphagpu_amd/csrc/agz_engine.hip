@@ -21,6 +21,7 @@
 #include "agz_nn.hpp"
 #include "agz_nn_fused.hpp"
 #include "agz_nn_fused3.hpp"
+#include "agz_nn_wave.hpp"
 #include "agz_selfplay.hpp"
 
 using namespace agz;
@@ -40,6 +41,7 @@ struct DevNet {
     float *W0 = nullptr, *Wres = nullptr, *Wp = nullptr, *bp = nullptr, *Wv = nullptr, *bv = nullptr;
     // bf16 mode: pre-tiled B fragments
     uint16_t *t0 = nullptr, *tres = nullptr, *thead = nullptr;
+    uint16_t* w16w = nullptr;      // uniform k-rows for agz_nn_wave.hpp
     uint16_t* w16 = nullptr;       // the same three sections tiled for v_mfma_f32_16x16x32_bf16 (agz_nn_fused3.hpp)
     float* bias_head = nullptr;
     int NT_h = 0, NT_head = 0;
@@ -59,6 +61,7 @@ struct agz_engine {
     hipStream_t aux[KCH - 1] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[KCH - 1] = {nullptr, nullptr, nullptr};
     int chains = 0;                     // 0 = automatic (AGZ_CHAINS overrides)
+    int nn_wave_maxl = 20000;           // batches up to this size use the latency-first network kernel (agz_nn_wave.hpp); measured crossover with k_mlp_fused3 (AGZ_NN_WAVE_MAXL overrides)
     int L = 0;                 // active slots
     int Lmax = 0, V = 0, NRV = 1;
     TreePar tp;                // template of kernel arguments
@@ -173,7 +176,7 @@ template <typename T> static hipError_t dmalloc(T** p, size_t n) { return hipMal
 
 static void free_net(DevNet& n) {
     hipFree(n.W0); hipFree(n.Wres); hipFree(n.Wp); hipFree(n.bp); hipFree(n.Wv); hipFree(n.bv);
-    hipFree(n.t0); hipFree(n.w16); hipFree(n.bias_head);          // tres / thead point into t0's allocation
+    hipFree(n.t0); hipFree(n.w16); hipFree(n.w16w); hipFree(n.bias_head);          // tres / thead point into t0's allocation
     n = DevNet();
 }
 
@@ -231,6 +234,8 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     {
         const char* e = getenv("AGZ_CHAINS");
         h->chains = e ? atoi(e) : 0;
+        e = getenv("AGZ_NN_WAVE_MAXL");
+        if (e) h->nn_wave_maxl = atoi(e);
         bool ok = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
         for (int c = 0; ok && c < agz_engine::KCH - 1; ++c)
             ok = hipStreamCreateWithFlags(&h->aux[c], hipStreamNonBlocking) == hipSuccess &&
@@ -424,6 +429,19 @@ int agz_set_network_slot(agz_engine* h, int which, int H, int T, const float* W0
             tile_weights16(Wv, 1, H, NTheadb, KThb, b16.data() + s0 + sr * T, P.A, 1);
             HIPCHK(h, dmalloc(&n.w16, b16.size()));
             HIPCHK(h, hipMemcpy(n.w16, b16.data(), b16.size() * 2, hipMemcpyHostToDevice));
+            // agz_nn_wave.hpp: groups of KThb k-rows x NTb tiles: layer 0 padded with zero rows to whole groups, zero-weight
+            // residual groups (identity) up to a multiple of NW_DEPTH, the head padded with zero tiles, NW_DEPTH groups of slack
+            if (NTheadb <= NTb && NTb % NW_WAVES == 0) {
+                const int G0 = (KT0b + KThb - 1) / KThb, NGH = nw_hidden_groups(n.INP, H, T);
+                const size_t s0p = (size_t)G0 * sr;
+                std::vector<uint16_t> bw((size_t)(NGH + 1 + NW_DEPTH) * sr, 0);
+                std::copy(b16.begin(), b16.begin() + s0, bw.begin());
+                std::copy(b16.begin() + s0, b16.begin() + (s0 + sr * T), bw.begin() + s0p);
+                tile_weights16(Wp, P.A, H, NTb, KThb, bw.data() + (size_t)NGH * sr);
+                tile_weights16(Wv, 1, H, NTb, KThb, bw.data() + (size_t)NGH * sr, P.A, 1);
+                HIPCHK(h, dmalloc(&n.w16w, bw.size()));
+                HIPCHK(h, hipMemcpy(n.w16w, bw.data(), bw.size() * 2, hipMemcpyHostToDevice));
+            }
         }
         std::vector<float> bh((size_t)n.AOP, 0.0f);
         for (int a = 0; a < P.A; ++a) bh[a] = bp[a];
@@ -534,7 +552,16 @@ static int launch_network(agz_engine* h, int which, int s0 = 0, int s1 = -1, hip
         f3_lds = (size_t)F3_M * (n.H * 2 + 16) + F3_WCHUNK + (size_t)F3_M * (n.INP * 2 + 16);
         if (f3_lds > 160 * 1024) f3_lds = 0;
     }
-    if (f3_lds) {                       // 16x16x32 tiles, 8 waves per workgroup
+    if (f3_lds && n.w16w && L <= h->nn_wave_maxl) {   // one wave per 16 leaves, weights streamed from L2: lowest latency
+        Fused3Par F;
+        F.planes = (const uint16_t*)planes; F.INP = n.INP; F.w16 = n.w16w; F.bias_head = n.bias_head;
+        F.logits = logits; F.LGS = h->LGS; F.vout = v_eval; F.L = L; F.T = n.T; F.A = h->G.A; F.AOP = n.AOP;
+        const int kth = n.H / 32, g0 = (n.INP / 32 + kth - 1) / kth;
+        const size_t lds = (size_t)16 * (2 * (n.H * 2 + 16) + (g0 * kth * 64 + 16));
+        dim3 grid((unsigned)((L + 15) / 16)), block(64 * NW_WAVES);
+        if (n.H == 128) hipLaunchKernelGGL(k_mlp_wave<128>, grid, block, lds, stream, F);
+        else hipLaunchKernelGGL(k_mlp_wave<64>, grid, block, lds, stream, F);
+    } else if (f3_lds) {                // 16x16x32 tiles, 8 waves per workgroup
         Fused3Par F;
         F.planes = (const uint16_t*)planes; F.INP = n.INP; F.w16 = n.w16; F.bias_head = n.bias_head;
         F.logits = logits; F.LGS = h->LGS; F.vout = v_eval; F.L = L; F.T = n.T; F.A = h->G.A; F.AOP = n.AOP;
@@ -606,7 +633,7 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
     // on the cut (every per-game quantity is keyed by game id).
     int K = 1;
     if (h->reg_lds != 0 && h->aux[0]) {
-        K = h->chains > 0 ? h->chains : agz_engine::KCH;
+        K = h->chains > 0 ? h->chains : 1;   // measured: <= 5 % at 32768 games, nothing below -> off unless AGZ_CHAINS is set
         const int kmax = (h->L + 255) / 256;               // at least 256 games per chain
         if (K > kmax) K = kmax;
         if (K > agz_engine::KCH) K = agz_engine::KCH;

@@ -324,3 +324,41 @@ def test_duel_runs_and_is_consistent():
     assert sum(wdl) == 64 and all(x >= 0 for x in wdl)
     v, n, d = M.duelnetwork(net, net, 16, 64, g, seed=5)
     assert v + n + d == 64
+
+
+def _bf16_search_bits(g, net, L, V, H):
+    with M.Engine(g, L, V, seed=11, nn_mode=M.NN_BF16) as e:
+        e.set_network(net)
+        e.set_roots(None, L=L)
+        e.search(V, cpuct=1.5, training=True, step=2)
+        return e.root_visits().copy(), e.policy().copy(), e.root_q().copy()
+
+
+@pytest.mark.parametrize("H,T", [(128, 6), (64, 3), (128, 1)])
+def test_bf16_network_kernels_agree_bitwise(H, T, monkeypatch):
+    """The latency-first network kernel (agz_nn_wave.hpp, default below 20000 leaves), the LDS-shared one
+    (agz_nn_fused3.hpp) and the per-layer MFMA kernels run the same MFMA sequence: identical bits, also for a ragged
+    last tile and for layer counts that need identity padding groups."""
+    g, _ = spec("gobang9")
+    net = ag.SNetwork2.random(g, H, T)
+    L, V = 300, 24
+    ref = _bf16_search_bits(g, net, L, V, H)
+    for env in ({"AGZ_NN_WAVE_MAXL": "0"}, {"AGZ_NN_WAVE_MAXL": "0", "AGZ_NO_FUSED_NN": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        got = _bf16_search_bits(g, net, L, V, H)
+        for a, b, what in zip(got, ref, ("visits", "policy", "q")):
+            assert_same_bits(a, b, what + " " + str(env))
+
+
+def test_sub_batch_chains_do_not_change_results(monkeypatch):
+    """AGZ_CHAINS=k cuts the batch into k sub-batches on parallel streams; every per-game quantity is keyed by game
+    id, so the cut must be invisible."""
+    g, _ = spec("connect4")
+    net = ag.SNetwork2.random(g, 64, 2)
+    L, V = 700, 32
+    ref = _bf16_search_bits(g, net, L, V, 64)
+    monkeypatch.setenv("AGZ_CHAINS", "3")
+    got = _bf16_search_bits(g, net, L, V, 64)
+    for a, b, what in zip(got, ref, ("visits", "policy", "q")):
+        assert_same_bits(a, b, what)
