@@ -61,7 +61,9 @@ struct agz_engine {
     hipStream_t aux[KCH - 1] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[KCH - 1] = {nullptr, nullptr, nullptr};
     int chains = 0;                     // 0 = automatic (AGZ_CHAINS overrides)
-    int nn_wave_maxl = 20000;           // batches up to this size use the latency-first network kernel (agz_nn_wave.hpp); measured crossover with k_mlp_fused3 (AGZ_NN_WAVE_MAXL overrides)
+    int nn_wave_depth = 0;              // layers of weights in flight: 0 = by batch size (AGZ_NN_WAVE_DEPTH = 2, 4)
+    int nn_wave_lt = 0;                 // 16-leaf tiles per workgroup of that kernel: 0 = by batch size (AGZ_NN_WAVE_LT = 1, 2, 4, 8)
+    int nn_wave_maxl = 1 << 30;         // batches up to this size use agz_nn_wave.hpp, larger ones k_mlp_fused3 (AGZ_NN_WAVE_MAXL); the wave kernel wins at every size measured
     int L = 0;                 // active slots
     int Lmax = 0, V = 0, NRV = 1;
     TreePar tp;                // template of kernel arguments
@@ -236,6 +238,10 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
         h->chains = e ? atoi(e) : 0;
         e = getenv("AGZ_NN_WAVE_MAXL");
         if (e) h->nn_wave_maxl = atoi(e);
+        e = getenv("AGZ_NN_WAVE_DEPTH");
+        if (e && (atoi(e) == 2 || atoi(e) == 4)) h->nn_wave_depth = atoi(e);
+        e = getenv("AGZ_NN_WAVE_LT");
+        if (e && (atoi(e) == 1 || atoi(e) == 2 || atoi(e) == 4 || atoi(e) == 8)) h->nn_wave_lt = atoi(e);
         bool ok = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
         for (int c = 0; ok && c < agz_engine::KCH - 1; ++c)
             ok = hipStreamCreateWithFlags(&h->aux[c], hipStreamNonBlocking) == hipSuccess &&
@@ -246,6 +252,12 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     h->Lmax = cfg->max_games; h->V = cfg->max_visits;
     h->NRV = h->V <= 64 ? 1 : (h->V <= 128 ? 2 : 4);
     if (!bind_kernels(h)) { h->fail("no kernel instantiation for this game shape"); return bail(AGZ_ERR_UNSUPPORTED); }
+    hipFuncSetAttribute((const void*)k_mlp_wave<128, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)k_mlp_wave<128, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)k_mlp_wave<128, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)k_mlp_wave<128, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)k_mlp_wave<64, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)k_mlp_wave<64, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)k_layer_exact<EX_RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)k_layer_exact<EX_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)k_layer_exact<EX_POLICY>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -557,10 +569,15 @@ static int launch_network(agz_engine* h, int which, int s0 = 0, int s1 = -1, hip
         F.planes = (const uint16_t*)planes; F.INP = n.INP; F.w16 = n.w16w; F.bias_head = n.bias_head;
         F.logits = logits; F.LGS = h->LGS; F.vout = v_eval; F.L = L; F.T = n.T; F.A = h->G.A; F.AOP = n.AOP;
         const int kth = n.H / 32, g0 = (n.INP / 32 + kth - 1) / kth;
-        const size_t lds = (size_t)16 * (2 * (n.H * 2 + 16) + (g0 * kth * 64 + 16));
-        dim3 grid((unsigned)((L + 15) / 16)), block(64 * NW_WAVES);
-        if (n.H == 128) hipLaunchKernelGGL(k_mlp_wave<128>, grid, block, lds, stream, F);
-        else hipLaunchKernelGGL(k_mlp_wave<64>, grid, block, lds, stream, F);
+        int lt = h->nn_wave_lt > 0 ? h->nn_wave_lt : (L <= 16384 ? 1 : 2);   // measured (128x6): 11 / 14 / 20 us at 2048 / 8192 / 16384 leaves with 1 tile, 27 us at 32768 with 2
+        const size_t lds = (size_t)16 * lt * (2 * (n.H * 2 + 16) + (g0 * kth * 64 + 16));
+        dim3 grid((unsigned)((L + 16 * lt - 1) / (16 * lt))), block(64 * NW_WAVES);
+        const int depth = h->nn_wave_depth > 0 ? h->nn_wave_depth : 2;   // two layers ahead already cover the L2 latency; 4 only costs occupancy
+#define NW_LAUNCH(HH, LL) do { if (depth == 4) hipLaunchKernelGGL((k_mlp_wave<HH, LL, 4>), grid, block, lds, stream, F); \
+                               else hipLaunchKernelGGL((k_mlp_wave<HH, LL, 2>), grid, block, lds, stream, F); } while (0)
+        if (n.H == 128) { if (lt == 1) NW_LAUNCH(128, 1); else if (lt == 2) NW_LAUNCH(128, 2); else if (lt == 4) NW_LAUNCH(128, 4); else NW_LAUNCH(128, 8); }
+        else { if (lt == 1) NW_LAUNCH(64, 1); else if (lt == 2) NW_LAUNCH(64, 2); else if (lt == 4) NW_LAUNCH(64, 4); else NW_LAUNCH(64, 8); }
+#undef NW_LAUNCH
     } else if (f3_lds) {                // 16x16x32 tiles, 8 waves per workgroup
         Fused3Par F;
         F.planes = (const uint16_t*)planes; F.INP = n.INP; F.w16 = n.w16; F.bias_head = n.bias_head;

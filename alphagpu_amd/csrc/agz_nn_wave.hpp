@@ -20,30 +20,36 @@
 namespace agz {
 
 constexpr int NW_WAVES = 4;               // waves per workgroup (= per 16-leaf tile)
-constexpr int NW_DEPTH = 4;               // groups (layers) of weight fragments in flight per wave
+constexpr int NW_DEPTH = 4;               // hidden groups are padded to a multiple of this (the deepest prefetch)
 
 __host__ __device__ inline int nw_hidden_groups(int INP, int H, int T) {
     const int kth = H / 32, g0 = (INP / 32 + kth - 1) / kth;
     return (g0 + T + NW_DEPTH - 1) / NW_DEPTH * NW_DEPTH;
 }
 
-template <int H>
+// LT = 16-leaf tiles per workgroup: every weight fragment fetched from L2 feeds LT MFMAs (LT = 1 for the lowest latency,
+// larger LT when the batch is big enough for the L2 weight stream to become the bound).
+// DEPTH = groups (layers) of weight fragments in flight per wave: 4 hides the whole L2 latency behind one workgroup's own
+// work, 2 halves the registers so that twice as many workgroups share a CU (throughput mode for big batches).
+template <int H, int LT, int DEPTH>
 __global__ __launch_bounds__(64 * NW_WAVES) void k_mlp_wave(const Fused3Par P) {
     constexpr int NTH = H / 16, KTH = H / 32, TPW = NTH / NW_WAVES;
     constexpr int ROWB = H * 2 + 16;
     static_assert(TPW >= 1, "at least one neuron tile per wave");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int leaf0 = (int)blockIdx.x * 16;
+    constexpr int ML = 16 * LT;                                   // leaves per workgroup
+    const int leaf0 = (int)blockIdx.x * ML;
     const int G0 = (P.INP / 32 + KTH - 1) / KTH;                 // groups of layer 0
     const int NGH = nw_hidden_groups(P.INP, H, P.T);             // groups before the head
     const int PROWB = G0 * KTH * 64 + 16;
-    uint8_t* const act0 = smem;                                   // [16][ROWB] x 2 (ping-pong), then [16][PROWB] input planes
-    uint8_t* const pl = smem + 2 * 16 * ROWB;
+    uint8_t* const act0 = smem;                                   // [ML][ROWB] x 2 (ping-pong), then [ML][PROWB] input planes
+    uint8_t* const pl = smem + 2 * ML * ROWB;
     const int lrow = lane & 15, q4 = lane >> 4;
     const AGZ_GLB v4u* wsrc = (const AGZ_GLB v4u*)P.w16 + (size_t)wave * TPW * 64 + lane;   // advances one group at a time
 
-    bf16x8 A[NW_DEPTH][KTH][TPW];
+    static_assert(DEPTH == 2 || DEPTH == 4, "the group loop below is unrolled by hand");
+    bf16x8 A[DEPTH][KTH][TPW];
 #define NW_LOADGROUP(d)                                                                                 \
     do {                                                                                                \
         _Pragma("unroll") for (int k = 0; k < KTH; ++k)                                                 \
@@ -52,13 +58,13 @@ __global__ __launch_bounds__(64 * NW_WAVES) void k_mlp_wave(const Fused3Par P) {
             }                                                                                           \
         wsrc += KTH * NTH * 64;                                                                         \
     } while (0)
-    NW_LOADGROUP(0); NW_LOADGROUP(1); NW_LOADGROUP(2); NW_LOADGROUP(3);
-    static_assert(NW_DEPTH == 4, "the group loop below is unrolled by hand for a depth of 4");
+    NW_LOADGROUP(0); NW_LOADGROUP(1);
+    if constexpr (DEPTH == 4) { NW_LOADGROUP(2); NW_LOADGROUP(3); }
 
-    {   // the 16 rows of input planes -> LDS (coalesced 16-B loads), zero beyond INP
+    {   // the ML rows of input planes -> LDS (coalesced 16-B loads), zero beyond INP
         const int segs = G0 * KTH * 4, isegs = P.INP / 8;
         const AGZ_GLB uint16_t* gp = (const AGZ_GLB uint16_t*)P.planes;
-        for (int c = threadIdx.x; c < 16 * segs; c += 64 * NW_WAVES) {
+        for (int c = threadIdx.x; c < ML * segs; c += 64 * NW_WAVES) {
             const int row = c / segs, seg = c - row * segs, mm = leaf0 + row;
             v4u v = {0u, 0u, 0u, 0u};
             if (mm < P.L && seg < isegs) v = *(const AGZ_GLB v4u*)(gp + (size_t)mm * P.INP + seg * 8);
@@ -67,72 +73,86 @@ __global__ __launch_bounds__(64 * NW_WAVES) void k_mlp_wave(const Fused3Par P) {
     }
     __syncthreads();
 
-    f32x4 acc[TPW];
+    f32x4 acc[LT][TPW];
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) { acc[t][0] = 0.0f; acc[t][1] = 0.0f; acc[t][2] = 0.0f; acc[t][3] = 0.0f; }
+    for (int lt = 0; lt < LT; ++lt)
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) { acc[lt][t][0] = 0.0f; acc[lt][t][1] = 0.0f; acc[lt][t][2] = 0.0f; acc[lt][t][3] = 0.0f; }
     int cur = 0;                                                  // activation strip holding the current layer's input
     // one group: KTH k-rows of this wave's TPW tiles; closes a layer unless it is an inner group of layer 0
 #define NW_GROUP(d, g)                                                                                  \
     do {                                                                                                \
         const int g_ = (g);                                                                             \
         const uint8_t* const brow_ = g_ < G0 ? pl + (size_t)lrow * PROWB + (size_t)g_ * KTH * 64         \
-                                             : act0 + (size_t)cur * 16 * ROWB + (size_t)lrow * ROWB;    \
-        _Pragma("unroll") for (int k = 0; k < KTH; ++k) {                                               \
-            const bf16x8 b_ = *reinterpret_cast<const bf16x8*>(brow_ + k * 64 + q4 * 16);               \
-            _Pragma("unroll") for (int t = 0; t < TPW; ++t)                                             \
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[d][k][t], b_, acc[t], 0, 0, 0);      \
-        }                                                                                               \
-        NW_LOADGROUP(d);                                          /* group g + NW_DEPTH */              \
+                                             : act0 + (size_t)cur * ML * ROWB + (size_t)lrow * ROWB;    \
+        const int bstride_ = 16 * (g_ < G0 ? PROWB : ROWB);       /* next 16-leaf tile */               \
+        _Pragma("unroll") for (int k = 0; k < KTH; ++k)                                                 \
+            _Pragma("unroll") for (int lt = 0; lt < LT; ++lt) {                                         \
+                const bf16x8 b_ = *reinterpret_cast<const bf16x8*>(brow_ + (size_t)lt * bstride_ + k * 64 + q4 * 16); \
+                _Pragma("unroll") for (int t = 0; t < TPW; ++t)                                         \
+                    acc[lt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[d][k][t], b_, acc[lt][t], 0, 0, 0); \
+            }                                                                                           \
+        NW_LOADGROUP(d);                                          /* group g + DEPTH */                 \
         if (g_ >= G0 - 1) {                                                                             \
             const bool res_ = g_ >= G0;                                                                 \
-            const uint8_t* const old_ = act0 + (size_t)cur * 16 * ROWB + (size_t)lrow * ROWB;           \
-            uint8_t* const new_ = act0 + (size_t)(cur ^ 1) * 16 * ROWB + (size_t)lrow * ROWB;           \
-            _Pragma("unroll") for (int t = 0; t < TPW; ++t) {                                           \
-                const int n = 16 * (wave * TPW + t) + 4 * q4;      /* acc[t][r] = out[neuron n + r][leaf lrow] */ \
-                float x0 = acc[t][0] > 0.0f ? acc[t][0] : 0.0f, x1 = acc[t][1] > 0.0f ? acc[t][1] : 0.0f; \
-                float x2 = acc[t][2] > 0.0f ? acc[t][2] : 0.0f, x3 = acc[t][3] > 0.0f ? acc[t][3] : 0.0f; \
-                if (res_) {                                        /* b = relu(b + relu(W b)) */        \
-                    const uint2 o = *reinterpret_cast<const uint2*>(old_ + n * 2);                      \
-                    x0 += __uint_as_float(o.x << 16); x1 += __uint_as_float(o.x & 0xffff0000u);         \
-                    x2 += __uint_as_float(o.y << 16); x3 += __uint_as_float(o.y & 0xffff0000u);         \
-                    x0 = x0 > 0.0f ? x0 : 0.0f; x1 = x1 > 0.0f ? x1 : 0.0f; x2 = x2 > 0.0f ? x2 : 0.0f; x3 = x3 > 0.0f ? x3 : 0.0f; \
+            _Pragma("unroll") for (int lt = 0; lt < LT; ++lt) {                                         \
+                const uint8_t* const old_ = act0 + (size_t)cur * ML * ROWB + (size_t)(lt * 16 + lrow) * ROWB; \
+                uint8_t* const new_ = act0 + (size_t)(cur ^ 1) * ML * ROWB + (size_t)(lt * 16 + lrow) * ROWB; \
+                _Pragma("unroll") for (int t = 0; t < TPW; ++t) {                                       \
+                    const int n = 16 * (wave * TPW + t) + 4 * q4;  /* acc[lt][t][r] = out[neuron n + r][leaf 16 lt + lrow] */ \
+                    float x0 = acc[lt][t][0] > 0.0f ? acc[lt][t][0] : 0.0f, x1 = acc[lt][t][1] > 0.0f ? acc[lt][t][1] : 0.0f; \
+                    float x2 = acc[lt][t][2] > 0.0f ? acc[lt][t][2] : 0.0f, x3 = acc[lt][t][3] > 0.0f ? acc[lt][t][3] : 0.0f; \
+                    if (res_) {                                    /* b = relu(b + relu(W b)) */        \
+                        const uint2 o = *reinterpret_cast<const uint2*>(old_ + n * 2);                  \
+                        x0 += __uint_as_float(o.x << 16); x1 += __uint_as_float(o.x & 0xffff0000u);     \
+                        x2 += __uint_as_float(o.y << 16); x3 += __uint_as_float(o.y & 0xffff0000u);     \
+                        x0 = x0 > 0.0f ? x0 : 0.0f; x1 = x1 > 0.0f ? x1 : 0.0f; x2 = x2 > 0.0f ? x2 : 0.0f; x3 = x3 > 0.0f ? x3 : 0.0f; \
+                    }                                                                                   \
+                    *reinterpret_cast<uint2*>(new_ + n * 2) = make_uint2(pk_bf16(x0, x1), pk_bf16(x2, x3)); \
+                    acc[lt][t][0] = 0.0f; acc[lt][t][1] = 0.0f; acc[lt][t][2] = 0.0f; acc[lt][t][3] = 0.0f; \
                 }                                                                                       \
-                *reinterpret_cast<uint2*>(new_ + n * 2) = make_uint2(pk_bf16(x0, x1), pk_bf16(x2, x3)); \
-                acc[t][0] = 0.0f; acc[t][1] = 0.0f; acc[t][2] = 0.0f; acc[t][3] = 0.0f;                 \
             }                                                                                           \
             cur ^= 1;                                                                                   \
             __syncthreads();                                                                            \
         }                                                                                               \
     } while (0)
 #pragma unroll 1
-    for (int g = 0; g < NGH; g += NW_DEPTH) { NW_GROUP(0, g); NW_GROUP(1, g + 1); NW_GROUP(2, g + 2); NW_GROUP(3, g + 3); }
+    for (int g = 0; g < NGH; g += DEPTH) {
+        NW_GROUP(0, g); NW_GROUP(1, g + 1);
+        if constexpr (DEPTH == 4) { NW_GROUP(2, g + 2); NW_GROUP(3, g + 3); }
+    }
 #undef NW_GROUP
 #undef NW_LOADGROUP
 
-    {   // head: D = X * W^T (logits leave row-major); its fragments sit in buffer 0 (NGH is a multiple of NW_DEPTH)
-        const uint8_t* const brow = act0 + (size_t)cur * 16 * ROWB + (size_t)lrow * ROWB;
+    {   // head: D = X * W^T (logits leave row-major); its fragments sit in buffer 0 (NGH is a multiple of DEPTH)
+        const uint8_t* const brow = act0 + (size_t)cur * ML * ROWB + (size_t)lrow * ROWB;
         const int NT = P.AOP / 16;
         if (wave * TPW < NT) {
 #pragma unroll
-            for (int k = 0; k < KTH; ++k) {
-                const bf16x8 b = *reinterpret_cast<const bf16x8*>(brow + k * 64 + q4 * 16);
+            for (int k = 0; k < KTH; ++k)
 #pragma unroll
-                for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, A[0][k][t], acc[t], 0, 0, 0);
-            }
-            // acc[t][r] = out[leaf = leaf0 + 4 q4 + r][n = 16 tile + (lane & 15)]
-            const int mw = leaf0 + 4 * q4;
+                for (int lt = 0; lt < LT; ++lt) {
+                    const bf16x8 b = *reinterpret_cast<const bf16x8*>(brow + (size_t)lt * 16 * ROWB + k * 64 + q4 * 16);
+#pragma unroll
+                    for (int t = 0; t < TPW; ++t) acc[lt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, A[0][k][t], acc[lt][t], 0, 0, 0);
+                }
+            // acc[lt][t][r] = out[leaf = leaf0 + 16 lt + 4 q4 + r][n = 16 tile + (lane & 15)]
 #pragma unroll
             for (int t = 0; t < TPW; ++t) {
                 const int tile = wave * TPW + t;
                 if (tile < NT) {
                     const int n = 16 * tile + (lane & 15);
                     const float bias = P.bias_head[n];
-                    if (n < P.A) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) if (mw + r < P.L) P.logits[(size_t)(mw + r) * P.LGS + n] = acc[t][r] + bias;
-                    } else if (n == P.A) {
+                    for (int lt = 0; lt < LT; ++lt) {
+                        const int mw = leaf0 + 16 * lt + 4 * q4;
+                        if (n < P.A) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) if (mw + r < P.L) P.vout[mw + r] = sigmoid_ool(acc[t][r] + bias);
+                            for (int r = 0; r < 4; ++r) if (mw + r < P.L) P.logits[(size_t)(mw + r) * P.LGS + n] = acc[lt][t][r] + bias;
+                        } else if (n == P.A) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) if (mw + r < P.L) P.vout[mw + r] = sigmoid_ool(acc[lt][t][r] + bias);
+                        }
                     }
                 }
             }

@@ -22,8 +22,10 @@ namespace agz {
 // first ACTIVE lane, so that the attribution is right inside divergent code as well
 #define STAMP(i) do { unsigned long long t_ = __builtin_amdgcn_s_memtime();                                   \
                       if (lane_id() == (int)__builtin_ctzll(__ballot(1))) { stamp_lds[i] += t_ - stamp_lds[16]; stamp_lds[16] = t_; } } while (0)
+#define CNT(i, n) do { if (lane_id() == (int)__builtin_ctzll(__ballot(1))) stamp_lds[i] += (n); } while (0)
 #else
 #define STAMP(i) do { } while (0)
+#define CNT(i, n) do { } while (0)
 #endif
 
 #define AGZ_WSYNC()                                              \

@@ -39,6 +39,9 @@ template <int G> __device__ __forceinline__ uint64_t grp_or64(uint64_t v) {
     if (G >= 16) { lo |= dpp_mov<DPP_MIRROR, 0xF>(0, lo); hi |= dpp_mov<DPP_MIRROR, 0xF>(0, hi); }
     return (uint64_t)(uint32_t)lo | ((uint64_t)(uint32_t)hi << 32);
 }
+template <int D> __device__ __forceinline__ float lane_shl(float x) {      // value of lane + D (same 16-lane row), own value past the row's end
+    return __int_as_float(dpp_mov<0x100 + D, 0xF>(__float_as_int(x), __float_as_int(x)));
+}
 __device__ __forceinline__ float lane_shr1(float x) { return __int_as_float(dpp_mov<DPP_SHR1, 0xF>(__float_as_int(x), __float_as_int(x))); }
 
 // Source-order sum of the group's G*KPL values (lane sub holds block sub).  Returns the total in every lane and
@@ -46,7 +49,7 @@ __device__ __forceinline__ float lane_shr1(float x) { return __int_as_float(dpp_
 template <int G, int KPL>
 __device__ __forceinline__ float grp_ordered_sum(const float (&x)[KPL], int sub, float& start) {
     float a = 0.0f, st = 0.0f;
-#pragma unroll
+#pragma unroll 1                                                // keeps the kernel inside the instruction cache
     for (int t = 0; t < G; ++t) {
         const float carry = lane_shr1(a);                       // what the previous lane ended with
         const float s0 = sub == 0 ? 0.0f : carry;
@@ -239,6 +242,7 @@ __global__ __launch_bounds__(64, G <= 4 ? 2 : AGZ_REG_WAVES) void k_rollout_reg(
         while (__ballot(descending)) {
             if (descending) {
                 if (lead) ++add_p;
+                CNT(1, 1);
                 // ---- this lane's block of the node row, straight from HBM
                 const uint8_t* rec = myrecs + (size_t)node * ROWS;
                 float p[KPL], q[KPL]; uint32_t vw[KPL / 2];                // vw[j] = vc[2j] | vc[2j+1] << 16
@@ -292,7 +296,11 @@ __global__ __launch_bounds__(64, G <= 4 ? 2 : AGZ_REG_WAVES) void k_rollout_reg(
                     }
                     const float nf = 1.0f + (float)vs, Af = (float)ac;
                     float st0;
+#ifdef AGZ_ABL_PREM
+                    float prior_rem = grp_sum<G>((int)(m[0] + m[5])) * 0.01f; st0 = 0;
+#else
                     float prior_rem = grp_ordered_sum<G, KPL>(m, sub, st0);   // ordered (:122-124)
+#endif
                     lambda = T.cpuct * __builtin_sqrtf(nf) / (Af + nf);    // :132
                     prior_rem *= lambda;                                    // :134
                     float am = 0.0f;                                        // :133-138
@@ -339,18 +347,25 @@ __global__ __launch_bounds__(64, G <= 4 ? 2 : AGZ_REG_WAVES) void k_rollout_reg(
                     float top_l = 0.0f, qv_l = 0.0f;
                     if (sub == 0) top_l = prior_rem;
                     else if (sub <= nch && fast) { top_l = lambda * tabp[sub - 1]; qv_l = tabq[sub - 1]; }   // :147-148
+#ifdef AGZ_ABL_NEWTON
+                    for (int it = 0; it < 1; ++it) {
+#else
                     for (int it = 0; it < 100; ++it) {                     // :141-162
+#endif
                         float S = 0.0f, gg = 0.0f;
+                        CNT(6, 1);
+                        if (__ballot(!fast)) CNT(3, 1);
                         if (fast) {
                             float t = 0.0f, uu = 0.0f;
                             if (sub <= nch) { const float bot = alpha - qv_l; t = top_l / bot; uu = -top_l / (bot * bot); }
-                            float a = 0.0f, b = 0.0f;
-                            for (int tn = 0; tn <= nch; ++tn) {            // lane tn continues the sums of lane tn-1
-                                const float ca = lane_shr1(a), cb = lane_shr1(b);
-                                a = (sub == 0 ? 0.0f : ca) + t;
-                                b = (sub == 0 ? 0.0f : cb) + uu;
-                            }
-                            S = __shfl(a, nch, G); gg = __shfl(b, nch, G);
+                            // the group's lead lane pulls element d from lane d (DPP row_shl:d) and adds them in order;
+                            // lanes beyond nch contribute +0 (exact), the other lanes' sums are discarded
+                            float a = t, b = uu;
+#define AGZ_PULL(d) if (G > d) { a += lane_shl<d>(t); b += lane_shl<d>(uu); }
+                            AGZ_PULL(1) AGZ_PULL(2) AGZ_PULL(3) AGZ_PULL(4) AGZ_PULL(5) AGZ_PULL(6) AGZ_PULL(7)
+                            AGZ_PULL(8) AGZ_PULL(9) AGZ_PULL(10) AGZ_PULL(11) AGZ_PULL(12) AGZ_PULL(13) AGZ_PULL(14) AGZ_PULL(15)
+#undef AGZ_PULL
+                            S = __int_as_float(grp_bcast<G>(__float_as_int(a))); gg = __int_as_float(grp_bcast<G>(__float_as_int(b)));
                         } else {
                             for (int c = sub; c <= nch; c += G) {
                                 float top = prior_rem, qv = 0.0f;
@@ -380,7 +395,11 @@ __global__ __launch_bounds__(64, G <= 4 ? 2 : AGZ_REG_WAVES) void k_rollout_reg(
                     }
                     STAMP(10);
 #pragma unroll
+#ifdef AGZ_ABL_POLICY
+                    for (int j = 0; j < KPL; ++j) pol[j] = lambda * p[j] * (alpha - q[j]);
+#else
                     for (int j = 0; j < KPL; ++j) pol[j] = lambda * p[j] / (alpha - q[j]);   // :165-169
+#endif
                 } else {
 #pragma unroll
                     for (int j = 0; j < KPL; ++j) pol[j] = p[j];           // policy == prior since expand (:297-299)
@@ -392,7 +411,11 @@ __global__ __launch_bounds__(64, G <= 4 ? 2 : AGZ_REG_WAVES) void k_rollout_reg(
                 STAMP(11);
                 // ---- sample (:172-182): ordered prefix by turns, then every lane re-derives its own prefixes
                 float st0;
+#ifdef AGZ_ABL_SAMPLE
+                st0 = 0.01f * sub;
+#else
                 (void)grp_ordered_sum<G, KPL>(pol, sub, st0);
+#endif
                 int jhit = KPL, jpos = -1;                                 // first j with prefix >= u ; last j <= jhit with policy > 0
                 {
                     float a = st0;

@@ -336,14 +336,17 @@ def _bf16_search_bits(g, net, L, V, H):
 
 @pytest.mark.parametrize("H,T", [(128, 6), (64, 3), (128, 1)])
 def test_bf16_network_kernels_agree_bitwise(H, T, monkeypatch):
-    """The latency-first network kernel (agz_nn_wave.hpp, default below 20000 leaves), the LDS-shared one
+    """The latency-first network kernel (agz_nn_wave.hpp, the default) at other tile counts / prefetch depths, the LDS-shared one
     (agz_nn_fused3.hpp) and the per-layer MFMA kernels run the same MFMA sequence: identical bits, also for a ragged
     last tile and for layer counts that need identity padding groups."""
     g, _ = spec("gobang9")
     net = ag.SNetwork2.random(g, H, T)
     L, V = 300, 24
     ref = _bf16_search_bits(g, net, L, V, H)
-    for env in ({"AGZ_NN_WAVE_MAXL": "0"}, {"AGZ_NN_WAVE_MAXL": "0", "AGZ_NO_FUSED_NN": "1"}):
+    for env in ({"AGZ_NN_WAVE_LT": "4", "AGZ_NN_WAVE_DEPTH": "4"}, {"AGZ_NN_WAVE_LT": "2"}, {"AGZ_NN_WAVE_MAXL": "0"},
+                {"AGZ_NN_WAVE_MAXL": "0", "AGZ_NO_FUSED_NN": "1"}):
+        for k in ("AGZ_NN_WAVE_LT", "AGZ_NN_WAVE_DEPTH", "AGZ_NN_WAVE_MAXL", "AGZ_NO_FUSED_NN"):
+            monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         got = _bf16_search_bits(g, net, L, V, H)
