@@ -104,6 +104,7 @@ struct TreePar {
     Pos* states;
     uint32_t* meta;
     uint32_t *ncount, *leaf, *game_id, *cnt_p, *cnt_new;
+    float2* aux;             // [L][V] {prior_rem sum before lambda, count of positive priors} (register-row kernel)
     // network i/o
     void* planes;            // [L][INP] bf16 (or f32 when planes_f32)
     int32_t INP, planes_f32;

@@ -70,6 +70,7 @@ struct agz_engine {
     // tree memory
     uint8_t* recs = nullptr; Pos* states = nullptr; uint32_t* meta = nullptr;
     uint32_t *ncount = nullptr, *leaf = nullptr, *game_id = nullptr, *game_id2 = nullptr, *cnt_p = nullptr, *cnt_new = nullptr;
+    float2* node_aux = nullptr;
     // network i/o
     void* planes = nullptr; float* logits = nullptr; float *prior_eval = nullptr, *v_eval = nullptr, *policy_final = nullptr;
     uint16_t *act0 = nullptr, *act1 = nullptr; float *actf0 = nullptr, *actf1 = nullptr;
@@ -93,6 +94,7 @@ struct agz_engine {
     size_t ev_tree_used = 0, ev_nn_used = 0;
     double tree_ms = 0, nn_ms = 0; int64_t tree_launches = 0;
     rollout_fn k_roll = nullptr; advance_fn k_adv = nullptr; softmax_fn k_soft = nullptr;
+    rollout_fn k_reg3 = nullptr; int reg3_max_waves = 0;   // the 3-waves-per-SIMD build of k_reg and the largest grid it is used for
     rollout_fn k_reg = nullptr; size_t reg_lds = 0; int reg_kpl = 0, reg_g = 8;   // register-row kernel (agz_tree_reg.hpp), 8 lanes per tree
     rollout_fn k_lpg = nullptr; size_t lpg_lds = 0; int grp_g = 16;   // group kernel (agz_tree_grp.hpp): G lanes per tree; lpg_lds == 0 -> wave-per-tree kernel
 
@@ -127,15 +129,15 @@ static bool bind_kernels(agz_engine* h) {
 #undef Y
     {   // register-row kernel: smallest block length KPL with 8*KPL >= A among the instantiated shapes
         const int kpl = P.A <= 32 ? 4 : (P.A <= 64 ? 8 : (P.A <= 96 ? 12 : (P.A <= 128 ? 16 : (P.A <= 192 ? 24 : 0))));
-#define Z(F, C, K) if (P.fam == F && P.NC == C && kpl == K) { h->k_reg = k_rollout_reg<F, C, 8, K>; h->reg_kpl = K; }
+#define Z(F, C, K) if (P.fam == F && P.NC == C && kpl == K) { h->k_reg = k_rollout_reg<F, C, 8, K, 4>; h->k_reg3 = k_rollout_reg<F, C, 8, K, 3>; h->reg_kpl = K; }
         Z(F_LINE, 1, 4) Z(F_LINE, 1, 8) Z(F_LINE, 2, 12) Z(F_LINE, 2, 16) Z(F_LINE, 3, 24)
         Z(F_C4, 1, 4)
         Z(F_HEX, 1, 4) Z(F_HEX, 1, 8) Z(F_HEX, 2, 8) Z(F_HEX, 2, 12) Z(F_HEX, 2, 16) Z(F_HEX, 3, 16) Z(F_HEX, 3, 24)
         Z(F_REV, 1, 12) Z(F_REV, 1, 8)
 #undef Z
         { const char* eg = getenv("AGZ_REG_G");     // experiment: 4 lanes per tree (Gobang 9x9 / Hex 9x9 shapes only)
-          if (eg && atoi(eg) == 4 && P.fam == F_LINE && P.NC == 2 && kpl == 12) { h->k_reg = k_rollout_reg<F_LINE, 2, 4, 24>; h->reg_kpl = 24; h->reg_g = 4; }
-          if (eg && atoi(eg) == 16 && P.fam == F_LINE && P.NC == 2 && kpl == 12) { h->k_reg = k_rollout_reg<F_LINE, 2, 16, 8>; h->reg_kpl = 8; h->reg_g = 16; } }
+          if (eg && atoi(eg) == 4 && P.fam == F_LINE && P.NC == 2 && kpl == 12) { h->k_reg = h->k_reg3 = k_rollout_reg<F_LINE, 2, 4, 24>; h->reg_kpl = 24; h->reg_g = 4; }
+          if (eg && atoi(eg) == 16 && P.fam == F_LINE && P.NC == 2 && kpl == 12) { h->k_reg = h->k_reg3 = k_rollout_reg<F_LINE, 2, 16, 8>; h->reg_kpl = 8; h->reg_g = 16; } }
     }
     if (P.NR == 1) h->k_soft = k_softmax<1>; else if (P.NR == 2) h->k_soft = k_softmax<2>; else h->k_soft = k_softmax<3>;
     return h->k_roll != nullptr;
@@ -203,7 +205,7 @@ void agz_destroy(agz_engine* h) {
     hipSetDevice(h->cfg.device);
     if (h->stream) hipStreamSynchronize(h->stream);
     hipFree(h->recs); hipFree(h->states); hipFree(h->meta); hipFree(h->ncount); hipFree(h->leaf); hipFree(h->game_id);
-    hipFree(h->game_id2); hipFree(h->cnt_p); hipFree(h->cnt_new); hipFree(h->planes); hipFree(h->logits);
+    hipFree(h->game_id2); hipFree(h->cnt_p); hipFree(h->cnt_new); hipFree(h->node_aux); hipFree(h->planes); hipFree(h->logits);
     hipFree(h->prior_eval); hipFree(h->v_eval); hipFree(h->policy_final); hipFree(h->act0); hipFree(h->act1);
     hipFree(h->actf0); hipFree(h->actf1); hipFree(h->newpos); hipFree(h->alive); hipFree(h->newslot); hipFree(h->d_count);
     hipFree(h->s_boards); hipFree(h->s_policy); hipFree(h->s_move); hipFree(h->g_nplies); hipFree(h->g_result);
@@ -281,7 +283,14 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     uint32_t rec_bytes = (uint32_t)round_up((int)(A2 * 10), 16);
     if (((rec_bytes / 16) & 1u) == 0) rec_bytes += 16;
     h->lpg_lds = (size_t)(64 / h->grp_g) * grp_lds_layout((int)rec_bytes, (int)A2, h->V).stride;
-    if (h->reg_lds) hipFuncSetAttribute((const void*)h->k_reg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->reg_lds);
+    if (h->reg_lds) {
+        hipFuncSetAttribute((const void*)h->k_reg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->reg_lds);
+        hipFuncSetAttribute((const void*)h->k_reg3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->reg_lds);
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) h->reg3_max_waves = 12 * prop.multiProcessorCount;   // 3 waves x 4 SIMDs per CU
+        const char* e3 = getenv("AGZ_REG3_MAX_WAVES");
+        if (e3) h->reg3_max_waves = atoi(e3);
+    }
     if (h->reg_lds || !h->k_lpg || h->lpg_lds > 64 * 1024 /* LDS-DMA destination offsets are 16 bit */ || (tk && !strcmp(tk, "v1"))) h->lpg_lds = 0;
     if (h->lpg_lds) hipFuncSetAttribute((const void*)h->k_lpg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lpg_lds);
     const size_t Lm = (size_t)h->Lmax, V = (size_t)h->V;
@@ -293,7 +302,7 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     A_(dmalloc(&h->states, Lm * V));
     A_(dmalloc(&h->meta, Lm * V));
     A_(dmalloc(&h->ncount, Lm)); A_(dmalloc(&h->leaf, Lm)); A_(dmalloc(&h->game_id, Lm)); A_(dmalloc(&h->game_id2, Lm));
-    A_(dmalloc(&h->cnt_p, Lm)); A_(dmalloc(&h->cnt_new, Lm));
+    A_(dmalloc(&h->cnt_p, Lm)); A_(dmalloc(&h->cnt_new, Lm)); A_(dmalloc(&h->node_aux, Lm * (size_t)h->V));
     if (cfg->nn_mode == AGZ_NN_BF16) { uint16_t* p = nullptr; A_(dmalloc(&p, Lm * h->INP)); h->planes = p; }
     else { float* p = nullptr; A_(dmalloc(&p, Lm * h->INP)); h->planes = p; }
     A_(dmalloc(&h->logits, Lm * h->LGS));
@@ -319,7 +328,7 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     memset(&T, 0, sizeof T);
     T.G = P; T.V = h->V; T.rec_bytes = rec_bytes; T.off_q = A2 * 4; T.off_vc = A2 * 8; T.A2 = A2;
     T.recs = h->recs; T.states = h->states; T.meta = h->meta; T.ncount = h->ncount; T.leaf = h->leaf; T.game_id = h->game_id;
-    T.cnt_p = h->cnt_p; T.cnt_new = h->cnt_new; T.planes = h->planes; T.INP = h->INP; T.planes_f32 = cfg->nn_mode == AGZ_NN_EXACT;
+    T.cnt_p = h->cnt_p; T.cnt_new = h->cnt_new; T.aux = h->node_aux; T.planes = h->planes; T.INP = h->INP; T.planes_f32 = cfg->nn_mode == AGZ_NN_EXACT;
     T.logits = h->logits; T.LGS = h->LGS; T.prior_eval = h->prior_eval; T.v_eval = h->v_eval; T.policy_final = h->policy_final;
     T.seed = cfg->seed; T.exact = cfg->nn_mode == AGZ_NN_EXACT;
 #ifdef AGZ_STAMPS
@@ -536,7 +545,7 @@ static int launch_rollout(agz_engine* h, uint32_t rollout, int do_reset, int do_
     dim3 grid((unsigned)((reg || lpg) ? (n + ng - 1) / ng : (n + 3) / 4)), block((reg || lpg) ? 64 : 256);
     std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
     if (h->profiling & 1) { ev = next_events(h, h->ev_tree, h->ev_tree_used); hipEventRecord(ev->first, stream); }
-    hipLaunchKernelGGL(reg ? h->k_reg : (lpg ? h->k_lpg : h->k_roll), grid, block, reg ? h->reg_lds : (lpg ? h->lpg_lds : 0), stream, T);
+    hipLaunchKernelGGL(reg ? ((int)grid.x <= h->reg3_max_waves ? h->k_reg3 : h->k_reg) : (lpg ? h->k_lpg : h->k_roll), grid, block, reg ? h->reg_lds : (lpg ? h->lpg_lds : 0), stream, T);
     if (ev) hipEventRecord(ev->second, stream);
     h->cnt_live = true;
     HIPCHK(h, hipGetLastError());

@@ -75,8 +75,10 @@ __host__ __device__ inline RegLds reg_lds_layout(int V) {
     return o;
 }
 
-template <int FAM, int NC, int G, int KPL>
-__global__ __launch_bounds__(64, G <= 4 ? 2 : AGZ_REG_WAVES) void k_rollout_reg(const TreePar T) {
+// WV = waves per SIMD the register budget is cut for: 4 (128 VGPRs, a few spills) keeps every wave of a 32768-game launch
+// resident; 3 (no spills) is faster as soon as the launch fits 3 waves per SIMD.
+template <int FAM, int NC, int G, int KPL, int WV = AGZ_REG_WAVES>
+__global__ __launch_bounds__(64, G <= 4 ? 2 : WV) void k_rollout_reg(const TreePar T) {
     using GM = Game<FAM, NC>;
     constexpr bool REV = FAM == F_REV;
     constexpr int NG = 64 / G;
@@ -99,6 +101,7 @@ __global__ __launch_bounds__(64, G <= 4 ? 2 : AGZ_REG_WAVES) void k_rollout_reg(
     const int sl = live ? slot : 0;
     uint8_t* const myrecs = T.recs + (size_t)sl * V * ROWS;
     Pos* const mystates = T.states + (size_t)sl * V;
+    float2* const myaux = T.aux + (size_t)sl * V;
     const uint32_t gbits_shift = (uint32_t)(g * G);
     const uint64_t gmask = G == 64 ? ~0ull : (((1ull << G) - 1ull) << gbits_shift);
     const int k0 = sub * KPL;                                    // first action of this lane's block
@@ -169,13 +172,17 @@ __global__ __launch_bounds__(64, G <= 4 ? 2 : AGZ_REG_WAVES) void k_rollout_reg(
             const bool rootmix = lf == 0 && T.training;               // :270-275 vs :277-279, :292-294
             const float Af = (float)nl;
             uint8_t* rec = myrecs + (size_t)lf * ROWS;
+            int npos = 0;
 #pragma unroll
             for (int j = 0; j < KPL; ++j) {
                 float pr = rootmix ? (lg[j] ? 0.75f * x[j] / normalize + 0.25f / Af : 0.0f) : x[j] / normalize;
                 if (k0 + j >= A) pr = 0.0f;
                 x[j] = pr;
+                npos += pr > 0.0f ? 1 : 0;
                 if (lf == 0 && k0 + j < A) T.policy_final[(size_t)slot * A + k0 + j] = pr;
             }
+            npos = grp_sum<G>(npos);                                  // "A" of :125-131 never changes after the expansion
+            if (lead) myaux[lf] = make_float2(0.0f, (float)npos);
 #pragma unroll
             for (int j = 0; j < KPL; j += 4) {
                 *reinterpret_cast<float4*>(rec + (size_t)(k0 + j) * 4) = make_float4(x[j], x[j + 1], x[j + 2], x[j + 3]);
@@ -246,6 +253,7 @@ __global__ __launch_bounds__(64, G <= 4 ? 2 : AGZ_REG_WAVES) void k_rollout_reg(
                 // ---- this lane's block of the node row, straight from HBM
                 const uint8_t* rec = myrecs + (size_t)node * ROWS;
                 float p[KPL], q[KPL]; uint32_t vw[KPL / 2];                // vw[j] = vc[2j] | vc[2j+1] << 16
+                const float2 ax = myaux[node];
 #pragma unroll
                 for (int j = 0; j < KPL; j += 4) {
                     const float4 a = *reinterpret_cast<const float4*>(rec + (size_t)(k0 + j) * 4);
@@ -268,19 +276,20 @@ __global__ __launch_bounds__(64, G <= 4 ? 2 : AGZ_REG_WAVES) void k_rollout_reg(
                 float alpha = 0.0f, lambda = 0.0f;
                 float pol[KPL];
                 if (stale) {                                               // :114
-                    int vs = 0, ac = 0; float m[KPL];                      // :120-131
+                    // :120-131.  prior_rem (the source-order sum of the priors of childless actions) and the count of positive
+                    // priors change only when a child is created under the node: both come from aux[] (written by the expansion
+                    // and by the creation step at the end of this kernel), only the visit total is re-counted here.
+                    int vs = 0;
                     uint64_t cm = 0;
 #pragma unroll
                     for (int j = 0; j < KPL; ++j) {
                         const uint32_t c = (j & 1) ? (vw[j / 2] >> 16) : (vw[j / 2] & 0xffffu);
                         vs += (int)(c & 0xffu);
-                        ac += p[j] > 0.0f ? 1 : 0;
                         const uint32_t ch = c >> 8;
-                        m[j] = ch == 0 ? p[j] : 0.0f;                      // prior of childless actions, +0 otherwise (exact)
                         if (small) cm |= ch != 0 ? 1ull << ch : 0ull;      // set of this node's child ids
                         else if (ch != 0) { tabp[ch] = p[j]; tabq[ch] = q[j]; }   // child table by child node id
                     }
-                    vs = grp_sum<G>(vs); ac = grp_sum<G>(ac);
+                    vs = grp_sum<G>(vs);
                     int nch = 0;
                     if (small) {
                         // children in creation order = ascending node id (:144-146): the rank of child id c among the set
@@ -294,13 +303,8 @@ __global__ __launch_bounds__(64, G <= 4 ? 2 : AGZ_REG_WAVES) void k_rollout_reg(
                             if (ch != 0) { const int r = __popcll(M & ((1ull << ch) - 1ull)); tabp[r] = p[j]; tabq[r] = q[j]; }
                         }
                     }
-                    const float nf = 1.0f + (float)vs, Af = (float)ac;
-                    float st0;
-#ifdef AGZ_ABL_PREM
-                    float prior_rem = grp_sum<G>((int)(m[0] + m[5])) * 0.01f; st0 = 0;
-#else
-                    float prior_rem = grp_ordered_sum<G, KPL>(m, sub, st0);   // ordered (:122-124)
-#endif
+                    const float nf = 1.0f + (float)vs, Af = ax.y;
+                    float prior_rem = ax.x;                                 // ordered (:122-124)
                     lambda = T.cpuct * __builtin_sqrtf(nf) / (Af + nf);    // :132
                     prior_rem *= lambda;                                    // :134
                     float am = 0.0f;                                        // :133-138
@@ -463,6 +467,25 @@ __global__ __launch_bounds__(64, G <= 4 ? 2 : AGZ_REG_WAVES) void k_rollout_reg(
             }
             AGZ_WSYNC();
             STAMP(12);
+        }
+        {   // the parent of the new child loses one childless action: its prior_rem is re-summed here, once per rollout and
+            // at a point where the whole wave is converged, instead of at every later visit (mcts_gpu.jl:120-124)
+            // (its row is re-read rather than kept in registers across the loop: the loads share the latency of the state load)
+            const uint8_t* rec = myrecs + (size_t)(create_from >= 0 ? create_from : 0) * ROWS;
+            float m[KPL];
+#pragma unroll
+            for (int j = 0; j < KPL; j += 4) {
+                const float4 a = *reinterpret_cast<const float4*>(rec + (size_t)(k0 + j) * 4);
+                const uint2 c = *reinterpret_cast<const uint2*>(rec + T.off_vc + (size_t)(k0 + j) * 2);
+                const bool on = create_from >= 0;
+                m[j] = (on && (c.x & 0xff00u) == 0 && k0 + j != create_move) ? a.x : 0.0f;            // +0 terms are exact
+                m[j + 1] = (on && (c.x >> 24) == 0 && k0 + j + 1 != create_move) ? a.y : 0.0f;
+                m[j + 2] = (on && (c.y & 0xff00u) == 0 && k0 + j + 2 != create_move) ? a.z : 0.0f;
+                m[j + 3] = (on && (c.y >> 24) == 0 && k0 + j + 3 != create_move) ? a.w : 0.0f;
+            }
+            float st0;
+            const float prem = grp_ordered_sum<G, KPL>(m, sub, st0);
+            if (live && lead && create_from >= 0) reinterpret_cast<float*>(myaux + create_from)[0] = prem;
         }
         if (live && create_from >= 0) {                                    // :183-191 node creation (at most one per rollout)
             const uint32_t child = ncount; ncount += 1;
