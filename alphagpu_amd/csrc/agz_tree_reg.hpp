@@ -113,16 +113,35 @@ __global__ __launch_bounds__(64, G <= 4 ? 2 : WV) void k_rollout_reg(const TreeP
 
     // ---- stage the meta rows of the wave's games (coalesced) ------------------------------------------
     uint32_t ncount = 1, leafn = 0;
+    uint32_t* const gmeta = T.meta + (size_t)sl * V;              // every change of a meta word is written through
     if (T.do_reset) {
-        if (lead) mymeta[0] = M_EXISTS;
+        if (lead) { mymeta[0] = M_EXISTS; if (live) gmeta[0] = M_EXISTS; }
     } else {
-        for (int j = 0; j < NG; ++j) {
-            const int sj = T.slot0 + (int)blockIdx.x * NG + j;
-            if (sj >= T.L) break;
-            uint32_t* dm = reinterpret_cast<uint32_t*>(lds + (size_t)j * LO.stride + LO.meta);
-            for (int c = lane; c < V; c += 64) dm[c] = T.meta[(size_t)sj * V + c];
-        }
         if (live) { ncount = T.ncount[slot]; leafn = T.leaf[slot]; }
+        if ((V & 3) == 0 && V <= 256) {                           // all rows of the wave in flight together: one memory latency
+            const int v4 = V >> 2, n4 = NG * v4;                   // 16-B pieces per game / per wave (<= 8 per lane)
+            uint4 buf[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = lane + 64 * i;
+                if (c < n4) {
+                    const int j = c / v4, sj = T.slot0 + (int)blockIdx.x * NG + j;
+                    buf[i] = sj < T.L ? reinterpret_cast<const uint4*>(T.meta + (size_t)sj * V)[c - j * v4] : make_uint4(0u, 0u, 0u, 0u);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = lane + 64 * i;
+                if (c < n4) { const int j = c / v4; *reinterpret_cast<uint4*>(lds + (size_t)j * LO.stride + LO.meta + (size_t)(c - j * v4) * 16) = buf[i]; }
+            }
+        } else {
+            for (int j = 0; j < NG; ++j) {
+                const int sj = T.slot0 + (int)blockIdx.x * NG + j;
+                if (sj >= T.L) break;
+                uint32_t* dm = reinterpret_cast<uint32_t*>(lds + (size_t)j * LO.stride + LO.meta);
+                for (int c = lane; c < V; c += 64) dm[c] = T.meta[(size_t)sj * V + c];
+            }
+        }
     }
     AGZ_WSYNC();
     STAMP(0);
@@ -190,7 +209,7 @@ __global__ __launch_bounds__(64, G <= 4 ? 2 : WV) void k_rollout_reg(const TreeP
                 *reinterpret_cast<uint2*>(rec + T.off_vc + (size_t)(k0 + j) * 2) = make_uint2(0u, 0u);
             }
             ml |= M_EXPANDED;                                         // :256
-            if (lead) mymeta[lf] = ml;
+            if (lead) { mymeta[lf] = ml; gmeta[lf] = ml; }
         } else if (live && lf == 0) {
 #pragma unroll
             for (int j = 0; j < KPL; ++j) if (k0 + j < A) T.policy_final[(size_t)slot * A + k0 + j] = 0.0f;   // terminal root
@@ -209,7 +228,7 @@ __global__ __launch_bounds__(64, G <= 4 ? 2 : WV) void k_rollout_reg(const TreeP
                     if (i == sub) { mypar = par; mymv = mv; myvf = valf; myvd = vald; }
                     valf = 1.0f - valf; vald = 1.0 - vald;                               // :324
                     mcur = mymeta[par];
-                    if (lead) mymeta[par] = mcur | M_STALE;                              // :321 uptodate = 0
+                    if (lead) { mymeta[par] = mcur | M_STALE; if (!(mcur & M_STALE)) gmeta[par] = mcur | M_STALE; }   // :321 uptodate = 0
                     cur = par;
                 }
                 if (mypar >= 0) {
@@ -249,7 +268,6 @@ __global__ __launch_bounds__(64, G <= 4 ? 2 : WV) void k_rollout_reg(const TreeP
         while (__ballot(descending)) {
             if (descending) {
                 if (lead) ++add_p;
-                CNT(1, 1);
                 // ---- this lane's block of the node row, straight from HBM
                 const uint8_t* rec = myrecs + (size_t)node * ROWS;
                 float p[KPL], q[KPL]; uint32_t vw[KPL / 2];                // vw[j] = vc[2j] | vc[2j+1] << 16
@@ -357,8 +375,7 @@ __global__ __launch_bounds__(64, G <= 4 ? 2 : WV) void k_rollout_reg(const TreeP
                     for (int it = 0; it < 100; ++it) {                     // :141-162
 #endif
                         float S = 0.0f, gg = 0.0f;
-                        CNT(6, 1);
-                        if (__ballot(!fast)) CNT(3, 1);
+                        STAMP(10);
                         if (fast) {
                             float t = 0.0f, uu = 0.0f;
                             if (sub <= nch) { const float bot = alpha - qv_l; t = top_l / bot; uu = -top_l / (bot * bot); }
@@ -370,6 +387,7 @@ __global__ __launch_bounds__(64, G <= 4 ? 2 : WV) void k_rollout_reg(const TreeP
                             AGZ_PULL(8) AGZ_PULL(9) AGZ_PULL(10) AGZ_PULL(11) AGZ_PULL(12) AGZ_PULL(13) AGZ_PULL(14) AGZ_PULL(15)
 #undef AGZ_PULL
                             S = __int_as_float(grp_bcast<G>(__float_as_int(a))); gg = __int_as_float(grp_bcast<G>(__float_as_int(b)));
+                            STAMP(1);
                         } else {
                             for (int c = sub; c <= nch; c += G) {
                                 float top = prior_rem, qv = 0.0f;
@@ -391,11 +409,13 @@ __global__ __launch_bounds__(64, G <= 4 ? 2 : WV) void k_rollout_reg(const TreeP
                             }
                             S = grp_bcast<G>(S); gg = grp_bcast<G>(gg);
                             AGZ_WSYNC();
+                            STAMP(3);
                         }
                         const float newerr = S - 1.0f;
                         if (newerr < 0.001f || newerr == err) break;
                         alpha -= newerr / gg;
                         err = newerr;
+                        STAMP(6);
                     }
                     STAMP(10);
 #pragma unroll
@@ -499,7 +519,7 @@ __global__ __launch_bounds__(64, G <= 4 ? 2 : WV) void k_rollout_reg(const TreeP
                 ++add_new;
                 reinterpret_cast<uint16_t*>(myrecs + (size_t)create_from * ROWS + T.off_vc)[create_move] = (uint16_t)(create_vc | (child << 8));
                 mystates[child] = pack(lst);
-                mymeta[child] = mc;
+                mymeta[child] = mc; gmeta[child] = mc;
             }
             mn = mc; node = (int)child;
         }
@@ -509,7 +529,7 @@ __global__ __launch_bounds__(64, G <= 4 ? 2 : WV) void k_rollout_reg(const TreeP
                 int rr; const bool f = GM::isOver(P, lst, rr);
                 mn |= M_EVAL;
                 if (f) mn |= M_TERM | ((uint32_t)(1 + lst.player * rr) << M_TV_SHIFT);
-                if (lead) mymeta[node] = mn;
+                if (lead) { mymeta[node] = mn; gmeta[node] = mn; }
             }
             if (!have_state) lst = grp_load_pos<NC, REV>(mystates + node);
             // decoder (:202-223): 8 planes (16 bytes of bf16, or 32 of fp32) per store, chunks dealt round-robin to the group
@@ -539,15 +559,7 @@ __global__ __launch_bounds__(64, G <= 4 ? 2 : WV) void k_rollout_reg(const TreeP
     }
 
     STAMP(14);
-    // ---- write back bookkeeping ---------------------------------------------------------------------
-    AGZ_WSYNC();
-    for (int j = 0; j < NG; ++j) {
-        const int sj = T.slot0 + (int)blockIdx.x * NG + j;
-        if (sj >= T.L) break;
-        const int nj = (int)rdlane(ncount, j * G);
-        const uint32_t* sm = reinterpret_cast<const uint32_t*>(lds + (size_t)j * LO.stride + LO.meta);
-        for (int c = lane; c < nj; c += 64) T.meta[(size_t)sj * V + c] = sm[c];
-    }
+    // ---- bookkeeping (the meta words were written through as they changed) --------------------------
     if (live && lead) {
         T.ncount[slot] = ncount;
         T.leaf[slot] = leafn;

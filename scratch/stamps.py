@@ -13,8 +13,8 @@ e.L.agz_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 e.L.agz_debug_stamps(e.h, out, 1)
 e.set_roots(None, L=L); e.search(V, cpuct=1.5, training=True, step=0); e.synchronize()
 e.L.agz_debug_stamps(e.h, out, 1)
-names = ['0 meta stage', '1 #rounds(wave)', '2 expand', '3 #newton its w/ slow path', '4 backup', '5 fence', '6 #newton its', '7 round: row load+philox', '8 round: stats/prior_rem/alpha0', '9 round: child table compaction', '10 round: newton', '11 round: policy', '12 round: child lookup/end', '13 round: sampling', '14 tail: create+planes', '15 writeback']
-tot = sum(v for i, v in enumerate(out) if i not in (1, 3, 6))
+names = ['0 meta stage', '1 newton: fast branch', '2 expand', '3 newton: slow branch', '4 backup', '5 fence', '6 newton: step+loop', '7 round: row load+philox', '8 round: stats/prior_rem/alpha0', '9 round: child table compaction', '10 round: newton', '11 round: policy', '12 round: child lookup/end', '13 round: sampling', '14 tail: create+planes', '15 writeback']
+tot = sum(out)
 G = 8; waves = (L * G // 64) * 65
 for n, v in zip(names, out):
     print(f"{n:32s} {v/waves:10.0f} cyc/wave  {100*v/tot:5.1f}%")
