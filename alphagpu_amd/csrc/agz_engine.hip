@@ -364,6 +364,11 @@ extern "C" int agz_debug_stamps(agz_engine* h, unsigned long long* out, int rese
     return 0;
 }
 #endif
+// diagnostic: per-slot count of expanded nodes traversed since the search began (not part of include/agz.h)
+extern "C" int agz_debug_slot_depths(agz_engine* h, uint32_t* out) {
+    hipStreamSynchronize(h->stream);
+    return hipMemcpy(out, h->cnt_p, (size_t)h->L * 4, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
+}
 int agz_synchronize(agz_engine* h) {
     if (!h) return AGZ_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device));

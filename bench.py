@@ -99,22 +99,33 @@ def main():
     eng.set_network(net)
     eng.set_profiling(1)          # HIP events around every PUCT-kernel launch (roofline); network time = search - tree
     rb = game.rec_bytes
-    sample_buf = torch.empty(G * game.max_plies * rb, dtype=torch.uint8, device="cuda") if world > 1 else None
+    # the exchange of generation k overlaps generation k+1: two sample buffers, at most two collectives in flight
+    sample_bufs = [torch.empty(G * game.max_plies * rb, dtype=torch.uint8, device="cuda") for _ in range(2)] if world > 1 else None
+    inflight = [None, None]
+    nstep = [0]
 
     def step():
         st = eng.selfplay(G, V, cpuct=args.cpuct, tau_plies=25)
         if not st["valid"]:
             raise SystemExit("illegal move sampled ('faute')")
         if world > 1:                       # the one exchange step: all-gather of the generated samples
-            n = eng.samples_packed_into(sample_buf.data_ptr(), G * game.max_plies)
+            k = nstep[0] & 1
+            nstep[0] += 1
+            if inflight[k] is not None:
+                inflight[k].wait()          # the collective that read sample_bufs[k] two generations ago
+            n = eng.samples_packed_into(sample_bufs[k].data_ptr(), G * game.max_plies)
             if args.backend == "nccl":
-                shard.allgather_records(sample_buf, n, rb)
+                inflight[k] = shard.allgather_records_async(sample_bufs[k], n, rb)
             else:                               # gloo smoke path: stage through host memory
-                shard.allgather_records(sample_buf[: n * rb].cpu(), n, rb)
+                inflight[k] = shard.allgather_records_async(sample_bufs[k][: n * rb].cpu(), n, rb)
         return st
 
     def fence():
         eng.synchronize()
+        for k in range(2):
+            if inflight[k] is not None:
+                inflight[k].wait()
+                inflight[k] = None
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

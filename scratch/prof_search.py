@@ -6,7 +6,7 @@ V = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 32768
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 g = ag.GameSpec('gobang', 9, 5)
-net = ag.SNetwork2.random(g, 128, int(os.environ.get('NT', '6')))
+net = ag.SNetwork2.random(g, int(os.environ.get('NH', '128')), int(os.environ.get('NT', '6')))
 e = M.Engine(g, L, V, seed=1, nn_mode=M.NN_BF16)
 e.set_network(net)
 e.set_profiling(os.environ.get("NOPROF") is None)
