@@ -22,6 +22,7 @@
 #include "agz_nn_fused.hpp"
 #include "agz_nn_fused3.hpp"
 #include "agz_nn_wave.hpp"
+#include "agz_nn_big.hpp"
 #include "agz_selfplay.hpp"
 
 using namespace agz;
@@ -42,6 +43,7 @@ struct DevNet {
     // bf16 mode: pre-tiled B fragments
     uint16_t *t0 = nullptr, *tres = nullptr, *thead = nullptr;
     uint16_t* w16w = nullptr;      // uniform k-rows for agz_nn_wave.hpp
+    uint16_t* wbig = nullptr; int k0r = 0;   // hidden k-rows for agz_nn_big.hpp (layer 0 padded to k0r rows)
     uint16_t* w16 = nullptr;       // the same three sections tiled for v_mfma_f32_16x16x32_bf16 (agz_nn_fused3.hpp)
     float* bias_head = nullptr;
     int NT_h = 0, NT_head = 0;
@@ -180,7 +182,7 @@ template <typename T> static hipError_t dmalloc(T** p, size_t n) { return hipMal
 
 static void free_net(DevNet& n) {
     hipFree(n.W0); hipFree(n.Wres); hipFree(n.Wp); hipFree(n.bp); hipFree(n.Wv); hipFree(n.bv);
-    hipFree(n.t0); hipFree(n.w16); hipFree(n.w16w); hipFree(n.bias_head);          // tres / thead point into t0's allocation
+    hipFree(n.t0); hipFree(n.w16); hipFree(n.w16w); hipFree(n.wbig); n.wbig = nullptr; hipFree(n.bias_head);          // tres / thead point into t0's allocation
     n = DevNet();
 }
 
@@ -260,6 +262,8 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     hipFuncSetAttribute((const void*)k_mlp_wave<128, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)k_mlp_wave<64, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)k_mlp_wave<64, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)k_mlp_big<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)k_mlp_big<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)k_layer_exact<EX_RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)k_layer_exact<EX_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)k_layer_exact<EX_POLICY>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -455,6 +459,16 @@ int agz_set_network_slot(agz_engine* h, int which, int H, int T, const float* W0
             tile_weights16(Wv, 1, H, NTheadb, KThb, b16.data() + s0 + sr * T, P.A, 1);
             HIPCHK(h, dmalloc(&n.w16, b16.size()));
             HIPCHK(h, hipMemcpy(n.w16, b16.data(), b16.size() * 2, hipMemcpyHostToDevice));
+            if ((H == 256 || H == 512) && ((KT0b + 1) / 2 * 2) * 32 <= H) {   // agz_nn_big.hpp: layer 0 padded to an even row count, 2 rows of slack
+                const int k0r = (KT0b + 1) / 2 * 2;
+                const size_t row = (size_t)NTb * 512;
+                std::vector<uint16_t> bb(((size_t)k0r + (size_t)T * KThb + 2) * row, 0);
+                std::copy(b16.begin(), b16.begin() + s0, bb.begin());
+                std::copy(b16.begin() + s0, b16.begin() + (s0 + sr * T), bb.begin() + (size_t)k0r * row);
+                HIPCHK(h, dmalloc(&n.wbig, bb.size()));
+                HIPCHK(h, hipMemcpy(n.wbig, bb.data(), bb.size() * 2, hipMemcpyHostToDevice));
+                n.k0r = k0r;
+            }
             // agz_nn_wave.hpp: groups of KThb k-rows x NTb tiles: layer 0 padded with zero rows to whole groups, zero-weight
             // residual groups (identity) up to a multiple of NW_DEPTH, the head padded with zero tiles, NW_DEPTH groups of slack
             if (NTheadb <= NTb && NTb % NW_WAVES == 0) {
@@ -578,7 +592,17 @@ static int launch_network(agz_engine* h, int which, int s0 = 0, int s1 = -1, hip
         f3_lds = (size_t)F3_M * (n.H * 2 + 16) + F3_WCHUNK + (size_t)F3_M * (n.INP * 2 + 16);
         if (f3_lds > 160 * 1024) f3_lds = 0;
     }
-    if (f3_lds && n.w16w && L <= h->nn_wave_maxl) {   // one wave per 16 leaves, weights streamed from L2: lowest latency
+    if (h->cfg.nn_mode == AGZ_NN_BF16 && n.wbig && !getenv("AGZ_NO_FUSED_NN")) {   // wide trunk: activations resident in LDS, weights streamed from L2
+        BigPar B;
+        B.planes = (const uint16_t*)planes; B.INP = n.INP; B.wh = n.wbig;
+        B.whead = n.w16 + (size_t)(n.INP / 32) * (n.H / 16) * 512 + (size_t)n.T * (n.H / 32) * (n.H / 16) * 512;
+        B.bias_head = n.bias_head; B.logits = logits; B.LGS = h->LGS; B.vout = v_eval;
+        B.L = L; B.T = n.T; B.A = h->G.A; B.AOP = n.AOP; B.K0R = n.k0r;
+        const size_t lds = (size_t)NB_M * (n.H * 2 + 16);
+        dim3 grid((unsigned)((L + NB_M - 1) / NB_M)), block(NB_THREADS);
+        if (n.H == 512) hipLaunchKernelGGL(k_mlp_big<512>, grid, block, lds, stream, B);
+        else hipLaunchKernelGGL(k_mlp_big<256>, grid, block, lds, stream, B);
+    } else if (f3_lds && n.w16w && L <= h->nn_wave_maxl) {   // one wave per 16 leaves, weights streamed from L2: lowest latency
         Fused3Par F;
         F.planes = (const uint16_t*)planes; F.INP = n.INP; F.w16 = n.w16w; F.bias_head = n.bias_head;
         F.logits = logits; F.LGS = h->LGS; F.vout = v_eval; F.L = L; F.T = n.T; F.A = h->G.A; F.AOP = n.AOP;

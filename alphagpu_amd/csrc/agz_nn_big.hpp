@@ -1,0 +1,142 @@
+// agz_nn_big.hpp — the snetwork2 forward (DenseNet.jl:294-304) for WIDE trunks (H = 256, 512; BASELINE configs 3-5 use
+// 512x8) in one launch: 8 waves, 128 leaves per workgroup, activations resident in LDS, weights streamed from L2.
+//
+// With H = 512 a layer is 128 x 512 x 512: the 133 KiB activation tile [128][H] bf16 stays in LDS for the whole network
+// and is updated IN PLACE — every wave first accumulates its whole share of the layer in registers (wave w owns the
+// neurons [w*H/8, (w+1)*H/8) of all 128 leaves: 8 leaf tiles x NTW neuron tiles of v_mfma_f32_16x16x32_bf16, 128 fp32
+// accumulator registers at H = 512), a barrier ends all reads of the layer's input, then the bf16 epilogue overwrites it.
+// Weights: the pre-tiled 1 KiB fragments (tile (kt, nt) of a layer at (kt*NT + nt) KiB) go from L2 straight into the
+// MFMA A operand; a wave reads only its own neuron tiles (no redundancy inside the workgroup) and keeps two k-rows in
+// flight ahead of the matrix core, across layer boundaries.  One workgroup per CU: a 32768-leaf batch is one round.
+// 2 * 128 * (INP*H + T*H*H + AOP*H) flop per workgroup; 512x8 on Gobang 9x9: 4.44 MFLOP / leaf, 146 GFLOP / launch.
+#pragma once
+#include "agz_nn_fused3.hpp"
+
+namespace agz {
+
+constexpr int NB_M = 128;                 // leaves per workgroup
+constexpr int NB_THREADS = 512;
+
+struct BigPar {
+    const uint16_t* planes; int INP;      // [L][INP] bf16
+    const uint16_t* wh;                   // hidden k-rows: layer 0 (padded with zero rows to an even count), T residual layers, 2 rows of slack
+    const uint16_t* whead;                // head k-rows, AOP/16 tiles each
+    const float* bias_head;
+    float* logits; int LGS; float* vout;
+    int L, T, A, AOP, K0R;                // K0R = k-rows of layer 0 after padding
+};
+
+template <int H>
+__global__ __launch_bounds__(NB_THREADS, 1) void k_mlp_big(const BigPar P) {
+    constexpr int NT = H / 16, KTH = H / 32, NTW = NT / 8;       // neuron tiles per layer / k-rows per layer / neuron tiles per wave
+    constexpr int MT = NB_M / 16;                                // leaf tiles
+    constexpr int ROWB = H * 2 + 16;
+    static_assert(NTW >= 1 && KTH % 2 == 0, "H must be a multiple of 128");
+    extern __shared__ __attribute__((aligned(16))) uint8_t act[];   // [128][ROWB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 15, q4 = lane >> 4;
+    const int leaf0 = (int)blockIdx.x * NB_M;
+    const AGZ_GLB v4u* wsrc = (const AGZ_GLB v4u*)P.wh + (size_t)wave * NTW * 64 + lane;   // this wave's tiles of k-row 0
+
+    bf16x8 A0[NTW], A1[NTW];
+#define NB_LOADROW(buf)                                                                                 \
+    do {                                                                                                \
+        _Pragma("unroll") for (int t = 0; t < NTW; ++t) { const v4u w_ = wsrc[t * 64]; buf[t] = *reinterpret_cast<const bf16x8*>(&w_); } \
+        wsrc += NT * 64;                                                                                \
+    } while (0)
+    NB_LOADROW(A0); NB_LOADROW(A1);
+
+    {   // input planes -> columns [0, 32*K0R) of the activation tile, zero beyond INP
+        const int segs = P.K0R * 4, isegs = P.INP / 8;
+        const AGZ_GLB uint16_t* gp = (const AGZ_GLB uint16_t*)P.planes;
+        for (int c = tid; c < NB_M * segs; c += NB_THREADS) {
+            const int row = c / segs, seg = c - row * segs, mm = leaf0 + row;
+            v4u v = {0u, 0u, 0u, 0u};
+            if (mm < P.L && seg < isegs) v = *(const AGZ_GLB v4u*)(gp + (size_t)mm * P.INP + seg * 8);
+            *reinterpret_cast<v4u*>(act + (size_t)row * ROWB + seg * 16) = v;
+        }
+    }
+    __syncthreads();
+
+    const uint8_t* const brow = act + (size_t)lrow * ROWB + q4 * 16;    // + 16*mt*ROWB + 64*kt
+    f32x4 acc[MT][NTW];
+#define NB_STEP(buf, kt)                                                                                \
+    do {                                                                                                \
+        bf16x8 b_[MT];                                                                                  \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) b_[mt] = *reinterpret_cast<const bf16x8*>(brow + (size_t)mt * 16 * ROWB + (kt) * 64); \
+        _Pragma("unroll") for (int t = 0; t < NTW; ++t)                                                 \
+            _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                           \
+                acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(buf[t], b_[mt], acc[mt][t], 0, 0, 0); \
+        NB_LOADROW(buf);                                          /* k-row + 2 (next layer's after the last two) */ \
+    } while (0)
+
+#pragma unroll 1
+    for (int l = 0; l <= P.T; ++l) {                             // input + residual layers: D = W * X^T
+        const int KTl = l == 0 ? P.K0R : KTH;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) { acc[mt][t][0] = 0.0f; acc[mt][t][1] = 0.0f; acc[mt][t][2] = 0.0f; acc[mt][t][3] = 0.0f; }
+#pragma unroll 1
+        for (int kt = 0; kt < KTl; kt += 2) { NB_STEP(A0, kt); NB_STEP(A1, kt + 1); }
+        __syncthreads();                                          // every wave has read the layer's input
+        const bool res = l > 0;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            uint8_t* const orow = act + (size_t)(mt * 16 + lrow) * ROWB;
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+                const int n = 16 * (wave * NTW + t) + 4 * q4;     // acc[mt][t][r] = out[neuron n + r][leaf 16 mt + lrow]
+                float x0 = acc[mt][t][0] > 0.0f ? acc[mt][t][0] : 0.0f, x1 = acc[mt][t][1] > 0.0f ? acc[mt][t][1] : 0.0f;
+                float x2 = acc[mt][t][2] > 0.0f ? acc[mt][t][2] : 0.0f, x3 = acc[mt][t][3] > 0.0f ? acc[mt][t][3] : 0.0f;
+                uint2* dst = reinterpret_cast<uint2*>(orow + n * 2);
+                if (res) {                                        // b = relu(b + relu(W b))
+                    const uint2 o = *dst;
+                    x0 += __uint_as_float(o.x << 16); x1 += __uint_as_float(o.x & 0xffff0000u);
+                    x2 += __uint_as_float(o.y << 16); x3 += __uint_as_float(o.y & 0xffff0000u);
+                    x0 = x0 > 0.0f ? x0 : 0.0f; x1 = x1 > 0.0f ? x1 : 0.0f; x2 = x2 > 0.0f ? x2 : 0.0f; x3 = x3 > 0.0f ? x3 : 0.0f;
+                }
+                *dst = make_uint2(pk_bf16(x0, x1), pk_bf16(x2, x3));
+            }
+        }
+        __syncthreads();
+    }
+#undef NB_STEP
+#undef NB_LOADROW
+
+    {   // head: D = X * W^T (logits leave row-major); wave w takes neuron tile w of the AOP/16 head tiles
+        const int NTH = P.AOP / 16;
+        for (int tile = wave; tile < NTH; tile += 8) {
+            f32x4 hacc[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) { hacc[mt][0] = 0.0f; hacc[mt][1] = 0.0f; hacc[mt][2] = 0.0f; hacc[mt][3] = 0.0f; }
+            const AGZ_GLB v4u* hw = (const AGZ_GLB v4u*)P.whead + (size_t)tile * 64 + lane;
+#pragma unroll 4
+            for (int kt = 0; kt < KTH; ++kt) {
+                const v4u w_ = hw[(size_t)kt * NTH * 64];
+                const bf16x8 w = *reinterpret_cast<const bf16x8*>(&w_);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const bf16x8 x = *reinterpret_cast<const bf16x8*>(brow + (size_t)mt * 16 * ROWB + kt * 64);
+                    hacc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, w, hacc[mt], 0, 0, 0);
+                }
+            }
+            // hacc[mt][r] = out[leaf = leaf0 + 16 mt + 4 q4 + r][n = 16 tile + (lane & 15)]
+            const int n = 16 * tile + (lane & 15);
+            const float bias = P.bias_head[n];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int mw = leaf0 + 16 * mt + 4 * q4;
+                if (n < P.A) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (mw + r < P.L) P.logits[(size_t)(mw + r) * P.LGS + n] = hacc[mt][r] + bias;
+                } else if (n == P.A) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (mw + r < P.L) P.vout[mw + r] = sigmoid_ool(hacc[mt][r] + bias);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace agz

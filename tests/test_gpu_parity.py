@@ -334,7 +334,7 @@ def _bf16_search_bits(g, net, L, V, H):
         return e.root_visits().copy(), e.policy().copy(), e.root_q().copy()
 
 
-@pytest.mark.parametrize("H,T", [(128, 6), (64, 3), (128, 1)])
+@pytest.mark.parametrize("H,T", [(128, 6), (64, 3), (128, 1), (512, 2), (256, 3)])
 def test_bf16_network_kernels_agree_bitwise(H, T, monkeypatch):
     """The latency-first network kernel (agz_nn_wave.hpp, the default) at other tile counts / prefetch depths, the LDS-shared one
     (agz_nn_fused3.hpp) and the per-layer MFMA kernels run the same MFMA sequence: identical bits, also for a ragged
