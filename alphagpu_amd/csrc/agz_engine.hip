@@ -459,7 +459,7 @@ int agz_set_network_slot(agz_engine* h, int which, int H, int T, const float* W0
             tile_weights16(Wv, 1, H, NTheadb, KThb, b16.data() + s0 + sr * T, P.A, 1);
             HIPCHK(h, dmalloc(&n.w16, b16.size()));
             HIPCHK(h, hipMemcpy(n.w16, b16.data(), b16.size() * 2, hipMemcpyHostToDevice));
-            if ((H == 256 || H == 512) && ((KT0b + 1) / 2 * 2) * 32 <= H) {   // agz_nn_big.hpp: layer 0 padded to an even row count, 2 rows of slack
+            if (H == 256 || H == 512) {   // agz_nn_big.hpp: layer 0 padded to an even row count, 2 rows of slack
                 const int k0r = (KT0b + 1) / 2 * 2;
                 const size_t row = (size_t)NTb * 512;
                 std::vector<uint16_t> bb(((size_t)k0r + (size_t)T * KThb + 2) * row, 0);
@@ -592,16 +592,17 @@ static int launch_network(agz_engine* h, int which, int s0 = 0, int s1 = -1, hip
         f3_lds = (size_t)F3_M * (n.H * 2 + 16) + F3_WCHUNK + (size_t)F3_M * (n.INP * 2 + 16);
         if (f3_lds > 160 * 1024) f3_lds = 0;
     }
-    if (h->cfg.nn_mode == AGZ_NN_BF16 && n.wbig && !getenv("AGZ_NO_FUSED_NN")) {   // wide trunk: activations resident in LDS, weights streamed from L2
+    const int big_rowb = 2 * std::max(n.H, 32 * n.k0r) + 16;
+    if (h->cfg.nn_mode == AGZ_NN_BF16 && n.wbig && (size_t)NB_M * big_rowb <= 160 * 1024 && !getenv("AGZ_NO_FUSED_NN")) {   // wide trunk: activations resident in LDS, weights streamed from L2
         BigPar B;
         B.planes = (const uint16_t*)planes; B.INP = n.INP; B.wh = n.wbig;
         B.whead = n.w16 + (size_t)(n.INP / 32) * (n.H / 16) * 512 + (size_t)n.T * (n.H / 32) * (n.H / 16) * 512;
         B.bias_head = n.bias_head; B.logits = logits; B.LGS = h->LGS; B.vout = v_eval;
-        B.L = L; B.T = n.T; B.A = h->G.A; B.AOP = n.AOP; B.K0R = n.k0r;
-        const size_t lds = (size_t)NB_M * (n.H * 2 + 16);
+        B.L = L; B.T = n.T; B.A = h->G.A; B.AOP = n.AOP; B.K0R = n.k0r; B.ROWB = big_rowb;
+        const size_t lds = (size_t)NB_M * big_rowb;
         dim3 grid((unsigned)((L + NB_M - 1) / NB_M)), block(NB_THREADS);
         if (n.H == 512) hipLaunchKernelGGL(k_mlp_big<512>, grid, block, lds, stream, B);
-        else hipLaunchKernelGGL(k_mlp_big<256>, grid, block, lds, stream, B);
+        else hipLaunchKernelGGL(k_mlp_big<256>, grid, block, lds, stream, B);   // (H = 128 measured 35-38 us at every batch size: the wave kernel is faster)
     } else if (f3_lds && n.w16w && L <= h->nn_wave_maxl) {   // one wave per 16 leaves, weights streamed from L2: lowest latency
         Fused3Par F;
         F.planes = (const uint16_t*)planes; F.INP = n.INP; F.w16 = n.w16w; F.bias_head = n.bias_head;

@@ -24,13 +24,14 @@ struct BigPar {
     const float* bias_head;
     float* logits; int LGS; float* vout;
     int L, T, A, AOP, K0R;                // K0R = k-rows of layer 0 after padding
+    int ROWB;                             // bytes per activation row in LDS: 2 * max(H, 32*K0R) + 16
 };
 
 template <int H>
 __global__ __launch_bounds__(NB_THREADS, 1) void k_mlp_big(const BigPar P) {
     constexpr int NT = H / 16, KTH = H / 32, NTW = NT / 8;       // neuron tiles per layer / k-rows per layer / neuron tiles per wave
     constexpr int MT = NB_M / 16;                                // leaf tiles
-    constexpr int ROWB = H * 2 + 16;
+    const int ROWB = P.ROWB;
     static_assert(NTW >= 1 && KTH % 2 == 0, "H must be a multiple of 128");
     extern __shared__ __attribute__((aligned(16))) uint8_t act[];   // [128][ROWB]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
