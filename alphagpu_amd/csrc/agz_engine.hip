@@ -11,6 +11,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <algorithm>
 
 #include "../../include/agz.h"
 #include "agz_games.hpp"
@@ -94,7 +95,8 @@ struct agz_engine {
     int profiling = 0;         // bit 0: HIP events around every tree-kernel launch, bit 1: around every network launch
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_tree, ev_nn;
     size_t ev_tree_used = 0, ev_nn_used = 0;
-    double tree_ms = 0, nn_ms = 0; int64_t tree_launches = 0;
+    double tree_ms = 0, nn_ms = 0, tree_busy_ms = 0; int64_t tree_launches = 0;
+    hipEvent_t ev_ref = nullptr; bool ev_ref_live = false;
     rollout_fn k_roll = nullptr; advance_fn k_adv = nullptr; softmax_fn k_soft = nullptr;
     rollout_fn k_reg3 = nullptr; int reg3_max_waves = 0;   // the 3-waves-per-SIMD build of k_reg and the largest grid it is used for
     rollout_fn k_reg = nullptr; size_t reg_lds = 0; int reg_kpl = 0, reg_g = 8;   // register-row kernel (agz_tree_reg.hpp), 8 lanes per tree
@@ -215,6 +217,7 @@ void agz_destroy(agz_engine* h) {
     free_net(h->net[0]); free_net(h->net[1]);
     for (auto& e : h->ev_tree) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto& e : h->ev_nn) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    if (h->ev_ref) hipEventDestroy(h->ev_ref);
     for (int c = 0; c < agz_engine::KCH - 1; ++c) { if (h->aux[c]) hipStreamDestroy(h->aux[c]); if (h->ev_join[c]) hipEventDestroy(h->ev_join[c]); }
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -536,6 +539,11 @@ int agz_set_roots(agz_engine* h, const void* positions, int format, const uint32
 
 // ---- launches ---------------------------------------------------------------------------------------
 static std::pair<hipEvent_t, hipEvent_t>* next_events(agz_engine* h, std::vector<std::pair<hipEvent_t, hipEvent_t>>& pool, size_t& used) {
+    if (!h->ev_ref_live) {                    // time origin of this batch of events (recorded before any of them)
+        if (!h->ev_ref) hipEventCreate(&h->ev_ref);
+        hipEventRecord(h->ev_ref, h->stream);
+        h->ev_ref_live = true;
+    }
     if (used == pool.size()) {
         hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
         pool.push_back({a, b});
@@ -543,10 +551,26 @@ static std::pair<hipEvent_t, hipEvent_t>* next_events(agz_engine* h, std::vector
     return &pool[used++];
 }
 static void drain_events(agz_engine* h) {     // stream must be idle
-    for (size_t i = 0; i < h->ev_tree_used; ++i) { float ms = 0; if (hipEventElapsedTime(&ms, h->ev_tree[i].first, h->ev_tree[i].second) == hipSuccess) h->tree_ms += ms; }
+    // tree kernels: sum of the launch durations, and the BUSY time = length of the union of the launch intervals (with
+    // sub-batch chains several launches run side by side; the union is the time during which the kernel type was active)
+    std::vector<std::pair<float, float>> iv;
+    iv.reserve(h->ev_tree_used);
+    for (size_t i = 0; i < h->ev_tree_used; ++i) {
+        float ms = 0, t0 = 0;
+        if (hipEventElapsedTime(&ms, h->ev_tree[i].first, h->ev_tree[i].second) == hipSuccess) h->tree_ms += ms;
+        if (h->ev_ref_live && hipEventElapsedTime(&t0, h->ev_ref, h->ev_tree[i].first) == hipSuccess) iv.push_back({t0, t0 + ms});
+    }
+    std::sort(iv.begin(), iv.end());
+    float cur_s = 0, cur_e = -1;
+    for (auto& x : iv) {
+        if (cur_e < cur_s || x.first > cur_e) { if (cur_e > cur_s) h->tree_busy_ms += cur_e - cur_s; cur_s = x.first; cur_e = x.second; }
+        else if (x.second > cur_e) cur_e = x.second;
+    }
+    if (cur_e > cur_s) h->tree_busy_ms += cur_e - cur_s;
     h->tree_launches += (int64_t)h->ev_tree_used;
     for (size_t i = 0; i < h->ev_nn_used; ++i) { float ms = 0; if (hipEventElapsedTime(&ms, h->ev_nn[i].first, h->ev_nn[i].second) == hipSuccess) h->nn_ms += ms; }
     h->ev_tree_used = h->ev_nn_used = 0;
+    h->ev_ref_live = false;
 }
 
 static int launch_rollout(agz_engine* h, uint32_t rollout, int do_reset, int do_expand, int do_select, int last, int inject, int capture,
@@ -689,7 +713,8 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
     // on the cut (every per-game quantity is keyed by game id).
     int K = 1;
     if (h->reg_lds != 0 && h->aux[0]) {
-        K = h->chains > 0 ? h->chains : 1;   // measured: <= 5 % at 32768 games, nothing below -> off unless AGZ_CHAINS is set
+        // measured (128x6, V = 64): 3 chains -9 % at 32768 and 24576 games, 2 chains -11 % at 16384, nothing below ~12000
+        K = h->chains > 0 ? h->chains : (h->L >= 20000 ? 3 : (h->L >= 12000 ? 2 : 1));
         const int kmax = (h->L + 255) / 256;               // at least 256 games per chain
         if (K > kmax) K = kmax;
         if (K > agz_engine::KCH) K = agz_engine::KCH;
@@ -859,7 +884,16 @@ int agz_get_kernel_times(agz_engine* h, double* tree_ms, double* nn_ms, int64_t*
     if (tree_ms) *tree_ms = h->tree_ms;
     if (nn_ms) *nn_ms = h->nn_ms;
     if (tree_launches) *tree_launches = h->tree_launches;
-    if (reset) { h->tree_ms = h->nn_ms = 0; h->tree_launches = 0; h->acc_p = h->acc_new = 0; h->total_rollouts = 0; }
+    if (reset) { h->tree_ms = h->nn_ms = h->tree_busy_ms = 0; h->tree_launches = 0; h->acc_p = h->acc_new = 0; h->total_rollouts = 0; }
+    return AGZ_OK;
+}
+
+int agz_get_tree_busy_ms(agz_engine* h, double* busy_ms) {
+    if (!h || !busy_ms) return AGZ_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    drain_events(h);
+    *busy_ms = h->tree_busy_ms;
     return AGZ_OK;
 }
 

@@ -163,6 +163,13 @@ class Engine:
         self._chk(self.L.agz_get_kernel_times(self.h, C.byref(t), C.byref(n), C.byref(k), int(reset)))
         return t.value, n.value, k.value
 
+    def tree_busy_ms(self):
+        """Time during which at least one tree-kernel launch was running (union of the launch intervals) since the last
+        kernel_times(reset=True); equals the summed tree time unless sub-batch chains overlap launches."""
+        t = C.c_double(0)
+        self._chk(self.L.agz_get_tree_busy_ms(self.h, C.byref(t)))
+        return t.value
+
     def synchronize(self):
         self._chk(self.L.agz_synchronize(self.h))
 

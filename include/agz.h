@@ -138,6 +138,9 @@ void *agz_stream(agz_engine *h);                       /* the engine's hipStream
 int  agz_synchronize(agz_engine *h);
 /* HIP-event timings (ms) accumulated since the last reset: [0] tree kernels, [1] network kernels, [2] launches */
 int  agz_get_kernel_times(agz_engine *h, double *tree_ms, double *nn_ms, int64_t *tree_launches, int reset);
+/* with sub-batch chains several tree-kernel launches run side by side: busy time (ms) = length of the union of the
+ * launch intervals since the last reset of agz_get_kernel_times (== tree_ms when launches never overlap) */
+int  agz_get_tree_busy_ms(agz_engine *h, double *busy_ms);
 int  agz_set_profiling(agz_engine *h, int mode);       /* HIP events per launch: bit 0 tree kernel, bit 1 network kernel */
 
 #ifdef __cplusplus
