@@ -190,7 +190,8 @@ def main():
                          "note": "achieved = algorithmic_bytes_per_launch * launch_concurrency / avg_launch_ms: with >= 12000 games alive the "
                                  "batch runs as 2-3 sub-batch chains on parallel streams, so tree-kernel launches overlap each other"},
             "rank0": {"search_only_rollouts_per_s": rollouts / search_s if search_s > 0 else None,
-                      "tree_kernel_ms": tree_ms, "search_ms": search_s * 1e3, "other_search_ms_network_and_gaps": search_s * 1e3 - tree_ms, "plies": plies, "samples": nsamples,
+                      "tree_kernel_ms_sum_of_launches": tree_ms, "tree_kernel_busy_ms": busy_ms, "search_ms": search_s * 1e3,
+                      "search_ms_without_a_tree_kernel_running": search_s * 1e3 - busy_ms, "plies": plies, "samples": nsamples,
                       "wall_s": dt},
         }
         if not args.no_cpu_baseline and world == 1:
