@@ -265,8 +265,10 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     hipFuncSetAttribute((const void*)k_mlp_wave<128, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)k_mlp_wave<64, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)k_mlp_wave<64, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)k_mlp_big<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)k_mlp_big<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)k_mlp_big<512, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)k_mlp_big<256, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)k_mlp_big<512, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)k_mlp_big<256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)k_layer_exact<EX_RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)k_layer_exact<EX_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)k_layer_exact<EX_POLICY>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -623,10 +625,11 @@ static int launch_network(agz_engine* h, int which, int s0 = 0, int s1 = -1, hip
         B.whead = n.w16 + (size_t)(n.INP / 32) * (n.H / 16) * 512 + (size_t)n.T * (n.H / 32) * (n.H / 16) * 512;
         B.bias_head = n.bias_head; B.logits = logits; B.LGS = h->LGS; B.vout = v_eval;
         B.L = L; B.T = n.T; B.A = h->G.A; B.AOP = n.AOP; B.K0R = n.k0r; B.ROWB = big_rowb;
-        const size_t lds = (size_t)NB_M * big_rowb;
-        dim3 grid((unsigned)((L + NB_M - 1) / NB_M)), block(NB_THREADS);
-        if (n.H == 512) hipLaunchKernelGGL(k_mlp_big<512>, grid, block, lds, stream, B);
-        else hipLaunchKernelGGL(k_mlp_big<256>, grid, block, lds, stream, B);   // (H = 128 measured 35-38 us at every batch size: the wave kernel is faster)
+        const int mt = L <= 8192 ? 2 : 8;                       // 32 or 128 leaves per workgroup
+        const size_t lds = (size_t)16 * mt * big_rowb;
+        dim3 grid((unsigned)((L + 16 * mt - 1) / (16 * mt))), block(NB_THREADS);
+        if (n.H == 512) { if (mt == 8) hipLaunchKernelGGL((k_mlp_big<512, 8>), grid, block, lds, stream, B); else hipLaunchKernelGGL((k_mlp_big<512, 2>), grid, block, lds, stream, B); }
+        else { if (mt == 8) hipLaunchKernelGGL((k_mlp_big<256, 8>), grid, block, lds, stream, B); else hipLaunchKernelGGL((k_mlp_big<256, 2>), grid, block, lds, stream, B); }
     } else if (f3_lds && n.w16w && L <= h->nn_wave_maxl) {   // one wave per 16 leaves, weights streamed from L2: lowest latency
         Fused3Par F;
         F.planes = (const uint16_t*)planes; F.INP = n.INP; F.w16 = n.w16w; F.bias_head = n.bias_head;

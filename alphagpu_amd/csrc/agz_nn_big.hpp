@@ -14,7 +14,7 @@
 
 namespace agz {
 
-constexpr int NB_M = 128;                 // leaves per workgroup
+constexpr int NB_M = 128;                 // leaves per workgroup (MT = 8 leaf tiles; MT = 2 -> 32 leaves for small batches)
 constexpr int NB_THREADS = 512;
 
 struct BigPar {
@@ -27,16 +27,18 @@ struct BigPar {
     int ROWB;                             // bytes per activation row in LDS: 2 * max(H, 32*K0R) + 16
 };
 
-template <int H>
+// MT = 16-leaf tiles per workgroup: 8 (128 leaves) when the batch fills the chip, 2 (32 leaves) below ~8192 leaves, where
+// the launch is bound by one workgroup's own chain of layers and a quarter of the work per workgroup is ~4x faster.
+template <int H, int MT>
 __global__ __launch_bounds__(NB_THREADS, 1) void k_mlp_big(const BigPar P) {
     constexpr int NT = H / 16, KTH = H / 32, NTW = NT / 8;       // neuron tiles per layer / k-rows per layer / neuron tiles per wave
-    constexpr int MT = NB_M / 16;                                // leaf tiles
+    constexpr int MB = 16 * MT;                                  // leaves per workgroup
     const int ROWB = P.ROWB;
     static_assert(NTW >= 1 && KTH % 2 == 0, "H must be a multiple of 128");
-    extern __shared__ __attribute__((aligned(16))) uint8_t act[];   // [128][ROWB]
+    extern __shared__ __attribute__((aligned(16))) uint8_t act[];   // [MB][ROWB]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 15, q4 = lane >> 4;
-    const int leaf0 = (int)blockIdx.x * NB_M;
+    const int leaf0 = (int)blockIdx.x * MB;
     const AGZ_GLB v4u* wsrc = (const AGZ_GLB v4u*)P.wh + (size_t)wave * NTW * 64 + lane;   // this wave's tiles of k-row 0
 
     bf16x8 A0[NTW], A1[NTW];
@@ -50,7 +52,7 @@ __global__ __launch_bounds__(NB_THREADS, 1) void k_mlp_big(const BigPar P) {
     {   // input planes -> columns [0, 32*K0R) of the activation tile, zero beyond INP
         const int segs = P.K0R * 4, isegs = P.INP / 8;
         const AGZ_GLB uint16_t* gp = (const AGZ_GLB uint16_t*)P.planes;
-        for (int c = tid; c < NB_M * segs; c += NB_THREADS) {
+        for (int c = tid; c < MB * segs; c += NB_THREADS) {
             const int row = c / segs, seg = c - row * segs, mm = leaf0 + row;
             v4u v = {0u, 0u, 0u, 0u};
             if (mm < P.L && seg < isegs) v = *(const AGZ_GLB v4u*)(gp + (size_t)mm * P.INP + seg * 8);

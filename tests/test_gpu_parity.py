@@ -365,3 +365,16 @@ def test_sub_batch_chains_do_not_change_results(monkeypatch):
     got = _bf16_search_bits(g, net, L, V, 64)
     for a, b, what in zip(got, ref, ("visits", "policy", "q")):
         assert_same_bits(a, b, what)
+
+
+def test_wide_trunk_128_leaf_tiles_agree_bitwise(monkeypatch):
+    """Above 8192 leaves k_mlp_big runs 128 leaves per workgroup (32 below): same bits as the per-layer kernels, ragged last tile."""
+    g, _ = spec("connect4")
+    net = ag.SNetwork2.random(g, 512, 1)
+    L, V = 8400, 3
+    monkeypatch.setenv("AGZ_CHAINS", "1")
+    ref = _bf16_search_bits(g, net, L, V, 512)
+    monkeypatch.setenv("AGZ_NO_FUSED_NN", "1")
+    got = _bf16_search_bits(g, net, L, V, 512)
+    for a, b, what in zip(got, ref, ("visits", "policy", "q")):
+        assert_same_bits(a, b, what)
