@@ -92,6 +92,7 @@ struct agz_engine {
     float cpuct = 1.5f; int training = 1; uint32_t step = 0; bool need_reset = true; bool injected = false;
     uint64_t total_rollouts = 0, acc_p = 0, acc_new = 0;
     // profiling
+    bool prof_this = true; uint32_t search_seq = 0;   // whether the current search is instrumented (profiling bit 2 = sample every 4th)
     int profiling = 0;         // bit 0: HIP events around every tree-kernel launch, bit 1: around every network launch
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_tree, ev_nn;
     size_t ev_tree_used = 0, ev_nn_used = 0;
@@ -589,7 +590,7 @@ static int launch_rollout(agz_engine* h, uint32_t rollout, int do_reset, int do_
     if (!reg && s0 != 0) { h->fail("sub-batches need the register-row kernel"); return AGZ_ERR_STATE; }
     dim3 grid((unsigned)((reg || lpg) ? (n + ng - 1) / ng : (n + 3) / 4)), block((reg || lpg) ? 64 : 256);
     std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
-    if (h->profiling & 1) { ev = next_events(h, h->ev_tree, h->ev_tree_used); hipEventRecord(ev->first, stream); }
+    if ((h->profiling & 1) && h->prof_this) { ev = next_events(h, h->ev_tree, h->ev_tree_used); hipEventRecord(ev->first, stream); }
     hipLaunchKernelGGL(reg ? ((int)grid.x <= h->reg3_max_waves ? h->k_reg3 : h->k_reg) : (lpg ? h->k_lpg : h->k_roll), grid, block, reg ? h->reg_lds : (lpg ? h->lpg_lds : 0), stream, T);
     if (ev) hipEventRecord(ev->second, stream);
     h->cnt_live = true;
@@ -608,7 +609,7 @@ static int launch_network(agz_engine* h, int which, int s0 = 0, int s1 = -1, hip
     const uint8_t* const planes = (const uint8_t*)h->planes + (size_t)s0 * h->INP * pe;
     float* const logits = h->logits + (size_t)s0 * h->LGS; float* const v_eval = h->v_eval + s0;
     std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
-    if (h->profiling & 2) { ev = next_events(h, h->ev_nn, h->ev_nn_used); hipEventRecord(ev->first, stream); }
+    if ((h->profiling & 2) && h->prof_this) { ev = next_events(h, h->ev_nn, h->ev_nn_used); hipEventRecord(ev->first, stream); }
     size_t fused_lds = 0;
     if (h->cfg.nn_mode == AGZ_NN_BF16 && (n.H == 64 || n.H == 128) && n.AOP / 32 <= n.H / 32 && !getenv("AGZ_NO_FUSED_NN"))
         fused_lds = (size_t)F2_M * (n.H * 2 + 16) + F2_WCHUNK + (size_t)F2_M * (n.INP * 2 + 16);
@@ -710,6 +711,9 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
     if (which < 0 || which > 1 || !h->net[which].loaded) { h->fail("no network loaded in slot %d", which); return AGZ_ERR_STATE; }
     HIPCHK(h, hipSetDevice(h->cfg.device));
     h->cpuct = cpuct; h->training = training; h->step = step;
+    // profiling bit 2: instrument (events, per-slot counters) only every 4th search: HIP events around ~10^4 launches per
+    // generation cost ~10 % of the time they are meant to measure
+    h->prof_this = !(h->profiling & 4) || (h->search_seq++ & 3u) == 0;
     // The slots are independent, so the batch is cut into up to KCH sub-batches (multiples of 128 slots = one network
     // tile) and each runs its own select -> network -> expand/backup chain on its own stream: while one chain's tree
     // kernel waits on memory latency the other chains' network and tree kernels fill the machine.  Results do not depend
@@ -744,7 +748,7 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
         HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join[c - 1], 0));
     }
     h->need_reset = true; h->injected = false;
-    h->total_rollouts += (uint64_t)h->L * (uint64_t)V;
+    if (h->prof_this) h->total_rollouts += (uint64_t)h->L * (uint64_t)V;
     return AGZ_OK;
 }
 int agz_search(agz_engine* h, int V, float cpuct, int training, uint32_t step) { return agz_search_actor(h, 0, V, cpuct, training, step); }
@@ -937,7 +941,7 @@ static int run_games(agz_engine* h, int ngames, int V, float cpuct, int tau_plie
         if (hipMemcpyAsync(hcount, h->d_count, 4, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
             hipStreamSynchronize(h->stream) != hipSuccess) { h->fail("ply loop failed: %s", hipGetErrorString(hipGetLastError())); rc = AGZ_ERR_HIP; break; }
         float ms = 0; hipEventElapsedTime(&ms, e0, e1); search_ms += ms;
-        if (h->profiling) { fold_counters(h); drain_events(h); }
+        if (h->profiling && h->prof_this) { fold_counters(h); drain_events(h); }
         { uint32_t* s = h->game_id; h->game_id = h->game_id2; h->game_id2 = s; h->tp.game_id = h->game_id; }
         h->L = (int)*hcount;
         ++ply;

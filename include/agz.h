@@ -141,7 +141,8 @@ int  agz_get_kernel_times(agz_engine *h, double *tree_ms, double *nn_ms, int64_t
 /* with sub-batch chains several tree-kernel launches run side by side: busy time (ms) = length of the union of the
  * launch intervals since the last reset of agz_get_kernel_times (== tree_ms when launches never overlap) */
 int  agz_get_tree_busy_ms(agz_engine *h, double *busy_ms);
-int  agz_set_profiling(agz_engine *h, int mode);       /* HIP events per launch: bit 0 tree kernel, bit 1 network kernel */
+int  agz_set_profiling(agz_engine *h, int mode);       /* HIP events per launch: bit 0 tree kernel, bit 1 network kernel;
+                                                          bit 2: instrument (events and agz_get_counters) every 4th search only */
 
 #ifdef __cplusplus
 }
