@@ -24,6 +24,7 @@
 #include "agz_nn_fused3.hpp"
 #include "agz_nn_wave.hpp"
 #include "agz_nn_big.hpp"
+#include "agz_search_small.hpp"
 #include "agz_selfplay.hpp"
 
 using namespace agz;
@@ -51,6 +52,7 @@ struct DevNet {
 };
 
 typedef void (*rollout_fn)(const TreePar);
+typedef void (*small_fn)(const SmallPar);
 typedef void (*advance_fn)(const PlyPar);
 typedef void (*softmax_fn)(const float*, int, float*, int, int, int);
 
@@ -99,6 +101,8 @@ struct agz_engine {
     double tree_ms = 0, nn_ms = 0, tree_busy_ms = 0; int64_t tree_launches = 0;
     hipEvent_t ev_ref = nullptr; bool ev_ref_live = false;
     rollout_fn k_roll = nullptr; advance_fn k_adv = nullptr; softmax_fn k_soft = nullptr;
+    small_fn k_small4 = nullptr; int small4_maxl = 16384;   // the same with 32 games per workgroup, for batches in (small_maxl, small4_maxl]
+    small_fn k_small = nullptr; int small_maxl = 8192;   // whole-search kernel (agz_search_small.hpp) for batches up to small_maxl games (AGZ_SMALL_MAXL)
     rollout_fn k_reg3 = nullptr; int reg3_max_waves = 0;   // the 3-waves-per-SIMD build of k_reg and the largest grid it is used for
     rollout_fn k_reg = nullptr; size_t reg_lds = 0; int reg_kpl = 0, reg_g = 8;   // register-row kernel (agz_tree_reg.hpp), 8 lanes per tree
     rollout_fn k_lpg = nullptr; size_t lpg_lds = 0; int grp_g = 16;   // group kernel (agz_tree_grp.hpp): G lanes per tree; lpg_lds == 0 -> wave-per-tree kernel
@@ -134,15 +138,15 @@ static bool bind_kernels(agz_engine* h) {
 #undef Y
     {   // register-row kernel: smallest block length KPL with 8*KPL >= A among the instantiated shapes
         const int kpl = P.A <= 32 ? 4 : (P.A <= 64 ? 8 : (P.A <= 96 ? 12 : (P.A <= 128 ? 16 : (P.A <= 192 ? 24 : 0))));
-#define Z(F, C, K) if (P.fam == F && P.NC == C && kpl == K) { h->k_reg = k_rollout_reg<F, C, 8, K, 4>; h->k_reg3 = k_rollout_reg<F, C, 8, K, 3>; h->reg_kpl = K; }
+#define Z(F, C, K) if (P.fam == F && P.NC == C && kpl == K) { h->k_reg = k_rollout_reg<F, C, 8, K, 4>; h->k_reg3 = k_rollout_reg<F, C, 8, K, 3>; h->k_small = k_search_small<F, C, K, 128, 2>; h->k_small4 = k_search_small<F, C, K, 128, 4>; h->reg_kpl = K; }
         Z(F_LINE, 1, 4) Z(F_LINE, 1, 8) Z(F_LINE, 2, 12) Z(F_LINE, 2, 16) Z(F_LINE, 3, 24)
         Z(F_C4, 1, 4)
         Z(F_HEX, 1, 4) Z(F_HEX, 1, 8) Z(F_HEX, 2, 8) Z(F_HEX, 2, 12) Z(F_HEX, 2, 16) Z(F_HEX, 3, 16) Z(F_HEX, 3, 24)
         Z(F_REV, 1, 12) Z(F_REV, 1, 8)
 #undef Z
         { const char* eg = getenv("AGZ_REG_G");     // experiment: 4 lanes per tree (Gobang 9x9 / Hex 9x9 shapes only)
-          if (eg && atoi(eg) == 4 && P.fam == F_LINE && P.NC == 2 && kpl == 12) { h->k_reg = h->k_reg3 = k_rollout_reg<F_LINE, 2, 4, 24>; h->reg_kpl = 24; h->reg_g = 4; }
-          if (eg && atoi(eg) == 16 && P.fam == F_LINE && P.NC == 2 && kpl == 12) { h->k_reg = h->k_reg3 = k_rollout_reg<F_LINE, 2, 16, 8>; h->reg_kpl = 8; h->reg_g = 16; } }
+          if (eg && atoi(eg) == 4 && P.fam == F_LINE && P.NC == 2 && kpl == 12) { h->k_reg = h->k_reg3 = k_rollout_reg<F_LINE, 2, 4, 24>; h->k_small = h->k_small4 = nullptr; h->reg_kpl = 24; h->reg_g = 4; }
+          if (eg && atoi(eg) == 16 && P.fam == F_LINE && P.NC == 2 && kpl == 12) { h->k_reg = h->k_reg3 = k_rollout_reg<F_LINE, 2, 16, 8>; h->k_small = h->k_small4 = nullptr; h->reg_kpl = 8; h->reg_g = 16; } }
     }
     if (P.NR == 1) h->k_soft = k_softmax<1>; else if (P.NR == 2) h->k_soft = k_softmax<2>; else h->k_soft = k_softmax<3>;
     return h->k_roll != nullptr;
@@ -300,6 +304,12 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
         if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) h->reg3_max_waves = 12 * prop.multiProcessorCount;   // 3 waves x 4 SIMDs per CU
         const char* e3 = getenv("AGZ_REG3_MAX_WAVES");
         if (e3) h->reg3_max_waves = atoi(e3);
+        e3 = getenv("AGZ_SMALL_MAXL");
+        if (e3) h->small_maxl = atoi(e3);
+        e3 = getenv("AGZ_SMALL4_MAXL");
+        if (e3) h->small4_maxl = atoi(e3);
+        if (h->k_small) hipFuncSetAttribute((const void*)h->k_small, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (h->k_small4) hipFuncSetAttribute((const void*)h->k_small4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     if (h->reg_lds || !h->k_lpg || h->lpg_lds > 64 * 1024 /* LDS-DMA destination offsets are 16 bit */ || (tk && !strcmp(tk, "v1"))) h->lpg_lds = 0;
     if (h->lpg_lds) hipFuncSetAttribute((const void*)h->k_lpg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lpg_lds);
@@ -718,6 +728,30 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
     // tile) and each runs its own select -> network -> expand/backup chain on its own stream: while one chain's tree
     // kernel waits on memory latency the other chains' network and tree kernels fill the machine.  Results do not depend
     // on the cut (every per-game quantity is keyed by game id).
+    {   // up to 16384 games alive: the whole search in one launch (agz_search_small.hpp).  Such a search has no per-launch
+        // events and is left out of the instrumented counters: the tree-kernel roofline covers the launches of k_rollout_reg only.
+        DevNet& n = h->net[which];
+        if (h->k_small && h->reg_lds != 0 && h->reg_g == 8 && h->cfg.nn_mode == AGZ_NN_BF16 && n.H == 128 && n.w16w && h->L > 0 &&
+            h->L <= std::max(h->small_maxl, h->small4_maxl) && !getenv("AGZ_NO_FUSED_NN")) {
+            const int tw = h->L <= h->small_maxl ? 2 : 4;     // tree waves per workgroup (8 games each)
+            SmallPar S;
+            S.T = h->tp;
+            S.T.L = h->L; S.T.slot0 = 0; S.T.step = h->step; S.T.cpuct = h->cpuct; S.T.training = h->training;
+            S.T.inject = 0; S.T.capture = 0; S.T.rollout = 0; S.T.do_reset = 1; S.T.do_expand = 0; S.T.do_select = 1; S.T.last = 0;
+            S.F.planes = (const uint16_t*)h->planes; S.F.INP = n.INP; S.F.w16 = n.w16w; S.F.bias_head = n.bias_head;
+            S.F.logits = h->logits; S.F.LGS = h->LGS; S.F.vout = h->v_eval; S.F.L = h->L; S.F.T = n.T; S.F.A = h->G.A; S.F.AOP = n.AOP;
+            S.V = V; S.tree_lds = (int)h->reg_lds;
+            const int kth = n.H / 32, g0 = (n.INP / 32 + kth - 1) / kth;
+            const size_t lds = tw * h->reg_lds + (size_t)8 * tw * (2 * (n.H * 2 + 16) + (g0 * kth * 64 + 16));
+            hipLaunchKernelGGL(tw == 2 ? h->k_small : h->k_small4, dim3((unsigned)((h->L + 8 * tw - 1) / (8 * tw))), dim3(64 * NW_WAVES), lds, h->stream, S);
+            HIPCHK(h, hipGetLastError());
+            h->cnt_live = true;
+            h->need_reset = true; h->injected = false;
+            if (h->profiling == 0) h->total_rollouts += (uint64_t)h->L * (uint64_t)V;
+            else h->prof_this = false;
+            return AGZ_OK;
+        }
+    }
     int K = 1;
     if (h->reg_lds != 0 && h->aux[0]) {
         // measured (128x6, V = 64): 3 chains -9 % at 32768 and 24576 games, 2 chains -11 % at 16384, nothing below ~12000

@@ -32,14 +32,24 @@ __host__ __device__ inline int nw_hidden_groups(int INP, int H, int T) {
 // DEPTH = groups (layers) of weight fragments in flight per wave: 4 hides the whole L2 latency behind one workgroup's own
 // work, 2 halves the registers so that twice as many workgroups share a CU (throughput mode for big batches).
 template <int H, int LT, int DEPTH>
+__device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const smem, const int bidx);
+
+template <int H, int LT, int DEPTH>
 __global__ __launch_bounds__(64 * NW_WAVES) void k_mlp_wave(const Fused3Par P) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem_wave[];
+    mlp_wave_body<H, LT, DEPTH>(P, smem_wave, (int)blockIdx.x);
+}
+
+// The 4-wave workgroup's forward for the leaves [bidx*16*LT, +16*LT) (also called from k_search_small); contains
+// workgroup barriers: every wave of the workgroup must call it.
+template <int H, int LT, int DEPTH>
+__device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const smem, const int bidx) {
     constexpr int NTH = H / 16, KTH = H / 32, TPW = NTH / NW_WAVES;
     constexpr int ROWB = H * 2 + 16;
     static_assert(TPW >= 1, "at least one neuron tile per wave");
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int ML = 16 * LT;                                   // leaves per workgroup
-    const int leaf0 = (int)blockIdx.x * ML;
+    const int leaf0 = bidx * ML;
     const int G0 = (P.INP / 32 + KTH - 1) / KTH;                 // groups of layer 0
     const int NGH = nw_hidden_groups(P.INP, H, P.T);             // groups before the head
     const int PROWB = G0 * KTH * 64 + 16;

@@ -77,17 +77,27 @@ __host__ __device__ inline RegLds reg_lds_layout(int V) {
 
 // WV = waves per SIMD the register budget is cut for: 4 (128 VGPRs, a few spills) keeps every wave of a 32768-game launch
 // resident; 3 (no spills) is faster as soon as the launch fits 3 waves per SIMD.
+template <int FAM, int NC, int G, int KPL>
+__device__ __forceinline__ void rollout_reg_body(const TreePar& T, uint8_t* const lds, const int bidx);
+
 template <int FAM, int NC, int G, int KPL, int WV = AGZ_REG_WAVES>
 __global__ __launch_bounds__(64, G <= 4 ? 2 : WV) void k_rollout_reg(const TreePar T) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_reg[];
+    rollout_reg_body<FAM, NC, G, KPL>(T, lds_reg, (int)blockIdx.x);
+}
+
+// One wave: expand + backup of the previous rollout and select + encode of this one for the 64/G games of wave-block `bidx`
+// (also called from k_search_small, agz_search_small.hpp, with the wave's own LDS window).
+template <int FAM, int NC, int G, int KPL>
+__device__ __forceinline__ void rollout_reg_body(const TreePar& T, uint8_t* const lds, const int bidx) {
     using GM = Game<FAM, NC>;
     constexpr bool REV = FAM == F_REV;
     constexpr int NG = 64 / G;
     constexpr int AP = G * KPL;                                  // padded row length (== T.A2)
     static_assert(KPL % 4 == 0, "block of actions per lane must be a multiple of 4");
     const GamePar& P = T.G;
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = lane_id(), g = lane / G, sub = lane % G;
-    const int slot = T.slot0 + (int)blockIdx.x * NG + g;
+    const int slot = T.slot0 + bidx * NG + g;
     const bool live = slot < T.L;
     const bool lead = sub == 0;
     const int A = P.A, V = T.V, ROWS = (int)T.rec_bytes;
@@ -125,7 +135,7 @@ __global__ __launch_bounds__(64, G <= 4 ? 2 : WV) void k_rollout_reg(const TreeP
             for (int i = 0; i < 8; ++i) {
                 const int c = lane + 64 * i;
                 if (c < n4) {
-                    const int j = c / v4, sj = T.slot0 + (int)blockIdx.x * NG + j;
+                    const int j = c / v4, sj = T.slot0 + bidx * NG + j;
                     buf[i] = sj < T.L ? reinterpret_cast<const uint4*>(T.meta + (size_t)sj * V)[c - j * v4] : make_uint4(0u, 0u, 0u, 0u);
                 }
             }
@@ -136,7 +146,7 @@ __global__ __launch_bounds__(64, G <= 4 ? 2 : WV) void k_rollout_reg(const TreeP
             }
         } else {
             for (int j = 0; j < NG; ++j) {
-                const int sj = T.slot0 + (int)blockIdx.x * NG + j;
+                const int sj = T.slot0 + bidx * NG + j;
                 if (sj >= T.L) break;
                 uint32_t* dm = reinterpret_cast<uint32_t*>(lds + (size_t)j * LO.stride + LO.meta);
                 for (int c = lane; c < V; c += 64) dm[c] = T.meta[(size_t)sj * V + c];
@@ -568,7 +578,7 @@ __global__ __launch_bounds__(64, G <= 4 ? 2 : WV) void k_rollout_reg(const TreeP
     }
 #ifdef AGZ_STAMPS
     STAMP(15);
-    if (lane < 16 && T.dbg) T.dbg[(size_t)blockIdx.x * 16 + lane] += stamp_lds[lane];
+    if (lane < 16 && T.dbg) T.dbg[(size_t)bidx * 16 + lane] += stamp_lds[lane];
 #endif
     (void)AP;
 }

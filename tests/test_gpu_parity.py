@@ -378,3 +378,30 @@ def test_wide_trunk_128_leaf_tiles_agree_bitwise(monkeypatch):
     got = _bf16_search_bits(g, net, L, V, 512)
     for a, b, what in zip(got, ref, ("visits", "policy", "q")):
         assert_same_bits(a, b, what)
+
+
+@pytest.mark.parametrize("name,L,V", [("gobang9", 300, 24), ("connect4", 77, 33), ("hex9", 40, 70)])
+def test_whole_search_kernel_agrees_bitwise(name, L, V, monkeypatch):
+    """k_search_small (one launch per mcts_single, 16 or 32 games per workgroup, default up to 16384 games) runs the same
+    tree step and network bodies as the two stand-alone kernels: identical bits, ragged last workgroup, V > 64 included."""
+    g, _ = spec(name)
+    net = ag.SNetwork2.random(g, 128, 2)
+
+    def run():
+        with M.Engine(g, L, V, seed=11, nn_mode=M.NN_BF16) as e:
+            e.set_network(net)
+            e.set_roots(None, L=L)
+            e.search(V, cpuct=1.5, training=True, step=2)
+            return e.root_visits().copy(), e.policy().copy(), e.root_q().copy(), e.leaf().copy(), e.node_count().copy()
+
+    monkeypatch.setenv("AGZ_SMALL_MAXL", "0")
+    monkeypatch.setenv("AGZ_SMALL4_MAXL", "0")
+    ref = run()                                     # two kernels per rollout
+    monkeypatch.delenv("AGZ_SMALL_MAXL")
+    monkeypatch.delenv("AGZ_SMALL4_MAXL")
+    for env in ({}, {"AGZ_SMALL_MAXL": "0"}):       # 16 games per workgroup, 32 games per workgroup
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        got = run()
+        for a, b, what in zip(got, ref, ("visits", "policy", "q", "leaf", "node_count")):
+            assert_same_bits(a, b, what + " " + str(env))
