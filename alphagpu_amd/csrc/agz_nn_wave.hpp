@@ -31,7 +31,7 @@ __host__ __device__ inline int nw_hidden_groups(int INP, int H, int T) {
 // larger LT when the batch is big enough for the L2 weight stream to become the bound).
 // DEPTH = groups (layers) of weight fragments in flight per wave: 4 hides the whole L2 latency behind one workgroup's own
 // work, 2 halves the registers so that twice as many workgroups share a CU (throughput mode for big batches).
-template <int H, int LT, int DEPTH>
+template <int H, int LT, int DEPTH, bool PRE_BARRIER = false>
 __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const smem, const int bidx);
 
 template <int H, int LT, int DEPTH>
@@ -41,8 +41,9 @@ __global__ __launch_bounds__(64 * NW_WAVES) void k_mlp_wave(const Fused3Par P) {
 }
 
 // The 4-wave workgroup's forward for the leaves [bidx*16*LT, +16*LT) (also called from k_search_small); contains
-// workgroup barriers: every wave of the workgroup must call it.
-template <int H, int LT, int DEPTH>
+// workgroup barriers: every wave of the workgroup must call it.  PRE_BARRIER: the input planes are being written by other
+// waves of this workgroup; the barrier that publishes them is taken AFTER the first weight fragments have been requested.
+template <int H, int LT, int DEPTH, bool PRE_BARRIER>
 __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const smem, const int bidx) {
     constexpr int NTH = H / 16, KTH = H / 32, TPW = NTH / NW_WAVES;
     constexpr int ROWB = H * 2 + 16;
@@ -70,6 +71,7 @@ __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const
     } while (0)
     NW_LOADGROUP(0); NW_LOADGROUP(1);
     if constexpr (DEPTH == 4) { NW_LOADGROUP(2); NW_LOADGROUP(3); }
+    if constexpr (PRE_BARRIER) __syncthreads();
 
     {   // the ML rows of input planes -> LDS (coalesced 16-B loads), zero beyond INP
         const int segs = G0 * KTH * 4, isegs = P.INP / 8;

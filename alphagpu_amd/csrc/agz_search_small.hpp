@@ -30,13 +30,12 @@ __global__ __launch_bounds__(64 * NW_WAVES, AGZ_SMALL_WAVES) void k_search_small
     static_assert(TW == 2 || TW == 4, "tree waves per workgroup");
     uint8_t* const tree_lds = lds_small + (size_t)(wave % TW) * S.tree_lds;
     uint8_t* const nn_lds = lds_small + (size_t)TW * S.tree_lds;
-    TreePar T = S.T;
     for (int k = 0; k <= S.V; ++k) {
-        T.rollout = (uint32_t)k; T.do_reset = k == 0; T.do_expand = k > 0; T.do_select = k < S.V; T.last = k == S.V - 1;
-        if (wave < TW) rollout_reg_body<FAM, NC, 8, KPL>(T, tree_lds, (int)blockIdx.x * TW + wave);
-        __syncthreads();                                          // planes of the 16 leaves are visible to the workgroup
+        const StepFlags SF = {(uint32_t)k, k == 0, k > 0, k < S.V, k == S.V - 1};
+        if (wave < TW) rollout_reg_body<FAM, NC, 8, KPL>(S.T, SF, tree_lds, (int)blockIdx.x * TW + wave);
         if (k < S.V) {
-            mlp_wave_body<H, TW / 2, 2>(S.F, nn_lds, (int)blockIdx.x);
+            // (the barrier that publishes the planes of the leaves sits inside, after the first weight fragments are requested)
+            mlp_wave_body<H, TW / 2, 2, true>(S.F, nn_lds, (int)blockIdx.x);
             __syncthreads();                                      // logits and values are visible to the tree waves
         }
     }

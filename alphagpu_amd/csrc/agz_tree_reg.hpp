@@ -77,19 +77,24 @@ __host__ __device__ inline RegLds reg_lds_layout(int V) {
 
 // WV = waves per SIMD the register budget is cut for: 4 (128 VGPRs, a few spills) keeps every wave of a 32768-game launch
 // resident; 3 (no spills) is faster as soon as the launch fits 3 waves per SIMD.
+// what changes from rollout to rollout (kept apart from TreePar so that a caller looping over rollouts — k_search_small —
+// can leave the big parameter block in constant kernel-argument memory)
+struct StepFlags { uint32_t rollout; int do_reset, do_expand, do_select, last; };
+
 template <int FAM, int NC, int G, int KPL>
-__device__ __forceinline__ void rollout_reg_body(const TreePar& T, uint8_t* const lds, const int bidx);
+__device__ __forceinline__ void rollout_reg_body(const TreePar& T, const StepFlags SF, uint8_t* const lds, const int bidx);
 
 template <int FAM, int NC, int G, int KPL, int WV = AGZ_REG_WAVES>
 __global__ __launch_bounds__(64, G <= 4 ? 2 : WV) void k_rollout_reg(const TreePar T) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_reg[];
-    rollout_reg_body<FAM, NC, G, KPL>(T, lds_reg, (int)blockIdx.x);
+    const StepFlags SF = {T.rollout, T.do_reset, T.do_expand, T.do_select, T.last};
+    rollout_reg_body<FAM, NC, G, KPL>(T, SF, lds_reg, (int)blockIdx.x);
 }
 
 // One wave: expand + backup of the previous rollout and select + encode of this one for the 64/G games of wave-block `bidx`
 // (also called from k_search_small, agz_search_small.hpp, with the wave's own LDS window).
 template <int FAM, int NC, int G, int KPL>
-__device__ __forceinline__ void rollout_reg_body(const TreePar& T, uint8_t* const lds, const int bidx) {
+__device__ __forceinline__ void rollout_reg_body(const TreePar& T, const StepFlags SF, uint8_t* const lds, const int bidx) {
     using GM = Game<FAM, NC>;
     constexpr bool REV = FAM == F_REV;
     constexpr int NG = 64 / G;
@@ -124,7 +129,7 @@ __device__ __forceinline__ void rollout_reg_body(const TreePar& T, uint8_t* cons
     // ---- stage the meta rows of the wave's games (coalesced) ------------------------------------------
     uint32_t ncount = 1, leafn = 0;
     uint32_t* const gmeta = T.meta + (size_t)sl * V;              // every change of a meta word is written through
-    if (T.do_reset) {
+    if (SF.do_reset) {
         if (lead) { mymeta[0] = M_EXISTS; if (live) gmeta[0] = M_EXISTS; }
     } else {
         if (live) { ncount = T.ncount[slot]; leafn = T.leaf[slot]; }
@@ -160,7 +165,7 @@ __device__ __forceinline__ void rollout_reg_body(const TreePar& T, uint8_t* cons
     // =============================================================================================
     // expand (mcts_gpu.jl:250-302) + backUp (:306-328) of the previous rollout's leaf
     // =============================================================================================
-    if (T.do_expand) {
+    if (SF.do_expand) {
         const int lf = (int)leafn;
         uint32_t ml = live ? mymeta[lf] : (uint32_t)M_TERM;
         const bool term = (ml & M_TERM) != 0;
@@ -265,7 +270,7 @@ __device__ __forceinline__ void rollout_reg_body(const TreePar& T, uint8_t* cons
     // =============================================================================================
     // kdescendTree! (mcts_gpu.jl:100-199) + decoder (:202-223)
     // =============================================================================================
-    if (T.do_select) {
+    if (SF.do_select) {
         const uint32_t gid = live ? T.game_id[slot] : 0u;
         int node = 0, depth = 0;
         uint32_t mn = live ? mymeta[0] : 0u;
@@ -297,7 +302,7 @@ __device__ __forceinline__ void rollout_reg_body(const TreePar& T, uint8_t* cons
                         q[j] = b.x; q[j + 1] = b.y; q[j + 2] = b.z; q[j + 3] = b.w;
                     }
                 }
-                if ((depth & 3) == 0) uniform_search4(T.seed, gid, T.step, T.rollout, (uint32_t)depth >> 2, uq);   // overlaps the loads
+                if ((depth & 3) == 0) uniform_search4(T.seed, gid, T.step, SF.rollout, (uint32_t)depth >> 2, uq);   // overlaps the loads
                 const int uw = depth & 3;
                 const float u = uw == 0 ? uq[0] : (uw == 1 ? uq[1] : (uw == 2 ? uq[2] : uq[3]));
                 STAMP(7);
@@ -438,7 +443,7 @@ __device__ __forceinline__ void rollout_reg_body(const TreePar& T, uint8_t* cons
 #pragma unroll
                     for (int j = 0; j < KPL; ++j) pol[j] = p[j];           // policy == prior since expand (:297-299)
                 }
-                if (node == 0 && T.last) {                                 // copy_pol (:330-339) of the last descent
+                if (node == 0 && SF.last) {                                 // copy_pol (:330-339) of the last descent
 #pragma unroll
                     for (int j = 0; j < KPL; ++j) if (k0 + j < A) T.policy_final[(size_t)slot * A + k0 + j] = pol[j];
                 }
@@ -573,7 +578,7 @@ __device__ __forceinline__ void rollout_reg_body(const TreePar& T, uint8_t* cons
     if (live && lead) {
         T.ncount[slot] = ncount;
         T.leaf[slot] = leafn;
-        if (T.do_reset) { T.cnt_p[slot] = add_p; T.cnt_new[slot] = add_new; }
+        if (SF.do_reset) { T.cnt_p[slot] = add_p; T.cnt_new[slot] = add_new; }
         else { T.cnt_p[slot] += add_p; T.cnt_new[slot] += add_new; }
     }
 #ifdef AGZ_STAMPS
