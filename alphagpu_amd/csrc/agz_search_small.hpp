@@ -32,10 +32,14 @@ __global__ __launch_bounds__(64 * NW_WAVES, AGZ_SMALL_WAVES) void k_search_small
     uint8_t* const nn_lds = lds_small + (size_t)TW * S.tree_lds;
     for (int k = 0; k <= S.V; ++k) {
         const StepFlags SF = {(uint32_t)k, k == 0, k > 0, k < S.V, k == S.V - 1};
-        if (wave < TW) rollout_reg_body<FAM, NC, 8, KPL>(S.T, SF, tree_lds, (int)blockIdx.x * TW + wave);
+        // the workgroup index is made opaque once per rollout: otherwise every per-game address of both bodies is hoisted out
+        // of this loop and kept alive across them (hundreds of registers, spills)
+        int bx = (int)blockIdx.x;
+        asm volatile("" : "+s"(bx));
+        if (wave < TW) rollout_reg_body<FAM, NC, 8, KPL>(S.T, SF, tree_lds, bx * TW + wave);
         if (k < S.V) {
             // (the barrier that publishes the planes of the leaves sits inside, after the first weight fragments are requested)
-            mlp_wave_body<H, TW / 2, 2, true>(S.F, nn_lds, (int)blockIdx.x);
+            mlp_wave_body<H, TW / 2, 2, true>(S.F, nn_lds, bx);
             __syncthreads();                                      // logits and values are visible to the tree waves
         }
     }
