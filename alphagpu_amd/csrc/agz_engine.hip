@@ -53,6 +53,11 @@ struct DevNet {
 
 typedef void (*rollout_fn)(const TreePar);
 typedef void (*small_fn)(const SmallPar);
+namespace agz {
+#define X(F, C, K) AGZ_SMALL_VARIANTS(F, C, K, extern)
+AGZ_SMALL_SHAPES(X)          // defined in agz_small_inst.hip
+#undef X
+}
 typedef void (*advance_fn)(const PlyPar);
 typedef void (*softmax_fn)(const float*, int, float*, int, int, int);
 
@@ -101,7 +106,9 @@ struct agz_engine {
     double tree_ms = 0, nn_ms = 0, tree_busy_ms = 0; int64_t tree_launches = 0;
     hipEvent_t ev_ref = nullptr; bool ev_ref_live = false;
     rollout_fn k_roll = nullptr; advance_fn k_adv = nullptr; softmax_fn k_soft = nullptr;
-    small_fn k_small4 = nullptr; int small4_maxl = 16384;   // the same with 32 games per workgroup, for batches in (small_maxl, small4_maxl]
+    small_fn k_small4[3] = {nullptr, nullptr, nullptr};   // the same with 32 games per workgroup, register budgets for 2 / 3 / 4 workgroups per SIMD set
+    int small4_maxl = 1 << 30;   // ... used for batches in (small_maxl, small4_maxl] that fit the chip at once (AGZ_SMALL4_MAXL)
+    int cus = 256;
     small_fn k_small = nullptr; int small_maxl = 8192;   // whole-search kernel (agz_search_small.hpp) for batches up to small_maxl games (AGZ_SMALL_MAXL)
     rollout_fn k_reg3 = nullptr; int reg3_max_waves = 0;   // the 3-waves-per-SIMD build of k_reg and the largest grid it is used for
     rollout_fn k_reg = nullptr; size_t reg_lds = 0; int reg_kpl = 0, reg_g = 8;   // register-row kernel (agz_tree_reg.hpp), 8 lanes per tree
@@ -138,15 +145,15 @@ static bool bind_kernels(agz_engine* h) {
 #undef Y
     {   // register-row kernel: smallest block length KPL with 8*KPL >= A among the instantiated shapes
         const int kpl = P.A <= 32 ? 4 : (P.A <= 64 ? 8 : (P.A <= 96 ? 12 : (P.A <= 128 ? 16 : (P.A <= 192 ? 24 : 0))));
-#define Z(F, C, K) if (P.fam == F && P.NC == C && kpl == K) { h->k_reg = k_rollout_reg<F, C, 8, K, 4>; h->k_reg3 = k_rollout_reg<F, C, 8, K, 3>; h->k_small = k_search_small<F, C, K, 128, 2>; h->k_small4 = k_search_small<F, C, K, 128, 4>; h->reg_kpl = K; }
+#define Z(F, C, K) if (P.fam == F && P.NC == C && kpl == K) { h->k_reg = k_rollout_reg<F, C, 8, K, 4>; h->k_reg3 = k_rollout_reg<F, C, 8, K, 3>; h->k_small = k_search_small<F, C, K, 128, 2, 2>; h->k_small4[0] = k_search_small<F, C, K, 128, 4, 2>; h->k_small4[1] = k_search_small<F, C, K, 128, 4, 3>; h->k_small4[2] = k_search_small<F, C, K, 128, 4, 4>; h->reg_kpl = K; }
         Z(F_LINE, 1, 4) Z(F_LINE, 1, 8) Z(F_LINE, 2, 12) Z(F_LINE, 2, 16) Z(F_LINE, 3, 24)
         Z(F_C4, 1, 4)
         Z(F_HEX, 1, 4) Z(F_HEX, 1, 8) Z(F_HEX, 2, 8) Z(F_HEX, 2, 12) Z(F_HEX, 2, 16) Z(F_HEX, 3, 16) Z(F_HEX, 3, 24)
         Z(F_REV, 1, 12) Z(F_REV, 1, 8)
 #undef Z
         { const char* eg = getenv("AGZ_REG_G");     // experiment: 4 lanes per tree (Gobang 9x9 / Hex 9x9 shapes only)
-          if (eg && atoi(eg) == 4 && P.fam == F_LINE && P.NC == 2 && kpl == 12) { h->k_reg = h->k_reg3 = k_rollout_reg<F_LINE, 2, 4, 24>; h->k_small = h->k_small4 = nullptr; h->reg_kpl = 24; h->reg_g = 4; }
-          if (eg && atoi(eg) == 16 && P.fam == F_LINE && P.NC == 2 && kpl == 12) { h->k_reg = h->k_reg3 = k_rollout_reg<F_LINE, 2, 16, 8>; h->k_small = h->k_small4 = nullptr; h->reg_kpl = 8; h->reg_g = 16; } }
+          if (eg && atoi(eg) == 4 && P.fam == F_LINE && P.NC == 2 && kpl == 12) { h->k_reg = h->k_reg3 = k_rollout_reg<F_LINE, 2, 4, 24>; h->k_small = h->k_small4[0] = h->k_small4[1] = h->k_small4[2] = nullptr; h->reg_kpl = 24; h->reg_g = 4; }
+          if (eg && atoi(eg) == 16 && P.fam == F_LINE && P.NC == 2 && kpl == 12) { h->k_reg = h->k_reg3 = k_rollout_reg<F_LINE, 2, 16, 8>; h->k_small = h->k_small4[0] = h->k_small4[1] = h->k_small4[2] = nullptr; h->reg_kpl = 8; h->reg_g = 16; } }
     }
     if (P.NR == 1) h->k_soft = k_softmax<1>; else if (P.NR == 2) h->k_soft = k_softmax<2>; else h->k_soft = k_softmax<3>;
     return h->k_roll != nullptr;
@@ -301,7 +308,7 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
         hipFuncSetAttribute((const void*)h->k_reg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->reg_lds);
         hipFuncSetAttribute((const void*)h->k_reg3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->reg_lds);
         hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) h->reg3_max_waves = 12 * prop.multiProcessorCount;   // 3 waves x 4 SIMDs per CU
+        if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) { h->reg3_max_waves = 12 * prop.multiProcessorCount; h->cus = prop.multiProcessorCount; }   // 3 waves x 4 SIMDs per CU
         const char* e3 = getenv("AGZ_REG3_MAX_WAVES");
         if (e3) h->reg3_max_waves = atoi(e3);
         e3 = getenv("AGZ_SMALL_MAXL");
@@ -309,7 +316,7 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
         e3 = getenv("AGZ_SMALL4_MAXL");
         if (e3) h->small4_maxl = atoi(e3);
         if (h->k_small) hipFuncSetAttribute((const void*)h->k_small, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (h->k_small4) hipFuncSetAttribute((const void*)h->k_small4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        for (int i = 0; i < 3; ++i) if (h->k_small4[i]) hipFuncSetAttribute((const void*)h->k_small4[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     if (h->reg_lds || !h->k_lpg || h->lpg_lds > 64 * 1024 /* LDS-DMA destination offsets are 16 bit */ || (tk && !strcmp(tk, "v1"))) h->lpg_lds = 0;
     if (h->lpg_lds) hipFuncSetAttribute((const void*)h->k_lpg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lpg_lds);
@@ -728,12 +735,16 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
     // tile) and each runs its own select -> network -> expand/backup chain on its own stream: while one chain's tree
     // kernel waits on memory latency the other chains' network and tree kernels fill the machine.  Results do not depend
     // on the cut (every per-game quantity is keyed by game id).
-    {   // up to 16384 games alive: the whole search in one launch (agz_search_small.hpp).  Such a search has no per-launch
-        // events and is left out of the instrumented counters: the tree-kernel roofline covers the launches of k_rollout_reg only.
+    {   // every game resident at once (<= 128 per CU): the whole search in one launch (agz_search_small.hpp); profiling bit 0
+        // then times that launch (it counts as one "tree launch" of agz_get_kernel_times)
         DevNet& n = h->net[which];
         if (h->k_small && h->reg_lds != 0 && h->reg_g == 8 && h->cfg.nn_mode == AGZ_NN_BF16 && n.H == 128 && n.w16w && h->L > 0 &&
-            h->L <= std::max(h->small_maxl, h->small4_maxl) && !getenv("AGZ_NO_FUSED_NN")) {
-            const int tw = h->L <= h->small_maxl ? 2 : 4;     // tree waves per workgroup (8 games each)
+            h->L <= std::min(std::max(h->small_maxl, h->small4_maxl), 128 * h->cus) && !getenv("AGZ_NO_FUSED_NN")) {
+            // 16 games per workgroup up to small_maxl; beyond, 32 games per workgroup with the loosest register budget that still
+            // keeps every workgroup resident (2 / 3 / 4 workgroups per CU = 64 / 96 / 128 games per CU)
+            const int tw = h->L <= h->small_maxl ? 2 : 4;
+            const int occ = h->L <= 64 * h->cus ? 0 : (h->L <= 96 * h->cus ? 1 : 2);
+            const small_fn kfn = tw == 2 ? h->k_small : h->k_small4[occ];
             SmallPar S;
             S.T = h->tp;
             S.T.L = h->L; S.T.slot0 = 0; S.T.step = h->step; S.T.cpuct = h->cpuct; S.T.training = h->training;
@@ -742,13 +753,15 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
             S.F.logits = h->logits; S.F.LGS = h->LGS; S.F.vout = h->v_eval; S.F.L = h->L; S.F.T = n.T; S.F.A = h->G.A; S.F.AOP = n.AOP;
             S.V = V; S.tree_lds = (int)h->reg_lds;
             const int kth = n.H / 32, g0 = (n.INP / 32 + kth - 1) / kth;
-            const size_t lds = tw * h->reg_lds + (size_t)8 * tw * (2 * (n.H * 2 + 16) + (g0 * kth * 64 + 16));
-            hipLaunchKernelGGL(tw == 2 ? h->k_small : h->k_small4, dim3((unsigned)((h->L + 8 * tw - 1) / (8 * tw))), dim3(64 * NW_WAVES), lds, h->stream, S);
+            const size_t lds = std::max((size_t)tw * h->reg_lds, (size_t)8 * tw * (2 * (n.H * 2 + 16) + (g0 * kth * 64 + 16)));   // tree and network phases share it
+            std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
+            if ((h->profiling & 1) && h->prof_this) { ev = next_events(h, h->ev_tree, h->ev_tree_used); hipEventRecord(ev->first, h->stream); }
+            hipLaunchKernelGGL(kfn, dim3((unsigned)((h->L + 8 * tw - 1) / (8 * tw))), dim3(64 * NW_WAVES), lds, h->stream, S);
+            if (ev) hipEventRecord(ev->second, h->stream);
             HIPCHK(h, hipGetLastError());
             h->cnt_live = true;
             h->need_reset = true; h->injected = false;
-            if (h->profiling == 0) h->total_rollouts += (uint64_t)h->L * (uint64_t)V;
-            else h->prof_this = false;
+            if (h->prof_this) h->total_rollouts += (uint64_t)h->L * (uint64_t)V;
             return AGZ_OK;
         }
     }

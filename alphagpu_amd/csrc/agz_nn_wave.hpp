@@ -48,7 +48,9 @@ __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const
     constexpr int NTH = H / 16, KTH = H / 32, TPW = NTH / NW_WAVES;
     constexpr int ROWB = H * 2 + 16;
     static_assert(TPW >= 1, "at least one neuron tile per wave");
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int tid_ = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid_));                            // opaque per call (see rollout_reg_body)
+    const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6) & (NW_WAVES - 1);
     constexpr int ML = 16 * LT;                                   // leaves per workgroup
     const int leaf0 = bidx * ML;
     const int G0 = (P.INP / 32 + KTH - 1) / KTH;                 // groups of layer 0
@@ -76,7 +78,7 @@ __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const
     {   // the ML rows of input planes -> LDS (coalesced 16-B loads), zero beyond INP
         const int segs = G0 * KTH * 4, isegs = P.INP / 8;
         const AGZ_GLB uint16_t* gp = (const AGZ_GLB uint16_t*)P.planes;
-        for (int c = threadIdx.x; c < ML * segs; c += 64 * NW_WAVES) {
+        for (int c = tid_ & (64 * NW_WAVES - 1); c < ML * segs; c += 64 * NW_WAVES) {
             const int row = c / segs, seg = c - row * segs, mm = leaf0 + row;
             v4u v = {0u, 0u, 0u, 0u};
             if (mm < P.L && seg < isegs) v = *(const AGZ_GLB v4u*)(gp + (size_t)mm * P.INP + seg * 8);

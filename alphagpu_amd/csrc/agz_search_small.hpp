@@ -19,17 +19,17 @@ struct SmallPar {
     int tree_lds;             // bytes of LDS of one tree wave
 };
 
-#ifndef AGZ_SMALL_WAVES
-#define AGZ_SMALL_WAVES 2
-#endif
 // TW = tree waves per workgroup (2 or 4): the workgroup owns 8*TW games and runs the network with TW/2 leaf tiles.
-template <int FAM, int NC, int KPL, int H, int TW>
-__global__ __launch_bounds__(64 * NW_WAVES, AGZ_SMALL_WAVES) void k_search_small(const SmallPar S) {
+// WV = waves per SIMD the register budget is cut for (2: 172 VGPRs, no spills; 3, 4: more workgroups per CU so that 24576 /
+// 32768 games are resident at once with 32 games per workgroup).
+template <int FAM, int NC, int KPL, int H, int TW, int WV>
+__global__ __launch_bounds__(64 * NW_WAVES, WV) void k_search_small(const SmallPar S) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_small[];
     const int wave = (int)threadIdx.x >> 6;
     static_assert(TW == 2 || TW == 4, "tree waves per workgroup");
     uint8_t* const tree_lds = lds_small + (size_t)(wave % TW) * S.tree_lds;
-    uint8_t* const nn_lds = lds_small + (size_t)TW * S.tree_lds;
+    uint8_t* const nn_lds = lds_small;                            // the two phases never overlap and the tree step keeps nothing
+                                                                  // in LDS from one rollout to the next: same memory
     for (int k = 0; k <= S.V; ++k) {
         const StepFlags SF = {(uint32_t)k, k == 0, k > 0, k < S.V, k == S.V - 1};
         // the workgroup index is made opaque once per rollout: otherwise every per-game address of both bodies is hoisted out
@@ -44,5 +44,18 @@ __global__ __launch_bounds__(64 * NW_WAVES, AGZ_SMALL_WAVES) void k_search_small
         }
     }
 }
+
+// The instantiated shapes (game family, bitboard chunks, actions per lane): agz_small_inst.hip compiles them in four
+// parts in parallel, agz_engine.hip only declares them.
+#define AGZ_SMALL_SHAPES_0(X) X(F_LINE, 1, 4) X(F_LINE, 1, 8) X(F_LINE, 2, 12) X(F_LINE, 2, 16)
+#define AGZ_SMALL_SHAPES_1(X) X(F_LINE, 3, 24) X(F_C4, 1, 4) X(F_HEX, 1, 4) X(F_HEX, 1, 8)
+#define AGZ_SMALL_SHAPES_2(X) X(F_HEX, 2, 8) X(F_HEX, 2, 12) X(F_HEX, 2, 16) X(F_HEX, 3, 16)
+#define AGZ_SMALL_SHAPES_3(X) X(F_HEX, 3, 24) X(F_REV, 1, 12) X(F_REV, 1, 8)
+#define AGZ_SMALL_SHAPES(X) AGZ_SMALL_SHAPES_0(X) AGZ_SMALL_SHAPES_1(X) AGZ_SMALL_SHAPES_2(X) AGZ_SMALL_SHAPES_3(X)
+#define AGZ_SMALL_VARIANTS(F, C, K, KW)                                      \
+    KW template __global__ void k_search_small<F, C, K, 128, 2, 2>(const SmallPar); \
+    KW template __global__ void k_search_small<F, C, K, 128, 4, 2>(const SmallPar); \
+    KW template __global__ void k_search_small<F, C, K, 128, 4, 3>(const SmallPar); \
+    KW template __global__ void k_search_small<F, C, K, 128, 4, 4>(const SmallPar);
 
 }  // namespace agz

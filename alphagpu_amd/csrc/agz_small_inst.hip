@@ -1,0 +1,24 @@
+// agz_small_inst.hip — explicit instantiations of k_search_small (agz_search_small.hpp), compiled as four translation
+// units (-DAGZ_PART=0..3) so that the ~60 kernels build in parallel; agz_engine.hip declares them `extern template`.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "../../include/agz.h"
+#include "agz_games.hpp"
+#include "agz_device.hpp"
+#include "agz_tree.hpp"
+#include "agz_tree_grp.hpp"
+#include "agz_search_small.hpp"
+
+namespace agz {
+#define X(F, C, K) AGZ_SMALL_VARIANTS(F, C, K, )
+#if AGZ_PART == 0
+AGZ_SMALL_SHAPES_0(X)
+#elif AGZ_PART == 1
+AGZ_SMALL_SHAPES_1(X)
+#elif AGZ_PART == 2
+AGZ_SMALL_SHAPES_2(X)
+#else
+AGZ_SMALL_SHAPES_3(X)
+#endif
+#undef X
+}  // namespace agz

@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void k_rollout(const TreePar T) {
 // ---- standalone pieces for the stepwise API and getters -------------------------------------------
 // softmax!(prior) as its own kernel (stepwise mode: agz_rollout_eval); same device function as the fused path
 template <int NR>
-__global__ __launch_bounds__(256) void k_softmax(const float* logits, int LGS, float* prior_eval, int A, int L, int exact) {
+static __global__ __launch_bounds__(256) void k_softmax(const float* logits, int LGS, float* prior_eval, int A, int L, int exact) {
     const int lane = lane_id();
     const int slot = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     if (slot >= L) return;
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void k_softmax(const float* logits, int LGS, f
 }
 
 // decoder_roots (mcts_gpu.jl:225-246) / decoder for getters: fp32 planes of node `which` (0 = root, else leaf[slot])
-__global__ void k_planes(const Pos* states, const uint32_t* leaf, int use_leaf, int V, int VS, int L, float* out) {
+static __global__ void k_planes(const Pos* states, const uint32_t* leaf, int use_leaf, int V, int VS, int L, float* out) {
     int slot = blockIdx.x;
     if (slot >= L) return;
     const Pos* s = states + (size_t)slot * V + (use_leaf ? leaf[slot] : 0u);
@@ -375,7 +375,7 @@ __global__ void k_planes(const Pos* states, const uint32_t* leaf, int use_leaf, 
 }
 
 // visits[:,1,:] and q[:,1,:] of the root as fp32 [L][A]
-__global__ void k_root_stats(const uint8_t* recs, const uint32_t* meta, int V, uint32_t rec_bytes, uint32_t off_q, uint32_t off_vc,
+static __global__ void k_root_stats(const uint8_t* recs, const uint32_t* meta, int V, uint32_t rec_bytes, uint32_t off_q, uint32_t off_vc,
                              int A, int L, float* visits, float* q) {
     int slot = blockIdx.x;
     if (slot >= L) return;

@@ -101,7 +101,9 @@ __device__ __forceinline__ void rollout_reg_body(const TreePar& T, const StepFla
     constexpr int AP = G * KPL;                                  // padded row length (== T.A2)
     static_assert(KPL % 4 == 0, "block of actions per lane must be a multiple of 4");
     const GamePar& P = T.G;
-    const int lane = lane_id(), g = lane / G, sub = lane % G;
+    int lane_ = lane_id();
+    asm volatile("" : "+v"(lane_));                           // opaque per call: per-lane addresses are not hoisted out of a caller's rollout loop
+    const int lane = lane_ & 63, g = lane / G, sub = lane % G;
     const int slot = T.slot0 + bidx * NG + g;
     const bool live = slot < T.L;
     const bool lead = sub == 0;

@@ -97,7 +97,7 @@ def main():
     eng = M.Engine(game, G, V, device=dev, seed=1, game_id_base=shard.shard_base(rank, G),
                    nn_mode=M.NN_BF16 if args.mode == "bf16" else M.NN_EXACT)
     eng.set_network(net)
-    eng.set_profiling(1 | 4)      # HIP events around the PUCT-kernel launches of every 4th ply (all of them cost ~10 % of the generation)
+    eng.set_profiling(1)          # HIP events around every launch of the search kernel (one launch per ply: mcts_single in one kernel)
     rb = game.rec_bytes
     # the exchange of generation k overlaps generation k+1: two sample buffers, at most two collectives in flight
     sample_bufs = [torch.empty(G * game.max_plies * rb, dtype=torch.uint8, device="cuda") for _ in range(2)] if world > 1 else None
@@ -181,17 +181,17 @@ def main():
                        "games_per_gpu": G, "rollouts_per_move": V, "cpuct": args.cpuct, "tau_plies": 25,
                        "tree_arithmetic": "f32 strict IEEE", "network": "bf16 MFMA, fp32 accumulate" if args.mode == "bf16" else "f32 exact",
                        "parallelism": f"game-shard x{world}, RCCL all-gather of samples at generation end" if world > 1 else "single GPU"},
-            "roofline": {"kernel": "k_rollout_reg (expand+backup+select+encode, 8 lanes per game tree, rows in registers)",
+            "roofline": {"kernel": "k_search_small (a whole mcts_single per launch: 65 x {expand+backup+select+encode, network forward}; "
+                                   "8 lanes per game tree, node rows in registers, 16/32 games per workgroup)",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "achieved_per_single_launch": alg / (tree_ms * 1e-3) / 1e9 if tree_ms > 0 else 0.0,
                          "algorithmic_bytes_per_launch": alg / max(launches, 1), "avg_launch_ms": tree_ms / max(launches, 1),
-                         "launches": launches, "launches_instrumented": "every 4th ply (all its launches)", "launch_concurrency": tree_ms / busy_ms if busy_ms > 0 else None,
-                         "kernel_busy_ms": busy_ms, "mean_depth_p": sum_p / max(r_cnt, 1),
-                         "note": "achieved = algorithmic_bytes_per_launch * launch_concurrency / avg_launch_ms: with >= 12000 games alive the "
-                                 "batch runs as 2-3 sub-batch chains on parallel streams, so tree-kernel launches overlap each other"},
+                         "launches": launches, "launch_concurrency": tree_ms / busy_ms if busy_ms > 0 else None,
+                         "mean_depth_p": sum_p / max(r_cnt, 1),
+                         "note": "one launch = one ply of the generation (all games alive, 64 rollouts); algorithmic bytes are the tree path's "
+                                 "(SURVEY 8d) - the network weights stream from L2 and the kernel is bound by instruction issue / latency, not HBM"},
             "rank0": {"search_only_rollouts_per_s": rollouts / search_s if search_s > 0 else None,
-                      "tree_kernel_ms_sum_of_instrumented_launches": tree_ms, "tree_kernel_busy_ms_instrumented": busy_ms, "search_ms_all_plies": search_s * 1e3,
+                      "search_kernel_ms": tree_ms, "search_ms": search_s * 1e3,
                       "plies": plies, "samples": nsamples,
                       "wall_s": dt},
         }

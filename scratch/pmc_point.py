@@ -17,5 +17,5 @@ for r in range(2):
     e.synchronize()
 p, n, ro = e.counters()
 alg = bench.algorithmic_bytes(g, p, n, ro, g.pos_image_bytes)
-print(json.dumps({"sum_p": p, "sum_new": n, "rollouts": ro, "launches": V + 1, "algorithmic_bytes_per_launch": alg / (V + 1)}))
+print(json.dumps({"sum_p": p, "sum_new": n, "rollouts": ro, "launches_per_search": 1, "algorithmic_bytes_per_search_launch": alg}))
 e.close()
