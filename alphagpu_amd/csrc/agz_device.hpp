@@ -99,6 +99,8 @@ struct TreePar {
     GamePar G;
     int32_t L, V;            // L = END of the slot range [slot0, L) of this launch
     int32_t slot0;           // first slot (register-row kernel only: sub-batches on parallel streams)
+    int32_t gpw;             // games per wave of the register-row kernel (<= 64/G; fewer = sparse waves for small batches: the
+                             // time of a rollout is the deepest descent among the games that share a wave / workgroup)
     uint32_t rec_bytes, off_q, off_vc, A2;
     uint8_t* recs;
     Pos* states;

@@ -109,6 +109,7 @@ struct agz_engine {
     small_fn k_small4[3] = {nullptr, nullptr, nullptr};   // the same with 32 games per workgroup, register budgets for 2 / 3 / 4 workgroups per SIMD set
     int small4_maxl = 1 << 30;   // ... used for batches in (small_maxl, small4_maxl] that fit the chip at once (AGZ_SMALL4_MAXL)
     int cus = 256;
+    int small_gpw = 0;           // games per tree wave of the 16-game variant: 0 = by batch size (AGZ_SMALL_GPW = 1, 2, 4, 8)
     small_fn k_small = nullptr; int small_maxl = 8192;   // whole-search kernel (agz_search_small.hpp) for batches up to small_maxl games (AGZ_SMALL_MAXL)
     rollout_fn k_reg3 = nullptr; int reg3_max_waves = 0;   // the 3-waves-per-SIMD build of k_reg and the largest grid it is used for
     rollout_fn k_reg = nullptr; size_t reg_lds = 0; int reg_kpl = 0, reg_g = 8;   // register-row kernel (agz_tree_reg.hpp), 8 lanes per tree
@@ -313,6 +314,8 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
         if (e3) h->reg3_max_waves = atoi(e3);
         e3 = getenv("AGZ_SMALL_MAXL");
         if (e3) h->small_maxl = atoi(e3);
+        e3 = getenv("AGZ_SMALL_GPW");
+        if (e3 && (atoi(e3) == 1 || atoi(e3) == 2 || atoi(e3) == 4 || atoi(e3) == 8)) h->small_gpw = atoi(e3);
         e3 = getenv("AGZ_SMALL4_MAXL");
         if (e3) h->small4_maxl = atoi(e3);
         if (h->k_small) hipFuncSetAttribute((const void*)h->k_small, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -600,7 +603,7 @@ static int launch_rollout(agz_engine* h, uint32_t rollout, int do_reset, int do_
     if (!stream) stream = h->stream;
     const int n = s1 - s0;
     TreePar T = h->tp;
-    T.L = s1; T.slot0 = s0; T.step = h->step; T.rollout = rollout; T.cpuct = h->cpuct; T.training = h->training;
+    T.L = s1; T.slot0 = s0; T.gpw = h->reg_lds ? 64 / h->reg_g : 0; T.step = h->step; T.rollout = rollout; T.cpuct = h->cpuct; T.training = h->training;
     T.do_reset = do_reset; T.do_expand = do_expand; T.do_select = do_select; T.last = last; T.inject = inject; T.capture = capture;
     const bool reg = h->reg_lds != 0, lpg = !reg && h->lpg_lds != 0;
     const int ng = reg ? 64 / h->reg_g : 64 / h->grp_g;
@@ -651,7 +654,7 @@ static int launch_network(agz_engine* h, int which, int s0 = 0, int s1 = -1, hip
     } else if (f3_lds && n.w16w && L <= h->nn_wave_maxl) {   // one wave per 16 leaves, weights streamed from L2: lowest latency
         Fused3Par F;
         F.planes = (const uint16_t*)planes; F.INP = n.INP; F.w16 = n.w16w; F.bias_head = n.bias_head;
-        F.logits = logits; F.LGS = h->LGS; F.vout = v_eval; F.L = L; F.T = n.T; F.A = h->G.A; F.AOP = n.AOP;
+        F.logits = logits; F.LGS = h->LGS; F.vout = v_eval; F.L = L; F.T = n.T; F.A = h->G.A; F.AOP = n.AOP; F.gpw = 0; F.tw = 0;
         const int kth = n.H / 32, g0 = (n.INP / 32 + kth - 1) / kth;
         int lt = h->nn_wave_lt > 0 ? h->nn_wave_lt : (L <= 16384 ? 1 : 2);   // measured (128x6): 11 / 14 / 20 us at 2048 / 8192 / 16384 leaves with 1 tile, 27 us at 32768 with 2
         const size_t lds = (size_t)16 * lt * (2 * (n.H * 2 + 16) + (g0 * kth * 64 + 16));
@@ -665,7 +668,7 @@ static int launch_network(agz_engine* h, int which, int s0 = 0, int s1 = -1, hip
     } else if (f3_lds) {                // 16x16x32 tiles, 8 waves per workgroup
         Fused3Par F;
         F.planes = (const uint16_t*)planes; F.INP = n.INP; F.w16 = n.w16; F.bias_head = n.bias_head;
-        F.logits = logits; F.LGS = h->LGS; F.vout = v_eval; F.L = L; F.T = n.T; F.A = h->G.A; F.AOP = n.AOP;
+        F.logits = logits; F.LGS = h->LGS; F.vout = v_eval; F.L = L; F.T = n.T; F.A = h->G.A; F.AOP = n.AOP; F.gpw = 0; F.tw = 0;
         dim3 grid((unsigned)((L + F3_M - 1) / F3_M)), block(F3_THREADS);
         if (n.H == 128) hipLaunchKernelGGL(k_mlp_fused3<128>, grid, block, f3_lds, stream, F);
         else hipLaunchKernelGGL(k_mlp_fused3<64>, grid, block, f3_lds, stream, F);
@@ -751,12 +754,18 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
             S.T.inject = 0; S.T.capture = 0; S.T.rollout = 0; S.T.do_reset = 1; S.T.do_expand = 0; S.T.do_select = 1; S.T.last = 0;
             S.F.planes = (const uint16_t*)h->planes; S.F.INP = n.INP; S.F.w16 = n.w16w; S.F.bias_head = n.bias_head;
             S.F.logits = h->logits; S.F.LGS = h->LGS; S.F.vout = h->v_eval; S.F.L = h->L; S.F.T = n.T; S.F.A = h->G.A; S.F.AOP = n.AOP;
+            // few games: sparse waves — a rollout lasts as long as the deepest descent among the games of a workgroup, and with
+            // <= 2 workgroups per CU idle lanes cost nothing: 1 / 2 games per tree wave up to 4 / 8 games per CU (measured per ply:
+            // 2.9 vs 4.0 ms at 256 games, 3.1 vs 3.9 at 1024, 3.5 vs 3.9 at 2048; no gain from 4 games per wave at 4096)
+            const int gpw = tw == 4 ? 8 : (h->L <= 4 * h->cus ? 1 : (h->L <= 8 * h->cus ? 2 : 8));
+            S.T.gpw = h->small_gpw > 0 && tw == 2 ? h->small_gpw : gpw;
+            S.F.gpw = S.T.gpw < 8 ? S.T.gpw : 0; S.F.tw = tw;
             S.V = V; S.tree_lds = (int)h->reg_lds;
             const int kth = n.H / 32, g0 = (n.INP / 32 + kth - 1) / kth;
             const size_t lds = std::max((size_t)tw * h->reg_lds, (size_t)8 * tw * (2 * (n.H * 2 + 16) + (g0 * kth * 64 + 16)));   // tree and network phases share it
             std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
             if ((h->profiling & 1) && h->prof_this) { ev = next_events(h, h->ev_tree, h->ev_tree_used); hipEventRecord(ev->first, h->stream); }
-            hipLaunchKernelGGL(kfn, dim3((unsigned)((h->L + 8 * tw - 1) / (8 * tw))), dim3(64 * NW_WAVES), lds, h->stream, S);
+            hipLaunchKernelGGL(kfn, dim3((unsigned)((h->L + S.T.gpw * tw - 1) / (S.T.gpw * tw))), dim3(64 * NW_WAVES), lds, h->stream, S);
             if (ev) hipEventRecord(ev->second, h->stream);
             HIPCHK(h, hipGetLastError());
             h->cnt_live = true;

@@ -30,6 +30,8 @@ struct Fused3Par {
     const float* bias_head;
     float* logits; int LGS; float* vout;
     int L, T, A, AOP;
+    int gpw, tw;                          // k_search_small with sparse waves: row r of a workgroup's tile is game slot
+                                          // (bidx*tw + r/8)*gpw + r%8 if r%8 < gpw (gpw = 0: rows are consecutive leaves)
 };
 
 __device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {

@@ -53,6 +53,11 @@ __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const
     const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6) & (NW_WAVES - 1);
     constexpr int ML = 16 * LT;                                   // leaves per workgroup
     const int leaf0 = bidx * ML;
+    // leaf (game slot) of tile row `row`, or a value >= P.L for an unused row
+    auto leaf_of = [&](int row) -> int {
+        if (P.gpw == 0) return leaf0 + row;
+        return (row & 7) < P.gpw ? (bidx * P.tw + (row >> 3)) * P.gpw + (row & 7) : P.L;
+    };
     const int G0 = (P.INP / 32 + KTH - 1) / KTH;                 // groups of layer 0
     const int NGH = nw_hidden_groups(P.INP, H, P.T);             // groups before the head
     const int PROWB = G0 * KTH * 64 + 16;
@@ -79,7 +84,7 @@ __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const
         const int segs = G0 * KTH * 4, isegs = P.INP / 8;
         const AGZ_GLB uint16_t* gp = (const AGZ_GLB uint16_t*)P.planes;
         for (int c = tid_ & (64 * NW_WAVES - 1); c < ML * segs; c += 64 * NW_WAVES) {
-            const int row = c / segs, seg = c - row * segs, mm = leaf0 + row;
+            const int row = c / segs, seg = c - row * segs, mm = leaf_of(row);
             v4u v = {0u, 0u, 0u, 0u};
             if (mm < P.L && seg < isegs) v = *(const AGZ_GLB v4u*)(gp + (size_t)mm * P.INP + seg * 8);
             *reinterpret_cast<v4u*>(pl + (size_t)row * PROWB + seg * 16) = v;
@@ -159,13 +164,13 @@ __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const
                     const float bias = P.bias_head[n];
 #pragma unroll
                     for (int lt = 0; lt < LT; ++lt) {
-                        const int mw = leaf0 + 16 * lt + 4 * q4;
+                        const int rw = 16 * lt + 4 * q4;              // tile row of acc[lt][t][0]
                         if (n < P.A) {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) if (mw + r < P.L) P.logits[(size_t)(mw + r) * P.LGS + n] = acc[lt][t][r] + bias;
+                            for (int r = 0; r < 4; ++r) { const int m = leaf_of(rw + r); if (m < P.L) P.logits[(size_t)m * P.LGS + n] = acc[lt][t][r] + bias; }
                         } else if (n == P.A) {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) if (mw + r < P.L) P.vout[mw + r] = sigmoid_ool(acc[lt][t][r] + bias);
+                            for (int r = 0; r < 4; ++r) { const int m = leaf_of(rw + r); if (m < P.L) P.vout[m] = sigmoid_ool(acc[lt][t][r] + bias); }
                         }
                     }
                 }

@@ -104,8 +104,9 @@ __device__ __forceinline__ void rollout_reg_body(const TreePar& T, const StepFla
     int lane_ = lane_id();
     asm volatile("" : "+v"(lane_));                           // opaque per call: per-lane addresses are not hoisted out of a caller's rollout loop
     const int lane = lane_ & 63, g = lane / G, sub = lane % G;
-    const int slot = T.slot0 + bidx * NG + g;
-    const bool live = slot < T.L;
+    const int GPW = T.gpw;                                        // games of this wave (<= NG)
+    const int slot = T.slot0 + bidx * GPW + g;
+    const bool live = g < GPW && slot < T.L;
     const bool lead = sub == 0;
     const int A = P.A, V = T.V, ROWS = (int)T.rec_bytes;
     const RegLds LO = reg_lds_layout(V);
@@ -142,8 +143,8 @@ __device__ __forceinline__ void rollout_reg_body(const TreePar& T, const StepFla
             for (int i = 0; i < 8; ++i) {
                 const int c = lane + 64 * i;
                 if (c < n4) {
-                    const int j = c / v4, sj = T.slot0 + bidx * NG + j;
-                    buf[i] = sj < T.L ? reinterpret_cast<const uint4*>(T.meta + (size_t)sj * V)[c - j * v4] : make_uint4(0u, 0u, 0u, 0u);
+                    const int j = c / v4, sj = T.slot0 + bidx * GPW + j;
+                    buf[i] = (j < GPW && sj < T.L) ? reinterpret_cast<const uint4*>(T.meta + (size_t)sj * V)[c - j * v4] : make_uint4(0u, 0u, 0u, 0u);
                 }
             }
 #pragma unroll
@@ -153,8 +154,8 @@ __device__ __forceinline__ void rollout_reg_body(const TreePar& T, const StepFla
             }
         } else {
             for (int j = 0; j < NG; ++j) {
-                const int sj = T.slot0 + bidx * NG + j;
-                if (sj >= T.L) break;
+                const int sj = T.slot0 + bidx * GPW + j;
+                if (j >= GPW || sj >= T.L) break;
                 uint32_t* dm = reinterpret_cast<uint32_t*>(lds + (size_t)j * LO.stride + LO.meta);
                 for (int c = lane; c < V; c += 64) dm[c] = T.meta[(size_t)sj * V + c];
             }

@@ -399,7 +399,10 @@ def test_whole_search_kernel_agrees_bitwise(name, L, V, monkeypatch):
     ref = run()                                     # two kernels per rollout
     monkeypatch.delenv("AGZ_SMALL_MAXL")
     monkeypatch.delenv("AGZ_SMALL4_MAXL")
-    for env in ({}, {"AGZ_SMALL_MAXL": "0"}):       # 16 games per workgroup, 32 games per workgroup
+    # 16 games per workgroup (default: sparse waves at these sizes), dense waves, 4 games per wave, 32 games per workgroup
+    for env in ({}, {"AGZ_SMALL_GPW": "8"}, {"AGZ_SMALL_GPW": "4"}, {"AGZ_SMALL_MAXL": "0"}):
+        monkeypatch.delenv("AGZ_SMALL_GPW", raising=False)
+        monkeypatch.delenv("AGZ_SMALL_MAXL", raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         got = run()
