@@ -20,7 +20,6 @@
 #include "agz_tree_grp.hpp"
 #include "agz_tree_reg.hpp"
 #include "agz_nn.hpp"
-#include "agz_nn_fused.hpp"
 #include "agz_nn_fused3.hpp"
 #include "agz_nn_wave.hpp"
 #include "agz_nn_big.hpp"
@@ -288,8 +287,6 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     hipFuncSetAttribute((const void*)k_layer_exact<EX_VALUE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)k_mlp_fused3<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)k_mlp_fused3<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)k_mlp_fused2<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)k_mlp_fused2<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     // node record: [prior f32 x A2][q f32 x A2][vc u16 x A2], A2 = A rounded up to 4 (16-B aligned sub-arrays);
     // the record size is an ODD multiple of 16 B so that the LDS image of 64 records is bank-conflict free for
     // per-lane 16-B reads (agz_tree_lpg.hpp)
@@ -375,15 +372,6 @@ int agz_get_info(const agz_engine* h, agz_game_info* out) {
 }
 void* agz_stream(agz_engine* h) { return h ? (void*)h->stream : nullptr; }
 #ifdef AGZ_STAMPS
-extern "C" int agz_debug_nn_stamps(agz_engine* h, unsigned long long* out) {
-    hipStreamSynchronize(h->stream);
-    std::vector<unsigned long long> all((size_t)4096 * 8);
-    hipMemcpy(all.data(), h->tp.dbg + (size_t)32768 * 16, all.size() * 8, hipMemcpyDeviceToHost);
-    for (int i = 0; i < 8; ++i) out[i] = 0;
-    for (size_t b = 0; b < 4096; ++b) for (int i = 0; i < 8; ++i) out[i] += all[b * 8 + i];
-    hipMemset(h->tp.dbg + (size_t)32768 * 16, 0, all.size() * 8);
-    return 0;
-}
 extern "C" int agz_debug_stamps(agz_engine* h, unsigned long long* out, int reset) {
     hipStreamSynchronize(h->stream);
     std::vector<unsigned long long> all((size_t)65536 * 16);
@@ -630,12 +618,8 @@ static int launch_network(agz_engine* h, int which, int s0 = 0, int s1 = -1, hip
     float* const logits = h->logits + (size_t)s0 * h->LGS; float* const v_eval = h->v_eval + s0;
     std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
     if ((h->profiling & 2) && h->prof_this) { ev = next_events(h, h->ev_nn, h->ev_nn_used); hipEventRecord(ev->first, stream); }
-    size_t fused_lds = 0;
-    if (h->cfg.nn_mode == AGZ_NN_BF16 && (n.H == 64 || n.H == 128) && n.AOP / 32 <= n.H / 32 && !getenv("AGZ_NO_FUSED_NN"))
-        fused_lds = (size_t)F2_M * (n.H * 2 + 16) + F2_WCHUNK + (size_t)F2_M * (n.INP * 2 + 16);
-    if (fused_lds > 160 * 1024) fused_lds = 0;
     size_t f3_lds = 0;
-    if (h->cfg.nn_mode == AGZ_NN_BF16 && (n.H == 64 || n.H == 128) && n.w16 && n.AOP / 16 <= n.H / 16 && !getenv("AGZ_NO_FUSED_NN") && !getenv("AGZ_NN_FUSED2")) {
+    if (h->cfg.nn_mode == AGZ_NN_BF16 && (n.H == 64 || n.H == 128) && n.w16 && n.AOP / 16 <= n.H / 16 && !getenv("AGZ_NO_FUSED_NN")) {
         f3_lds = (size_t)F3_M * (n.H * 2 + 16) + F3_WCHUNK + (size_t)F3_M * (n.INP * 2 + 16);
         if (f3_lds > 160 * 1024) f3_lds = 0;
     }
@@ -672,16 +656,6 @@ static int launch_network(agz_engine* h, int which, int s0 = 0, int s1 = -1, hip
         dim3 grid((unsigned)((L + F3_M - 1) / F3_M)), block(F3_THREADS);
         if (n.H == 128) hipLaunchKernelGGL(k_mlp_fused3<128>, grid, block, f3_lds, stream, F);
         else hipLaunchKernelGGL(k_mlp_fused3<64>, grid, block, f3_lds, stream, F);
-    } else if (fused_lds) {             // the whole forward in one launch, activations never leave LDS
-        Fused2Par F;
-        F.planes = (const uint16_t*)planes; F.INP = n.INP; F.t0 = n.t0; F.tres = n.tres; F.thead = n.thead; F.bias_head = n.bias_head;
-        F.logits = logits; F.LGS = h->LGS; F.vout = v_eval; F.L = L; F.T = n.T; F.A = h->G.A; F.AOP = n.AOP; F.dbg = nullptr;
-#ifdef AGZ_STAMPS
-        F.dbg = h->tp.dbg + (size_t)32768 * 16;
-#endif
-        dim3 grid((unsigned)((L + F2_M - 1) / F2_M)), block(256);
-        if (n.H == 128) hipLaunchKernelGGL(k_mlp_fused2<128>, grid, block, fused_lds, stream, F);
-        else hipLaunchKernelGGL(k_mlp_fused2<64>, grid, block, fused_lds, stream, F);
     } else if (h->cfg.nn_mode == AGZ_NN_BF16) {
         dim3 block(256);
         dim3 gh((unsigned)((L + GB_M - 1) / GB_M), (unsigned)((n.H + GB_N - 1) / GB_N));

@@ -1,7 +1,7 @@
 // agz_nn_fused3.hpp — the whole snetwork2 forward (DenseNet.jl:294-304) for 128 leaves per workgroup in ONE launch,
 // third layout: v_mfma_f32_16x16x32_bf16, 8 waves per workgroup, each wave owns 16 leaves completely.
 //
-// Measured on the 32x32x16 / 4-wave version (agz_nn_fused.hpp): one wave per SIMD, so every LDS->MFMA dependency and
+// Measured on an earlier 32x32x16 / 4-wave version (removed): one wave per SIMD, so every LDS->MFMA dependency and
 // the whole bf16 epilogue (44 % of the kernel) sat exposed; 46 us for 8.5 GFLOP.  Here two waves share a SIMD and
 // overlap each other's MFMA and epilogue phases, and a wave's epilogue is half as long (8 groups of 4 neurons).
 //
