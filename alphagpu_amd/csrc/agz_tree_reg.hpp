@@ -10,8 +10,7 @@
 //     loop.  The sampling prefix is then re-derived by all lanes in parallel from their now-known starting sums.
 //   * Newton's child terms (:142-151) go through a small LDS table indexed by child node id (written while the row is
 //     scanned), are compacted in creation order and summed by the group's lane 0.
-// LDS per game: meta (V words) + child table (2 V floats) + Newton terms (2 V floats) = 1280 B at V = 64, i.e. 10 KiB
-// per wave at G = 8 -> 16 waves per CU, all 4096 waves of a 32768-game launch resident at once.
+// LDS per game: meta (V words) + child table (2 V floats) = 768 B at V = 64, i.e. 6 KiB per wave at G = 8.
 #pragma once
 #include "agz_tree_grp.hpp"
 
@@ -62,16 +61,14 @@ __device__ __forceinline__ float grp_ordered_sum(const float (&x)[KPL], int sub,
     return grp_bcast_last<G>(a);
 }
 
-struct RegLds { int meta, tabp, tabq, ct, cu, stride; };
+struct RegLds { int meta, tabp, tabq, stride; };
 __host__ __device__ inline RegLds reg_lds_layout(int V) {
     RegLds o;
     auto up16 = [](int x) { return (x + 15) & ~15; };
     o.meta = 0;
     o.tabp = up16(V * 4);                                       // child table: prior / q by child node id; compacted in place
     o.tabq = o.tabp + up16(V * 4);
-    o.ct = o.tabq + up16(V * 4);                                // Newton terms (index 0 = the prior_rem term)
-    o.cu = o.ct + up16(V * 4);
-    o.stride = o.cu + up16(V * 4);
+    o.stride = o.tabq + up16(V * 4);
     return o;
 }
 
@@ -114,8 +111,6 @@ __device__ __forceinline__ void rollout_reg_body(const TreePar& T, const StepFla
     uint32_t* const mymeta = reinterpret_cast<uint32_t*>(mine + LO.meta);
     float* const tabp = reinterpret_cast<float*>(mine + LO.tabp);
     float* const tabq = reinterpret_cast<float*>(mine + LO.tabq);
-    float* const ct = reinterpret_cast<float*>(mine + LO.ct);
-    float* const cu = reinterpret_cast<float*>(mine + LO.cu);
     const int sl = live ? slot : 0;
     uint8_t* const myrecs = T.recs + (size_t)sl * V * ROWS;
     Pos* const mystates = T.states + (size_t)sl * V;
@@ -382,7 +377,7 @@ __device__ __forceinline__ void rollout_reg_body(const TreePar& T, const StepFla
                     float err = __builtin_inff();
                     // element c of the Newton sums: c == 0 is the prior_rem term (S = prior_rem/alpha, g = -prior_rem/alpha^2,
                     // :142-143), c = 1..nch the children in creation order (:144-151).  With nch < G there is one element per
-                    // lane and the ordered sums run lane to lane through DPP; otherwise through the LDS arrays ct / cu.
+                    // lane; with more, blocks of G elements at a time.  Either way the ordered sums run lane to lane through DPP.
                     const bool fast = nch < G;
                     float top_l = 0.0f, qv_l = 0.0f;
                     if (sub == 0) top_l = prior_rem;
@@ -407,26 +402,25 @@ __device__ __forceinline__ void rollout_reg_body(const TreePar& T, const StepFla
                             S = __int_as_float(grp_bcast<G>(__float_as_int(a))); gg = __int_as_float(grp_bcast<G>(__float_as_int(b)));
                             STAMP(1);
                         } else {
-                            for (int c = sub; c <= nch; c += G) {
-                                float top = prior_rem, qv = 0.0f;
-                                if (c > 0) { top = lambda * tabp[c - 1]; qv = tabq[c - 1]; }
-                                const float bot = alpha - qv;
-                                ct[c] = top / bot;
-                                cu[c] = -top / (bot * bot);
-                            }
-                            AGZ_WSYNC();
-                            if (lead) {
-                                S = ct[0]; gg = cu[0];
-                                for (int c0 = 1; c0 <= nch; c0 += 4) {
-                                    float tv[4], uv[4];
-#pragma unroll
-                                    for (int j = 0; j < 4; ++j) { tv[j] = c0 + j <= nch ? ct[c0 + j] : 0.0f; uv[j] = c0 + j <= nch ? cu[c0 + j] : 0.0f; }
-#pragma unroll
-                                    for (int j = 0; j < 4; ++j) { S += tv[j]; gg += uv[j]; }
+                            // more children than lanes: blocks of G consecutive elements (element j0 + sub in lane sub), each block
+                            // pulled into the lead lane's running sums exactly like the single block of the fast path
+                            float a = 0.0f, b = 0.0f;
+                            for (int j0 = 0; j0 <= nch; j0 += G) {
+                                const int c = j0 + sub;
+                                float t = 0.0f, uu = 0.0f;
+                                if (c <= nch) {
+                                    float top = prior_rem, qv = 0.0f;
+                                    if (c > 0) { top = lambda * tabp[c - 1]; qv = tabq[c - 1]; }
+                                    const float bot = alpha - qv;
+                                    t = top / bot; uu = -top / (bot * bot);
                                 }
+                                if (j0 == 0) { a = t; b = uu; } else { a += t; b += uu; }
+#define AGZ_PULL(d) if (G > d) { a += lane_shl<d>(t); b += lane_shl<d>(uu); }
+                                AGZ_PULL(1) AGZ_PULL(2) AGZ_PULL(3) AGZ_PULL(4) AGZ_PULL(5) AGZ_PULL(6) AGZ_PULL(7)
+                                AGZ_PULL(8) AGZ_PULL(9) AGZ_PULL(10) AGZ_PULL(11) AGZ_PULL(12) AGZ_PULL(13) AGZ_PULL(14) AGZ_PULL(15)
+#undef AGZ_PULL
                             }
-                            S = grp_bcast<G>(S); gg = grp_bcast<G>(gg);
-                            AGZ_WSYNC();
+                            S = __int_as_float(grp_bcast<G>(__float_as_int(a))); gg = __int_as_float(grp_bcast<G>(__float_as_int(b)));
                             STAMP(3);
                         }
                         const float newerr = S - 1.0f;

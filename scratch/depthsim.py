@@ -35,5 +35,17 @@ for k in range(1, V):
     tot_prev += waves(d, np.argsort(D[k - 1], kind='stable'))
     tot_ema += waves(d, np.argsort(ema, kind='stable'))
     ema = 0.7 * ema + 0.3 * d
+def regroup(d, wg):
+    dd = d.copy(); pad = (-len(dd)) % wg
+    dd = np.concatenate([dd, np.zeros(pad, dd.dtype)]).reshape(-1, wg)
+    tot = 0
+    for r in range(1, int(dd.max()) + 1):
+        n_r = (dd >= r).sum(1)
+        tot += np.ceil(n_r / 8.0).sum()
+    return tot
+tot_rg32 = sum(regroup(D[k], 32) for k in range(1, V))
+tot_rg16 = sum(regroup(D[k], 16) for k in range(1, V))
+tot_rg64 = sum(regroup(D[k], 64) for k in range(1, V))
+print(f"regrouped within workgroups of 16 / 32 / 64 games: {tot_rg16:.0f} / {tot_rg32:.0f} / {tot_rg64:.0f}")
 print(f"L={L}: wave-rounds  ideal {tot_ideal:.0f}  slot order {tot_ident}  perfect sort {tot_perfect}  sort by prev depth {tot_prev}  sort by ema {tot_ema}")
 print("mean depth per rollout idx (every 8th):", [round(float(D[k].mean()), 2) for k in range(0, V, 8)], "max", int(D.max()))
