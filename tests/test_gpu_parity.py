@@ -342,7 +342,12 @@ def test_bf16_network_kernels_agree_bitwise(H, T, monkeypatch):
     g, _ = spec("gobang9")
     net = ag.SNetwork2.random(g, H, T)
     L, V = 300, 24
-    ref = _bf16_search_bits(g, net, L, V, H)
+    ref = _bf16_search_bits(g, net, L, V, H)              # default path (H = 128: the whole-search kernel)
+    monkeypatch.setenv("AGZ_SMALL_MAXL", "0")             # from here on: one tree launch + one network launch per rollout
+    monkeypatch.setenv("AGZ_SMALL4_MAXL", "0")
+    got = _bf16_search_bits(g, net, L, V, H)
+    for a, b, what in zip(got, ref, ("visits", "policy", "q")):
+        assert_same_bits(a, b, what + " two-kernel form")
     for env in ({"AGZ_NN_WAVE_LT": "4", "AGZ_NN_WAVE_DEPTH": "4"}, {"AGZ_NN_WAVE_LT": "2"}, {"AGZ_NN_WAVE_MAXL": "0"},
                 {"AGZ_NN_WAVE_MAXL": "0", "AGZ_NO_FUSED_NN": "1"}):
         for k in ("AGZ_NN_WAVE_LT", "AGZ_NN_WAVE_DEPTH", "AGZ_NN_WAVE_MAXL", "AGZ_NO_FUSED_NN"):
@@ -360,6 +365,8 @@ def test_sub_batch_chains_do_not_change_results(monkeypatch):
     g, _ = spec("connect4")
     net = ag.SNetwork2.random(g, 64, 2)
     L, V = 700, 32
+    monkeypatch.setenv("AGZ_SMALL_MAXL", "0")             # the two-kernel form (chains apply to it only)
+    monkeypatch.setenv("AGZ_SMALL4_MAXL", "0")
     ref = _bf16_search_bits(g, net, L, V, 64)
     monkeypatch.setenv("AGZ_CHAINS", "3")
     got = _bf16_search_bits(g, net, L, V, 64)
