@@ -91,6 +91,7 @@ struct agz_engine {
     uint64_t* s_boards = nullptr; float* s_policy = nullptr; int16_t* s_move = nullptr;
     int32_t* g_nplies = nullptr; int8_t* g_result = nullptr; Pos* g_final = nullptr;
     unsigned long long* d_stats = nullptr;
+    unsigned long long* d_acc = nullptr;   // device-side sums of cnt_p / cnt_new over the instrumented plies of a generation
     int sp_games = 0;          // games of the last selfplay
     bool cnt_live = false;     // per-slot counters of the last search not yet folded into acc_*
     float* scratch_f = nullptr; // [Lmax][max(A,2VS)] getter staging
@@ -225,7 +226,7 @@ void agz_destroy(agz_engine* h) {
     hipFree(h->prior_eval); hipFree(h->v_eval); hipFree(h->policy_final); hipFree(h->act0); hipFree(h->act1);
     hipFree(h->actf0); hipFree(h->actf1); hipFree(h->newpos); hipFree(h->alive); hipFree(h->newslot); hipFree(h->d_count);
     hipFree(h->s_boards); hipFree(h->s_policy); hipFree(h->s_move); hipFree(h->g_nplies); hipFree(h->g_result);
-    hipFree(h->g_final); hipFree(h->d_stats); hipFree(h->scratch_f);
+    hipFree(h->g_final); hipFree(h->d_stats); hipFree(h->d_acc); hipFree(h->scratch_f);
     free_net(h->net[0]); free_net(h->net[1]);
     for (auto& e : h->ev_tree) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto& e : h->ev_nn) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
@@ -335,7 +336,8 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     A_(dmalloc(&h->logits, Lm * h->LGS));
     A_(dmalloc(&h->prior_eval, Lm * P.A + 64)); A_(dmalloc(&h->v_eval, Lm)); A_(dmalloc(&h->policy_final, Lm * P.A));
     A_(dmalloc(&h->newpos, Lm)); A_(dmalloc(&h->alive, Lm)); A_(dmalloc(&h->newslot, Lm)); A_(dmalloc(&h->d_count, 4));
-    A_(dmalloc(&h->d_stats, 8));
+    A_(dmalloc(&h->d_stats, 8)); A_(dmalloc(&h->d_acc, 2));
+    hipMemset(h->d_acc, 0, 16);
     A_(dmalloc(&h->scratch_f, Lm * (size_t)((P.A > 2 * P.VS) ? P.A : 2 * P.VS)));
     h->sample_games = cfg->sample_capacity_games > 0 ? cfg->sample_capacity_games : h->Lmax;
     const size_t SG = (size_t)h->sample_games, MP = (size_t)P.max_plies;
@@ -896,6 +898,7 @@ int agz_get_counters(agz_engine* h, uint64_t* sum_p, uint64_t* sum_new, uint64_t
     HIPCHK(h, hipSetDevice(h->cfg.device));
     // counters of the last search are folded lazily: acc_* holds completed folds (selfplay folds every ply)
     uint64_t p = h->acc_p, n = h->acc_new;
+    { unsigned long long d[2] = {0, 0}; int rc0 = fetch(h, d, h->d_acc, 16); if (rc0) return rc0; p += d[0]; n += d[1]; }
     if (h->L > 0 && h->cnt_live) {
         std::vector<uint32_t> a((size_t)h->L), b((size_t)h->L);
         int rc = fetch(h, a.data(), h->cnt_p, (size_t)h->L * 4); if (rc) return rc;
@@ -921,7 +924,7 @@ int agz_get_kernel_times(agz_engine* h, double* tree_ms, double* nn_ms, int64_t*
     if (tree_ms) *tree_ms = h->tree_ms;
     if (nn_ms) *nn_ms = h->nn_ms;
     if (tree_launches) *tree_launches = h->tree_launches;
-    if (reset) { h->tree_ms = h->nn_ms = h->tree_busy_ms = 0; h->tree_launches = 0; h->acc_p = h->acc_new = 0; h->total_rollouts = 0; }
+    if (reset) { h->tree_ms = h->nn_ms = h->tree_busy_ms = 0; h->tree_launches = 0; h->acc_p = h->acc_new = 0; h->total_rollouts = 0; hipMemsetAsync(h->d_acc, 0, 16, h->stream); }
     return AGZ_OK;
 }
 
@@ -971,7 +974,12 @@ static int run_games(agz_engine* h, int ngames, int V, float cpuct, int tau_plie
         if (hipMemcpyAsync(hcount, h->d_count, 4, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
             hipStreamSynchronize(h->stream) != hipSuccess) { h->fail("ply loop failed: %s", hipGetErrorString(hipGetLastError())); rc = AGZ_ERR_HIP; break; }
         float ms = 0; hipEventElapsedTime(&ms, e0, e1); search_ms += ms;
-        if (h->profiling && h->prof_this) { fold_counters(h); drain_events(h); }
+        if (h->profiling && h->prof_this) {                                     // (L is still the size of the search just done)
+            hipLaunchKernelGGL(k_fold_counters, dim3((unsigned)std::min(64, (h->L + 255) / 256)), dim3(256), 0, h->stream, (const uint32_t*)h->cnt_p,
+                               (const uint32_t*)h->cnt_new, h->L, h->d_acc);
+            h->cnt_live = false;
+            drain_events(h);
+        }
         { uint32_t* s = h->game_id; h->game_id = h->game_id2; h->game_id2 = s; h->tp.game_id = h->game_id; }
         h->L = (int)*hcount;
         ++ply;

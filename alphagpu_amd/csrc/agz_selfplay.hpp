@@ -112,6 +112,15 @@ __global__ __launch_bounds__(256) void k_advance(const PlyPar T) {
     }
 }
 
+// sums of the per-slot descent counters of the last search, added to two device accumulators (roofline bookkeeping without a
+// device-to-host copy per ply)
+__global__ __launch_bounds__(256) void k_fold_counters(const uint32_t* cnt_p, const uint32_t* cnt_new, int L, unsigned long long* acc) {
+    unsigned long long a = 0, b = 0;
+    for (int i = (int)(blockIdx.x * 256 + threadIdx.x); i < L; i += (int)gridDim.x * 256) { a += cnt_p[i]; b += cnt_new[i]; }
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); b += __shfl_down(b, o, 64); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&acc[0], a); atomicAdd(&acc[1], b); }
+}
+
 // exclusive scan of alive[0..L) by one workgroup of 1024 threads -> newslot[], total -> *count
 __global__ __launch_bounds__(1024) void k_scan_alive(const uint32_t* alive, uint32_t* newslot, int L, uint32_t* count) {
     __shared__ uint32_t part[1024];
