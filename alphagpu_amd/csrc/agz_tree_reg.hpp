@@ -382,11 +382,7 @@ __device__ __forceinline__ void rollout_reg_body(const TreePar& T, const StepFla
                     float top_l = 0.0f, qv_l = 0.0f;
                     if (sub == 0) top_l = prior_rem;
                     else if (sub <= nch && fast) { top_l = lambda * tabp[sub - 1]; qv_l = tabq[sub - 1]; }   // :147-148
-#ifdef AGZ_ABL_NEWTON
-                    for (int it = 0; it < 1; ++it) {
-#else
                     for (int it = 0; it < 100; ++it) {                     // :141-162
-#endif
                         float S = 0.0f, gg = 0.0f;
                         STAMP(10);
                         if (fast) {
@@ -431,11 +427,7 @@ __device__ __forceinline__ void rollout_reg_body(const TreePar& T, const StepFla
                     }
                     STAMP(10);
 #pragma unroll
-#ifdef AGZ_ABL_POLICY
-                    for (int j = 0; j < KPL; ++j) pol[j] = lambda * p[j] * (alpha - q[j]);
-#else
                     for (int j = 0; j < KPL; ++j) pol[j] = lambda * p[j] / (alpha - q[j]);   // :165-169
-#endif
                 } else {
 #pragma unroll
                     for (int j = 0; j < KPL; ++j) pol[j] = p[j];           // policy == prior since expand (:297-299)
@@ -447,11 +439,7 @@ __device__ __forceinline__ void rollout_reg_body(const TreePar& T, const StepFla
                 STAMP(11);
                 // ---- sample (:172-182): ordered prefix by turns, then every lane re-derives its own prefixes
                 float st0;
-#ifdef AGZ_ABL_SAMPLE
-                st0 = 0.01f * sub;
-#else
                 (void)grp_ordered_sum<G, KPL>(pol, sub, st0);
-#endif
                 int jhit = KPL, jpos = -1;                                 // first j with prefix >= u ; last j <= jhit with policy > 0
                 {
                     float a = st0;
