@@ -36,7 +36,7 @@ __global__ __launch_bounds__(64 * NW_WAVES, WV) void k_search_small(const SmallP
         // of this loop and kept alive across them (hundreds of registers, spills)
         int bx = (int)blockIdx.x;
         asm volatile("" : "+s"(bx));
-        if (wave < TW) rollout_reg_body<FAM, NC, 8, KPL>(S.T, SF, tree_lds, bx * TW + wave);
+        if (wave < TW) rollout_reg_body<FAM, NC, 8, KPL, true>(S.T, SF, tree_lds, bx * TW + wave);
         if (k < S.V) {
             // (the barrier that publishes the planes of the leaves sits inside, after the first weight fragments are requested)
             mlp_wave_body<H, TW / 2, 2, true>(S.F, nn_lds, bx);
