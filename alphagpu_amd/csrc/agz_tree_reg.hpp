@@ -135,7 +135,18 @@ __device__ __forceinline__ void rollout_reg_body(const TreePar& T, const StepFla
         if (lead) { mymeta[0] = M_EXISTS; if (live) gmeta[0] = M_EXISTS; }
     } else {
         if (live) { ncount = T.ncount[slot]; leafn = T.leaf[slot]; }
-        if (LEAN || ((V & 3) == 0 && V <= 256)) {                           // all rows of the wave in flight together: one memory latency
+        if constexpr (LEAN) {                                     // V <= 64: one 16-B piece per lane and game, all games in flight together
+            const int v4 = V >> 2;
+            uint4 buf[NG];
+#pragma unroll
+            for (int j = 0; j < NG; ++j) {
+                const int sj = T.slot0 + bidx * GPW + j;
+                buf[j] = (lane < v4 && j < GPW && sj < T.L) ? reinterpret_cast<const uint4*>(T.meta + (size_t)sj * V)[lane] : make_uint4(0u, 0u, 0u, 0u);
+            }
+#pragma unroll
+            for (int j = 0; j < NG; ++j)
+                if (lane < v4) *reinterpret_cast<uint4*>(lds + (size_t)j * LO.stride + LO.meta + (size_t)lane * 16) = buf[j];
+        } else if ((V & 3) == 0 && V <= 256) {                    // all rows of the wave in flight together: one memory latency
             const int v4 = V >> 2, n4 = NG * v4;                   // 16-B pieces per game / per wave (<= 8 per lane)
             uint4 buf[8];
 #pragma unroll
@@ -211,7 +222,8 @@ __device__ __forceinline__ void rollout_reg_body(const TreePar& T, const StepFla
             int npos = 0;
 #pragma unroll
             for (int j = 0; j < KPL; ++j) {
-                float pr = rootmix ? (lg[j] ? 0.75f * x[j] / normalize + 0.25f / Af : 0.0f) : x[j] / normalize;
+                const float qn = (rootmix ? 0.75f * x[j] : x[j]) / normalize;      // one division serves both forms
+                float pr = rootmix ? (lg[j] ? qn + 0.25f / Af : 0.0f) : qn;
                 if (k0 + j >= A) pr = 0.0f;
                 x[j] = pr;
                 npos += pr > 0.0f ? 1 : 0;
@@ -537,6 +549,34 @@ __device__ __forceinline__ void rollout_reg_body(const TreePar& T, const StepFla
             }
             if (!have_state) lst = grp_load_pos<NC, REV>(mystates + node);
             // decoder (:202-223): 8 planes (16 bytes of bf16, or 32 of fp32) per store, chunks dealt round-robin to the group
+            if (G == 8 && !planes_f32) {
+                // the 2 VS plane bits as one bit string W (side to move, then opponent); lane sub takes byte sub of every 64-bit word
+                constexpr int NW = 2 * NC;
+                uint64_t W[NW];
+                const int VS = P.VS, sw = VS >> 6, sb = VS & 63;
+#pragma unroll
+                for (int i = 0; i < NW; ++i) W[i] = 0;
+#pragma unroll
+                for (int i = 0; i < NC; ++i) {
+                    const int lo = 64 * i;
+                    const uint64_t m = VS >= lo + 64 ? ~0ull : (VS > lo ? ((1ull << (VS - lo)) - 1ull) : 0ull);
+                    const uint64_t pc = lst.p.c[i] & m, oc = lst.o.c[i] & m;
+                    W[i] |= pc;
+                    if (sw == NC - 1) { W[i + NC - 1] |= oc << sb; W[i + NC] |= sb ? oc >> (64 - sb) : 0ull; }
+                    else W[i + NC] |= oc;                                  // VS == 64 NC
+                }
+#pragma unroll
+                for (int k = 0; k < NW; ++k) {
+                    const int j0 = 64 * k + 8 * sub;
+                    if (j0 < T.INP) {
+                        const uint32_t f = (uint32_t)(W[k] >> (8 * sub)) & 0xffu;
+                        uint4 o;
+                        o.x = ((f & 1u) ? 0x3F80u : 0u) | ((f & 2u) ? 0x3F800000u : 0u); o.y = ((f & 4u) ? 0x3F80u : 0u) | ((f & 8u) ? 0x3F800000u : 0u);
+                        o.z = ((f & 16u) ? 0x3F80u : 0u) | ((f & 32u) ? 0x3F800000u : 0u); o.w = ((f & 64u) ? 0x3F80u : 0u) | ((f & 128u) ? 0x3F800000u : 0u);
+                        *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(T.planes) + (size_t)slot * T.INP + j0) = o;
+                    }
+                }
+            } else
             for (int j0 = 8 * sub; j0 < T.INP; j0 += 8 * G) {
                 uint32_t w[8];
 #pragma unroll
