@@ -83,8 +83,9 @@ __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const
     {   // the ML rows of input planes -> LDS (coalesced 16-B loads), zero beyond INP
         const int segs = G0 * KTH * 4, isegs = P.INP / 8;
         const AGZ_GLB uint16_t* gp = (const AGZ_GLB uint16_t*)P.planes;
-        for (int c = tid_ & (64 * NW_WAVES - 1); c < ML * segs; c += 64 * NW_WAVES) {
-            const int row = c / segs, seg = c - row * segs, mm = leaf_of(row);
+        constexpr int TPR = 64 * NW_WAVES / ML;                   // threads per tile row (a power of two): no division by segs
+        const int row = (tid_ & (64 * NW_WAVES - 1)) / TPR, mm = leaf_of(row);
+        for (int seg = tid_ & (TPR - 1); seg < segs; seg += TPR) {
             v4u v = {0u, 0u, 0u, 0u};
             if (mm < P.L && seg < isegs) v = *(const AGZ_GLB v4u*)(gp + (size_t)mm * P.INP + seg * 8);
             *reinterpret_cast<v4u*>(pl + (size_t)row * PROWB + seg * 16) = v;
@@ -156,6 +157,11 @@ __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const
                     for (int t = 0; t < TPW; ++t) acc[lt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, A[0][k][t], acc[lt][t], 0, 0, 0);
                 }
             // acc[lt][t][r] = out[leaf = leaf0 + 16 lt + 4 q4 + r][n = 16 tile + (lane & 15)]
+            int mrow[LT][4];                                        // game slot of tile row 16 lt + 4 q4 + r (once, not per tile)
+#pragma unroll
+            for (int lt = 0; lt < LT; ++lt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mrow[lt][r] = leaf_of(16 * lt + 4 * q4 + r);
 #pragma unroll
             for (int t = 0; t < TPW; ++t) {
                 const int tile = wave * TPW + t;
@@ -164,13 +170,12 @@ __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const
                     const float bias = P.bias_head[n];
 #pragma unroll
                     for (int lt = 0; lt < LT; ++lt) {
-                        const int rw = 16 * lt + 4 * q4;              // tile row of acc[lt][t][0]
                         if (n < P.A) {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) { const int m = leaf_of(rw + r); if (m < P.L) P.logits[(size_t)m * P.LGS + n] = acc[lt][t][r] + bias; }
+                            for (int r = 0; r < 4; ++r) { const int m = mrow[lt][r]; if (m < P.L) P.logits[(size_t)m * P.LGS + n] = acc[lt][t][r] + bias; }
                         } else if (n == P.A) {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) { const int m = leaf_of(rw + r); if (m < P.L) P.vout[m] = sigmoid_ool(acc[lt][t][r] + bias); }
+                            for (int r = 0; r < 4; ++r) { const int m = mrow[lt][r]; if (m < P.L) P.vout[m] = sigmoid_ool(acc[lt][t][r] + bias); }
                         }
                     }
                 }
