@@ -227,7 +227,10 @@ __device__ __forceinline__ void rollout_reg_body(const TreePar& T, const StepFla
                 if (k0 + j >= A) pr = 0.0f;
                 x[j] = pr;
                 npos += pr > 0.0f ? 1 : 0;
-                if (lf == 0 && k0 + j < A) T.policy_final[(size_t)slot * A + k0 + j] = pr;
+            }
+            if (__builtin_expect(lf == 0, 0)) {                       // root expansion (second launch of a search): rare, kept out of line
+#pragma unroll
+                for (int j = 0; j < KPL; ++j) if (k0 + j < A) T.policy_final[(size_t)slot * A + k0 + j] = x[j];
             }
             npos = grp_sum<G>(npos);                                  // "A" of :125-131 never changes after the expansion
             if (lead) myaux[lf] = make_float2(0.0f, (float)npos);
@@ -239,7 +242,7 @@ __device__ __forceinline__ void rollout_reg_body(const TreePar& T, const StepFla
             }
             ml |= M_EXPANDED;                                         // :256
             if (lead) { mymeta[lf] = ml; gmeta[lf] = ml; }
-        } else if (live && lf == 0) {
+        } else if (__builtin_expect(live && lf == 0, 0)) {
 #pragma unroll
             for (int j = 0; j < KPL; ++j) if (k0 + j < A) T.policy_final[(size_t)slot * A + k0 + j] = 0.0f;   // terminal root
         }
@@ -448,7 +451,7 @@ __device__ __forceinline__ void rollout_reg_body(const TreePar& T, const StepFla
 #pragma unroll
                     for (int j = 0; j < KPL; ++j) pol[j] = p[j];           // policy == prior since expand (:297-299)
                 }
-                if (node == 0 && SF.last) {                                 // copy_pol (:330-339) of the last descent
+                if (__builtin_expect(node == 0 && SF.last, 0)) {            // copy_pol (:330-339) of the last descent
 #pragma unroll
                     for (int j = 0; j < KPL; ++j) if (k0 + j < A) T.policy_final[(size_t)slot * A + k0 + j] = pol[j];
                 }
