@@ -189,8 +189,18 @@ __device__ __forceinline__ void rollout_reg_body(const TreePar& T, const StepFla
             const WPos<NC> st = grp_load_pos<NC, REV>(mystates + lf);
             float x[KPL];
             const float* src = inject ? T.prior_eval + (size_t)slot * A : T.logits + (size_t)slot * T.LGS;
+            if constexpr (LEAN) {                                     // logits rows are padded to LGS >= G*KPL floats: 16-B loads, then mask
 #pragma unroll
-            for (int j = 0; j < KPL; ++j) x[j] = (k0 + j < A) ? src[k0 + j] : (inject ? 0.0f : -__builtin_inff());
+                for (int j = 0; j < KPL; j += 4) {
+                    const float4 a = *reinterpret_cast<const float4*>(src + k0 + j);
+                    x[j] = a.x; x[j + 1] = a.y; x[j + 2] = a.z; x[j + 3] = a.w;
+                }
+#pragma unroll
+                for (int j = 0; j < KPL; ++j) x[j] = (k0 + j < A) ? x[j] : -__builtin_inff();
+            } else {
+#pragma unroll
+                for (int j = 0; j < KPL; ++j) x[j] = (k0 + j < A) ? src[k0 + j] : (inject ? 0.0f : -__builtin_inff());
+            }
             if (!inject) {                                            // softmax!(prior) (:417), source-order sum
                 float mx = -__builtin_inff();
 #pragma unroll
