@@ -159,9 +159,12 @@ __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const
             // acc[lt][t][r] = out[leaf = leaf0 + 16 lt + 4 q4 + r][n = 16 tile + (lane & 15)]
             int mrow[LT][4];                                        // game slot of tile row 16 lt + 4 q4 + r (once, not per tile)
 #pragma unroll
-            for (int lt = 0; lt < LT; ++lt)
+            for (int lt = 0; lt < LT; ++lt) {                      // rows 16 lt + 4 q4 + r: tree wave 2 lt + q4/2, game 4 (q4 & 1) + r of it
+                const int gq = 4 * (q4 & 1);
+                const int base = P.gpw == 0 ? leaf0 + 16 * lt + 4 * q4 : (bidx * P.tw + 2 * lt + (q4 >> 1)) * P.gpw + gq;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) mrow[lt][r] = leaf_of(16 * lt + 4 * q4 + r);
+                for (int r = 0; r < 4; ++r) mrow[lt][r] = (P.gpw == 0 || gq + r < P.gpw) ? base + r : P.L;
+            }
 #pragma unroll
             for (int t = 0; t < TPW; ++t) {
                 const int tile = wave * TPW + t;
