@@ -13,6 +13,7 @@
 // LDS per game: meta (V words) + child table (2 V floats) = 768 B at V = 64, i.e. 6 KiB per wave at G = 8.
 #pragma once
 #include "agz_tree_grp.hpp"
+#include "agz_divpair.hpp"
 
 namespace agz {
 
@@ -211,9 +212,10 @@ __device__ __forceinline__ void rollout_reg_body(const TreePar& T, const StepFla
                 float st0;
                 const float s = grp_ordered_sum<G, KPL>(x, sub, st0);
 #pragma unroll
-                for (int j = 0; j < KPL; ++j) {
-                    x[j] = x[j] / s;
-                    if (capture && k0 + j < A) T.prior_eval[(size_t)slot * A + k0 + j] = x[j];
+                for (int j = 0; j < KPL; j += 2) div_pair(x[j], s, x[j + 1], s, x[j], x[j + 1]);
+                if (capture) {
+#pragma unroll
+                    for (int j = 0; j < KPL; ++j) if (k0 + j < A) T.prior_eval[(size_t)slot * A + k0 + j] = x[j];
                 }
             }
             bool lg[KPL]; int nl = 0;                                 // legal mask; masked priors (:260-268 / :284-290)
@@ -230,9 +232,13 @@ __device__ __forceinline__ void rollout_reg_body(const TreePar& T, const StepFla
             const float Af = (float)nl;
             uint8_t* rec = myrecs + (size_t)lf * ROWS;
             int npos = 0;
+            float qn_[KPL];
+#pragma unroll
+            for (int j = 0; j < KPL; j += 2)                                // one division serves both forms, two per call
+                div_pair(rootmix ? 0.75f * x[j] : x[j], normalize, rootmix ? 0.75f * x[j + 1] : x[j + 1], normalize, qn_[j], qn_[j + 1]);
 #pragma unroll
             for (int j = 0; j < KPL; ++j) {
-                const float qn = (rootmix ? 0.75f * x[j] : x[j]) / normalize;      // one division serves both forms
+                const float qn = qn_[j];
                 float pr = rootmix ? (lg[j] ? qn + 0.25f / Af : 0.0f) : qn;
                 if (k0 + j >= A) pr = 0.0f;
                 x[j] = pr;
@@ -416,7 +422,7 @@ __device__ __forceinline__ void rollout_reg_body(const TreePar& T, const StepFla
                         STAMP(10);
                         if (fast) {
                             float t = 0.0f, uu = 0.0f;
-                            if (sub <= nch) { const float bot = alpha - qv_l; t = top_l / bot; uu = -top_l / (bot * bot); }
+                            if (sub <= nch) { const float bot = alpha - qv_l; div_pair(top_l, bot, -top_l, bot * bot, t, uu); }
                             // the group's lead lane pulls element d from lane d (DPP row_shl:d) and adds them in order;
                             // lanes beyond nch contribute +0 (exact), the other lanes' sums are discarded
                             float a = t, b = uu;
@@ -437,7 +443,7 @@ __device__ __forceinline__ void rollout_reg_body(const TreePar& T, const StepFla
                                     float top = prior_rem, qv = 0.0f;
                                     if (c > 0) { top = lambda * tabp[c - 1]; qv = tabq[c - 1]; }
                                     const float bot = alpha - qv;
-                                    t = top / bot; uu = -top / (bot * bot);
+                                    div_pair(top, bot, -top, bot * bot, t, uu);
                                 }
                                 if (j0 == 0) { a = t; b = uu; } else { a += t; b += uu; }
 #define AGZ_PULL(d) if (G > d) { a += lane_shl<d>(t); b += lane_shl<d>(uu); }
@@ -456,7 +462,8 @@ __device__ __forceinline__ void rollout_reg_body(const TreePar& T, const StepFla
                     }
                     STAMP(10);
 #pragma unroll
-                    for (int j = 0; j < KPL; ++j) pol[j] = lambda * p[j] / (alpha - q[j]);   // :165-169
+                    for (int j = 0; j < KPL; j += 2)                       // :165-169, two exact quotients per call (agz_divpair.hpp)
+                        div_pair(lambda * p[j], alpha - q[j], lambda * p[j + 1], alpha - q[j + 1], pol[j], pol[j + 1]);
                 } else {
 #pragma unroll
                     for (int j = 0; j < KPL; ++j) pol[j] = p[j];           // policy == prior since expand (:297-299)
