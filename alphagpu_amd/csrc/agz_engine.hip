@@ -107,6 +107,8 @@ struct agz_engine {
     hipEvent_t ev_ref = nullptr; bool ev_ref_live = false;
     rollout_fn k_roll = nullptr; advance_fn k_adv = nullptr; softmax_fn k_soft = nullptr;
     small_fn k_small4[3] = {nullptr, nullptr, nullptr};   // the same with 32 games per workgroup, register budgets for 2 / 3 / 4 workgroups per SIMD set
+    std::string form_tree, form_nn;   // kernels of the last search (agz_get_search_form)
+    int small4_occ = -1;         // >= 0: force the register budget k_small4[occ] (AGZ_SMALL4_OCC = 0, 1, 2)
     int small4_maxl = 1 << 30;   // ... used for batches in (small_maxl, small4_maxl] that fit the chip at once (AGZ_SMALL4_MAXL)
     int cus = 256;
     int small_gpw = 0;           // games per tree wave of the 16-game variant: 0 = by batch size (AGZ_SMALL_GPW = 1, 2, 4, 8)
@@ -316,6 +318,8 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
         if (e3 && (atoi(e3) == 1 || atoi(e3) == 2 || atoi(e3) == 4 || atoi(e3) == 8)) h->small_gpw = atoi(e3);
         e3 = getenv("AGZ_SMALL4_MAXL");
         if (e3) h->small4_maxl = atoi(e3);
+        e3 = getenv("AGZ_SMALL4_OCC");
+        if (e3 && atoi(e3) >= 0 && atoi(e3) <= 2) h->small4_occ = atoi(e3);
         if (h->k_small) hipFuncSetAttribute((const void*)h->k_small, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         for (int i = 0; i < 3; ++i) if (h->k_small4[i]) hipFuncSetAttribute((const void*)h->k_small4[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
@@ -368,6 +372,17 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     return AGZ_OK;
 }
 
+int agz_get_search_form(agz_engine* h, char* tree_kernel, char* nn_kernel, int cap) {
+    if (!h || cap < 1) return AGZ_ERR_ARG;
+    if (tree_kernel) { strncpy(tree_kernel, h->form_tree.c_str(), (size_t)cap - 1); tree_kernel[cap - 1] = 0; }
+    if (nn_kernel) { strncpy(nn_kernel, h->form_nn.c_str(), (size_t)cap - 1); nn_kernel[cap - 1] = 0; }
+    return AGZ_OK;
+}
+int agz_set_seed(agz_engine* h, uint64_t seed) {
+    if (!h) return AGZ_ERR_ARG;
+    h->cfg.seed = seed; h->tp.seed = seed;
+    return AGZ_OK;
+}
 int agz_get_info(const agz_engine* h, agz_game_info* out) {
     if (!h || !out) return AGZ_ERR_ARG;
     *out = h->info; return AGZ_OK;
@@ -633,6 +648,7 @@ static int launch_network(agz_engine* h, int which, int s0 = 0, int s1 = -1, hip
         B.bias_head = n.bias_head; B.logits = logits; B.LGS = h->LGS; B.vout = v_eval;
         B.L = L; B.T = n.T; B.A = h->G.A; B.AOP = n.AOP; B.K0R = n.k0r; B.ROWB = big_rowb;
         const int mt = L <= 8192 ? 2 : 8;                       // 32 or 128 leaves per workgroup
+        { char b[96]; snprintf(b, sizeof b, "k_mlp_big<H=%d,MT=%d> (%d leaves per workgroup, one launch)", n.H, mt, 16 * mt); h->form_nn = b; }
         const size_t lds = (size_t)16 * mt * big_rowb;
         dim3 grid((unsigned)((L + 16 * mt - 1) / (16 * mt))), block(NB_THREADS);
         if (n.H == 512) { if (mt == 8) hipLaunchKernelGGL((k_mlp_big<512, 8>), grid, block, lds, stream, B); else hipLaunchKernelGGL((k_mlp_big<512, 2>), grid, block, lds, stream, B); }
@@ -646,6 +662,7 @@ static int launch_network(agz_engine* h, int which, int s0 = 0, int s1 = -1, hip
         const size_t lds = (size_t)16 * lt * (2 * (n.H * 2 + 16) + (g0 * kth * 64 + 16));
         dim3 grid((unsigned)((L + 16 * lt - 1) / (16 * lt))), block(64 * NW_WAVES);
         const int depth = h->nn_wave_depth > 0 ? h->nn_wave_depth : 2;   // two layers ahead already cover the L2 latency; 4 only costs occupancy
+        { char b[96]; snprintf(b, sizeof b, "k_mlp_wave<H=%d,LT=%d,DEPTH=%d> (one launch)", n.H, lt, depth); h->form_nn = b; }
 #define NW_LAUNCH(HH, LL) do { if (depth == 4) hipLaunchKernelGGL((k_mlp_wave<HH, LL, 4>), grid, block, lds, stream, F); \
                                else hipLaunchKernelGGL((k_mlp_wave<HH, LL, 2>), grid, block, lds, stream, F); } while (0)
         if (n.H == 128) { if (lt == 1) NW_LAUNCH(128, 1); else if (lt == 2) NW_LAUNCH(128, 2); else if (lt == 4) NW_LAUNCH(128, 4); else NW_LAUNCH(128, 8); }
@@ -656,9 +673,11 @@ static int launch_network(agz_engine* h, int which, int s0 = 0, int s1 = -1, hip
         F.planes = (const uint16_t*)planes; F.INP = n.INP; F.w16 = n.w16; F.bias_head = n.bias_head;
         F.logits = logits; F.LGS = h->LGS; F.vout = v_eval; F.L = L; F.T = n.T; F.A = h->G.A; F.AOP = n.AOP; F.gpw = 0; F.tw = 0;
         dim3 grid((unsigned)((L + F3_M - 1) / F3_M)), block(F3_THREADS);
+        h->form_nn = "k_mlp_fused3 (one launch)";
         if (n.H == 128) hipLaunchKernelGGL(k_mlp_fused3<128>, grid, block, f3_lds, stream, F);
         else hipLaunchKernelGGL(k_mlp_fused3<64>, grid, block, f3_lds, stream, F);
     } else if (h->cfg.nn_mode == AGZ_NN_BF16) {
+        h->form_nn = "k_layer_bf16 (one launch per layer)";
         dim3 block(256);
         dim3 gh((unsigned)((L + GB_M - 1) / GB_M), (unsigned)((n.H + GB_N - 1) / GB_N));
         const uint16_t* x = (const uint16_t*)planes;
@@ -675,6 +694,7 @@ static int launch_network(agz_engine* h, int which, int s0 = 0, int s1 = -1, hip
         hipLaunchKernelGGL(k_layer_bf16<EPI_HEAD>, gp, block, 0, stream, (const uint16_t*)a, n.H, n.H, n.thead, n.NT_head, (uint16_t*)nullptr, 0,
                            n.AOP, L, (const float*)n.bias_head, logits, h->LGS, v_eval, h->G.A);
     } else {
+        h->form_nn = "k_layer_exact (fp32, one launch per layer)";
         dim3 block(64, 4);
         auto grid = [&](int O) { return dim3((unsigned)((L + EX_TL - 1) / EX_TL), (unsigned)((O + 63) / 64)); };
         auto shm = [&](int K) { return (size_t)EX_TL * (size_t)((K + 3) & ~3) * 4; };
@@ -723,7 +743,8 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
             // 16 games per workgroup up to small_maxl; beyond, 32 games per workgroup with the loosest register budget that still
             // keeps every workgroup resident (2 / 3 / 4 workgroups per CU = 64 / 96 / 128 games per CU)
             const int tw = h->L <= h->small_maxl ? 2 : 4;
-            const int occ = h->L <= 64 * h->cus ? 0 : (h->L <= 96 * h->cus ? 1 : 2);
+            int occ = h->L <= 64 * h->cus ? 0 : (h->L <= 96 * h->cus ? 1 : 2);
+            if (h->small4_occ >= 0) occ = h->small4_occ;      // AGZ_SMALL4_OCC (tests: every register budget at small sizes)
             const small_fn kfn = tw == 2 ? h->k_small : h->k_small4[occ];
             SmallPar S;
             S.T = h->tp;
@@ -743,6 +764,8 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
             std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
             if ((h->profiling & 1) && h->prof_this) { ev = next_events(h, h->ev_tree, h->ev_tree_used); hipEventRecord(ev->first, h->stream); }
             hipLaunchKernelGGL(kfn, dim3((unsigned)((h->L + S.T.gpw * tw - 1) / (S.T.gpw * tw))), dim3(64 * NW_WAVES), lds, h->stream, S);
+            { char b[160]; snprintf(b, sizeof b, "k_search_small<KPL=%d,H=128,TW=%d,WV=%d> (whole mcts_single per launch, %d games per workgroup, %d per tree wave)",
+                                    h->reg_kpl, tw, tw == 2 ? 2 : 2 + occ, S.T.gpw * tw, S.T.gpw); h->form_tree = b; h->form_nn = "inside k_search_small (mlp_wave_body<128>)"; }
             if (ev) hipEventRecord(ev->second, h->stream);
             HIPCHK(h, hipGetLastError());
             h->cnt_live = true;
@@ -761,6 +784,8 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
         if (K < 1) K = 1;
     }
     const int chunk = ((h->L + K - 1) / K + 127) / 128 * 128;
+    { char b[160]; snprintf(b, sizeof b, "%s (one launch per rollout, %d sub-batch chain%s)", h->reg_lds ? "k_rollout_reg<G=8>" : (h->lpg_lds ? "k_rollout_grp" : "k_rollout"), K, K > 1 ? "s" : "");
+      h->form_tree = b; }
     if (K > 1) HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
     for (int c = 1; c < K; ++c) if (c * chunk < h->L) HIPCHK(h, hipStreamWaitEvent(h->aux[c - 1], h->ev_fork, 0));
     for (int k = 0; k <= V; ++k) {
@@ -815,6 +840,15 @@ int agz_get_eval(agz_engine* h, float* prior, float* v) {
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (prior) HIPCHK(h, hipMemcpy(prior, h->prior_eval, (size_t)h->L * h->G.A * 4, hipMemcpyDeviceToHost));
+    if (v) HIPCHK(h, hipMemcpy(v, h->v_eval, (size_t)h->L * 4, hipMemcpyDeviceToHost));
+    return AGZ_OK;
+}
+int agz_get_logits(agz_engine* h, float* logits, float* v) {
+    if (!h) return AGZ_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (logits && h->L > 0)
+        HIPCHK(h, hipMemcpy2D(logits, (size_t)h->G.A * 4, h->logits, (size_t)h->LGS * 4, (size_t)h->G.A * 4, (size_t)h->L, hipMemcpyDeviceToHost));
     if (v) HIPCHK(h, hipMemcpy(v, h->v_eval, (size_t)h->L * 4, hipMemcpyDeviceToHost));
     return AGZ_OK;
 }
@@ -939,8 +973,9 @@ int agz_get_tree_busy_ms(agz_engine* h, double* busy_ms) {
 }
 
 // ---- self-play --------------------------------------------------------------------------------------
-static void fill_plypar(agz_engine* h, PlyPar& T, int ply, int tau_plies) {
+static void fill_plypar(agz_engine* h, PlyPar& T, int ply, int tau_plies, bool all_actions) {
     memset(&T, 0, sizeof T);
+    T.all_actions = all_actions ? 1 : 0;
     T.G = h->G; T.L = h->L; T.V = h->V; T.ply = ply; T.tau_plies = tau_plies; T.seed = h->cfg.seed; T.game_id_base = h->cfg.game_id_base;
     T.states = h->states; T.game_id = h->game_id; T.policy_final = h->policy_final; T.newpos = h->newpos; T.alive = h->alive;
     T.sample_games = h->sample_games; T.max_plies = h->G.max_plies;
@@ -967,7 +1002,7 @@ static int run_games(agz_engine* h, int ngames, int V, float cpuct, int tau_plie
         rc = agz_search_actor(h, which, V, cpuct, training, (uint32_t)ply); if (rc) break;      // :503
         hipEventRecord(e1, h->stream);
         rollouts += (int64_t)h->L * V;
-        PlyPar T; fill_plypar(h, T, ply, tau_plies);
+        PlyPar T; fill_plypar(h, T, ply, tau_plies, duel);
         hipLaunchKernelGGL(h->k_adv, dim3((unsigned)((h->L + 3) / 4)), dim3(256), 0, h->stream, T);          // :513-549
         hipLaunchKernelGGL(k_scan_alive, dim3(1), dim3(1024), 0, h->stream, (const uint32_t*)h->alive, h->newslot, h->L, h->d_count);
         hipLaunchKernelGGL(k_compact, dim3((unsigned)((h->L + 255) / 256)), dim3(256), 0, h->stream, T, (const uint32_t*)h->newslot,
@@ -1015,9 +1050,10 @@ int agz_duel(agz_engine* h, int ngames, int V, float cpuct, int tau_plies, int f
     if (!h || !wdl) return AGZ_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     if (!h->net[0].loaded || !h->net[1].loaded) { h->fail("agz_duel needs both network slots"); return AGZ_ERR_STATE; }
-    agz_selfplay_stats st;
+    agz_selfplay_stats st{};
+    wdl[0] = wdl[1] = wdl[2] = 0;
     int rc = run_games(h, ngames, V, cpuct, tau_plies, 0, first ? 1 : 0, true, &st);
-    wdl[0] = st.wins; wdl[1] = st.draws; wdl[2] = st.losses;
+    if (rc == AGZ_OK || rc == AGZ_ERR_ILLEGAL_MOVE) { wdl[0] = st.wins; wdl[1] = st.draws; wdl[2] = st.losses; }
     return rc;
 }
 

@@ -66,6 +66,9 @@ __global__ __launch_bounds__(256) void k_advance(const PlyPar T) {
         }
         const float u = ufirst(uniform_move(T.seed, gid, (uint32_t)T.ply));
         const float tt = u * total;
+        // duel (:606): sample(1:maxActions, Weights(policy)) walks ALL actions, zero weights included — the same index as the
+        // nonzero-list walk of self-play (:519-520) except for tt == 0, where the walk stops at action 1 whatever its weight
+        if (T.all_actions && !(tt > 0.0f)) c = 0;
         float carry = 0.0f; bool stopped = false; int last = -1;
         for (int r = 0; r < NR; ++r) {
             if (!nzm[r]) continue;

@@ -69,6 +69,9 @@ def load_library():
     L.agz_rollout_eval.argtypes = [vp]
     L.agz_get_eval.argtypes = [vp, f32p, f32p]
     L.agz_inject_eval.argtypes = [vp, f32p, f32p]
+    L.agz_get_logits.argtypes = [vp, f32p, f32p]
+    L.agz_set_seed.argtypes = [vp, C.c_uint64]
+    L.agz_get_search_form.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_int]
     L.agz_rollout_expand_backup.argtypes = [vp]
     L.agz_search_end.argtypes = [vp]
     for n in ("policy", "batch", "leaf_batch", "root_visits", "root_q", "leaf", "node_count"):

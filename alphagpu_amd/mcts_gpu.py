@@ -13,6 +13,7 @@ The CUDA arrays the reference passes around (vnodes, vnodesStats, leaf, newindex
 engine handle; `Engine` is what `init` returns.  All compute happens in HIP kernels; there is no CPU path.
 """
 import ctypes as C
+import secrets
 
 import numpy as np
 
@@ -26,6 +27,12 @@ POS_JULIA, POS_COMPACT = 0, 1
 
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def fresh_seed():
+    """A new Philox key per generation / duel call: the reference draws unseeded CUDA.rand / StatsBase randomness on
+    every call (mcts_gpu.jl:397,520), so two generations with an unchanged network must not replay the same games."""
+    return secrets.randbits(63) | 1
 
 
 class Engine:
@@ -44,7 +51,7 @@ class Engine:
         if rc != 0:
             msg = self.L.agz_last_error(None)
             raise _lib.AgzError(rc, msg.decode() if msg else "agz_create failed")
-        self.max_games, self.visits, self.nn_mode = int(max_games), int(visits), int(nn_mode)
+        self.max_games, self.visits, self.nn_mode, self.device = int(max_games), int(visits), int(nn_mode), int(device)
         self.nslots = 0
         self._nets = {}
 
@@ -70,6 +77,10 @@ class Engine:
 
     def __exit__(self, *a):
         self.close()
+
+    def set_seed(self, seed):
+        """Philox key of every later search / selfplay / duel of this engine (agz_set_seed)."""
+        self._chk(self.L.agz_set_seed(self.h, int(seed)))
 
     # -- network ----------------------------------------------------------------------------------------
     def set_network(self, net, which=0):
@@ -111,6 +122,13 @@ class Engine:
         v = np.zeros(self.nslots, np.float32)
         self._chk(self.L.agz_get_eval(self.h, _p(pr), _p(v)))
         return pr, v
+
+    def get_logits(self):
+        """Raw actor output of the last network launch: logits [L][A] (before softmax!), v [L]."""
+        lg = np.zeros((self.nslots, self.game.A), np.float32)
+        v = np.zeros(self.nslots, np.float32)
+        self._chk(self.L.agz_get_logits(self.h, _p(lg), _p(v)))
+        return lg, v
 
     def inject_eval(self, prior, v):
         prior = np.ascontiguousarray(prior, np.float32)
@@ -154,6 +172,23 @@ class Engine:
         a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
         self._chk(self.L.agz_get_counters(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
+
+    def search_form(self):
+        """(tree kernel, network kernel) the last search ran."""
+        a, b = C.create_string_buffer(256), C.create_string_buffer(256)
+        self._chk(self.L.agz_get_search_form(self.h, a, b, 256))
+        return a.value.decode(), b.value.decode()
+
+    def samples_packed_host(self):
+        """Packed sample records of the last selfplay (agz.h layout) copied to host memory: uint8 array [n, rec_bytes]."""
+        import torch
+        n = self.num_samples()
+        rb = self.game.rec_bytes
+        dev = torch.empty(max(n, 1) * rb, dtype=torch.uint8, device=f"cuda:{self.device}")
+        self.samples_packed_into(dev.data_ptr(), n)
+        host = torch.empty(n * rb, dtype=torch.uint8, pin_memory=True)
+        host.copy_(dev[: n * rb])
+        return host.numpy().reshape(n, rb)
 
     def set_profiling(self, on):
         self._chk(self.L.agz_set_profiling(self.h, 3 if on is True else int(on)))
@@ -247,13 +282,17 @@ def mcts_single(actor, visits, engine, training=True, cpuct=2.0, step=0):
     engine.search(visits, cpuct=cpuct, training=training, step=step)
 
 
-def mcts(actor, visits, ngames, buffer, game=None, cpuct=2.0, engine=None, tau_plies=25, **kw):
+def mcts(actor, visits, ngames, buffer, game=None, cpuct=2.0, engine=None, tau_plies=25, seed=None, **kw):
     """mcts(actor, visits, ngames, buffer::PoolSample; cpuct) — mcts_gpu.jl:477-579.
     Plays `ngames` self-play games to the end, pushes every (state, policy, player, value, fstate) sample into
-    `buffer` in the reference's order and returns (data, valid) like the reference's named tuple."""
+    `buffer` in the reference's order and returns (data, valid) like the reference's named tuple.
+    seed=None draws a fresh Philox key per call (the reference's randomness is unseeded); pass a seed to reproduce."""
     own = engine is None
+    seed = fresh_seed() if seed is None else int(seed)
     if own:
-        engine = Engine(game if game is not None else buffer.game, ngames, visits, **kw)
+        engine = Engine(game if game is not None else buffer.game, ngames, visits, seed=seed, **kw)
+    else:
+        engine.set_seed(seed)
     try:
         if engine._nets.get(0) is not actor:
             engine.set_network(actor, 0)
@@ -266,11 +305,15 @@ def mcts(actor, visits, ngames, buffer, game=None, cpuct=2.0, engine=None, tau_p
             engine.close()
 
 
-def mcts_duel(actor1, actor2, visits, ngames, game, cpuct=2.0, engine=None, tau_plies=15, **kw):
-    """mcts(actor1, actor2, visits, ngames; cpuct) — mcts_gpu.jl:581-651 -> [v, n, d] (actor1 moves first)."""
+def mcts_duel(actor1, actor2, visits, ngames, game, cpuct=2.0, engine=None, tau_plies=15, seed=None, **kw):
+    """mcts(actor1, actor2, visits, ngames; cpuct) — mcts_gpu.jl:581-651 -> [v, n, d] (actor1 moves first).
+    seed=None: fresh Philox key per call."""
     own = engine is None
+    seed = fresh_seed() if seed is None else int(seed)
     if own:
-        engine = Engine(game, ngames, visits, **kw)
+        engine = Engine(game, ngames, visits, seed=seed, **kw)
+    else:
+        engine.set_seed(seed)
     try:
         engine.set_network(actor1, 0)
         engine.set_network(actor2, 1)
@@ -280,11 +323,13 @@ def mcts_duel(actor1, actor2, visits, ngames, game, cpuct=2.0, engine=None, tau_
             engine.close()
 
 
-def duelnetwork(actor1, actor2, visits, ngames, game, **kw):
-    """duelnetwork(actor1, actor2, visits, ngames) — mcts_gpu.jl:653-668 -> (v, n, d) from actor1's side."""
+def duelnetwork(actor1, actor2, visits, ngames, game, seed=None, **kw):
+    """duelnetwork(actor1, actor2, visits, ngames) — mcts_gpu.jl:653-668 -> (v, n, d) from actor1's side.
+    The two halves use different Philox keys (seed, seed + 1); seed=None draws a fresh pair."""
     hn = ngames // 2
-    v1, n1, d1 = mcts_duel(actor1, actor2, visits, hn, game, **kw)
-    d2, n2, v2 = mcts_duel(actor2, actor1, visits, hn, game, **kw)
+    seed = fresh_seed() if seed is None else int(seed)
+    v1, n1, d1 = mcts_duel(actor1, actor2, visits, hn, game, seed=seed, **kw)
+    d2, n2, v2 = mcts_duel(actor2, actor1, visits, hn, game, seed=seed + 1, **kw)
     return v1 + v2, n1 + n2, d1 + d2
 
 

@@ -15,11 +15,25 @@ class SNetwork2:
     def __init__(self, game, n_filter, n_tower, W0=None, Wres=None, Wp=None, bp=None, Wv=None, bv=None):
         self.inp, self.H, self.T, self.A = 2 * game.VS, int(n_filter), int(n_tower), game.A
         z = lambda n: np.zeros(n, np.float32)  # noqa: E731
-        self.W0 = z(self.H * self.inp) if W0 is None else np.ascontiguousarray(W0, np.float32).reshape(-1)
-        self.Wres = z(max(self.T, 1) * self.H * self.H) if Wres is None else np.ascontiguousarray(Wres, np.float32).reshape(-1)
-        self.Wp = z(self.A * self.H) if Wp is None else np.ascontiguousarray(Wp, np.float32).reshape(-1)
+
+        def flat(w, rows):
+            """1-D input: already Flux's memory order (W[o + out*i]).  2-D (out, in) input: flattened column-major, which is
+            that order.  Wres may be (T, H, H): every block column-major."""
+            w = np.asarray(w, np.float32)
+            if w.ndim == 1:
+                return np.ascontiguousarray(w)
+            if w.ndim == 2:
+                if w.shape[0] != rows:
+                    raise ValueError(f"weight matrix must be (out={rows}, in), got {w.shape}")
+                return np.ascontiguousarray(w.reshape(-1, order="F"))
+            if w.ndim == 3:
+                return np.ascontiguousarray(np.concatenate([b.reshape(-1, order="F") for b in w]))
+            raise ValueError("weights must be 1-D (Flux memory order), 2-D (out, in) or 3-D (T, out, in)")
+        self.W0 = z(self.H * self.inp) if W0 is None else flat(W0, self.H)
+        self.Wres = z(max(self.T, 1) * self.H * self.H) if Wres is None else flat(Wres, self.H)
+        self.Wp = z(self.A * self.H) if Wp is None else flat(Wp, self.A)
         self.bp = z(self.A) if bp is None else np.ascontiguousarray(bp, np.float32).reshape(-1)
-        self.Wv = z(self.H) if Wv is None else np.ascontiguousarray(Wv, np.float32).reshape(-1)
+        self.Wv = z(self.H) if Wv is None else flat(Wv, 1)
         self.bv = z(1) if bv is None else np.ascontiguousarray(bv, np.float32).reshape(-1)
 
     @classmethod

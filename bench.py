@@ -1,12 +1,15 @@
 #!/usr/bin/env python3
-"""bench.py — self-play rollouts/s, the BASELINE.json metric.
+"""bench.py — self-play rollouts/s, the BASELINE.json metric, for every BASELINE config through one harness.
 
-A step = ONE whole self-play generation of the configuration the metric is quoted on: Gobang 9x9 (Nvict=5),
-32768 games per GPU x 64 rollouts per move, random-init 128x6 snetwork2, bf16 MFMA network + fp32 tree
-arithmetic, all games played to the end on the device (mcts(), mcts_gpu.jl:477-579).  Inputs (start positions,
-weights) are resident in HBM before the timed region.  value = rollouts of all ranks / max-over-ranks time.
-With N > 1 ranks each rank plays its own shard of game ids and the step ends with the RCCL all-gather of the
-packed sample records.
+A step = ONE whole self-play generation: `--games` games per GPU x `--rollouts` rollouts per move, random-init snetwork2
+`--filters` x `--towers`, bf16 MFMA network + fp32 strict-IEEE tree arithmetic, all games played to the end on the device
+(mcts(), mcts_gpu.jl:477-579).  Inputs (start positions, weights) are resident in HBM before the timed region.
+value = rollouts of all ranks / max-over-ranks time.  With N > 1 ranks each rank plays its own shard of game ids and the
+step ends with the RCCL all-gather of the packed sample records.
+
+The default is the configuration the metric is quoted on (Gobang 9x9 Nvict=5, 32768 x 64, 128x6).  `--config k` selects
+BASELINE.json configs[k-1] (2: Connect4 128x6, 3: Gobang 9x9 512x8, 4: Hex 9x9 V=128 512x8, 5: Reversi 8x8 512x8 — the
+per-GPU shard of the 8-GPU run), or give --game/--n/--nvict/--filters/--towers/--rollouts/--games directly.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
@@ -21,6 +24,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak (same guide)
+
+CONFIGS = {                    # BASELINE.json configs[k-1]
+    1: dict(game="gobang", n=3, nvict=3, games=256, rollouts=16, filters=128, towers=6),
+    2: dict(game="connect4", n=0, nvict=0, games=32768, rollouts=64, filters=128, towers=6),
+    3: dict(game="gobang", n=9, nvict=5, games=32768, rollouts=64, filters=512, towers=8),
+    4: dict(game="hex", n=9, nvict=0, games=32768, rollouts=128, filters=512, towers=8),
+    5: dict(game="reversi8", n=0, nvict=0, games=32768, rollouts=64, filters=512, towers=8),
+}
 
 
 def algorithmic_bytes(game, sum_p, sum_new, rollouts, S):
@@ -29,11 +41,24 @@ def algorithmic_bytes(game, sum_p, sum_new, rollouts, S):
     return sum_p * (18 * A + 16) + sum_new * 2 * S + rollouts * ((48 + 4 * VS) + (4 * A + 4) + 8 * A + S)
 
 
+def nn_flops_per_leaf(game, H, T):
+    """2 (in H + T H^2 + (A+1) H)."""
+    return 2.0 * (2 * game.VS * H + T * H * H + (game.A + 1) * H)
+
+
+def game_label(args):
+    if args.game == "gobang":
+        return f"gobang{args.n}x{args.n}_nvict{args.nvict}", f"Gobang {args.n}x{args.n}"
+    if args.game == "hex":
+        return f"hex{args.n}x{args.n}", f"Hex {args.n}x{args.n}"
+    return args.game, {"connect4": "Connect4", "reversi8": "Reversi 8x8", "reversi6": "Reversi 6x6"}[args.game]
+
+
 def cpu_baseline(args):
     """fast_mcts.jl restatement (oracle/agz_oracle.c agzo_fmcts_selfplay, kind 'port') on the host cores."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
-    og = O.make_game("gobang", args.n, args.nvict)
+    og = O.make_game(args.game, args.n, args.nvict)
     net = O.OracleNet(og, args.filters, args.towers)
     cores = os.cpu_count() or 1
     ngames, plies = 4 * cores, 1
@@ -54,6 +79,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", type=int, default=0, help="BASELINE.json configs[k-1] (1..5); 0 = the headline metric config")
+    ap.add_argument("--game", default="gobang", choices=["gobang", "connect4", "hex", "reversi8", "reversi6"])
     ap.add_argument("--games", type=int, default=32768, help="games per GPU (--samples, mainGobang.jl:96)")
     ap.add_argument("--rollouts", type=int, default=64, help="--rollout, mainGobang.jl:100")
     ap.add_argument("--cpuct", type=float, default=1.5, help="--cpuct, mainGobang.jl:113")
@@ -64,8 +91,16 @@ def main():
     ap.add_argument("--mode", choices=["bf16", "exact"], default="bf16")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-delivery", action="store_true", help="skip the extra (untimed) generation that measures sample delivery to the host")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI); gloo only for single-GPU smoke tests of the N>1 path")
     args = ap.parse_args()
+    if args.config:
+        for k, v in CONFIGS[args.config].items():
+            setattr(args, k, v)
+    if args.game in ("connect4", "reversi8", "reversi6"):
+        args.n = args.nvict = 0
+    if args.game == "hex":
+        args.nvict = 0
 
     import torch
     import alphagpu_amd as ag
@@ -91,13 +126,12 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
-    game = ag.GameSpec("gobang", args.n, args.nvict)
+    game = ag.GameSpec(args.game, args.n, args.nvict)
     net = ag.SNetwork2.random(game, args.filters, args.towers)
     G, V = args.games, args.rollouts
     eng = M.Engine(game, G, V, device=dev, seed=1, game_id_base=shard.shard_base(rank, G),
                    nn_mode=M.NN_BF16 if args.mode == "bf16" else M.NN_EXACT)
     eng.set_network(net)
-    eng.set_profiling(1)          # HIP events around every launch of the search kernel (one launch per ply: mcts_single in one kernel)
     rb = game.rec_bytes
     # the exchange of generation k overlaps generation k+1: two sample buffers, at most two collectives in flight
     sample_bufs = [torch.empty(G * game.max_plies * rb, dtype=torch.uint8, device="cuda") for _ in range(2)] if world > 1 else None
@@ -105,12 +139,13 @@ def main():
     nstep = [0]
 
     def step():
+        eng.set_seed(1 + nstep[0])              # a fresh Philox key per generation, as the reference's unseeded draws
         st = eng.selfplay(G, V, cpuct=args.cpuct, tau_plies=25)
         if not st["valid"]:
             raise SystemExit("illegal move sampled ('faute')")
+        k = nstep[0] & 1
+        nstep[0] += 1
         if world > 1:                       # the one exchange step: all-gather of the generated samples
-            k = nstep[0] & 1
-            nstep[0] += 1
             if inflight[k] is not None:
                 inflight[k].wait()          # the collective that read sample_bufs[k] two generations ago
             n = eng.samples_packed_into(sample_bufs[k].data_ptr(), G * game.max_plies)
@@ -131,8 +166,18 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # which kernels does this configuration run?  One launch per ply (whole mcts_single in k_search_small): events around every
+    # launch.  Two kernels per rollout (wide trunks, V > 64): events around ~10^4 launches cost ~10 % of a generation, so only
+    # every 4th search is instrumented (profiling bit 2); the fractions are taken over the instrumented searches.
+    eng.set_profiling(1)
+    for _ in range(max(args.warmup, 0)):
         step()
+    if args.warmup == 0:                        # the form is needed before the timed region: one probe search of the first ply
+        eng.set_roots(None, L=G)
+        eng.search(V, cpuct=args.cpuct, training=True, step=0)
+    form_tree, form_nn = eng.search_form()
+    whole = form_tree.startswith("k_search_small")
+    eng.set_profiling(1 if whole else 7)
     eng.kernel_times(reset=True)
     fence()
     t0 = time.perf_counter()
@@ -151,6 +196,27 @@ def main():
     tree_ms, nn_ms, launches = eng.kernel_times()
     busy_ms = eng.tree_busy_ms()      # union of the launch intervals: sub-batch chains run launches side by side
     sum_p, sum_new, r_cnt = eng.counters()
+    form_tree, form_nn = eng.search_form()
+
+    # host delivery (SURVEY §8d "end-to-end"): the reference's generation ends with the samples in the host PoolSample
+    # (mcts_gpu.jl:515, mainGobang.jl:54-80).  One extra generation, outside the timed region: generation + packed records D2H
+    # into pinned host memory (+ push into the PoolSample arrays).
+    host = None
+    if world == 1 and not args.no_host_delivery:
+        eng.set_profiling(0)
+        buf = ag.PoolSample(game, 2_000_000)               # mainGobang.jl:130
+        eng.synchronize()
+        h0 = time.perf_counter()
+        st = step()
+        h1 = time.perf_counter()
+        recs = eng.samples_packed_host()
+        h2 = time.perf_counter()
+        buf.push_generation(shard.unpack_records(recs.reshape(-1), recs.shape[0], game))
+        h3 = time.perf_counter()
+        host = {"generation_s": h1 - h0, "packed_records_to_pinned_host_s": h2 - h1, "push_into_PoolSample_s": h3 - h2,
+                "bytes": int(recs.size), "samples": int(recs.shape[0]),
+                "rollouts_per_s_with_host_delivery": st["rollouts"] / (h2 - h0),
+                "rollouts_per_s_with_host_delivery_and_PoolSample": st["rollouts"] / (h3 - h0)}
 
     cdev = "cuda" if args.backend == "nccl" else "cpu"
     tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
@@ -163,37 +229,53 @@ def main():
     if rank == 0:
         S = game.pos_image_bytes
         alg = algorithmic_bytes(game, sum_p, sum_new, r_cnt, S)
+        gl, gname = game_label(args)
         traffic = None          # HBM bytes per launch from the committed PMC passes, scaled by this run's algorithmic bytes
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if args.n == 9 and args.rollouts == 64:
-                traffic = pm["traffic_over_algorithmic"] * alg / max(launches, 1)
+            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            key = f"{gl}_{V}_{args.filters}x{args.towers}"
+            if key in pm:
+                traffic = pm[key]["traffic_over_algorithmic"] * alg / max(launches, 1)
         except Exception:
             traffic = None
-        achieved = alg / (busy_ms * 1e-3) / 1e9 if busy_ms > 0 else 0.0   # aggregate over the launches in flight together
+        hbm_achieved = alg / (busy_ms * 1e-3) / 1e9 if busy_ms > 0 else 0.0   # aggregate over the launches in flight together
+        flops = nn_flops_per_leaf(game, args.filters, args.towers) * r_cnt
+        if whole:
+            # the network forward runs inside the search kernel: its time is not separable, the fraction is taken against the
+            # whole launch (a lower bound of the MFMA pipe's rate while the network phase runs)
+            nn_t_ms, nn_note = busy_ms, "network inside k_search_small: flops / whole-launch time (lower bound)"
+        else:
+            nn_t_ms, nn_note = nn_ms, "HIP events around the network launches of the instrumented searches"
+        mfma_achieved = flops / (nn_t_ms * 1e-3) / 1e12 if nn_t_ms > 0 else 0.0
+        tree_obj = {"kernel": form_tree, "bound": "hbm", "achieved": hbm_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": hbm_achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "algorithmic_bytes_per_launch": alg / max(launches, 1), "avg_launch_ms": tree_ms / max(launches, 1),
+                    "launches": launches, "launch_concurrency": tree_ms / busy_ms if busy_ms > 0 else None,
+                    "mean_depth_p": sum_p / max(r_cnt, 1),
+                    "note": ("one launch = one ply of the generation (all games alive, V rollouts)" if whole else
+                             "one launch = one rollout of all games alive; busy time = union of the launch intervals of the sub-batch chains")
+                            + "; algorithmic bytes are the tree path's (SURVEY 8d)"}
+        nn_obj = {"kernel": form_nn, "bound": "mfma", "achieved": mfma_achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                  "frac": mfma_achieved / MFMA_PEAK_TFLOPS, "traffic": None,
+                  "flops_per_leaf": nn_flops_per_leaf(game, args.filters, args.towers), "leaves": r_cnt, "time_ms": nn_t_ms, "note": nn_note}
+        # the dominant kernel of the configuration: the network when its launches take longer than the tree kernel's
+        nn_dominant = (not whole) and nn_ms > busy_ms
         out = {
-            "metric": "self-play rollouts/sec at 32768 games x 64 rollouts, Gobang 9x9",
+            "metric": f"self-play rollouts/sec at {G} games x {V} rollouts, {gname}",
             "value": total_rollouts / dt_max, "unit": "rollouts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt_max * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if args.mode == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": f"gobang{args.n}x{args.n}_nvict{args.nvict}_{G}games_per_gpu_x{V}rollouts_"
-                                   f"snetwork2_{args.filters}x{args.towers}_full_generation",
+            "config": {"workload": f"{gl}_{G}games_per_gpu_x{V}rollouts_snetwork2_{args.filters}x{args.towers}_full_generation",
+                       "baseline_config": args.config if args.config else "headline (metric)",
                        "games_per_gpu": G, "rollouts_per_move": V, "cpuct": args.cpuct, "tau_plies": 25,
                        "tree_arithmetic": "f32 strict IEEE", "network": "bf16 MFMA, fp32 accumulate" if args.mode == "bf16" else "f32 exact",
                        "parallelism": f"game-shard x{world}, RCCL all-gather of samples at generation end" if world > 1 else "single GPU"},
-            "roofline": {"kernel": "k_search_small (a whole mcts_single per launch: 65 x {expand+backup+select+encode, network forward}; "
-                                   "8 lanes per game tree, node rows in registers, 16/32 games per workgroup)",
-                         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg / max(launches, 1), "avg_launch_ms": tree_ms / max(launches, 1),
-                         "launches": launches, "launch_concurrency": tree_ms / busy_ms if busy_ms > 0 else None,
-                         "mean_depth_p": sum_p / max(r_cnt, 1),
-                         "note": "one launch = one ply of the generation (all games alive, 64 rollouts); algorithmic bytes are the tree path's "
-                                 "(SURVEY 8d) - the network weights stream from L2 and the kernel is bound by instruction issue / latency, not HBM"},
+            "roofline": nn_obj if nn_dominant else tree_obj,
+            "roofline_other": tree_obj if nn_dominant else nn_obj,
             "rank0": {"search_only_rollouts_per_s": rollouts / search_s if search_s > 0 else None,
-                      "search_kernel_ms": tree_ms, "search_ms": search_s * 1e3,
-                      "plies": plies, "samples": nsamples,
-                      "wall_s": dt},
+                      "search_kernel_ms": tree_ms, "network_kernel_ms": nn_ms, "search_ms": search_s * 1e3,
+                      "instrumented_rollouts": r_cnt, "plies": plies, "samples": nsamples, "wall_s": dt,
+                      "host_delivery": host},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args)

@@ -69,6 +69,10 @@ int  agz_create(const agz_config *cfg, agz_engine **out);          /* mcts_gpu.j
 void agz_destroy(agz_engine *h);
 const char *agz_last_error(const agz_engine *h);                   /* NULL handle: last create error */
 int  agz_get_info(const agz_engine *h, agz_game_info *out);
+/* Replaces the Philox key of every later search / self-play / duel call of this handle.  The reference draws fresh
+ * CUDA.rand / StatsBase randomness on every call (mcts_gpu.jl:397,520): a host loop that keeps one engine alive passes a
+ * new seed per generation (the Python and Julia wrappers do), a parity test keeps it fixed. */
+int  agz_set_seed(agz_engine *h, uint64_t seed);
 
 /* convert_back(net) -> snetwork2 (DenseNet.jl:331-333, 279-286).  Host fp32, Flux (out,in) column-major:
  * W0 H x in, Wres T consecutive H x H blocks, Wp A x H, bp A, Wv 1 x H, bv 1.  in = 2*VS. */
@@ -95,6 +99,8 @@ int  agz_rollout_select(agz_engine *h, uint32_t rollout, int last);             
 int  agz_rollout_eval(agz_engine *h);                                             /* :414-417 actor + softmax! */
 int  agz_get_eval(agz_engine *h, float *prior /*[L][A]*/, float *v /*[L]*/);      /* softmaxed priors as used */
 int  agz_inject_eval(agz_engine *h, const float *prior, const float *v);          /* replaces the actor output */
+int  agz_get_logits(agz_engine *h, float *logits /*[L][A]*/, float *v /*[L]*/);   /* raw actor output of the last network launch
+                                                                                     (DenseNet.jl:294-304, before softmax!) */
 int  agz_rollout_expand_backup(agz_engine *h);                                    /* :424-431 expand + backUp */
 int  agz_search_end(agz_engine *h);                                               /* :441-444 decoder_roots, copy_pol */
 
@@ -141,6 +147,8 @@ int  agz_get_kernel_times(agz_engine *h, double *tree_ms, double *nn_ms, int64_t
 /* with sub-batch chains several tree-kernel launches run side by side: busy time (ms) = length of the union of the
  * launch intervals since the last reset of agz_get_kernel_times (== tree_ms when launches never overlap) */
 int  agz_get_tree_busy_ms(agz_engine *h, double *busy_ms);
+/* names of the kernels the last search ran (the engine picks the execution form by batch size and network width) */
+int  agz_get_search_form(agz_engine *h, char *tree_kernel, char *nn_kernel, int cap);
 int  agz_set_profiling(agz_engine *h, int mode);       /* HIP events per launch: bit 0 tree kernel, bit 1 network kernel;
                                                           bit 2: instrument (events and agz_get_counters) every 4th search only */
 

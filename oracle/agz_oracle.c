@@ -824,6 +824,72 @@ done:
 }
 
 /* ============================================================================================
+ * Duel — mcts(actor1,actor2,visits,ngames;cpuct=2f0) mcts_gpu.jl:581-651
+ * ========================================================================================== */
+/* sample(1:maxActions, Weights(policy[:,i])) (:606): StatsBase's cumulative walk over ALL actions
+ * (t = rand()*sum(w); i=1; cw=w[1]; while cw<t && i<n: i+=1; cw+=w[i]); zero weights are walked over, so
+ * the only difference from the nonzero-list form of self-play (:519-520) is u == 0, which returns action 1. */
+static int choose_move_all(const float *pol, int A, float u) {
+    float total = 0.0f;
+    for (int c = 0; c < A; ++c) total += pol[c];
+    float tt = u * total, cw = pol[0];
+    int i = 0;
+    while (cw < tt && i < A - 1) { ++i; cw += pol[i]; }
+    return i;
+}
+
+/* first = 0: net1 moves at even rounds (:592-596).  moves: [ngames][max_plies] chosen actions by game (index
+ * game_id - game_id_base), -1 beyond the game's end; nplies: [ngames].  wdl = [v, n, d] (:618-624: res == 1 / 0 / -1).
+ * Returns 0, or -1 on an illegal sampled move ("faute" :609-612). */
+int agzo_duel(const agzo_game *g, const agzo_net *net1, const agzo_net *net2, int ngames, int V, float cpuct,
+              int tau_plies, uint64_t seed, uint32_t game_id_base, int first, long wdl[3],
+              int32_t *moves, int max_plies, int32_t *nplies) {
+    agzo_tree *t = agzo_tree_create(g, ngames, V);
+    agzo_pos *positions = malloc((size_t)ngames * sizeof(agzo_pos));
+    uint32_t *ids = malloc((size_t)ngames * 4);
+    float *policy = malloc((size_t)ngames * g->A * 4);
+    char *fin = calloc((size_t)ngames, 1);
+    for (int k = 0; k < ngames; ++k) { agzo_pos_init(g, &positions[k]); ids[k] = game_id_base + (uint32_t)k; }
+    if (moves) for (long k = 0; k < (long)ngames * max_plies; ++k) moves[k] = -1;
+    if (nplies) for (int k = 0; k < ngames; ++k) nplies[k] = 0;
+    int L = ngames, round = 0, rc = 0;
+    wdl[0] = wdl[1] = wdl[2] = 0;
+    agzo_tree_set_roots(t, positions, ids, L);
+    while (L > 0) {                                                       /* :590 */
+        const agzo_net *actor = ((round % 2 == 0) ? (first == 0) : (first != 0)) ? net1 : net2; /* :592-596 */
+        agzo_search(t, actor, V, cpuct, 0 /* training=false :599 */, seed, (uint32_t)round, NULL, NULL, NULL, NULL);
+        agzo_get_policy(t, policy);
+        for (int i = 0; i < L; ++i) {                                     /* :603-627 */
+            const float *pol = policy + (size_t)i * g->A;
+            int c;
+            if (round < tau_plies) c = choose_move_all(pol, g->A, agzo_uniform_move(seed, ids[i], (uint32_t)round)); /* :605-606 */
+            else c = choose_move(pol, g->A, 0, 0.0f);                     /* argmax :608 */
+            int gi = (int)(ids[i] - game_id_base);
+            if (moves && round < max_plies) moves[(size_t)gi * max_plies + round] = c;
+            if (nplies) nplies[gi] = round + 1;
+            if (!agzo_can_play(g, &positions[i], c)) { rc = -1; goto done; } /* "faute" */
+            agzo_pos np; agzo_play(g, &positions[i], c, &np); positions[i] = np;
+            int res, f = agzo_is_over(g, &positions[i], &res);
+            if (f) {
+                if (res == 1) wdl[0]++; else if (res == 0) wdl[1]++; else wdl[2]++;
+                fin[i] = 1;                                               /* push!(finished,i) :616 */
+            }
+        }
+        int w = 0;                                                        /* deleteat! :629-631 */
+        for (int i = 0; i < L; ++i) {
+            if (fin[i]) { fin[i] = 0; continue; }
+            positions[w] = positions[i]; ids[w] = ids[i]; ++w;
+        }
+        L = w; round += 1;
+        if (L > 0) agzo_tree_set_roots(t, positions, ids, L);             /* re_init :634-638 */
+    }
+done:
+    free(policy); free(positions); free(ids); free(fin);
+    agzo_tree_destroy(t);
+    return rc;
+}
+
+/* ============================================================================================
  * CPU baseline — fast_mcts.jl (FMCTS).  Timing baseline only (cpu_baseline.kind = "port");
  * its semantics differ from the GPU path and it is NOT the parity oracle.
  * Julia's promotions (Float64 λ/α because sqrt(::Int)) are kept.

@@ -127,6 +127,12 @@ void agzo_samples_destroy(agzo_samples *s);
 int  agzo_selfplay(const agzo_game *g, const agzo_net *net, int ngames, int V, float cpuct,
                    int tau_plies, uint64_t seed, uint32_t game_id_base, agzo_samples *out);
 
+/* ---- duel: mcts(actor1,actor2,visits,ngames;cpuct) mcts_gpu.jl:581-651 (training=false, sample over ALL
+ * actions for round < tau_plies (15), argmax after; actor by ply parity).  first = 0: net1 moves first. ---- */
+int  agzo_duel(const agzo_game *g, const agzo_net *net1, const agzo_net *net2, int ngames, int V, float cpuct,
+               int tau_plies, uint64_t seed, uint32_t game_id_base, int first, long wdl[3],
+               int32_t *moves, int max_plies, int32_t *nplies);
+
 /* ---- CPU baseline: fast_mcts.jl single-tree search ---- */
 void agzo_fmcts(const agzo_game *g, const agzo_net *net, const agzo_pos *pos, int readout, float c,
                 uint64_t seed, uint32_t game_id, float *policy_out, float *value_out);

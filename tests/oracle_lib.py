@@ -85,6 +85,8 @@ def lib():
         L.agzo_samples_destroy.argtypes = [C.POINTER(Samples)]
         L.agzo_selfplay.argtypes = [C.POINTER(Game), C.POINTER(Net), C.c_int, C.c_int, C.c_float, C.c_int,
                                     C.c_uint64, C.c_uint32, C.POINTER(Samples)]
+        L.agzo_duel.argtypes = [C.POINTER(Game), C.POINTER(Net), C.POINTER(Net), C.c_int, C.c_int, C.c_float, C.c_int,
+                                C.c_uint64, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.agzo_fmcts.argtypes = [C.POINTER(Game), C.POINTER(Net), C.POINTER(Pos), C.c_int, C.c_float,
                                  C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]
         L.agzo_fmcts_selfplay.restype = C.c_long
@@ -308,6 +310,47 @@ def selfplay(g, net, ngames, V, cpuct, tau_plies, seed, game_id_base=0):
         wins=sc.wins, draws=sc.draws, losses=sc.losses, total_plies=sc.total_plies, faults=sc.faults)
     lib().agzo_samples_destroy(s)
     return out
+
+
+def duel(g, net1, net2, ngames, V, cpuct, tau_plies, seed, game_id_base=0, first=0):
+    """mcts(actor1, actor2, visits, ngames; cpuct) (mcts_gpu.jl:581-651) -> dict(rc, wdl [v, n, d], moves [ngames][max_plies]
+    (-1 past the end), nplies [ngames])."""
+    max_plies = 2 * g.len + 8
+    wdl = np.zeros(3, np.int64)
+    moves = np.zeros((ngames, max_plies), np.int32)
+    nplies = np.zeros(ngames, np.int32)
+    rc = lib().agzo_duel(C.byref(g), C.byref(net1.c), C.byref(net2.c), ngames, V, cpuct, tau_plies, seed, game_id_base,
+                         first, _p(wdl), _p(moves), max_plies, _p(nplies))
+    return dict(rc=rc, wdl=[int(x) for x in wdl], moves=moves, nplies=nplies)
+
+
+def bf16_round(x):
+    """fp32 -> bf16 (round to nearest even) -> fp32, as v_cvt_pk_bf16_f32 and the host weight tiling do."""
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return (r & 0xFFFFFFFF).astype(np.uint32).view(np.float32).reshape(np.shape(x))
+
+
+def forward_bf16_model(net, planes):
+    """The snetwork2 forward (DenseNet.jl:294-304) with the ROUNDING POINTS of the bf16 MFMA path (agz_nn_wave.hpp /
+    agz_nn_big.hpp): weights and layer outputs rounded to bf16, products and sums exact-ish (float64 accumulate, the
+    MFMA's fp32 accumulation order is not modelled), residual add and ReLU in fp32, heads in fp32 + bias.
+    planes [n][in] (0/1) -> logits [n][A] float64, value pre-activation [n] float64."""
+    H, T, A, inp = net.H, net.T, net.A, net.inp
+    W0 = bf16_round(net.W0).reshape(inp, H).astype(np.float64)            # Flux (out,in) column-major: W[o + H*i]
+    x = np.asarray(planes, np.float64)
+    b = np.maximum(x @ W0, 0.0)
+    b = bf16_round(b.astype(np.float32)).astype(np.float64)
+    for t in range(T):
+        W = bf16_round(net.Wres[t * H * H:(t + 1) * H * H]).reshape(H, H).astype(np.float64)
+        y = np.maximum((b @ W).astype(np.float32), np.float32(0))           # relu(W b) in fp32
+        y = np.maximum(y + b.astype(np.float32), np.float32(0))             # relu(b + .)
+        b = bf16_round(y).astype(np.float64)
+    Wp = bf16_round(net.Wp).reshape(H, A).astype(np.float64)
+    Wv = bf16_round(net.Wv).reshape(H, 1).astype(np.float64)
+    logits = b @ Wp + net.bp.astype(np.float64)
+    vpre = (b @ Wv)[:, 0] + float(net.bv[0])
+    return logits, vpre
 
 
 def fmcts(g, net, pos, readout, c, seed, game_id=0):

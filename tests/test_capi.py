@@ -80,3 +80,49 @@ def test_pool_sample_ring_semantics():
     assert idx == [1, 2, 3, 4, 5, 1, 2] and buf.full and buf.currentIndex == 3 and buf.length_buffer() == 5
     buf.update_buffer([1, 2], -1, np.ones(9, np.int8))
     assert buf.value[0] == 1.0 and buf.value[1] == 0.0 and (buf.fstate[0] == -1).all() and (buf.fstate[1] == 1).all()
+
+
+@pytest.mark.parametrize("game,n,k", [("gobang", 9, 5), ("reversi8", 0, 0), ("connect4", 0, 0), ("hex", 9, 0)])
+def test_packed_record_layout_is_the_one_agz_h_documents(game, n, k):
+    """include/agz.h (agz_get_samples_packed): {u32 game_id, i32 ply, i32 move, f32 value, i8 player, i8 pad[3],
+    f32 policy[A], i8 state[2VS], i8 fstate[FS], pad to 16 B}.  A record written field by field with struct.pack must decode
+    through shard.unpack_records (the consumer of the all-gather) — pins the layout on both sides of the exchange."""
+    import struct
+    from alphagpu_amd import shard
+    g = ag.GameSpec(game, n, k)
+    body = 20 + 4 * g.A + 2 * g.VS + g.FS
+    assert g.rec_bytes == (body + 15) // 16 * 16                       # SURVEY §8e: padded to a 16-B multiple
+    hdr = open(os.path.join(ROOT, "include", "agz.h")).read()
+    assert "u32 game_id, i32 ply, i32 move, f32 value" in hdr and "f32 policy[A], i8 state[2VS], i8 fstate[FS]" in hdr
+    rng = np.random.default_rng(1)
+    recs, want = [], []
+    for i in range(3):
+        pol = rng.random(g.A).astype(np.float32)
+        st = rng.integers(0, 2, 2 * g.VS).astype(np.int8)
+        fs = rng.integers(-1, 2, g.FS).astype(np.int8)
+        r = struct.pack("<IiifbBBB", 7000 + i, i, 3 + i, 0.5 * i, -1 if i & 1 else 1, 0, 0, 0) + pol.tobytes() + st.tobytes() + fs.tobytes()
+        recs.append(r + bytes(g.rec_bytes - len(r)))
+        want.append((7000 + i, i, 3 + i, 0.5 * i, -1 if i & 1 else 1, pol, st, fs))
+    u = shard.unpack_records(np.frombuffer(b"".join(recs), np.uint8), 3, g)
+    for i, (gid, ply, mv, val, pl, pol, st, fs) in enumerate(want):
+        assert (u["game_id"][i], u["ply"][i], u["move"][i], u["value"][i], u["player"][i]) == (gid, ply, mv, val, pl)
+        assert np.array_equal(u["policy"][i], pol) and np.array_equal(u["state"][i], st) and np.array_equal(u["fstate"][i], fs)
+
+
+def test_snetwork2_accepts_flux_matrices_in_column_major_order():
+    """Flux stores Dense(in,out).weight as an (out,in) column-major matrix: W[o + out*i].  A 2-D numpy (out,in) array must
+    land in that memory order (not be silently transposed); 1-D input is taken as already in that order."""
+    g = ag.GameSpec("gobang", 3, 3)
+    H = 4
+    W0 = np.arange(H * 18, dtype=np.float32).reshape(H, 18)             # W0[o, i]
+    net = ag.SNetwork2(g, H, 1, W0=W0, Wres=np.zeros((1, H, H), np.float32), Wp=np.zeros((9, H), np.float32), Wv=np.zeros((1, H), np.float32))
+    assert net.W0[2 + H * 5] == W0[2, 5]
+    flat = ag.SNetwork2(g, H, 1, W0=net.W0.copy())
+    assert np.array_equal(flat.W0, net.W0)
+    with pytest.raises(ValueError):
+        ag.SNetwork2(g, H, 1, W0=W0.T)
+
+
+def test_wrappers_draw_a_fresh_seed_per_call():
+    seeds = {M.fresh_seed() for _ in range(64)}
+    assert len(seeds) == 64 and all(0 < s < 2 ** 63 for s in seeds)

@@ -142,3 +142,50 @@ def test_fmcts_baseline_runs():
     pol, val = O.fmcts(g, net, O.pos_init(g), 32, 1.5, 1)
     assert abs(pol.sum() - 1.0) < 5e-3 and 0.0 <= val <= 1.0
     assert O.fmcts_selfplay(g, net, 8, 8, 1.5, 25, 1, 2) > 0
+
+
+def test_oracle_duel_semantics():
+    """mcts(actor1, actor2, ...) (mcts_gpu.jl:581-651): every game ends, W+D+L = ngames, moves are legal, the actor at ply p is
+    actor1 iff p is even (checked through a network that always prefers one action: zero weights + a policy bias)."""
+    g = O.make_game("gobang", 3, 3)
+    a, b = O.OracleNet(g, 16, 1, seed=1), O.OracleNet(g, 16, 1, seed=2)
+    r = O.duel(g, a, b, 32, 8, 2.0, 15, 9, 100, 0)
+    assert r["rc"] == 0 and sum(r["wdl"]) == 32
+    for gi in range(32):
+        p = O.pos_init(g)
+        n = int(r["nplies"][gi])
+        assert 5 <= n <= 9 and (r["moves"][gi, n:] == -1).all()
+        for ply in range(n):
+            mv = int(r["moves"][gi, ply])
+            assert O.can_play(g, p, mv)
+            p = O.play(g, p, mv)
+        assert O.is_over(g, p)[0]
+    # same seeds -> same games; swapping who moves first changes them
+    r2 = O.duel(g, a, b, 32, 8, 2.0, 15, 9, 100, 0)
+    assert np.array_equal(r["moves"], r2["moves"]) and r["wdl"] == r2["wdl"]
+    r3 = O.duel(g, a, b, 32, 8, 2.0, 15, 9, 100, 1)
+    r4 = O.duel(g, b, a, 32, 8, 2.0, 15, 9, 100, 0)
+    assert np.array_equal(r3["moves"], r4["moves"]) and r3["wdl"] == r4["wdl"]        # first=1 == roles swapped
+    # argmax plies (tau_plies = 0) with a net biased towards action 4 then 0: ply 0 must be the centre
+    for net in (a, b):
+        net.W0[:] = 0; net.Wres[:] = 0; net.Wp[:] = 0; net.Wv[:] = 0
+    a.bp[:] = 0; a.bp[4] = 5.0
+    b.bp[:] = 0; b.bp[0] = 5.0
+    r5 = O.duel(g, a, b, 4, 16, 2.0, 0, 3, 0, 0)
+    assert (r5["moves"][:, 0] == 4).all() and (r5["moves"][:, 1] == 0).all()
+
+
+def test_bf16_rounding_model():
+    x = np.array([1.0, 1.00390625, 1.001953125, 1.005859375, -3.14159, 0.0, 1e-30], np.float32)
+    r = O.bf16_round(x)
+    assert r[0] == 1.0 and r[1] == 1.0 and r[5] == 0.0                 # 1 + 2^-8 is a tie -> even (1.0)
+    assert r[2] == 1.0 and r[3] == np.float32(1.0078125)               # 1 + 1.5 * 2^-8 -> 1 + 2^-7
+    assert np.all(np.abs(r - x) <= np.abs(x) * 2.0 ** -8)
+    g = O.make_game("gobang", 9, 5)
+    net = O.OracleNet(g, 128, 6)
+    planes = (np.random.default_rng(0).random((6, 162)) < 0.2).astype(np.float32)
+    lg, v = net.logits(planes)
+    mlg, mv = O.forward_bf16_model(net, planes)
+    scale = np.maximum(1.0, np.abs(lg).max(axis=1, keepdims=True))
+    assert (np.abs(lg - mlg) / scale).max() < 2.0 ** -6                 # the bf16 model is a small perturbation of the fp32 forward
+    assert np.abs(v - 1.0 / (1.0 + np.exp(-mv))).max() < 2.0 ** -6
