@@ -73,6 +73,26 @@ AGZ_HD float exp_spec(float x) {
     s.u = (uint32_t)(k + 127 + 64) << 23;
     return (y * s.f) * 5.42101086242752217e-20f;
 }
+// exp of the bf16-mode softmax (argument <= 0): 2^(x log2 e) from a degree-6 polynomial on the fraction and an exact scaling
+// (v_ldexp_f32).  13 instructions; unlike v_exp_f32 it is a DEFINITION that a CPU restatement can follow, so the bf16
+// mode is reproducible bit for bit.  2^t with t < -125 is 0.
+AGZ_HD float exp2_spec(float x) {
+    const float t = x * 1.44269504088896341f;
+    if (!(t >= -125.0f)) return 0.0f;
+    const float n = __builtin_rintf(t), f = t - n;
+    float p = 1.5403530393381609e-4f;
+    p = fma_rn(p, f, 1.3333558146428443e-3f);
+    p = fma_rn(p, f, 9.6181291076284772e-3f);
+    p = fma_rn(p, f, 5.5504108664821580e-2f);
+    p = fma_rn(p, f, 2.4022650695910071e-1f);
+    p = fma_rn(p, f, 6.9314718055994531e-1f);
+    p = fma_rn(p, f, 1.0f);
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ldexpf(p, (int)n);
+#else
+    return __builtin_ldexpf(p, (int)n);
+#endif
+}
 AGZ_HD float sigmoid_spec(float x) {      // NNlib sigma (DenseNet.jl:197, :301)
     float t = exp_spec(-__builtin_fabsf(x));
     return x >= 0.0f ? 1.0f / (1.0f + t) : t / (1.0f + t);

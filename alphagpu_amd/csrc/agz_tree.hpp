@@ -61,7 +61,7 @@ template <int NR> __device__ __forceinline__ void softmax_row(float (&x)[NR], in
     float carry = 0.0f; bool st = false;
     for (int r = 0; r < NR; ++r) {
         int k = 64 * r + lane;
-        float e = exact ? exp_spec(x[r] - m) : __expf(x[r] - m);
+        float e = exact ? exp_spec(x[r] - m) : exp2_spec(x[r] - m);
         x[r] = k < A ? e : 0.0f;
         int nr = A - 64 * r; uint64_t full = nr >= 64 ? ~0ull : ((1ull << nr) - 1ull);
         (void)chain64(x[r], full, carry, false, 0.0f, st);

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(64, G >= 16 ? 4 : (G >= 8 ? 2 : 1)) void k_rollout_
                 float mx = -__builtin_inff();
                 for (int k = sub; k < A; k += G) mx = rp[k] > mx ? rp[k] : mx;
                 mx = grp_max<G>(mx);
-                for (int k = sub; k < A4; k += G) rp[k] = k < A ? (T.exact ? exp_spec(rp[k] - mx) : __expf(rp[k] - mx)) : 0.0f;
+                for (int k = sub; k < A4; k += G) rp[k] = k < A ? (T.exact ? exp_spec(rp[k] - mx) : exp2_spec(rp[k] - mx)) : 0.0f;
                 AGZ_WSYNC();
                 float s = 0.0f;
                 if (lead) s = lds_ordered_sum(rp, A4, 0.0f);

@@ -101,7 +101,7 @@ __device__ __forceinline__ void rollout_reg_body(const TreePar& T, const StepFla
     constexpr int AP = G * KPL;                                  // padded row length (== T.A2)
     static_assert(KPL % 4 == 0, "block of actions per lane must be a multiple of 4");
     const GamePar& P = T.G;
-    int lane_ = lane_id();
+    int lane_ = lane_id();   // PHASE setup
     asm volatile("" : "+v"(lane_));                           // opaque per call: per-lane addresses are not hoisted out of a caller's rollout loop
     const int lane = lane_ & 63, g = lane / G, sub = lane % G;
     const int GPW = T.gpw;                                        // games of this wave (<= NG)
@@ -130,7 +130,7 @@ __device__ __forceinline__ void rollout_reg_body(const TreePar& T, const StepFla
 #endif
 
     // ---- stage the meta rows of the wave's games (coalesced) ------------------------------------------
-    uint32_t ncount = 1, leafn = 0;
+    uint32_t ncount = 1, leafn = 0;   // PHASE stage meta rows
     uint32_t* const gmeta = T.meta + (size_t)sl * V;              // every change of a meta word is written through
     if (SF.do_reset) {
         if (lead) { mymeta[0] = M_EXISTS; if (live) gmeta[0] = M_EXISTS; }
@@ -179,7 +179,7 @@ __device__ __forceinline__ void rollout_reg_body(const TreePar& T, const StepFla
     // =============================================================================================
     // expand (mcts_gpu.jl:250-302) + backUp (:306-328) of the previous rollout's leaf
     // =============================================================================================
-    if (SF.do_expand) {
+    if (SF.do_expand) {   // PHASE expand: load logits
         const int lf = (int)leafn;
         uint32_t ml = live ? mymeta[lf] : (uint32_t)M_TERM;
         const bool term = (ml & M_TERM) != 0;
@@ -202,13 +202,13 @@ __device__ __forceinline__ void rollout_reg_body(const TreePar& T, const StepFla
 #pragma unroll
                 for (int j = 0; j < KPL; ++j) x[j] = (k0 + j < A) ? src[k0 + j] : (inject ? 0.0f : -__builtin_inff());
             }
-            if (!inject) {                                            // softmax!(prior) (:417), source-order sum
+            if (!inject) {                                            // softmax!(prior) (:417), source-order sum   // PHASE expand: softmax
                 float mx = -__builtin_inff();
 #pragma unroll
                 for (int j = 0; j < KPL; ++j) mx = x[j] > mx ? x[j] : mx;
                 mx = grp_max<G>(mx);
 #pragma unroll
-                for (int j = 0; j < KPL; ++j) x[j] = (k0 + j < A) ? (exact ? exp_spec(x[j] - mx) : __expf(x[j] - mx)) : 0.0f;
+                for (int j = 0; j < KPL; ++j) x[j] = (k0 + j < A) ? (exact ? exp_spec(x[j] - mx) : exp2_spec(x[j] - mx)) : 0.0f;
                 float st0;
                 const float s = grp_ordered_sum<G, KPL>(x, sub, st0);
 #pragma unroll
@@ -218,7 +218,7 @@ __device__ __forceinline__ void rollout_reg_body(const TreePar& T, const StepFla
                     for (int j = 0; j < KPL; ++j) if (k0 + j < A) T.prior_eval[(size_t)slot * A + k0 + j] = x[j];
                 }
             }
-            bool lg[KPL]; int nl = 0;                                 // legal mask; masked priors (:260-268 / :284-290)
+            bool lg[KPL]; int nl = 0;                                 // legal mask; masked priors (:260-268 / :284-290)   // PHASE expand: legal mask + normalize sum
 #pragma unroll
             for (int j = 0; j < KPL; ++j) {
                 lg[j] = (k0 + j < A) && GM::canPlay(P, st, k0 + j);
@@ -228,7 +228,7 @@ __device__ __forceinline__ void rollout_reg_body(const TreePar& T, const StepFla
             nl = grp_sum<G>(nl);
             float st1;
             const float normalize = grp_ordered_sum<G, KPL>(x, sub, st1);
-            const bool rootmix = lf == 0 && T.training;               // :270-275 vs :277-279, :292-294
+            const bool rootmix = lf == 0 && T.training;               // :270-275 vs :277-279, :292-294   // PHASE expand: mix / divide + write row
             const float Af = (float)nl;
             uint8_t* rec = myrecs + (size_t)lf * ROWS;
             int npos = 0;
@@ -265,7 +265,7 @@ __device__ __forceinline__ void rollout_reg_body(const TreePar& T, const StepFla
         STAMP(2);
         // ---- backUp (:306-328): the group walks the path together (meta words are in LDS) and lane (i mod G) takes
         // ancestor i; the read-modify-writes of all ancestors are then issued at once, one memory latency per G levels.
-        if (live) {
+        if (live) {   // PHASE backup
             const int tv2 = (int)((ml >> M_TV_SHIFT) & 3u);
             float valf = vleaf; double vald = 0.5 * (double)tv2;
             int cur = lf; uint32_t mcur = ml;
@@ -303,7 +303,7 @@ __device__ __forceinline__ void rollout_reg_body(const TreePar& T, const StepFla
     // =============================================================================================
     // kdescendTree! (mcts_gpu.jl:100-199) + decoder (:202-223)
     // =============================================================================================
-    if (SF.do_select) {
+    if (SF.do_select) {   // PHASE select: setup
         const uint32_t gid = live ? T.game_id[slot] : 0u;
         int node = 0, depth = 0;
         uint32_t mn = live ? mymeta[0] : 0u;
@@ -314,7 +314,7 @@ __device__ __forceinline__ void rollout_reg_body(const TreePar& T, const StepFla
         int create_from = -1, create_move = 0; uint32_t create_vc = 0;
         float uq[4] = {1.0f, 1.0f, 1.0f, 1.0f};
         while (__ballot(descending)) {
-            if (descending) {
+            if (descending) {   // PHASE descent: row loads + Philox
                 if (lead) ++add_p;
                 // ---- this lane's block of the node row, straight from HBM
                 const uint8_t* rec = myrecs + (size_t)node * ROWS;
@@ -339,7 +339,7 @@ __device__ __forceinline__ void rollout_reg_body(const TreePar& T, const StepFla
                 const int uw = depth & 3;
                 const float u = uw == 0 ? uq[0] : (uw == 1 ? uq[1] : (uw == 2 ? uq[2] : uq[3]));
                 STAMP(7);
-                float alpha = 0.0f, lambda = 0.0f;
+                float alpha = 0.0f, lambda = 0.0f;   // PHASE descent: visit count, child mask, rank scatter
                 float pol[KPL];
                 if (stale) {                                               // :114
                     // :120-131.  prior_rem (the source-order sum of the priors of childless actions) and the count of positive
@@ -369,7 +369,7 @@ __device__ __forceinline__ void rollout_reg_body(const TreePar& T, const StepFla
                             if (ch != 0) { const int r = __popcll(M & ((1ull << ch) - 1ull)); tabp[r] = p[j]; tabq[r] = q[j]; }
                         }
                     }
-                    const float nf = 1.0f + (float)vs, Af = ax.y;
+                    const float nf = 1.0f + (float)vs, Af = ax.y;   // PHASE descent: lambda, alpha0
                     float prior_rem = ax.x;                                 // ordered (:122-124)
                     lambda = T.cpuct * __builtin_sqrtf(nf) / (Af + nf);    // :132
                     prior_rem *= lambda;                                    // :134
@@ -383,7 +383,7 @@ __device__ __forceinline__ void rollout_reg_body(const TreePar& T, const StepFla
                     }
                     alpha = grp_max<G>(am);
                     STAMP(8);
-                    // V > 64: children in creation order = nodes i with parent(i) == node, ascending i (:144-146); compact the
+                    // V > 64: children in creation order = nodes i with parent(i) == node, ascending i (:144-146); compact the   // PHASE descent: child compaction (V > 64)
                     // id-indexed table in place
                     AGZ_WSYNC();
                     for (int base = 1; !small && base < (int)ncount; base += 8 * G) {
@@ -409,7 +409,7 @@ __device__ __forceinline__ void rollout_reg_body(const TreePar& T, const StepFla
                         AGZ_WSYNC();
                     }
                     STAMP(9);
-                    float err = __builtin_inff();
+                    float err = __builtin_inff();   // PHASE descent: Newton
                     // element c of the Newton sums: c == 0 is the prior_rem term (S = prior_rem/alpha, g = -prior_rem/alpha^2,
                     // :142-143), c = 1..nch the children in creation order (:144-151).  With nch < G there is one element per
                     // lane; with more, blocks of G elements at a time.  Either way the ordered sums run lane to lane through DPP.
@@ -461,19 +461,19 @@ __device__ __forceinline__ void rollout_reg_body(const TreePar& T, const StepFla
                         STAMP(6);
                     }
                     STAMP(10);
-#pragma unroll
+#pragma unroll   // PHASE descent: policy row
                     for (int j = 0; j < KPL; j += 2)                       // :165-169, two exact quotients per call (agz_divpair.hpp)
                         div_pair(lambda * p[j], alpha - q[j], lambda * p[j + 1], alpha - q[j + 1], pol[j], pol[j + 1]);
                 } else {
 #pragma unroll
                     for (int j = 0; j < KPL; ++j) pol[j] = p[j];           // policy == prior since expand (:297-299)
                 }
-                if (__builtin_expect(node == 0 && SF.last, 0)) {            // copy_pol (:330-339) of the last descent
+                if (__builtin_expect(node == 0 && SF.last, 0)) {            // copy_pol (:330-339) of the last descent   // PHASE descent: copy_pol
 #pragma unroll
                     for (int j = 0; j < KPL; ++j) if (k0 + j < A) T.policy_final[(size_t)slot * A + k0 + j] = pol[j];
                 }
                 STAMP(11);
-                // ---- sample (:172-182): ordered prefix by turns, then every lane re-derives its own prefixes
+                // ---- sample (:172-182): ordered prefix by turns, then every lane re-derives its own prefixes   // PHASE descent: sampling prefix
                 float st0;
                 (void)grp_ordered_sum<G, KPL>(pol, sub, st0);
                 int jhit = KPL, jpos = -1;                                 // first j with prefix >= u ; last j <= jhit with policy > 0
@@ -498,7 +498,7 @@ __device__ __forceinline__ void rollout_reg_body(const TreePar& T, const StepFla
                 }
                 const int bestmove = cand;
                 STAMP(13);
-                if (bestmove < 0) {
+                if (bestmove < 0) {   // PHASE descent: child lookup / step
                     descending = false;                                    // reference would index [-1]; leaf = node
                 } else {
                     // child id of bestmove: the owning lane looks it up in its block
@@ -524,7 +524,7 @@ __device__ __forceinline__ void rollout_reg_body(const TreePar& T, const StepFla
             AGZ_WSYNC();
             STAMP(12);
         }
-        {   // the parent of the new child loses one childless action: its prior_rem is re-summed here, once per rollout and
+        {   // the parent of the new child loses one childless action: its prior_rem is re-summed here, once per rollout and   // PHASE prior_rem re-sum
             // at a point where the whole wave is converged, instead of at every later visit (mcts_gpu.jl:120-124)
             // (its row is re-read rather than kept in registers across the loop: the loads share the latency of the state load)
             const uint8_t* rec = myrecs + (size_t)(create_from >= 0 ? create_from : 0) * ROWS;
@@ -543,7 +543,7 @@ __device__ __forceinline__ void rollout_reg_body(const TreePar& T, const StepFla
             const float prem = grp_ordered_sum<G, KPL>(m, sub, st0);
             if (live && lead && create_from >= 0) reinterpret_cast<float*>(myaux + create_from)[0] = prem;
         }
-        if (live && create_from >= 0) {                                    // :183-191 node creation (at most one per rollout)
+        if (live && create_from >= 0) {                                    // :183-191 node creation (at most one per rollout)   // PHASE create child (play, isOver)
             const uint32_t child = ncount; ncount += 1;
             const WPos<NC> ps = grp_load_pos<NC, REV>(mystates + create_from);
             lst = GM::play(P, ps, create_move);
@@ -559,7 +559,7 @@ __device__ __forceinline__ void rollout_reg_body(const TreePar& T, const StepFla
             }
             mn = mc; node = (int)child;
         }
-        if (live) {
+        if (live) {   // PHASE leaf: isOver(root), encode planes
             if (!(mn & M_EVAL)) {                                           // root on the first rollout
                 lst = grp_load_pos<NC, REV>(mystates + node); have_state = true;
                 int rr; const bool f = GM::isOver(P, lst, rr);
@@ -622,7 +622,7 @@ __device__ __forceinline__ void rollout_reg_body(const TreePar& T, const StepFla
         }
     }
 
-    STAMP(14);
+    STAMP(14);   // PHASE bookkeeping
     // ---- bookkeeping (the meta words were written through as they changed) --------------------------
     if (live && lead) {
         T.ncount[slot] = ncount;

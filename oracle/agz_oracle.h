@@ -45,12 +45,15 @@ typedef struct {
     int A, VS, FS, ML;                                     /* maxActions, VectorizedState, FeatureSize, maxLengthGame */
 } agzo_game;
 
+typedef struct agzo_net_bf16 agzo_net_bf16;                /* weights rounded to bf16 (agzo_net_bf16_create) */
 typedef struct {                                           /* DenseNet.jl:279-286 (snetwork2), weights in Flux (out,in) column-major */
     int in, H, T, A;
     const float *W0;                                       /* H x in  */
     const float *Wres;                                     /* T blocks of H x H */
     const float *Wp, *bp;                                  /* A x H, A */
     const float *Wv, *bv;                                  /* 1 x H, 1 */
+    const agzo_net_bf16 *bf16;                             /* non-NULL: agzo_search / agzo_selfplay / agzo_duel evaluate the network
+                                                              as the product's bf16 MFMA mode does (bit-level model) */
 } agzo_net;
 
 /* ---- games ---- */
@@ -80,6 +83,13 @@ float agzo_expf(float x);
 void  agzo_encode(const agzo_game *g, const agzo_pos *p, float *planes);              /* mcts_gpu.jl:202-223 */
 void  agzo_forward(const agzo_net *net, const float *planes, float *logits, float *v); /* DenseNet.jl:294-304 */
 void  agzo_softmax(float *x, int n);                                                   /* mcts_gpu.jl:417 */
+/* the same forward as the product's bf16 MFMA kernels compute it (bit-level model of v_mfma_f32_16x16x32_bf16, see .c) */
+float agzo_mfma_dot(const uint16_t *a, const uint16_t *b, int K, float acc);          /* K multiple of 8, bf16 bit patterns */
+agzo_net_bf16 *agzo_net_bf16_create(const agzo_net *net);
+void  agzo_net_bf16_destroy(agzo_net_bf16 *n);
+void  agzo_forward_bf16(const agzo_net_bf16 *n, const float *planes, float *logits, float *v);
+float agzo_exp2_spec(float x);
+void  agzo_softmax_bf16mode(float *x, int n);
 
 /* ---- batched search (mcts_gpu.jl semantics) ---- */
 typedef struct agzo_tree agzo_tree;

@@ -34,7 +34,7 @@ class Game(C.Structure):
 class Net(C.Structure):
     _fields_ = [("inp", C.c_int), ("H", C.c_int), ("T", C.c_int), ("A", C.c_int),
                 ("W0", C.c_void_p), ("Wres", C.c_void_p), ("Wp", C.c_void_p), ("bp", C.c_void_p),
-                ("Wv", C.c_void_p), ("bv", C.c_void_p)]
+                ("Wv", C.c_void_p), ("bv", C.c_void_p), ("bf16", C.c_void_p)]
 
 
 class Samples(C.Structure):
@@ -95,6 +95,15 @@ def lib():
         L.agzo_init_weights.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6
         L.agzo_forward.argtypes = [C.POINTER(Net), C.c_void_p, C.c_void_p, C.c_void_p]
         L.agzo_softmax.argtypes = [C.c_void_p, C.c_int]
+        L.agzo_mfma_dot.restype = C.c_float
+        L.agzo_mfma_dot.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float]
+        L.agzo_net_bf16_create.restype = C.c_void_p
+        L.agzo_net_bf16_create.argtypes = [C.POINTER(Net)]
+        L.agzo_net_bf16_destroy.argtypes = [C.c_void_p]
+        L.agzo_forward_bf16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.agzo_exp2_spec.restype = C.c_float
+        L.agzo_exp2_spec.argtypes = [C.c_float]
+        L.agzo_softmax_bf16mode.argtypes = [C.c_void_p, C.c_int]
         L.agzo_encode.argtypes = [C.POINTER(Game), C.POINTER(Pos), C.c_void_p]
         L.agzo_pos_to_image.argtypes = [C.POINTER(Game), C.POINTER(Pos), C.c_void_p]
         L.agzo_pos_from_image.argtypes = [C.POINTER(Game), C.c_void_p, C.POINTER(Pos)]
@@ -177,7 +186,31 @@ class OracleNet:
 
     def _sync(self):
         self.c = Net(self.inp, self.H, self.T, self.A, _p(self.W0).value, _p(self.Wres).value,
-                     _p(self.Wp).value, _p(self.bp).value, _p(self.Wv).value, _p(self.bv).value)
+                     _p(self.Wp).value, _p(self.bp).value, _p(self.Wv).value, _p(self.bv).value, None)
+        self._prep = None
+
+    def bf16(self):
+        """The same network evaluated as the product's bf16 MFMA mode does (bit-level model): a view whose searches,
+        self-play and duels use agzo_forward_bf16 + the bf16-mode softmax."""
+        o = OracleNet.__new__(OracleNet)
+        o.__dict__.update(self.__dict__)
+        o._prep = lib().agzo_net_bf16_create(C.byref(self.c))          # (leaked at exit: test infrastructure)
+        o.c = Net(self.inp, self.H, self.T, self.A, _p(self.W0).value, _p(self.Wres).value,
+                  _p(self.Wp).value, _p(self.bp).value, _p(self.Wv).value, _p(self.bv).value, o._prep)
+        return o
+
+    def logits_bf16(self, planes):
+        """planes [n][in] -> logits [n][A], v [n] of the bf16 MFMA forward (bit-level model)."""
+        prep = self._prep or lib().agzo_net_bf16_create(C.byref(self.c))
+        planes = np.ascontiguousarray(planes, np.float32)
+        n = planes.shape[0]
+        lg = np.zeros((n, self.A), np.float32)
+        v = np.zeros(n, np.float32)
+        for i in range(n):
+            lib().agzo_forward_bf16(prep, _p(planes[i]), _p(lg[i]), C.c_void_p(v.ctypes.data + 4 * i))
+        if self._prep is None:
+            lib().agzo_net_bf16_destroy(prep)
+        return lg, v
 
     def forward(self, planes):
         """planes [n][in] -> softmaxed priors [n][A], v [n]"""
