@@ -127,6 +127,13 @@ struct TreePar {
     uint32_t* meta;
     uint32_t *ncount, *leaf, *game_id, *cnt_p, *cnt_new;
     float2* aux;             // [L][V] {prior_rem sum before lambda, count of positive priors} (register-row kernel)
+    // eager-policy kernel (agz_tree_eager.hpp)
+    uint8_t* sel;            // [L][V] {cum f32 x A2, cid u8 x A2}
+    uint32_t sel_bytes, off_cid;
+    uint4* aux4;             // [L][V] {prior_rem, -, npos | nvis << 8 | nch << 16 | lastpos << 24, -}
+    uint32_t *wl, *wl_n, *sp;   // work lists [blocks][wl_cap], their lengths [blocks], last path node per slot [L]
+    uint32_t wl_cap;
+    int32_t final_;          // this launch only closes the search (expand + backup of the last rollout): nothing is recomputed
     // network i/o
     void* planes;            // [L][INP] bf16 (or f32 when planes_f32)
     int32_t INP, planes_f32;

@@ -19,6 +19,7 @@
 #include "agz_tree.hpp"
 #include "agz_tree_grp.hpp"
 #include "agz_tree_reg.hpp"
+#include "agz_tree_eager.hpp"
 #include "agz_nn.hpp"
 #include "agz_nn_fused3.hpp"
 #include "agz_nn_wave.hpp"
@@ -99,6 +100,7 @@ struct agz_engine {
     float cpuct = 1.5f; int training = 1; uint32_t step = 0; bool need_reset = true; bool injected = false;
     uint64_t total_rollouts = 0, acc_p = 0, acc_new = 0;
     // profiling
+    bool step_last = false;    // stepwise API: the last select of the search has been launched
     bool prof_this = true; uint32_t search_seq = 0;   // whether the current search is instrumented (profiling bit 2 = sample every 4th)
     int profiling = 0;         // bit 0: HIP events around every tree-kernel launch, bit 1: around every network launch
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_tree, ev_nn;
@@ -114,6 +116,8 @@ struct agz_engine {
     int small_gpw = 0;           // games per tree wave of the 16-game variant: 0 = by batch size (AGZ_SMALL_GPW = 1, 2, 4, 8)
     small_fn k_small = nullptr; int small_maxl = 8192;   // whole-search kernel (agz_search_small.hpp) for batches up to small_maxl games (AGZ_SMALL_MAXL)
     rollout_fn k_reg3 = nullptr; int reg3_max_waves = 0;   // the 3-waves-per-SIMD build of k_reg and the largest grid it is used for
+    rollout_fn k_eager = nullptr, k_eager3 = nullptr; bool eager = false;   // eager-policy kernel (agz_tree_eager.hpp): the default
+    uint8_t* sel = nullptr; uint4* aux4 = nullptr; uint32_t *wl = nullptr, *wl_n = nullptr, *sp = nullptr; uint32_t wl_cap = 0;
     rollout_fn k_reg = nullptr; size_t reg_lds = 0; int reg_kpl = 0, reg_g = 8;   // register-row kernel (agz_tree_reg.hpp), 8 lanes per tree
     rollout_fn k_lpg = nullptr; size_t lpg_lds = 0; int grp_g = 16;   // group kernel (agz_tree_grp.hpp): G lanes per tree; lpg_lds == 0 -> wave-per-tree kernel
 
@@ -148,7 +152,7 @@ static bool bind_kernels(agz_engine* h) {
 #undef Y
     {   // register-row kernel: smallest block length KPL with 8*KPL >= A among the instantiated shapes
         const int kpl = P.A <= 32 ? 4 : (P.A <= 64 ? 8 : (P.A <= 96 ? 12 : (P.A <= 128 ? 16 : (P.A <= 192 ? 24 : 0))));
-#define Z(F, C, K) if (P.fam == F && P.NC == C && kpl == K) { h->k_reg = k_rollout_reg<F, C, 8, K, 4>; h->k_reg3 = k_rollout_reg<F, C, 8, K, 3>; h->k_small = k_search_small<F, C, K, 128, 2, 2>; h->k_small4[0] = k_search_small<F, C, K, 128, 4, 2>; h->k_small4[1] = k_search_small<F, C, K, 128, 4, 3>; h->k_small4[2] = k_search_small<F, C, K, 128, 4, 4>; h->reg_kpl = K; }
+#define Z(F, C, K) if (P.fam == F && P.NC == C && kpl == K) { h->k_reg = k_rollout_reg<F, C, 8, K, 4>; h->k_reg3 = k_rollout_reg<F, C, 8, K, 3>; h->k_eager = k_rollout_eager<F, C, K, 4>; h->k_eager3 = k_rollout_eager<F, C, K, 3>; h->k_small = k_search_small<F, C, K, 128, 2, 2>; h->k_small4[0] = k_search_small<F, C, K, 128, 4, 2>; h->k_small4[1] = k_search_small<F, C, K, 128, 4, 3>; h->k_small4[2] = k_search_small<F, C, K, 128, 4, 4>; h->reg_kpl = K; }
         Z(F_LINE, 1, 4) Z(F_LINE, 1, 8) Z(F_LINE, 2, 12) Z(F_LINE, 2, 16) Z(F_LINE, 3, 24)
         Z(F_C4, 1, 4)
         Z(F_HEX, 1, 4) Z(F_HEX, 1, 8) Z(F_HEX, 2, 8) Z(F_HEX, 2, 12) Z(F_HEX, 2, 16) Z(F_HEX, 3, 16) Z(F_HEX, 3, 24)
@@ -229,6 +233,7 @@ void agz_destroy(agz_engine* h) {
     hipFree(h->actf0); hipFree(h->actf1); hipFree(h->newpos); hipFree(h->alive); hipFree(h->newslot); hipFree(h->d_count);
     hipFree(h->s_boards); hipFree(h->s_policy); hipFree(h->s_move); hipFree(h->g_nplies); hipFree(h->g_result);
     hipFree(h->g_final); hipFree(h->d_stats); hipFree(h->d_acc); hipFree(h->scratch_f);
+    hipFree(h->sel); hipFree(h->aux4); hipFree(h->wl); hipFree(h->wl_n); hipFree(h->sp);
     free_net(h->net[0]); free_net(h->net[1]);
     for (auto& e : h->ev_tree) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto& e : h->ev_nn) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
@@ -295,7 +300,10 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     // per-lane 16-B reads (agz_tree_lpg.hpp)
     const char* tk = getenv("AGZ_TREE_KERNEL");
     const bool want_reg = h->k_reg && !(tk && (!strcmp(tk, "v1") || !strcmp(tk, "grp")));
-    h->reg_lds = want_reg ? (size_t)(64 / h->reg_g) * reg_lds_layout(h->V).stride : 0;
+    // default: the eager-policy kernel (trees of up to 128 nodes: 7-bit child ids); AGZ_TREE_KERNEL=reg|grp|v1 select the
+    // earlier generations (cross-checks)
+    h->eager = want_reg && h->k_eager && h->reg_g == 8 && h->V <= 128 && !(tk && !strcmp(tk, "reg"));
+    h->reg_lds = want_reg ? (h->eager ? (size_t)eager_lds_layout(h->V).total : (size_t)(64 / h->reg_g) * reg_lds_layout(h->V).stride) : 0;
 #ifdef AGZ_STAMPS
     if (h->reg_lds) h->reg_lds += 256;
 #endif
@@ -306,8 +314,8 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     if (((rec_bytes / 16) & 1u) == 0) rec_bytes += 16;
     h->lpg_lds = (size_t)(64 / h->grp_g) * grp_lds_layout((int)rec_bytes, (int)A2, h->V).stride;
     if (h->reg_lds) {
-        hipFuncSetAttribute((const void*)h->k_reg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->reg_lds);
-        hipFuncSetAttribute((const void*)h->k_reg3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->reg_lds);
+        hipFuncSetAttribute((const void*)(h->eager ? h->k_eager : h->k_reg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->reg_lds);
+        hipFuncSetAttribute((const void*)(h->eager ? h->k_eager3 : h->k_reg3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->reg_lds);
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) { h->reg3_max_waves = 12 * prop.multiProcessorCount; h->cus = prop.multiProcessorCount; }   // 3 waves x 4 SIMDs per CU
         const char* e3 = getenv("AGZ_REG3_MAX_WAVES");
@@ -335,6 +343,14 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     A_(dmalloc(&h->meta, Lm * V));
     A_(dmalloc(&h->ncount, Lm)); A_(dmalloc(&h->leaf, Lm)); A_(dmalloc(&h->game_id, Lm)); A_(dmalloc(&h->game_id2, Lm));
     A_(dmalloc(&h->cnt_p, Lm)); A_(dmalloc(&h->cnt_new, Lm)); A_(dmalloc(&h->node_aux, Lm * (size_t)h->V));
+    const uint32_t sel_bytes = A2 * 5;                            // [cum f32 x A2][cid u8 x A2]; A2 is a multiple of 32 here
+    size_t wl_blocks = 0;
+    if (h->eager) {
+        h->wl_cap = (uint32_t)(8 * h->V);
+        wl_blocks = std::max((size_t)(h->Lmax / 8 + 64), (size_t)(8 * std::max(h->cus, 256)));   // sparse waves: up to 8 cus one-game blocks
+        A_(dmalloc(&h->sel, Lm * V * sel_bytes)); A_(dmalloc(&h->aux4, Lm * V));
+        A_(dmalloc(&h->wl, wl_blocks * h->wl_cap)); A_(dmalloc(&h->wl_n, wl_blocks)); A_(dmalloc(&h->sp, Lm));
+    }
     if (cfg->nn_mode == AGZ_NN_BF16) { uint16_t* p = nullptr; A_(dmalloc(&p, Lm * h->INP)); h->planes = p; }
     else { float* p = nullptr; A_(dmalloc(&p, Lm * h->INP)); h->planes = p; }
     A_(dmalloc(&h->logits, Lm * h->LGS));
@@ -364,6 +380,8 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     T.cnt_p = h->cnt_p; T.cnt_new = h->cnt_new; T.aux = h->node_aux; T.planes = h->planes; T.INP = h->INP; T.planes_f32 = cfg->nn_mode == AGZ_NN_EXACT;
     T.logits = h->logits; T.LGS = h->LGS; T.prior_eval = h->prior_eval; T.v_eval = h->v_eval; T.policy_final = h->policy_final;
     T.seed = cfg->seed; T.exact = cfg->nn_mode == AGZ_NN_EXACT;
+    T.sel = h->sel; T.sel_bytes = sel_bytes; T.off_cid = A2 * 4; T.aux4 = h->aux4; T.wl = h->wl; T.wl_n = h->wl_n; T.sp = h->sp; T.wl_cap = h->wl_cap;
+    if (h->eager) { hipMemsetAsync(h->wl_n, 0, wl_blocks * 4, h->stream); hipMemsetAsync(h->sp, 0, Lm * 4, h->stream); }
 #ifdef AGZ_STAMPS
     { unsigned long long* d = nullptr; hipMalloc((void**)&d, (size_t)65536 * 16 * 8); hipMemset(d, 0, (size_t)65536 * 16 * 8); T.dbg = d; }
 #endif
@@ -602,7 +620,7 @@ static void drain_events(agz_engine* h) {     // stream must be idle
 }
 
 static int launch_rollout(agz_engine* h, uint32_t rollout, int do_reset, int do_expand, int do_select, int last, int inject, int capture,
-                          int s0 = 0, int s1 = -1, hipStream_t stream = nullptr) {
+                          int s0 = 0, int s1 = -1, hipStream_t stream = nullptr, int final_ = 0) {
     if (h->L == 0) return AGZ_OK;
     if (s1 < 0) s1 = h->L;
     if (!stream) stream = h->stream;
@@ -610,13 +628,15 @@ static int launch_rollout(agz_engine* h, uint32_t rollout, int do_reset, int do_
     TreePar T = h->tp;
     T.L = s1; T.slot0 = s0; T.gpw = h->reg_lds ? 64 / h->reg_g : 0; T.step = h->step; T.rollout = rollout; T.cpuct = h->cpuct; T.training = h->training;
     T.do_reset = do_reset; T.do_expand = do_expand; T.do_select = do_select; T.last = last; T.inject = inject; T.capture = capture;
+    T.final_ = final_;
     const bool reg = h->reg_lds != 0, lpg = !reg && h->lpg_lds != 0;
     const int ng = reg ? 64 / h->reg_g : 64 / h->grp_g;
     if (!reg && s0 != 0) { h->fail("sub-batches need the register-row kernel"); return AGZ_ERR_STATE; }
     dim3 grid((unsigned)((reg || lpg) ? (n + ng - 1) / ng : (n + 3) / 4)), block((reg || lpg) ? 64 : 256);
     std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
     if ((h->profiling & 1) && h->prof_this) { ev = next_events(h, h->ev_tree, h->ev_tree_used); hipEventRecord(ev->first, stream); }
-    hipLaunchKernelGGL(reg ? ((int)grid.x <= h->reg3_max_waves ? h->k_reg3 : h->k_reg) : (lpg ? h->k_lpg : h->k_roll), grid, block, reg ? h->reg_lds : (lpg ? h->lpg_lds : 0), stream, T);
+    const rollout_fn k4 = h->eager ? h->k_eager : h->k_reg, k3 = h->eager ? h->k_eager3 : h->k_reg3;
+    hipLaunchKernelGGL(reg ? ((int)grid.x <= h->reg3_max_waves ? k3 : k4) : (lpg ? h->k_lpg : h->k_roll), grid, block, reg ? h->reg_lds : (lpg ? h->lpg_lds : 0), stream, T);
     if (ev) hipEventRecord(ev->second, stream);
     h->cnt_live = true;
     HIPCHK(h, hipGetLastError());
@@ -737,7 +757,7 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
     {   // every game resident at once (<= 128 per CU): the whole search in one launch (agz_search_small.hpp); profiling bit 0
         // then times that launch (it counts as one "tree launch" of agz_get_kernel_times)
         DevNet& n = h->net[which];
-        if (h->k_small && h->reg_lds != 0 && h->reg_g == 8 && h->cfg.nn_mode == AGZ_NN_BF16 && n.H == 128 && n.w16w && h->L > 0 &&
+        if (h->k_small && h->reg_lds != 0 && h->eager && h->cfg.nn_mode == AGZ_NN_BF16 && n.H == 128 && n.w16w && h->L > 0 &&
             h->V <= 64 && (h->V & 3) == 0 && h->reg_g * h->reg_kpl <= h->LGS &&   // the lean build of the tree step (rollout_reg_body<..., LEAN>)
             h->L <= std::min(std::max(h->small_maxl, h->small4_maxl), 128 * h->cus) && !getenv("AGZ_NO_FUSED_NN")) {
             // 16 games per workgroup up to small_maxl; beyond, 32 games per workgroup with the loosest register budget that still
@@ -784,7 +804,7 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
         if (K < 1) K = 1;
     }
     const int chunk = ((h->L + K - 1) / K + 127) / 128 * 128;
-    { char b[160]; snprintf(b, sizeof b, "%s (one launch per rollout, %d sub-batch chain%s)", h->reg_lds ? "k_rollout_reg<G=8>" : (h->lpg_lds ? "k_rollout_grp" : "k_rollout"), K, K > 1 ? "s" : "");
+    { char b[160]; snprintf(b, sizeof b, "%s (one launch per rollout, %d sub-batch chain%s)", h->reg_lds ? (h->eager ? "k_rollout_eager" : "k_rollout_reg<G=8>") : (h->lpg_lds ? "k_rollout_grp" : "k_rollout"), K, K > 1 ? "s" : "");
       h->form_tree = b; }
     if (K > 1) HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
     for (int c = 1; c < K; ++c) if (c * chunk < h->L) HIPCHK(h, hipStreamWaitEvent(h->aux[c - 1], h->ev_fork, 0));
@@ -797,7 +817,7 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
                 rc = launch_rollout(h, (uint32_t)k, k == 0, k > 0, 1, k == V - 1, 0, 0, s0, s1, st); if (rc) return rc;
                 rc = launch_network(h, which, s0, s1, st); if (rc) return rc;
             } else {
-                rc = launch_rollout(h, (uint32_t)V, 0, 1, 0, 0, 0, 0, s0, s1, st); if (rc) return rc;
+                rc = launch_rollout(h, (uint32_t)V, 0, 1, 0, 0, 0, 0, s0, s1, st, 1); if (rc) return rc;
             }
         }
     }
@@ -814,14 +834,14 @@ int agz_search(agz_engine* h, int V, float cpuct, int training, uint32_t step) {
 // ---- stepwise (teacher-forced parity) ---------------------------------------------------------------
 int agz_search_begin(agz_engine* h, float cpuct, int training, uint32_t step) {
     if (!h) return AGZ_ERR_ARG;
-    h->cpuct = cpuct; h->training = training; h->step = step; h->need_reset = true; h->injected = false;
+    h->cpuct = cpuct; h->training = training; h->step = step; h->need_reset = true; h->injected = false; h->step_last = false;
     return AGZ_OK;
 }
 int agz_rollout_select(agz_engine* h, uint32_t rollout, int last) {
     if (!h) return AGZ_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     int rc = launch_rollout(h, rollout, h->need_reset ? 1 : 0, 0, 1, last, 0, 0);
-    h->need_reset = false;
+    h->need_reset = false; h->step_last = last != 0;
     return rc;
 }
 int agz_rollout_eval(agz_engine* h) {
@@ -867,7 +887,9 @@ int agz_rollout_expand_backup(agz_engine* h) {
     HIPCHK(h, hipSetDevice(h->cfg.device));
     h->injected = false;
     h->total_rollouts += (uint64_t)h->L;
-    return launch_rollout(h, 0, 0, 1, 0, 0, 1, 0);
+    // eager kernel: the backup recomputes the rows the next descent samples from and keeps policy_final = the root's row as of
+    // now (copy_pol :330-339 reads it at the start of the last rollout); after the last select nothing is recomputed any more
+    return launch_rollout(h, 0, 0, 1, 0, 1, 1, 0, 0, -1, nullptr, h->step_last ? 1 : 0);
 }
 int agz_search_end(agz_engine* h) {
     if (!h) return AGZ_ERR_ARG;

@@ -3,11 +3,11 @@
 //
 // With < ~2000 games every launch is bound by its own dependency chain, and a rollout pays two kernel boundaries
 // (dispatch, ramp-up, drain, the round trip of planes / logits through L2).  Here a 4-wave workgroup owns 16 games for the
-// whole search: waves 0-1 run the register-row tree step (rollout_reg_body, 8 games each), a workgroup barrier hands the
+// whole search: waves 0-1 run the eager-policy tree step (rollout_eager_body, 8 games each), a workgroup barrier hands the
 // 16 leaves to all four waves for the network forward (mlp_wave_body), a second barrier hands logits and values back.
 // The two bodies are the very functions the stand-alone kernels run — same arithmetic, same bits (tested).
 #pragma once
-#include "agz_tree_reg.hpp"
+#include "agz_tree_eager.hpp"
 #include "agz_nn_wave.hpp"
 
 namespace agz {
@@ -31,17 +31,23 @@ __global__ __launch_bounds__(64 * NW_WAVES, WV) void k_search_small(const SmallP
     uint8_t* const nn_lds = lds_small;                            // the two phases never overlap and the tree step keeps nothing
                                                                   // in LDS from one rollout to the next: same memory
     for (int k = 0; k <= S.V; ++k) {
-        const StepFlags SF = {(uint32_t)k, k == 0, k > 0, k < S.V, k == S.V - 1};
+        const StepFlags SF = {(uint32_t)k, k == 0, k > 0, k < S.V, k == S.V - 1, k == S.V};
         // the workgroup index is made opaque once per rollout: otherwise every per-game address of both bodies is hoisted out
         // of this loop and kept alive across them (hundreds of registers, spills)
         int bx = (int)blockIdx.x;
         asm volatile("" : "+s"(bx));
-        if (wave < TW) rollout_reg_body<FAM, NC, 8, KPL, true>(S.T, SF, tree_lds, bx * TW + wave);
+        if (wave < TW) rollout_eager_body<FAM, NC, KPL, true>(S.T, SF, tree_lds, bx * TW + wave);
+#ifdef AGZ_STAMPS
+        const unsigned long long t_nn0 = __builtin_amdgcn_s_memtime();
+#endif
         if (k < S.V) {
             // (the barrier that publishes the planes of the leaves sits inside, after the first weight fragments are requested)
             mlp_wave_body<H, TW / 2, 2, true>(S.F, nn_lds, bx);
             __syncthreads();                                      // logits and values are visible to the tree waves
         }
+#ifdef AGZ_STAMPS
+        if ((threadIdx.x & 63) == 0 && wave < TW && S.T.dbg) S.T.dbg[(size_t)(bx * TW + wave) * 16 + 15] += __builtin_amdgcn_s_memtime() - t_nn0;
+#endif
     }
 }
 

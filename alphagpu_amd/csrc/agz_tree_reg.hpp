@@ -77,7 +77,7 @@ __host__ __device__ inline RegLds reg_lds_layout(int V) {
 // resident; 3 (no spills) is faster as soon as the launch fits 3 waves per SIMD.
 // what changes from rollout to rollout (kept apart from TreePar so that a caller looping over rollouts — k_search_small —
 // can leave the big parameter block in constant kernel-argument memory)
-struct StepFlags { uint32_t rollout; int do_reset, do_expand, do_select, last; };
+struct StepFlags { uint32_t rollout; int do_reset, do_expand, do_select, last, fin = 0; };   // fin: the launch only closes the search (eager kernel)
 
 // LEAN: the caller guarantees V <= 64, V % 4 == 0, bf16 network mode and no inject / capture (k_search_small): the code for
 // larger trees, odd tree sizes, the exact mode and the teacher-forcing hooks is compiled out — 3-5 % faster (less code in the instruction cache).

@@ -27,14 +27,20 @@ def phase_of(line, ph):
     return name
 
 
+BODY, SRC = "rollout_eager_body", "agz_tree_eager.hpp"
+
+
 def main():
+    global BODY, SRC
     d = json.load(open(sys.argv[1]))
-    ph = load_phases(sys.argv[2] if len(sys.argv) > 2 else "alphagpu_amd/csrc/agz_tree_reg.hpp")
+    if len(sys.argv) > 2 and sys.argv[2] == "reg":
+        BODY, SRC = "rollout_reg_body", "agz_tree_reg.hpp"
+    ph = load_phases("alphagpu_amd/csrc/" + SRC)
     tab = collections.defaultdict(collections.Counter)
     for x in d["ins"]:
         body = None
         for fn, f, ln in x["frames"]:
-            if "rollout_reg_body" in fn and f == "agz_tree_reg.hpp":
+            if BODY in fn and f == SRC:
                 body = ln
         if body is None:
             if any("mlp_wave_body" in fn for fn, _, _ in x["frames"]):
