@@ -75,10 +75,10 @@ AGZ_HD float exp_spec(float x) {
 }
 // exp of the bf16-mode softmax (argument <= 0): 2^(x log2 e) from a degree-6 polynomial on the fraction and an exact scaling
 // (v_ldexp_f32).  13 instructions; unlike v_exp_f32 it is a DEFINITION that a CPU restatement can follow, so the bf16
-// mode is reproducible bit for bit.  2^t with t < -125 is 0.
+// mode is reproducible bit for bit.  2^t with t < -60 is 0: a softmax numerator is 0 or at least 2^-61 (agz_fastdiv.hpp relies on it).
 AGZ_HD float exp2_spec(float x) {
     const float t = x * 1.44269504088896341f;
-    if (!(t >= -125.0f)) return 0.0f;
+    if (!(t >= -60.0f)) return 0.0f;
     const float n = __builtin_rintf(t), f = t - n;
     float p = 1.5403530393381609e-4f;
     p = fma_rn(p, f, 1.3333558146428443e-3f);
@@ -101,9 +101,9 @@ AGZ_HD float sigmoid_spec(float x) {      // NNlib sigma (DenseNet.jl:197, :301)
 // ---------------------------------------------------------------------------------------------------
 // Tree layout in HBM (per slot = one game tree, one wavefront works on it):
 //   meta  [L][V]   u32   : node word  (parent | action<<8 | flags<<16)            256 B/slot at V=64
-//   recs  [L][V]   rec   : [prior f32 x A2][q f32 x A2][vc u16 x A2] padded to 64 B; vc = visits | child<<8
+//   recs  [L][V]   rec   : [prior f32 x A2][q f32 x A2][rank u8 x A2][cid u8 x A2][vis u8 x A2]   (agz_tree_eager.hpp)
 //   states[L][V]   Pos   : 80 B positions
-// A2 = A rounded up to even.  Node 0 is the root.  No array is ever re-zeroed: a record is fully written
+// A2 = 8 lanes x KPL actions >= A.  Node 0 is the root.  No array is ever re-zeroed: a record is fully written
 // when its node is expanded and only read while the node's EXPANDED bit is set.
 // ---------------------------------------------------------------------------------------------------
 enum : uint32_t {
@@ -118,21 +118,18 @@ enum : uint32_t {
 struct TreePar {
     GamePar G;
     int32_t L, V;            // L = END of the slot range [slot0, L) of this launch
-    int32_t slot0;           // first slot (register-row kernel only: sub-batches on parallel streams)
-    int32_t gpw;             // games per wave of the register-row kernel (<= 64/G; fewer = sparse waves for small batches: the
+    int32_t slot0;           // first slot (sub-batches on parallel streams)
+    int32_t gpw;             // games per wave (<= 8; fewer = sparse waves for small batches: the
                              // time of a rollout is the deepest descent among the games that share a wave / workgroup)
-    uint32_t rec_bytes, off_q, off_vc, A2;
+    uint32_t rec_bytes, off_q, off_vis, A2;
     uint8_t* recs;
     Pos* states;
     uint32_t* meta;
     uint32_t *ncount, *leaf, *game_id, *cnt_p, *cnt_new;
-    float2* aux;             // [L][V] {prior_rem sum before lambda, count of positive priors} (register-row kernel)
-    // eager-policy kernel (agz_tree_eager.hpp)
-    uint8_t* sel;            // [L][V] {cum f32 x A2, cid u8 x A2}
-    uint32_t sel_bytes, off_cid;
-    uint4* aux4;             // [L][V] {prior_rem, -, npos | nvis << 8 | nch << 16 | lastpos << 24, -}
+    uint4* aux4;             // [L][V] {prior_rem before lambda, next word (action | child << 8 | valid), npos | nvis << 8 | nch << 16, -}
     uint32_t *wl, *wl_n, *sp;   // work lists [blocks][wl_cap], their lengths [blocks], last path node per slot [L]
     uint32_t wl_cap;
+    int32_t fastdiv;         // operands of the tree's divisions are inside agz_fastdiv.hpp's range (bf16 mode, cpuct in [2^-10, 2^10])
     int32_t final_;          // this launch only closes the search (expand + backup of the last rollout): nothing is recomputed
     // network i/o
     void* planes;            // [L][INP] bf16 (or f32 when planes_f32)

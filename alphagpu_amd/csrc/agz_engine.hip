@@ -16,9 +16,8 @@
 #include "../../include/agz.h"
 #include "agz_games.hpp"
 #include "agz_device.hpp"
-#include "agz_tree.hpp"
-#include "agz_tree_grp.hpp"
-#include "agz_tree_reg.hpp"
+#include "agz_wave.hpp"
+#include "agz_small_kernels.hpp"
 #include "agz_tree_eager.hpp"
 #include "agz_nn.hpp"
 #include "agz_nn_fused3.hpp"
@@ -75,12 +74,11 @@ struct agz_engine {
     int nn_wave_lt = 0;                 // 16-leaf tiles per workgroup of that kernel: 0 = by batch size (AGZ_NN_WAVE_LT = 1, 2, 4, 8)
     int nn_wave_maxl = 1 << 30;         // batches up to this size use agz_nn_wave.hpp, larger ones k_mlp_fused3 (AGZ_NN_WAVE_MAXL); the wave kernel wins at every size measured
     int L = 0;                 // active slots
-    int Lmax = 0, V = 0, NRV = 1;
+    int Lmax = 0, V = 0;
     TreePar tp;                // template of kernel arguments
     // tree memory
     uint8_t* recs = nullptr; Pos* states = nullptr; uint32_t* meta = nullptr;
     uint32_t *ncount = nullptr, *leaf = nullptr, *game_id = nullptr, *game_id2 = nullptr, *cnt_p = nullptr, *cnt_new = nullptr;
-    float2* node_aux = nullptr;
     // network i/o
     void* planes = nullptr; float* logits = nullptr; float *prior_eval = nullptr, *v_eval = nullptr, *policy_final = nullptr;
     uint16_t *act0 = nullptr, *act1 = nullptr; float *actf0 = nullptr, *actf1 = nullptr;
@@ -107,7 +105,7 @@ struct agz_engine {
     size_t ev_tree_used = 0, ev_nn_used = 0;
     double tree_ms = 0, nn_ms = 0, tree_busy_ms = 0; int64_t tree_launches = 0;
     hipEvent_t ev_ref = nullptr; bool ev_ref_live = false;
-    rollout_fn k_roll = nullptr; advance_fn k_adv = nullptr; softmax_fn k_soft = nullptr;
+    advance_fn k_adv = nullptr; softmax_fn k_soft = nullptr;
     small_fn k_small4[3] = {nullptr, nullptr, nullptr};   // the same with 32 games per workgroup, register budgets for 2 / 3 / 4 workgroups per SIMD set
     std::string form_tree, form_nn;   // kernels of the last search (agz_get_search_form)
     int small4_occ = -1;         // >= 0: force the register budget k_small4[occ] (AGZ_SMALL4_OCC = 0, 1, 2)
@@ -115,11 +113,11 @@ struct agz_engine {
     int cus = 256;
     int small_gpw = 0;           // games per tree wave of the 16-game variant: 0 = by batch size (AGZ_SMALL_GPW = 1, 2, 4, 8)
     small_fn k_small = nullptr; int small_maxl = 8192;   // whole-search kernel (agz_search_small.hpp) for batches up to small_maxl games (AGZ_SMALL_MAXL)
-    rollout_fn k_reg3 = nullptr; int reg3_max_waves = 0;   // the 3-waves-per-SIMD build of k_reg and the largest grid it is used for
-    rollout_fn k_eager = nullptr, k_eager3 = nullptr; bool eager = false;   // eager-policy kernel (agz_tree_eager.hpp): the default
-    uint8_t* sel = nullptr; uint4* aux4 = nullptr; uint32_t *wl = nullptr, *wl_n = nullptr, *sp = nullptr; uint32_t wl_cap = 0;
-    rollout_fn k_reg = nullptr; size_t reg_lds = 0; int reg_kpl = 0, reg_g = 8;   // register-row kernel (agz_tree_reg.hpp), 8 lanes per tree
-    rollout_fn k_lpg = nullptr; size_t lpg_lds = 0; int grp_g = 16;   // group kernel (agz_tree_grp.hpp): G lanes per tree; lpg_lds == 0 -> wave-per-tree kernel
+    int reg3_max_waves = 0;      // largest grid the 3-waves-per-SIMD build of the stand-alone tree kernel is used for
+    rollout_fn k_eager = nullptr, k_eager3 = nullptr;   // the tree kernel (agz_tree_eager.hpp), register budgets for 4 / 3 waves per SIMD
+    uint4* aux4 = nullptr; uint32_t *wl = nullptr, *wl_n = nullptr, *sp = nullptr; uint32_t wl_cap = 0;
+    size_t reg_lds = 0; int reg_kpl = 0;   // LDS of one tree wave; actions per lane (8 lanes per tree)
+    uint32_t step_rollout = 0;   // stepwise API: rollout index of the last select
 
     int fail(const char* fmt, ...) {
         char buf[512]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
@@ -128,13 +126,8 @@ struct agz_engine {
 };
 
 // ---- kernel dispatch tables -------------------------------------------------------------------------
-template <int FAM, int NR, int NC> static rollout_fn pick_rollout(int NRV) {
-    switch (NRV) {
-    case 1: return k_rollout<FAM, NR, NC, 1>;
-    case 2: return k_rollout<FAM, NR, NC, 2>;
-    default: return k_rollout<FAM, NR, NC, 4>;
-    }
-}
+// game shapes: (family, 64-bit words of a row of the board, 64-bit chunks of a bitboard) for the ply kernel; (family, chunks,
+// actions per lane) for the tree kernels (agz_search_small.hpp AGZ_SMALL_SHAPES lists the same shapes for the whole-search form)
 #define AGZ_COMBOS(X) \
     X(F_LINE, 1, 1) X(F_LINE, 2, 2) X(F_LINE, 3, 3) X(F_C4, 1, 1) \
     X(F_HEX, 1, 1) X(F_HEX, 1, 2) X(F_HEX, 2, 2) X(F_HEX, 2, 3) X(F_HEX, 3, 3) \
@@ -142,28 +135,18 @@ template <int FAM, int NR, int NC> static rollout_fn pick_rollout(int NRV) {
 
 static bool bind_kernels(agz_engine* h) {
     const GamePar& P = h->G;
-#define X(F, R, C) \
-    if (P.fam == F && P.NR == R && P.NC == C) { h->k_roll = pick_rollout<F, R, C>(h->NRV); h->k_adv = k_advance<F, R, C>; }
+#define X(F, R, C) if (P.fam == F && P.NR == R && P.NC == C) h->k_adv = k_advance<F, R, C>;
     AGZ_COMBOS(X)
 #undef X
-    { const char* eg = getenv("AGZ_TREE_G"); if (eg) h->grp_g = atoi(eg); if (h->grp_g != 2 && h->grp_g != 4 && h->grp_g != 8) h->grp_g = 16; }
-#define Y(F, C) if (P.fam == F && P.NC == C) h->k_lpg = h->grp_g == 2 ? k_rollout_grp<F, C, 2> : (h->grp_g == 4 ? k_rollout_grp<F, C, 4> : (h->grp_g == 16 ? k_rollout_grp<F, C, 16> : k_rollout_grp<F, C, 8>));
-    Y(F_LINE, 1) Y(F_LINE, 2) Y(F_LINE, 3) Y(F_C4, 1) Y(F_HEX, 1) Y(F_HEX, 2) Y(F_HEX, 3) Y(F_REV, 1)
-#undef Y
-    {   // register-row kernel: smallest block length KPL with 8*KPL >= A among the instantiated shapes
-        const int kpl = P.A <= 32 ? 4 : (P.A <= 64 ? 8 : (P.A <= 96 ? 12 : (P.A <= 128 ? 16 : (P.A <= 192 ? 24 : 0))));
-#define Z(F, C, K) if (P.fam == F && P.NC == C && kpl == K) { h->k_reg = k_rollout_reg<F, C, 8, K, 4>; h->k_reg3 = k_rollout_reg<F, C, 8, K, 3>; h->k_eager = k_rollout_eager<F, C, K, 4>; h->k_eager3 = k_rollout_eager<F, C, K, 3>; h->k_small = k_search_small<F, C, K, 128, 2, 2>; h->k_small4[0] = k_search_small<F, C, K, 128, 4, 2>; h->k_small4[1] = k_search_small<F, C, K, 128, 4, 3>; h->k_small4[2] = k_search_small<F, C, K, 128, 4, 4>; h->reg_kpl = K; }
-        Z(F_LINE, 1, 4) Z(F_LINE, 1, 8) Z(F_LINE, 2, 12) Z(F_LINE, 2, 16) Z(F_LINE, 3, 24)
-        Z(F_C4, 1, 4)
-        Z(F_HEX, 1, 4) Z(F_HEX, 1, 8) Z(F_HEX, 2, 8) Z(F_HEX, 2, 12) Z(F_HEX, 2, 16) Z(F_HEX, 3, 16) Z(F_HEX, 3, 24)
-        Z(F_REV, 1, 12) Z(F_REV, 1, 8)
+    // smallest block length KPL with 8*KPL >= A among the instantiated shapes
+    const int kpl = P.A <= 32 ? 4 : (P.A <= 64 ? 8 : (P.A <= 96 ? 12 : (P.A <= 128 ? 16 : (P.A <= 192 ? 24 : 0))));
+#define Z(F, C, K) if (P.fam == F && P.NC == C && kpl == K) { h->k_eager = k_rollout_eager<F, C, K, 4>; h->k_eager3 = k_rollout_eager<F, C, K, 3>; \
+        h->k_small = k_search_small<F, C, K, 128, 2, 2>; h->k_small4[0] = k_search_small<F, C, K, 128, 4, 2>; h->k_small4[1] = k_search_small<F, C, K, 128, 4, 3>; \
+        h->k_small4[2] = k_search_small<F, C, K, 128, 4, 4>; h->reg_kpl = K; }
+    AGZ_SMALL_SHAPES(Z)
 #undef Z
-        { const char* eg = getenv("AGZ_REG_G");     // experiment: 4 lanes per tree (Gobang 9x9 / Hex 9x9 shapes only)
-          if (eg && atoi(eg) == 4 && P.fam == F_LINE && P.NC == 2 && kpl == 12) { h->k_reg = h->k_reg3 = k_rollout_reg<F_LINE, 2, 4, 24>; h->k_small = h->k_small4[0] = h->k_small4[1] = h->k_small4[2] = nullptr; h->reg_kpl = 24; h->reg_g = 4; }
-          if (eg && atoi(eg) == 16 && P.fam == F_LINE && P.NC == 2 && kpl == 12) { h->k_reg = h->k_reg3 = k_rollout_reg<F_LINE, 2, 16, 8>; h->k_small = h->k_small4[0] = h->k_small4[1] = h->k_small4[2] = nullptr; h->reg_kpl = 8; h->reg_g = 16; } }
-    }
     if (P.NR == 1) h->k_soft = k_softmax<1>; else if (P.NR == 2) h->k_soft = k_softmax<2>; else h->k_soft = k_softmax<3>;
-    return h->k_roll != nullptr;
+    return h->k_adv != nullptr && h->k_eager != nullptr;
 }
 
 // ---- helpers ----------------------------------------------------------------------------------------
@@ -228,12 +211,12 @@ void agz_destroy(agz_engine* h) {
     hipSetDevice(h->cfg.device);
     if (h->stream) hipStreamSynchronize(h->stream);
     hipFree(h->recs); hipFree(h->states); hipFree(h->meta); hipFree(h->ncount); hipFree(h->leaf); hipFree(h->game_id);
-    hipFree(h->game_id2); hipFree(h->cnt_p); hipFree(h->cnt_new); hipFree(h->node_aux); hipFree(h->planes); hipFree(h->logits);
+    hipFree(h->game_id2); hipFree(h->cnt_p); hipFree(h->cnt_new); hipFree(h->planes); hipFree(h->logits);
     hipFree(h->prior_eval); hipFree(h->v_eval); hipFree(h->policy_final); hipFree(h->act0); hipFree(h->act1);
     hipFree(h->actf0); hipFree(h->actf1); hipFree(h->newpos); hipFree(h->alive); hipFree(h->newslot); hipFree(h->d_count);
     hipFree(h->s_boards); hipFree(h->s_policy); hipFree(h->s_move); hipFree(h->g_nplies); hipFree(h->g_result);
     hipFree(h->g_final); hipFree(h->d_stats); hipFree(h->d_acc); hipFree(h->scratch_f);
-    hipFree(h->sel); hipFree(h->aux4); hipFree(h->wl); hipFree(h->wl_n); hipFree(h->sp);
+    hipFree(h->aux4); hipFree(h->wl); hipFree(h->wl_n); hipFree(h->sp);
     free_net(h->net[0]); free_net(h->net[1]);
     for (auto& e : h->ev_tree) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto& e : h->ev_nn) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
@@ -277,7 +260,6 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     }
     const GamePar& P = h->G;
     h->Lmax = cfg->max_games; h->V = cfg->max_visits;
-    h->NRV = h->V <= 64 ? 1 : (h->V <= 128 ? 2 : 4);
     if (!bind_kernels(h)) { h->fail("no kernel instantiation for this game shape"); return bail(AGZ_ERR_UNSUPPORTED); }
     hipFuncSetAttribute((const void*)k_mlp_wave<128, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)k_mlp_wave<128, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -295,27 +277,17 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     hipFuncSetAttribute((const void*)k_layer_exact<EX_VALUE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)k_mlp_fused3<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)k_mlp_fused3<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    // node record: [prior f32 x A2][q f32 x A2][vc u16 x A2], A2 = A rounded up to 4 (16-B aligned sub-arrays);
-    // the record size is an ODD multiple of 16 B so that the LDS image of 64 records is bank-conflict free for
-    // per-lane 16-B reads (agz_tree_lpg.hpp)
-    const char* tk = getenv("AGZ_TREE_KERNEL");
-    const bool want_reg = h->k_reg && !(tk && (!strcmp(tk, "v1") || !strcmp(tk, "grp")));
-    // default: the eager-policy kernel (trees of up to 128 nodes: 7-bit child ids); AGZ_TREE_KERNEL=reg|grp|v1 select the
-    // earlier generations (cross-checks)
-    h->eager = want_reg && h->k_eager && h->reg_g == 8 && h->V <= 128 && !(tk && !strcmp(tk, "reg"));
-    h->reg_lds = want_reg ? (h->eager ? (size_t)eager_lds_layout(h->V).total : (size_t)(64 / h->reg_g) * reg_lds_layout(h->V).stride) : 0;
+    // node record: [prior f32 x A2][q f32 x A2][rank u8 x A2][cid u8 x A2][vis u8 x A2], A2 = 8 lanes x KPL actions
+    // (agz_tree_eager.hpp)
+    h->reg_lds = (size_t)eager_lds_layout(h->V).total;
 #ifdef AGZ_STAMPS
-    if (h->reg_lds) h->reg_lds += 256;
+    h->reg_lds += 256;
 #endif
-    if (h->reg_lds > 160 * 1024) h->reg_lds = 0;
-    // row length: the register-row kernel gives each of its 8 lanes a block of KPL actions
-    const uint32_t A2 = h->reg_lds ? (uint32_t)(h->reg_g * h->reg_kpl) : (uint32_t)round_up(P.A, 4);
-    uint32_t rec_bytes = (uint32_t)round_up((int)(A2 * 10), 16);
-    if (((rec_bytes / 16) & 1u) == 0) rec_bytes += 16;
-    h->lpg_lds = (size_t)(64 / h->grp_g) * grp_lds_layout((int)rec_bytes, (int)A2, h->V).stride;
-    if (h->reg_lds) {
-        hipFuncSetAttribute((const void*)(h->eager ? h->k_eager : h->k_reg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->reg_lds);
-        hipFuncSetAttribute((const void*)(h->eager ? h->k_eager3 : h->k_reg3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->reg_lds);
+    const uint32_t A2 = (uint32_t)(8 * h->reg_kpl);
+    const uint32_t rec_bytes = (uint32_t)eager_rec_bytes((int)A2);
+    {
+        hipFuncSetAttribute((const void*)h->k_eager, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->reg_lds);
+        hipFuncSetAttribute((const void*)h->k_eager3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->reg_lds);
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) { h->reg3_max_waves = 12 * prop.multiProcessorCount; h->cus = prop.multiProcessorCount; }   // 3 waves x 4 SIMDs per CU
         const char* e3 = getenv("AGZ_REG3_MAX_WAVES");
@@ -331,8 +303,6 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
         if (h->k_small) hipFuncSetAttribute((const void*)h->k_small, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         for (int i = 0; i < 3; ++i) if (h->k_small4[i]) hipFuncSetAttribute((const void*)h->k_small4[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
-    if (h->reg_lds || !h->k_lpg || h->lpg_lds > 64 * 1024 /* LDS-DMA destination offsets are 16 bit */ || (tk && !strcmp(tk, "v1"))) h->lpg_lds = 0;
-    if (h->lpg_lds) hipFuncSetAttribute((const void*)h->k_lpg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lpg_lds);
     const size_t Lm = (size_t)h->Lmax, V = (size_t)h->V;
     h->INP = round_up(2 * P.VS, 32);
     h->LGS = round_up(P.A + 1, 32);
@@ -342,13 +312,12 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     A_(dmalloc(&h->states, Lm * V));
     A_(dmalloc(&h->meta, Lm * V));
     A_(dmalloc(&h->ncount, Lm)); A_(dmalloc(&h->leaf, Lm)); A_(dmalloc(&h->game_id, Lm)); A_(dmalloc(&h->game_id2, Lm));
-    A_(dmalloc(&h->cnt_p, Lm)); A_(dmalloc(&h->cnt_new, Lm)); A_(dmalloc(&h->node_aux, Lm * (size_t)h->V));
-    const uint32_t sel_bytes = A2 * 5;                            // [cum f32 x A2][cid u8 x A2]; A2 is a multiple of 32 here
+    A_(dmalloc(&h->cnt_p, Lm)); A_(dmalloc(&h->cnt_new, Lm));
     size_t wl_blocks = 0;
-    if (h->eager) {
+    {
         h->wl_cap = (uint32_t)(8 * h->V);
         wl_blocks = std::max((size_t)(h->Lmax / 8 + 64), (size_t)(8 * std::max(h->cus, 256)));   // sparse waves: up to 8 cus one-game blocks
-        A_(dmalloc(&h->sel, Lm * V * sel_bytes)); A_(dmalloc(&h->aux4, Lm * V));
+        A_(dmalloc(&h->aux4, Lm * V));
         A_(dmalloc(&h->wl, wl_blocks * h->wl_cap)); A_(dmalloc(&h->wl_n, wl_blocks)); A_(dmalloc(&h->sp, Lm));
     }
     if (cfg->nn_mode == AGZ_NN_BF16) { uint16_t* p = nullptr; A_(dmalloc(&p, Lm * h->INP)); h->planes = p; }
@@ -375,13 +344,13 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
 
     TreePar& T = h->tp;
     memset(&T, 0, sizeof T);
-    T.G = P; T.V = h->V; T.rec_bytes = rec_bytes; T.off_q = A2 * 4; T.off_vc = A2 * 8; T.A2 = A2;
+    T.G = P; T.V = h->V; T.rec_bytes = rec_bytes; T.off_q = A2 * 4; T.off_vis = A2 * 10; T.A2 = A2;
     T.recs = h->recs; T.states = h->states; T.meta = h->meta; T.ncount = h->ncount; T.leaf = h->leaf; T.game_id = h->game_id;
-    T.cnt_p = h->cnt_p; T.cnt_new = h->cnt_new; T.aux = h->node_aux; T.planes = h->planes; T.INP = h->INP; T.planes_f32 = cfg->nn_mode == AGZ_NN_EXACT;
+    T.cnt_p = h->cnt_p; T.cnt_new = h->cnt_new; T.planes = h->planes; T.INP = h->INP; T.planes_f32 = cfg->nn_mode == AGZ_NN_EXACT;
     T.logits = h->logits; T.LGS = h->LGS; T.prior_eval = h->prior_eval; T.v_eval = h->v_eval; T.policy_final = h->policy_final;
     T.seed = cfg->seed; T.exact = cfg->nn_mode == AGZ_NN_EXACT;
-    T.sel = h->sel; T.sel_bytes = sel_bytes; T.off_cid = A2 * 4; T.aux4 = h->aux4; T.wl = h->wl; T.wl_n = h->wl_n; T.sp = h->sp; T.wl_cap = h->wl_cap;
-    if (h->eager) { hipMemsetAsync(h->wl_n, 0, wl_blocks * 4, h->stream); hipMemsetAsync(h->sp, 0, Lm * 4, h->stream); }
+    T.aux4 = h->aux4; T.wl = h->wl; T.wl_n = h->wl_n; T.sp = h->sp; T.wl_cap = h->wl_cap;
+    hipMemsetAsync(h->wl_n, 0, wl_blocks * 4, h->stream); hipMemsetAsync(h->sp, 0, Lm * 4, h->stream);
 #ifdef AGZ_STAMPS
     { unsigned long long* d = nullptr; hipMalloc((void**)&d, (size_t)65536 * 16 * 8); hipMemset(d, 0, (size_t)65536 * 16 * 8); T.dbg = d; }
 #endif
@@ -626,17 +595,14 @@ static int launch_rollout(agz_engine* h, uint32_t rollout, int do_reset, int do_
     if (!stream) stream = h->stream;
     const int n = s1 - s0;
     TreePar T = h->tp;
-    T.L = s1; T.slot0 = s0; T.gpw = h->reg_lds ? 64 / h->reg_g : 0; T.step = h->step; T.rollout = rollout; T.cpuct = h->cpuct; T.training = h->training;
+    T.L = s1; T.slot0 = s0; T.gpw = 8; T.step = h->step; T.rollout = rollout; T.cpuct = h->cpuct; T.training = h->training;
     T.do_reset = do_reset; T.do_expand = do_expand; T.do_select = do_select; T.last = last; T.inject = inject; T.capture = capture;
     T.final_ = final_;
-    const bool reg = h->reg_lds != 0, lpg = !reg && h->lpg_lds != 0;
-    const int ng = reg ? 64 / h->reg_g : 64 / h->grp_g;
-    if (!reg && s0 != 0) { h->fail("sub-batches need the register-row kernel"); return AGZ_ERR_STATE; }
-    dim3 grid((unsigned)((reg || lpg) ? (n + ng - 1) / ng : (n + 3) / 4)), block((reg || lpg) ? 64 : 256);
+    T.fastdiv = h->cfg.nn_mode == AGZ_NN_BF16 && h->cpuct >= 0.0009765625f && h->cpuct <= 1024.0f && !getenv("AGZ_NO_FASTDIV");
+    dim3 grid((unsigned)((n + 7) / 8)), block(64);                // 8 games per wavefront
     std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
     if ((h->profiling & 1) && h->prof_this) { ev = next_events(h, h->ev_tree, h->ev_tree_used); hipEventRecord(ev->first, stream); }
-    const rollout_fn k4 = h->eager ? h->k_eager : h->k_reg, k3 = h->eager ? h->k_eager3 : h->k_reg3;
-    hipLaunchKernelGGL(reg ? ((int)grid.x <= h->reg3_max_waves ? k3 : k4) : (lpg ? h->k_lpg : h->k_roll), grid, block, reg ? h->reg_lds : (lpg ? h->lpg_lds : 0), stream, T);
+    hipLaunchKernelGGL((int)grid.x <= h->reg3_max_waves ? h->k_eager3 : h->k_eager, grid, block, h->reg_lds, stream, T);
     if (ev) hipEventRecord(ev->second, stream);
     h->cnt_live = true;
     HIPCHK(h, hipGetLastError());
@@ -757,8 +723,8 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
     {   // every game resident at once (<= 128 per CU): the whole search in one launch (agz_search_small.hpp); profiling bit 0
         // then times that launch (it counts as one "tree launch" of agz_get_kernel_times)
         DevNet& n = h->net[which];
-        if (h->k_small && h->reg_lds != 0 && h->eager && h->cfg.nn_mode == AGZ_NN_BF16 && n.H == 128 && n.w16w && h->L > 0 &&
-            h->V <= 64 && (h->V & 3) == 0 && h->reg_g * h->reg_kpl <= h->LGS &&   // the lean build of the tree step (rollout_reg_body<..., LEAN>)
+        if (h->k_small && h->cfg.nn_mode == AGZ_NN_BF16 && n.H == 128 && n.w16w && h->L > 0 &&
+            h->V <= 64 && (h->V & 3) == 0 && 8 * h->reg_kpl <= h->LGS &&   // the lean build of the tree step (rollout_eager_body<..., LEAN>)
             h->L <= std::min(std::max(h->small_maxl, h->small4_maxl), 128 * h->cus) && !getenv("AGZ_NO_FUSED_NN")) {
             // 16 games per workgroup up to small_maxl; beyond, 32 games per workgroup with the loosest register budget that still
             // keeps every workgroup resident (2 / 3 / 4 workgroups per CU = 64 / 96 / 128 games per CU)
@@ -769,6 +735,7 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
             SmallPar S;
             S.T = h->tp;
             S.T.L = h->L; S.T.slot0 = 0; S.T.step = h->step; S.T.cpuct = h->cpuct; S.T.training = h->training;
+            S.T.fastdiv = h->cpuct >= 0.0009765625f && h->cpuct <= 1024.0f && !getenv("AGZ_NO_FASTDIV");
             S.T.inject = 0; S.T.capture = 0; S.T.rollout = 0; S.T.do_reset = 1; S.T.do_expand = 0; S.T.do_select = 1; S.T.last = 0;
             S.F.planes = (const uint16_t*)h->planes; S.F.INP = n.INP; S.F.w16 = n.w16w; S.F.bias_head = n.bias_head;
             S.F.logits = h->logits; S.F.LGS = h->LGS; S.F.vout = h->v_eval; S.F.L = h->L; S.F.T = n.T; S.F.A = h->G.A; S.F.AOP = n.AOP;
@@ -780,7 +747,13 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
             S.F.gpw = S.T.gpw < 8 ? S.T.gpw : 0; S.F.tw = tw;
             S.V = V; S.tree_lds = (int)h->reg_lds;
             const int kth = n.H / 32, g0 = (n.INP / 32 + kth - 1) / kth;
-            const size_t lds = std::max((size_t)tw * h->reg_lds, (size_t)8 * tw * (2 * (n.H * 2 + 16) + (g0 * kth * 64 + 16)));   // tree and network phases share it
+            const size_t shared = (std::max((size_t)tw * h->reg_lds, (size_t)8 * tw * (2 * (n.H * 2 + 16) + (g0 * kth * 64 + 16))) + 15) & ~(size_t)15;   // tree and network phases share it
+            // + the tree waves' work lists (kept across the network phase): what the CU's LDS leaves when every workgroup of the launch
+            // must be resident (4 per CU at 32768 games); entries beyond the region, rare, go to the global list
+            const int wgs_per_cu = tw == 2 ? 2 : 2 + occ;
+            const size_t room = (size_t)(160 * 1024) / (size_t)wgs_per_cu > shared ? (size_t)(160 * 1024) / (size_t)wgs_per_cu - shared : 0;
+            S.wl_off = (int)shared; S.wl_bytes = (int)std::min((size_t)(8 * h->V * 4), (room / (size_t)tw) & ~(size_t)15);
+            const size_t lds = shared + (size_t)tw * S.wl_bytes;
             std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
             if ((h->profiling & 1) && h->prof_this) { ev = next_events(h, h->ev_tree, h->ev_tree_used); hipEventRecord(ev->first, h->stream); }
             hipLaunchKernelGGL(kfn, dim3((unsigned)((h->L + S.T.gpw * tw - 1) / (S.T.gpw * tw))), dim3(64 * NW_WAVES), lds, h->stream, S);
@@ -795,7 +768,7 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
         }
     }
     int K = 1;
-    if (h->reg_lds != 0 && h->aux[0]) {
+    if (h->aux[0]) {
         // measured (128x6, V = 64): 3 chains -9 % at 32768 and 24576 games, 2 chains -11 % at 16384, nothing below ~12000
         K = h->chains > 0 ? h->chains : (h->L >= 20000 ? 3 : (h->L >= 12000 ? 2 : 1));
         const int kmax = (h->L + 255) / 256;               // at least 256 games per chain
@@ -804,7 +777,7 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
         if (K < 1) K = 1;
     }
     const int chunk = ((h->L + K - 1) / K + 127) / 128 * 128;
-    { char b[160]; snprintf(b, sizeof b, "%s (one launch per rollout, %d sub-batch chain%s)", h->reg_lds ? (h->eager ? "k_rollout_eager" : "k_rollout_reg<G=8>") : (h->lpg_lds ? "k_rollout_grp" : "k_rollout"), K, K > 1 ? "s" : "");
+    { char b[160]; snprintf(b, sizeof b, "%s (one launch per rollout, %d sub-batch chain%s)", "k_rollout_eager", K, K > 1 ? "s" : "");
       h->form_tree = b; }
     if (K > 1) HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
     for (int c = 1; c < K; ++c) if (c * chunk < h->L) HIPCHK(h, hipStreamWaitEvent(h->aux[c - 1], h->ev_fork, 0));
@@ -841,7 +814,7 @@ int agz_rollout_select(agz_engine* h, uint32_t rollout, int last) {
     if (!h) return AGZ_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     int rc = launch_rollout(h, rollout, h->need_reset ? 1 : 0, 0, 1, last, 0, 0);
-    h->need_reset = false; h->step_last = last != 0;
+    h->need_reset = false; h->step_last = last != 0; h->step_rollout = rollout;
     return rc;
 }
 int agz_rollout_eval(agz_engine* h) {
@@ -889,7 +862,7 @@ int agz_rollout_expand_backup(agz_engine* h) {
     h->total_rollouts += (uint64_t)h->L;
     // eager kernel: the backup recomputes the rows the next descent samples from and keeps policy_final = the root's row as of
     // now (copy_pol :330-339 reads it at the start of the last rollout); after the last select nothing is recomputed any more
-    return launch_rollout(h, 0, 0, 1, 0, 1, 1, 0, 0, -1, nullptr, h->step_last ? 1 : 0);
+    return launch_rollout(h, h->step_rollout + 1u, 0, 1, 0, 1, 1, 0, 0, -1, nullptr, h->step_last ? 1 : 0);
 }
 int agz_search_end(agz_engine* h) {
     if (!h) return AGZ_ERR_ARG;
@@ -924,7 +897,7 @@ static int stats_getter(agz_engine* h, float* out, int want_q) {
     HIPCHK(h, hipSetDevice(h->cfg.device));
     if (h->L == 0) return AGZ_OK;
     hipLaunchKernelGGL(k_root_stats, dim3((unsigned)h->L), dim3(128), 0, h->stream, (const uint8_t*)h->recs, (const uint32_t*)h->meta, h->V,
-                       h->tp.rec_bytes, h->tp.off_q, h->tp.off_vc, h->G.A, h->L, want_q ? (float*)nullptr : h->scratch_f,
+                       h->tp.rec_bytes, h->tp.off_q, h->tp.off_vis, h->G.A, h->L, want_q ? (float*)nullptr : h->scratch_f,
                        want_q ? h->scratch_f : (float*)nullptr);
     HIPCHK(h, hipGetLastError());
     return fetch(h, out, h->scratch_f, (size_t)h->L * h->G.A * 4);

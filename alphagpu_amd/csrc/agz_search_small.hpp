@@ -17,6 +17,7 @@ struct SmallPar {
     Fused3Par F;              // the uniform weight tiling of agz_nn_wave.hpp, L = number of games
     int V;                    // rollouts
     int tree_lds;             // bytes of LDS of one tree wave
+    int wl_off, wl_bytes;     // the tree waves' work lists live past the window the two phases share: offset, bytes per wave
 };
 
 // TW = tree waves per workgroup (2 or 4): the workgroup owns 8*TW games and runs the network with TW/2 leaf tiles.
@@ -29,14 +30,17 @@ __global__ __launch_bounds__(64 * NW_WAVES, WV) void k_search_small(const SmallP
     static_assert(TW == 2 || TW == 4, "tree waves per workgroup");
     uint8_t* const tree_lds = lds_small + (size_t)(wave % TW) * S.tree_lds;
     uint8_t* const nn_lds = lds_small;                            // the two phases never overlap and the tree step keeps nothing
-                                                                  // in LDS from one rollout to the next: same memory
+                                                                  // in this window from one rollout to the next: same memory
+    uint32_t* const wl_lds = reinterpret_cast<uint32_t*>(lds_small + S.wl_off + (size_t)(wave % TW) * S.wl_bytes);
+    EagerCarry C = {1u, 0u, 0u, 0u, 0u, 0u};                      // what a game carries from rollout to rollout: in registers
+    uint32_t wcount = 0;
     for (int k = 0; k <= S.V; ++k) {
         const StepFlags SF = {(uint32_t)k, k == 0, k > 0, k < S.V, k == S.V - 1, k == S.V};
         // the workgroup index is made opaque once per rollout: otherwise every per-game address of both bodies is hoisted out
         // of this loop and kept alive across them (hundreds of registers, spills)
         int bx = (int)blockIdx.x;
         asm volatile("" : "+s"(bx));
-        if (wave < TW) rollout_eager_body<FAM, NC, KPL, true>(S.T, SF, tree_lds, bx * TW + wave);
+        if (wave < TW) rollout_eager_body<FAM, NC, KPL, true, (WV < 4 ? 2 : 1)>(S.T, SF, tree_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount);
 #ifdef AGZ_STAMPS
         const unsigned long long t_nn0 = __builtin_amdgcn_s_memtime();
 #endif

@@ -5,8 +5,6 @@
 #include "../../include/agz.h"
 #include "agz_games.hpp"
 #include "agz_device.hpp"
-#include "agz_tree.hpp"
-#include "agz_tree_grp.hpp"
 #include "agz_search_small.hpp"
 
 namespace agz {

@@ -1,38 +1,39 @@
-// agz_tree_eager.hpp — PUCT tree kernel, fifth generation: the regularised policy is computed EAGERLY, by the backup.
+// agz_tree_eager.hpp — the PUCT tree kernel: policy rows AND the next sampled action are computed eagerly, by the backup.
 //
 // The reference recomputes a node's policy row lazily, at the next visit after a backup has passed through it
-// (mcts_gpu.jl:114-169: uptodate is cleared by backUp :321 and never set again), inside the descent.  A descent is a chain of
-// dependent node visits whose length differs from game to game: with 8 games per wavefront the wave runs to the deepest of
-// its games (8.4 rounds for a mean depth of 4.4 on Gobang 9x9), so nearly half of the lanes idle through the expensive part —
-// lambda, alpha0, Newton, 81 IEEE divisions, the ordered prefix.  But the row a visit will find depends only on the node's own
-// state after the LAST backup through it, and every node a backup passes through is known when the backup starts.  So:
-//   * backup + recompute: every node on the path of the previous rollout is one independent WORK ITEM (update q / visits of
-//     the edge taken, then lambda, alpha0, Newton, the policy row and its source-order running sums), and the items of all 8
-//     games of the wave are dealt to the 8 lane-groups 8 at a time — ceil(sum of depths / 8) balanced rounds instead of
-//     max(depth) divergent ones;
-//   * the descent only reads the stored running sums: the sampled action of :172-182 is the number of entries of the
-//     nondecreasing row cum[] that are < u (one compare per action, no ordered sum, no division), the child id comes from a
-//     byte array stored next to it.  ~70 instructions per round instead of ~1000.
-// Same arithmetic, same order of every fp32 operation as the reference (and as agz_tree_reg.hpp, which stays as the cross-check):
-// only the time at which a row is computed changes.  Details:
-//   rec[L][V]  [prior f32 x A2][q f32 x A2][vc u16 x A2], vc = visits | (creation rank of the child + 1) << 8
-//   sel[L][V]  [cum f32 x A2][cid u8 x A2]: cum[k] = fl(cum[k-1] + policy[k]) (+inf for k >= A), cid = child node id | expanded << 7
-//   aux[L][V]  {prior_rem before lambda (:120-124), -, npos | nvis << 8 | nch << 16 | lastpos << 24, -}
-//   wl[block][8 V] work list of the wave: one word per expanded node passed below which the descent went on; sp[slot]: the last
-//   expanded node of the path (the parent of the leaf) — these 8 items are processed together in the first round because they
-//   alone may have a new child to register (creation rank, cid, re-summed prior_rem).
+// (mcts_gpu.jl:114-169: uptodate is cleared by backUp :321 and never set again), inside the descent, and samples from it with
+// a fresh uniform (:172-182).  A descent is a chain of dependent node visits whose length differs from game to game: with 8
+// games per wavefront the wave runs to the deepest of its games (8.4 rounds for a mean depth of 4.4 on Gobang 9x9), so nearly
+// half of the lanes idle through the expensive part — lambda, alpha0, Newton, 81 IEEE divisions, the ordered prefix.  But the
+// row a visit will find depends only on the node's own state after the LAST backup through it, every node a backup passes
+// through is known when the backup starts, and the uniform of the visit is keyed by that backup: U(seed; game, step, rollout of
+// the backup, depth of the node) — one independent uniform per node visit, as the reference draws them (agz_device.hpp
+// uniform_search).  So:
+//   * backup + recompute: every node on the path of the previous rollout is one independent WORK ITEM — update q / visits of the
+//     edge taken (:319-320), then lambda, alpha0, Newton, the policy row, its source-order running sums, and the action the
+//     NEXT visit of the node will sample (:172-182: the number of running sums below u) with the child it leads to.  The items of
+//     all 8 games of the wave are dealt to the 8 lane-groups 8 at a time: ceil(sum of depths / 8) balanced rounds instead of
+//     max(depth) divergent ones.  Nothing of the row is stored: one 32-bit word per node (action | child << 8 | valid).
+//   * the descent follows those words: one 4-byte load per level, no arithmetic.
+// Same arithmetic, same order of every fp32 operation as the reference restated by the oracle; only the time at which a row is
+// computed changes.  Layout (A2 = 8 KPL >= A):
+//   rec[L][V]  [prior f32 x A2][q f32 x A2][rank u8 x A2][cid u8 x A2][vis u8 x A2]: creation rank + 1 and node id of the child
+//              under each action (0 = none), visits of the edge
+//   aux[L][V]  {prior_rem before lambda (:120-124), next word, npos | nvis << 8 | nch << 16, -}
+//   wl[block][8 V] work list of the wave (in LDS inside the whole-search kernel): one word per expanded node passed below which
+//   the descent went on; sp[slot]: the last expanded node of the path (the parent of the leaf) — these 8 items are processed
+//   together in the first round because they alone may have a new child to register (rank, cid, re-summed prior_rem).
 #pragma once
-#include "agz_tree_reg.hpp"
+#include "agz_wave.hpp"
+#include "agz_divpair.hpp"
+#include "agz_fastdiv.hpp"
 
 namespace agz {
 
-enum : uint32_t { SP_VALID = 1u << 24, SP_CREATED = 1u << 25 };
+enum : uint32_t { SP_VALID = 1u << 24, SP_CREATED = 1u << 25, NX_VALID = 1u << 16 };
 
-#ifdef AGZ_STAMPS
-#define STAMPW(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); STAMP(i); } while (0)   // waits are charged to the phase that issued the loads
-#else
-#define STAMPW(i) do { } while (0)
-#endif
+// bytes of a node record [prior f32 x A2][q f32 x A2][rank u8 x A2][cid u8 x A2][vis u8 x A2] (A2 is a multiple of 32)
+__host__ __device__ constexpr int eager_rec_bytes(int A2) { return 11 * A2; }
 
 struct EagerLds { int tabp, tabq, tstride, val, utab, total; };
 __host__ __device__ inline EagerLds eager_lds_layout(int V) {
@@ -47,42 +48,47 @@ __host__ __device__ inline EagerLds eager_lds_layout(int V) {
     return o;
 }
 
-// source-order running sums over the group's 8*KPL values (lane sub holds block sub): returns the sum of everything BEFORE the
-// lane's own block — the lanes take turns, lane t adds its KPL values to what lane t-1 ended with (one DPP row_shr:1 per turn),
-// bit-identical to the source-order loop.  The last lane's start needs no turn of its own; its end (the total) does.
-template <int KPL, bool WANT_TOTAL>
-__device__ __forceinline__ float grp_ordered_start(const float (&x)[KPL], int sub, float& total) {
-    float a = 0.0f, st = 0.0f;
-#pragma unroll 1
-    for (int t = 0; t < (WANT_TOTAL ? 8 : 7); ++t) {
-        const float carry = lane_shr1(a);                       // what the previous lane ended with
-        const float s0 = sub == 0 ? 0.0f : carry;
-        if (sub == t) st = s0;
-        a = s0;
-#pragma unroll
-        for (int j = 0; j < KPL; ++j) a += x[j];                // only lane t's result is final in turn t
-    }
-    if (WANT_TOTAL) total = grp_bcast_last<8>(a);
-    else { const float carry = lane_shr1(a); if (sub == 7) st = carry; }
-    return st;
-}
+// what a game carries from one rollout to the next.  The stand-alone kernel keeps it in global memory (T.ncount, T.leaf, T.sp,
+// T.cnt_*); the whole-search kernel (agz_search_small.hpp) keeps it in registers across its rollout loop.
+struct EagerCarry { uint32_t ncount, leafn, spw, add_p, add_new, root_exp; };
 
-template <int FAM, int NC, int KPL, bool LEAN>
-__device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepFlags SF, uint8_t* const lds, const int bidx) {
+// rows of one work item, loaded one round ahead of their use
+template <int KPL> struct ItemRows {
+    float p[KPL], q[KPL]; uint32_t rk[KPL / 4], cd[KPL / 4];      // rank + 1 / child id bytes of the lane's KPL actions
+    uint32_t ax_x, ax_z;                                          // aux: prior_rem bits, npos | nvis << 8 | nch << 16
+    float pm, qm; uint32_t vism;                                  // the edge taken: prior, q, visits
+    uint32_t ent; int gi; bool valid;
+};
+
+// LEAN: the caller is the whole-search kernel: V <= 64 (a multiple of 4), bf16 network mode, no inject / capture, the carry
+// lives in registers (C) and the wave's work list in LDS (wl_lds, wcount); otherwise both live in global memory.
+// PFM = 2: the rows of the next work item are requested while the running sums of the current one are computed, and those of
+// the first item before the leaf's rows are written (35 more live registers: only where the register budget has room for them
+// — in the 128-register build the spills cost more than the latency saved, measured 12.5 vs 7.8 ms per 32768-game search).
+// PFM = 1: the next item's record is only TOUCHED a round ahead (each of the 8 lanes of the group reads one dword of one of the
+// record's 8 cache lines into a scratch register), so that the real loads find it in L2 instead of paying an HBM miss.
+// wl_cap_lds: entries of the work list that fit the LDS region (the rest, rare, goes to the global list).
+template <int FAM, int NC, int KPL, bool LEAN, int PFM>
+__device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepFlags SF, uint8_t* const lds, const int bidx,
+                                                   EagerCarry& C, uint32_t* const wl_lds, const uint32_t wl_cap_lds, uint32_t& wcount) {
     using GM = Game<FAM, NC>;
     constexpr bool REV = FAM == F_REV;
     constexpr int G = 8, NG = 8;
     static_assert(KPL % 4 == 0, "block of actions per lane must be a multiple of 4");
     const GamePar& P = T.G;
-    int lane_ = lane_id();   // PHASE setup
-    asm volatile("" : "+v"(lane_));                              // opaque per call (see rollout_reg_body)
+    int lane_ = lane_id();
+    asm volatile("" : "+v"(lane_));                              // opaque per call (see rollout_reg_body)   // PHASE setup
     const int lane = lane_ & 63, g = lane / G, sub = lane % G;
     const int GPW = T.gpw;
     const int slot_base = T.slot0 + bidx * GPW;
     const int slot = slot_base + g;
     const bool live = g < GPW && slot < T.L;
     const bool lead = sub == 0;
-    const int A = P.A, V = T.V, ROWS = (int)T.rec_bytes, SELB = (int)T.sel_bytes;
+    // the row geometry follows from KPL alone (the engine lays the records out with the same formulas): compile-time offsets,
+    // so that every load / store of a row is one base address + an immediate
+    constexpr int A2 = G * KPL, ROWS = eager_rec_bytes(A2);
+    constexpr int OFF_Q = 4 * A2, OFF_RK = 8 * A2, OFF_CID = 9 * A2, OFF_VIS = 10 * A2;
+    const int A = P.A, V = T.V;
     const EagerLds LO = eager_lds_layout(V);
     float* const tabp = reinterpret_cast<float*>(lds + (size_t)g * LO.tstride + LO.tabp);
     float* const tabq = reinterpret_cast<float*>(lds + (size_t)g * LO.tstride + LO.tabq);
@@ -92,39 +98,151 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
     const int k0 = sub * KPL;
     const bool inject = !LEAN && T.inject, capture = !LEAN && T.capture;
     const bool exact = !LEAN && T.exact, planes_f32 = !LEAN && T.planes_f32;
-    const size_t wl_base = (size_t)(T.slot0 / NG + bidx) * (size_t)T.wl_cap;      // this wave's work list
+    // FD: quotients by agz_fastdiv.hpp (same bits as '/', half the instructions) wherever the operands are inside its range by
+    // construction — bf16 mode with cpuct in [2^-10, 2^10] (T.fastdiv), no injected priors:
+    //   softmax     x / s          x = exp2_spec(.) is 0 or in [2^-61, 1];  s in [1, 8 KPL]
+    //   normalize   x' / norm      x' in {0} U [2^-68, 1] (x / s, times 0.75 at the root);  norm = sum of those, checked >= 2^-100
+    //   policy      lambda p / (alpha - q):  p >= 2^-68 or 0, lambda in [2^-19, 2^10];  alpha - q >= 1e-4 for every action (alpha
+    //               starts at max(q + max(lambda p, 1e-4)) and Newton only moves it up), <= 2^4
+    //   Newton      top / bot, -top / bot^2: same bounds;  newerr / g: newerr in [1e-3, 2^25] and then |g| in [2^-10, 2^39]
+    // The backup's own quotient (vis q + 1 - v) / (vis + 1) keeps '/': a value head output may be arbitrarily small.
+    const bool FD = T.fastdiv && !inject && !exact;
     const int wl_block = T.slot0 / NG + bidx;
+    uint32_t* const wl_g = T.wl + (size_t)wl_block * (size_t)T.wl_cap;            // this wave's work list (global form)
     uint32_t* const gmeta = T.meta + (size_t)sl * V;
-
 #ifdef AGZ_STAMPS
     unsigned long long* const stamp_lds = reinterpret_cast<unsigned long long*>(lds + LO.total);
     if (lane < 17) stamp_lds[lane] = lane == 16 ? __builtin_amdgcn_s_memtime() : 0ull;
     AGZ_WSYNC();
 #endif
-    uint32_t ncount = 1, leafn = 0;
     if (SF.do_reset) {
-        if (live && lead) { gmeta[0] = M_EXISTS; T.sp[slot] = 0u; }
-        if (lane == 0) T.wl_n[wl_block] = 0u;
-    } else if (live) { ncount = T.ncount[slot]; leafn = T.leaf[slot]; }
-    uint32_t add_p = 0, add_new = 0;
+        C.ncount = 1; C.leafn = 0; C.spw = 0; C.add_p = 0; C.add_new = 0; C.root_exp = 0;
+        wcount = 0;
+        if (live && lead) gmeta[0] = M_EXISTS;
+    } else if constexpr (!LEAN) {
+        C.ncount = 1; C.leafn = 0; C.spw = 0; C.root_exp = 0;
+        if (live) { C.ncount = T.ncount[slot]; C.leafn = T.leaf[slot]; C.spw = T.sp[slot]; C.root_exp = (gmeta[0] & M_EXPANDED) ? 1u : 0u; }
+        C.add_p = 0; C.add_new = 0;
+        wcount = ufirst(T.wl_n[wl_block]);
+    }
     STAMPW(0);
+
+    // The action the next visit of a row samples (:172-182), given the row pol[] (block sub of the group), the running sum st before
+    // the block, the visit's uniform u and the child bytes of the block: the number of running sums below u — the row of sums is
+    // nondecreasing — or, when the whole row sums below u, the last positive action.  Returns the next word.
+    auto sample_next = [&](const float (&pol)[KPL], const float st, const float u, const uint32_t (&cd)[KPL / 4], const int fix_move,
+                           const uint32_t fix_child) -> uint32_t {
+        float c = st; int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) { c += pol[j]; cnt += c < u ? 1 : 0; }
+        const int nvalid = A - k0 < 0 ? 0 : (A - k0 > KPL ? KPL : A - k0);     // padded actions (k >= A) sit at the end of the last blocks
+        cnt = cnt < nvalid ? cnt : nvalid;
+        int bestmove = grp_sum<G>(cnt);
+        if (__builtin_expect(__ballot(bestmove >= A) != 0, 0)) {               // the row sums below u: the last positive action wins (:175-181)
+            int lastpos = -1;
+#pragma unroll
+            for (int j = 0; j < KPL; ++j) lastpos = pol[j] > 0.0f ? k0 + j : lastpos;
+            lastpos = grp_max_i<G>(lastpos);
+            bestmove = bestmove >= A ? lastpos : bestmove;
+        }
+        if (bestmove < 0) return 0u;                                           // (the reference would index [-1]: the visit ends here)
+        const uint32_t idx = (uint32_t)(bestmove - k0);
+        uint32_t wsel = cd[0];
+#pragma unroll
+        for (int j = 1; j < KPL / 4; ++j) wsel = (idx >> 2) == (uint32_t)j ? cd[j] : wsel;
+        const uint32_t byte = idx < (uint32_t)KPL ? __builtin_amdgcn_ubfe(wsel, (idx & 3u) * 8u, 8u) : 0u;
+        uint32_t child = (uint32_t)grp_sum<G>((int)byte);
+        if (bestmove == fix_move) child = fix_child;                           // the child registered by this very item
+        return (uint32_t)bestmove | (child << 8) | NX_VALID;
+    };
+
+    // one work item's rows -> registers (zeros for a lane-group without an item).  entry: node | move << 8 | depth << 16 | game << 24
+    auto item_fetch = [&](ItemRows<KPL>& R, const int r, const uint32_t nwl) {
+        R.ent = 0u; R.gi = g; R.valid = false;
+        if (r == 0) { R.ent = C.spw; R.valid = live && (C.spw & SP_VALID); }
+        else {
+            const uint32_t idx = 8u * (uint32_t)(r - 1) + (uint32_t)g;
+            if (idx < nwl) {
+                if (LEAN && idx < wl_cap_lds) R.ent = wl_lds[idx]; else R.ent = wl_g[idx];
+                R.valid = true; R.gi = (int)(R.ent >> 24) & 7;
+            }
+        }
+        const int node = (int)(R.ent & 0xffu), move = (int)((R.ent >> 8) & 0xffu);
+        const int islot = R.valid ? slot_base + R.gi : sl;
+        const uint8_t* const rec = T.recs + ((size_t)islot * V + node) * ROWS;
+        if (R.valid) {
+            const uint4 ax = T.aux4[(size_t)islot * V + node];
+            R.ax_x = ax.x; R.ax_z = ax.z;
+#pragma unroll
+            for (int j = 0; j < KPL; j += 4) {
+                const float4 a = *reinterpret_cast<const float4*>(rec + (size_t)(k0 + j) * 4);
+                R.p[j] = a.x; R.p[j + 1] = a.y; R.p[j + 2] = a.z; R.p[j + 3] = a.w;
+                const float4 b = *reinterpret_cast<const float4*>(rec + OFF_Q + (size_t)(k0 + j) * 4);
+                R.q[j] = b.x; R.q[j + 1] = b.y; R.q[j + 2] = b.z; R.q[j + 3] = b.w;
+                R.rk[j / 4] = *reinterpret_cast<const uint32_t*>(rec + OFF_RK + (size_t)(k0 + j));
+                R.cd[j / 4] = *reinterpret_cast<const uint32_t*>(rec + OFF_CID + (size_t)(k0 + j));
+            }
+            R.pm = reinterpret_cast<const float*>(rec)[move];
+            R.qm = reinterpret_cast<const float*>(rec + OFF_Q)[move];
+            R.vism = rec[OFF_VIS + move];
+        } else {
+            R.ax_x = 0u; R.ax_z = 0u; R.pm = 0.0f; R.qm = 0.0f; R.vism = 0u;
+#pragma unroll
+            for (int j = 0; j < KPL; ++j) { R.p[j] = 0.0f; R.q[j] = 0.0f; }
+#pragma unroll
+            for (int j = 0; j < KPL / 4; ++j) { R.rk[j] = 0u; R.cd[j] = 0u; }
+        }
+    };
+
+    constexpr bool PF = PFM == 2;
+    // touch the record (and the aux word) of the item of round r: one dword per cache line
+    auto item_touch = [&](const int r, const uint32_t nwl) -> uint32_t {
+        uint32_t ent = 0u; int gi = g; bool valid = false;
+        if (r == 0) { ent = C.spw; valid = live && (C.spw & SP_VALID); }
+        else {
+            const uint32_t idx = 8u * (uint32_t)(r - 1) + (uint32_t)g;
+            if (idx < nwl) {
+                if (LEAN && idx < wl_cap_lds) ent = wl_lds[idx]; else ent = wl_g[idx];
+                valid = true; gi = (int)(ent >> 24) & 7;
+            }
+        }
+        uint32_t v = 0u;
+        if (valid) {
+            const size_t nd = (size_t)(slot_base + gi) * V + (ent & 0xffu);
+            v = *reinterpret_cast<const uint32_t*>(T.recs + nd * ROWS + (size_t)sub * 128);
+            if (sub == 0) v ^= reinterpret_cast<const uint32_t*>(T.aux4 + nd)[0];
+        }
+        return v;
+    };
 
     // =============================================================================================
     // expand (mcts_gpu.jl:250-302) of the previous rollout's leaf, then backUp (:306-328) + the recomputation of every row
     // the backup makes stale (:114-169)
     // =============================================================================================
     if (SF.do_expand) {   // PHASE expand: load logits
+        const uint32_t nwl = wcount;
+        const int rounds = 1 + (int)((nwl + 7u) >> 3);
+        ItemRows<KPL> R;
+        const uint32_t gid = live ? T.game_id[slot] : 0u;
+        {   // the uniforms of the rows this call makes: U(seed; game, step, rollout whose leaf is expanded / backed up, depth);
+            // lane sub draws depths 4 sub .. 4 sub + 3 (deeper nodes, rare: drawn where they are needed)
+            float uq[4];
+            uniform_search4(T.seed, gid, T.step, SF.rollout - 1u, (uint32_t)sub, uq);
+            *reinterpret_cast<float4*>(utab + g * 32 + 4 * sub) = make_float4(uq[0], uq[1], uq[2], uq[3]);
+        }
+        uint32_t sink = 0u;
+        if constexpr (PFM == 1) sink = item_touch(0, nwl);           // the first item's record starts travelling towards L2 now
         // ---------------------------------------------------------------------------- expand (lane-group g = game g)
-        const int lf = (int)leafn;
+        const int lf = (int)C.leafn;
         uint32_t ml = live ? gmeta[lf] : (uint32_t)M_TERM;
         const bool term = (ml & M_TERM) != 0;
         const bool doexp = live && !term;
         float vleaf = 0.0f;
-        const uint32_t spw = live ? T.sp[slot] : 0u;
+        const uint32_t spw = C.spw;
+        float x[KPL]; int npos = 0;
         if (doexp) {
             vleaf = T.v_eval[slot];
             const WPos<NC> st = grp_load_pos<NC, REV>(T.states + (size_t)sl * V + lf);
-            float x[KPL];
             const float* src = inject ? T.prior_eval + (size_t)slot * A : T.logits + (size_t)slot * T.LGS;
             if constexpr (LEAN) {
 #pragma unroll
@@ -147,8 +265,14 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
                 for (int j = 0; j < KPL; ++j) x[j] = (k0 + j < A) ? (exact ? exp_spec(x[j] - mx) : exp2_spec(x[j] - mx)) : 0.0f;
                 float s;
                 (void)grp_ordered_start<KPL, true>(x, sub, s);
+                if (FD) {
+                    const float rs = fd_rcp(s);
 #pragma unroll
-                for (int j = 0; j < KPL; j += 2) div_pair(x[j], s, x[j + 1], s, x[j], x[j + 1]);
+                    for (int j = 0; j < KPL; j += 2) fd_div2(x[j], s, rs, x[j + 1], s, rs, x[j], x[j + 1]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < KPL; j += 2) div_pair(x[j], s, x[j + 1], s, x[j], x[j + 1]);
+                }
                 if (capture) {
 #pragma unroll
                     for (int j = 0; j < KPL; ++j) if (k0 + j < A) T.prior_eval[(size_t)slot * A + k0 + j] = x[j];
@@ -167,51 +291,53 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
             const bool rootmix = lf == 0 && T.training;               // :270-275 vs :277-279, :292-294   // PHASE expand: mix / divide
             const float Af = (float)nl;
             float qn_[KPL];
+            if (FD && !__ballot(doexp && !(normalize >= 7.8886090522101181e-31f))) {        // 2^-100
+                const float rn = fd_rcp(normalize);
 #pragma unroll
-            for (int j = 0; j < KPL; j += 2)
-                div_pair(rootmix ? 0.75f * x[j] : x[j], normalize, rootmix ? 0.75f * x[j + 1] : x[j + 1], normalize, qn_[j], qn_[j + 1]);
-            int npos = 0, lastpos = -1;
+                for (int j = 0; j < KPL; j += 2)
+                    fd_div2(rootmix ? 0.75f * x[j] : x[j], normalize, rn, rootmix ? 0.75f * x[j + 1] : x[j + 1], normalize, rn, qn_[j], qn_[j + 1]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < KPL; j += 2)
+                    div_pair(rootmix ? 0.75f * x[j] : x[j], normalize, rootmix ? 0.75f * x[j + 1] : x[j + 1], normalize, qn_[j], qn_[j + 1]);
+            }
 #pragma unroll
             for (int j = 0; j < KPL; ++j) {
                 float pr = rootmix ? (lg[j] ? qn_[j] + 0.25f / Af : 0.0f) : qn_[j];
                 if (k0 + j >= A) pr = 0.0f;
                 x[j] = pr;
                 npos += pr > 0.0f ? 1 : 0;
-                lastpos = pr > 0.0f ? k0 + j : lastpos;
             }
             if (__builtin_expect(lf == 0, 0)) {                       // root expansion: policy == prior is what copy_pol sees for V <= 2
 #pragma unroll
                 for (int j = 0; j < KPL; ++j) if (k0 + j < A) T.policy_final[(size_t)slot * A + k0 + j] = x[j];
+                C.root_exp = 1u;
             }
             npos = grp_sum<G>(npos);                                  // "A" of :125-131 never changes after the expansion
-            {   int y;
-                y = dpp_mov<DPP_XOR1, 0xF>(-1, lastpos); lastpos = y > lastpos ? y : lastpos;
-                y = dpp_mov<DPP_XOR2, 0xF>(-1, lastpos); lastpos = y > lastpos ? y : lastpos;
-                y = dpp_mov<DPP_HALF_MIRROR, 0xF>(-1, lastpos); lastpos = y > lastpos ? y : lastpos; }
-            // policy = prior (:297-299): the running sums the first revisit will sample from; their total is prior_rem (:120-124,   // PHASE expand: running sums + write rows
-            // no child yet)
+        }
+        if constexpr (PF) item_fetch(R, 0, nwl);                      // the first round's rows travel while the leaf's rows are written
+        if (doexp) {
+            // policy = prior (:297-299): the first revisit samples from these running sums; their total is prior_rem (:120-124, no   // PHASE expand: running sums + write rows
+            // child yet)
             float total;
             const float st0 = grp_ordered_start<KPL, true>(x, sub, total);
+            const int Dl = (int)((spw >> 16) & 0xffu);                // depth of the leaf = expanded nodes above it
+            const float ul = Dl < 32 ? utab[g * 32 + Dl] : uniform_search(T.seed, gid, T.step, SF.rollout - 1u, (uint32_t)Dl);
+            const uint32_t nocd[KPL / 4] = {};
+            const uint32_t nx = sample_next(x, st0, ul, nocd, -1, 0u);
             uint8_t* rec = T.recs + ((size_t)sl * V + lf) * ROWS;
-            uint8_t* srow = T.sel + ((size_t)sl * V + lf) * SELB;
-            float c = st0;
 #pragma unroll
             for (int j = 0; j < KPL; j += 4) {
                 *reinterpret_cast<float4*>(rec + (size_t)(k0 + j) * 4) = make_float4(x[j], x[j + 1], x[j + 2], x[j + 3]);
-                *reinterpret_cast<float4*>(rec + T.off_q + (size_t)(k0 + j) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-                *reinterpret_cast<uint2*>(rec + T.off_vc + (size_t)(k0 + j) * 2) = make_uint2(0u, 0u);
-                float4 cc;
-                c += x[j]; cc.x = k0 + j < A ? c : __builtin_inff();
-                c += x[j + 1]; cc.y = k0 + j + 1 < A ? c : __builtin_inff();
-                c += x[j + 2]; cc.z = k0 + j + 2 < A ? c : __builtin_inff();
-                c += x[j + 3]; cc.w = k0 + j + 3 < A ? c : __builtin_inff();
-                *reinterpret_cast<float4*>(srow + (size_t)(k0 + j) * 4) = cc;
-                *reinterpret_cast<uint32_t*>(srow + T.off_cid + (size_t)(k0 + j)) = 0u;
+                *reinterpret_cast<float4*>(rec + OFF_Q + (size_t)(k0 + j) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<uint32_t*>(rec + OFF_RK + (size_t)(k0 + j)) = 0u;
+                *reinterpret_cast<uint32_t*>(rec + OFF_CID + (size_t)(k0 + j)) = 0u;
+                *reinterpret_cast<uint32_t*>(rec + OFF_VIS + (size_t)(k0 + j)) = 0u;
             }
             ml |= M_EXPANDED;                                         // :256
             if (lead) {
                 gmeta[lf] = ml;
-                T.aux4[(size_t)sl * V + lf] = make_uint4(__float_as_uint(total), 0u, (uint32_t)npos | ((uint32_t)(lastpos & 0xff) << 24), 0u);
+                T.aux4[(size_t)sl * V + lf] = make_uint4(__float_as_uint(total), nx, (uint32_t)npos, 0u);
             }
         } else if (__builtin_expect(live && lf == 0, 0)) {
 #pragma unroll
@@ -227,120 +353,91 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
             const float v1 = 1.0f - v0, v2 = 1.0f - v1;
             valtab[g] = make_float4(v1, v2, __uint_as_float((term ? 1u : 0u) | (((spw >> 16) & 0xffu) << 8) | ((uint32_t)lf << 16) | (doexp ? 1u << 24 : 0u)), 0.0f);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");        // rows written above are read by the items below (another lane-group may own them)
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         AGZ_WSYNC();
 
         STAMPW(2);
         // ---------------------------------------------------------------------------- work items
-        const uint32_t nwl = SF.do_reset ? 0u : ufirst(T.wl_n[wl_block]);   // PHASE items: loop control
-        const int rounds = 1 + (int)((nwl + 7u) >> 3);
-        const bool recompute = !(T.final_ || SF.fin);                             // after the last rollout of a search nobody descends again
+        const bool recompute = !(T.final_ || SF.fin);                 // after the last rollout of a search nobody descends again   // PHASE items: loop control
 #pragma unroll 1
         for (int r = 0; r < rounds; ++r) {
-            // ---- which item does this lane-group take?  round 0: the parent of game g's leaf; later: entry 8 (r-1) + g of the list
-            uint32_t ent = 0u; int gi = g; bool valid = false, special = r == 0;   // PHASE items: fetch item
-            if (r == 0) { ent = spw; valid = live && (spw & SP_VALID); }
-            else {
-                const uint32_t idx = 8u * (uint32_t)(r - 1) + (uint32_t)g;
-                if (idx < nwl) { ent = T.wl[wl_base + idx]; valid = true; gi = (int)(ent >> 24) & 7; }
+            if constexpr (!PF) item_fetch(R, r, nwl);
+            if constexpr (PFM == 1) {
+                asm volatile("" :: "v"(sink));                        // (keeps the touch loads alive; they completed long ago)
+                if (r + 1 < rounds) sink = item_touch(r + 1, nwl);
             }
-            if (!__ballot(valid)) continue;
-            const int node = (int)(ent & 0xffu), move = (int)((ent >> 8) & 0xffu), dpt = (int)((ent >> 16) & 0xffu);
-            const bool created = special && (ent & SP_CREATED);
+            const bool valid = R.valid, special = r == 0;
+            const int gi = R.gi;   // PHASE items: fetch item
+            const int node = (int)(R.ent & 0xffu), move = (int)((R.ent >> 8) & 0xffu), dpt_e = (int)((R.ent >> 16) & 0xffu);
+            const bool created = special && (R.ent & SP_CREATED);
             const int islot = valid ? slot_base + gi : sl;
             const float4 vt = valtab[gi];
             const uint32_t vflags = __float_as_uint(vt.z);
             const bool iterm = vflags & 1u;
             const int D = (int)((vflags >> 8) & 0xffu), ileaf = (int)((vflags >> 16) & 0xffu);
-            const bool leaf_expanded = (vflags >> 24) & 1u;
-            const int level = special ? 0 : D - 1 - dpt;
+            const int dpt = special ? D - 1 : dpt_e;                  // depth of the item's node
+            const int level = D - 1 - dpt;
             const float w = (level & 1) ? vt.y : vt.x;                // 1 - value at this level
             uint8_t* const rec = T.recs + ((size_t)islot * V + node) * ROWS;
-            uint8_t* const srow = T.sel + ((size_t)islot * V + node) * SELB;
-            float p[KPL], q[KPL]; uint32_t vw[KPL / 2];   // PHASE items: row loads
-            uint4 ax = make_uint4(0u, 0u, 0u, 0u);
-            float pm = 0.0f, qm = 0.0f; uint32_t vcm = 0u;
-            if (valid) {
-                ax = T.aux4[(size_t)islot * V + node];
-#pragma unroll
-                for (int j = 0; j < KPL; j += 4) {
-                    const float4 a = *reinterpret_cast<const float4*>(rec + (size_t)(k0 + j) * 4);
-                    p[j] = a.x; p[j + 1] = a.y; p[j + 2] = a.z; p[j + 3] = a.w;
-                    const float4 b = *reinterpret_cast<const float4*>(rec + T.off_q + (size_t)(k0 + j) * 4);
-                    q[j] = b.x; q[j + 1] = b.y; q[j + 2] = b.z; q[j + 3] = b.w;
-                    const uint2 c = *reinterpret_cast<const uint2*>(rec + T.off_vc + (size_t)(k0 + j) * 2);
-                    vw[j / 2] = c.x; vw[j / 2 + 1] = c.y;
-                }
-                pm = reinterpret_cast<const float*>(rec)[move];
-                qm = reinterpret_cast<const float*>(rec + T.off_q)[move];
-                vcm = reinterpret_cast<const uint16_t*>(rec + T.off_vc)[move];
-            } else {
-#pragma unroll
-                for (int j = 0; j < KPL; ++j) { p[j] = 0.0f; q[j] = 0.0f; }
-#pragma unroll
-                for (int j = 0; j < KPL / 2; ++j) vw[j] = 0u;
-            }
             STAMPW(3);
             // ---- backUp of this edge (:319-320)   // PHASE items: backUp of the edge, prior_rem re-sum, q patch
-            const float vis = (float)(vcm & 0xffu);
+            const float vis = (float)R.vism;
             float nq;
             if (__builtin_expect(__ballot(valid && iterm) != 0, 0)) {
-                const float nqf = (vis * qm + w) / (vis + 1.0f);
-                const float nqd = (float)(((double)(vis * qm) + (double)w) / (double)(vis + 1.0f));
+                const float nqf = (vis * R.qm + w) / (vis + 1.0f);
+                const float nqd = (float)(((double)(vis * R.qm) + (double)w) / (double)(vis + 1.0f));
                 nq = iterm ? nqd : nqf;
-            } else nq = (vis * qm + w) / (vis + 1.0f);
-            const uint32_t npos = ax.z & 0xffu, nvis = ((ax.z >> 8) & 0xffu) + 1u, nch_old = (ax.z >> 16) & 0xffu;
+            } else nq = (vis * R.qm + w) / (vis + 1.0f);
+            const uint32_t npos = R.ax_z & 0xffu, nvis = ((R.ax_z >> 8) & 0xffu) + 1u, nch_old = (R.ax_z >> 16) & 0xffu;
             const uint32_t nch = nch_old + (created ? 1u : 0u);
-            uint32_t nvc = vcm + 1u;
-            if (created) nvc |= nch << 8;                             // creation rank + 1 (:183-191)
-            float prem_raw = __uint_as_float(ax.x);                  // sum of the priors of childless actions, before lambda
+            float prem_raw = __uint_as_float(R.ax_x);                 // sum of the priors of childless actions, before lambda
             if (__builtin_expect(__ballot(valid && created) != 0, 0)) {
                 // the node loses one childless action: re-sum prior_rem in source order (:120-124), once per rollout
                 float m[KPL];
 #pragma unroll
                 for (int j = 0; j < KPL; ++j) {
-                    const uint32_t c = (j & 1) ? (vw[j / 2] >> 16) : (vw[j / 2] & 0xffffu);
-                    m[j] = (created && (c >> 8) == 0 && k0 + j != move) ? p[j] : 0.0f;
+                    const uint32_t rk = (R.rk[j / 4] >> (8 * (j & 3))) & 0xffu;
+                    m[j] = (created && rk == 0 && k0 + j != move) ? R.p[j] : 0.0f;
                 }
                 float tot;
                 (void)grp_ordered_start<KPL, true>(m, sub, tot);
                 prem_raw = created ? tot : prem_raw;
             }
             if (valid && lead) {
-                reinterpret_cast<float*>(rec + T.off_q)[move] = nq;
-                reinterpret_cast<uint16_t*>(rec + T.off_vc)[move] = (uint16_t)nvc;
-                if (special) srow[T.off_cid + move] = (uint8_t)((uint32_t)ileaf | (leaf_expanded ? 0x80u : 0u));
+                reinterpret_cast<float*>(rec + OFF_Q)[move] = nq;
+                rec[OFF_VIS + move] = (uint8_t)(R.vism + 1u);
+                if (created) { rec[OFF_RK + move] = (uint8_t)nch; rec[OFF_CID + move] = (uint8_t)ileaf; }   // creation rank + 1, node id (:183-191)
+            }
+            const uint32_t auxz = npos | (nvis << 8) | (nch << 16);
+            if (!recompute) {
+                if (valid && lead) T.aux4[(size_t)islot * V + node] = make_uint4(__float_as_uint(prem_raw), 0u, auxz, 0u);
+                if constexpr (PF) { if (r + 1 < rounds) item_fetch(R, r + 1, nwl); }
+                continue;
             }
             {   const int idx = move - k0;                            // the row in registers follows the update
 #pragma unroll
-                for (int j = 0; j < KPL; ++j) q[j] = (j == idx) ? nq : q[j];
-            }
-            if (!recompute) {
-                if (valid && lead) T.aux4[(size_t)islot * V + node] = make_uint4(__float_as_uint(prem_raw), 0u, npos | (nvis << 8) | (nch << 16) | (ax.z & 0xff000000u), 0u);
-                continue;
+                for (int j = 0; j < KPL; ++j) R.q[j] = (j == idx) ? nq : R.q[j];
             }
             STAMPW(4);
             // ---- Newton inputs in creation order (:144-148): the rank stored with the child id is the place   // PHASE items: Newton inputs (rank scatter)
 #pragma unroll
             for (int j = 0; j < KPL; ++j) {
-                const uint32_t c = (j & 1) ? (vw[j / 2] >> 16) : (vw[j / 2] & 0xffffu);
-                const uint32_t rk = c >> 8;
-                if (rk != 0) { tabp[rk - 1] = p[j]; tabq[rk - 1] = q[j]; }
+                const uint32_t rk = (R.rk[j / 4] >> (8 * (j & 3))) & 0xffu;
+                if (rk != 0) { tabp[rk - 1] = R.p[j]; tabq[rk - 1] = R.q[j]; }
             }
             AGZ_WSYNC();
-            if (created && lead) { tabp[nch - 1] = pm; tabq[nch - 1] = nq; }
+            if (created && lead) { tabp[nch - 1] = R.pm; tabq[nch - 1] = nq; }
             AGZ_WSYNC();
             // ---- :116-138   // PHASE items: lambda, alpha0
             const float nf = 1.0f + (float)nvis, Af = (float)npos;
-            const float lambda = T.cpuct * __builtin_sqrtf(nf) / (Af + nf);
+            const float lnum = T.cpuct * __builtin_sqrtf(nf), lden = Af + nf;
+            const float lambda = FD ? fd_div(lnum, lden, fd_rcp(lden)) : lnum / lden;   // :132
             const float prior_rem = prem_raw * lambda;               // :134
             float am = 0.0f;
 #pragma unroll
             for (int j = 0; j < KPL; ++j) {
-                const float lp = lambda * p[j];
+                const float lp = lambda * R.p[j];
                 const float gap = lp > 1e-4f ? lp : 1e-4f;
-                const float c = q[j] + gap;
+                const float c = R.q[j] + gap;
                 am = c > am ? c : am;
             }
             float alpha = grp_max<G>(am);
@@ -356,7 +453,10 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
                     float S, gg;
                     if (fast) {
                         float t = 0.0f, uu = 0.0f;
-                        if (sub <= (int)nch) { const float bot = alpha - qv_l; div_pair(top_l, bot, -top_l, bot * bot, t, uu); }
+                        if (sub <= (int)nch) {
+                            const float bot = alpha - qv_l;
+                            if (FD) fd_div_pair(top_l, bot, -top_l, bot * bot, t, uu); else div_pair(top_l, bot, -top_l, bot * bot, t, uu);
+                        }
                         float a = t, b = uu;
 #define AGZ_PULL(d) { a += lane_shl<d>(t); b += lane_shl<d>(uu); }
                         AGZ_PULL(1) AGZ_PULL(2) AGZ_PULL(3) AGZ_PULL(4) AGZ_PULL(5) AGZ_PULL(6) AGZ_PULL(7)
@@ -371,7 +471,7 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
                                 float top = prior_rem, qv = 0.0f;
                                 if (c > 0) { top = lambda * tabp[c - 1]; qv = tabq[c - 1]; }
                                 const float bot = alpha - qv;
-                                div_pair(top, bot, -top, bot * bot, t, uu);
+                                if (FD) fd_div_pair(top, bot, -top, bot * bot, t, uu); else div_pair(top, bot, -top, bot * bot, t, uu);
                             }
                             if (j0 == 0) { a = t; b = uu; } else { a += t; b += uu; }
 #define AGZ_PULL(d) { a += lane_shl<d>(t); b += lane_shl<d>(uu); }
@@ -382,48 +482,45 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
                     }
                     const float newerr = S - 1.0f;
                     if (newerr < 0.001f || newerr == err) break;
-                    alpha -= newerr / gg;
+                    alpha -= FD ? fd_div(newerr, gg, fd_rcp(gg)) : newerr / gg;
                     err = newerr;
                 }
             }
             STAMPW(6);
             // ---- the policy row (:165-169) and its running sums (:172-181)   // PHASE items: policy row
             float pol[KPL];
+            if (FD) {
 #pragma unroll
-            for (int j = 0; j < KPL; j += 2)
-                div_pair(lambda * p[j], alpha - q[j], lambda * p[j + 1], alpha - q[j + 1], pol[j], pol[j + 1]);
+                for (int j = 0; j < KPL; j += 2)
+                    fd_div_pair(lambda * R.p[j], alpha - R.q[j], lambda * R.p[j + 1], alpha - R.q[j + 1], pol[j], pol[j + 1]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < KPL; j += 2)
+                    div_pair(lambda * R.p[j], alpha - R.q[j], lambda * R.p[j + 1], alpha - R.q[j + 1], pol[j], pol[j + 1]);
+            }
+            uint32_t cdk[KPL / 4];
+#pragma unroll
+            for (int j = 0; j < KPL / 4; ++j) cdk[j] = R.cd[j];
+            // the rows of this item are dead: the next item's start travelling now (its table entries are written after the
+            // AGZ_WSYNC below)
+            AGZ_WSYNC();
+            if constexpr (PF) { if (r + 1 < rounds) item_fetch(R, r + 1, nwl); }
             if (__builtin_expect(__ballot(valid && node == 0 && SF.last) != 0, 0)) {     // copy_pol (:330-339): the row the last descent samples from
                 if (valid && node == 0) {
 #pragma unroll
                     for (int j = 0; j < KPL; ++j) if (k0 + j < A) T.policy_final[(size_t)islot * A + k0 + j] = pol[j];
                 }
             }
-            int lastpos = -1;   // PHASE items: lastpos
-#pragma unroll
-            for (int j = 0; j < KPL; ++j) lastpos = pol[j] > 0.0f ? k0 + j : lastpos;
-            {   int y;
-                y = dpp_mov<DPP_XOR1, 0xF>(-1, lastpos); lastpos = y > lastpos ? y : lastpos;
-                y = dpp_mov<DPP_XOR2, 0xF>(-1, lastpos); lastpos = y > lastpos ? y : lastpos;
-                y = dpp_mov<DPP_HALF_MIRROR, 0xF>(-1, lastpos); lastpos = y > lastpos ? y : lastpos; }
+            // the child bytes are needed past the prefetch of the next item: kept aside   // PHASE items: running sums + sampling
             STAMPW(7);
-            float dummy;   // PHASE items: running sums + stores
-            float c = grp_ordered_start<KPL, false>(pol, sub, dummy);
-            if (valid) {
-#pragma unroll
-                for (int j = 0; j < KPL; j += 4) {
-                    float4 cc;
-                    c += pol[j]; cc.x = k0 + j < A ? c : __builtin_inff();
-                    c += pol[j + 1]; cc.y = k0 + j + 1 < A ? c : __builtin_inff();
-                    c += pol[j + 2]; cc.z = k0 + j + 2 < A ? c : __builtin_inff();
-                    c += pol[j + 3]; cc.w = k0 + j + 3 < A ? c : __builtin_inff();
-                    *reinterpret_cast<float4*>(srow + (size_t)(k0 + j) * 4) = cc;
-                }
-                if (lead) T.aux4[(size_t)islot * V + node] = make_uint4(__float_as_uint(prem_raw), 0u, npos | (nvis << 8) | (nch << 16) | ((uint32_t)(lastpos & 0xff) << 24), 0u);
-            }
-            AGZ_WSYNC();                                              // the child table is rewritten by the next round
+            float dummy;
+            const float st = grp_ordered_start<KPL, false>(pol, sub, dummy);
+            const float u = dpt < 32 ? utab[gi * 32 + dpt] : uniform_search(T.seed, T.game_id[islot], T.step, SF.rollout - 1u, (uint32_t)dpt);
+            const uint32_t nx = sample_next(pol, st, u, cdk, created ? move : -1, (uint32_t)ileaf);
+            if (valid && lead) T.aux4[(size_t)islot * V + node] = make_uint4(__float_as_uint(prem_raw), nx, auxz, 0u);
             STAMPW(8);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");        // rows written by one lane-group are read by the descent of another
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         AGZ_WSYNC();
         STAMPW(9);
@@ -432,94 +529,54 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
     // =============================================================================================
     // kdescendTree! (mcts_gpu.jl:100-199) over the stored running sums + decoder (:202-223)
     // =============================================================================================
-    if (SF.do_select) {   // PHASE descent: uniforms (Philox)
-        const uint32_t gid = live ? T.game_id[slot] : 0u;
-        {   // prob[1..32, i] (:397): lane sub draws the uniforms of depths 4 sub .. 4 sub + 3
-            float uq[4];
-            uniform_search4(T.seed, gid, T.step, SF.rollout, (uint32_t)sub, uq);
-            *reinterpret_cast<float4*>(utab + g * 32 + 4 * sub) = make_float4(uq[0], uq[1], uq[2], uq[3]);
-        }
-        AGZ_WSYNC();
-        STAMPW(10);
+    if (SF.do_select) {   // PHASE descent: rounds
+        // every expanded node carries the action its next visit samples and the child under it: the descent follows the words
         int node = 0, depth = 0;
-        uint32_t mroot = live ? gmeta[0] : 0u;
-        bool descending = live && (mroot & M_EXPANDED);
+        uint32_t nx = (live && C.root_exp) ? T.aux4[(size_t)sl * V].y : 0u;
+        bool descending = (nx & NX_VALID) != 0;
         int create_from = -1, create_move = 0;
         uint32_t spnew = 0u;
-        uint32_t wcount = 0;                                          // wave-uniform: entries of the work list so far
-        bool at_leaf_known = !descending;                             // leaf = root when the root is not expanded
-        uint32_t mn = mroot;
-        while (__ballot(descending)) {   // PHASE descent: rounds
+        wcount = 0;                                                   // wave-uniform: entries of the work list so far
+        STAMPW(10);
+        while (__ballot(descending)) {
             if (descending) {
-                const uint8_t* srow = T.sel + ((size_t)sl * V + node) * SELB;
-                float cum[KPL]; uint32_t cw[KPL / 4];
-#pragma unroll
-                for (int j = 0; j < KPL; j += 4) {
-                    const float4 a = *reinterpret_cast<const float4*>(srow + (size_t)(k0 + j) * 4);
-                    cum[j] = a.x; cum[j + 1] = a.y; cum[j + 2] = a.z; cum[j + 3] = a.w;
-                    cw[j / 4] = *reinterpret_cast<const uint32_t*>(srow + T.off_cid + (size_t)(k0 + j));
-                }
-                STAMPW(11);
-                float u;
-                if (__builtin_expect(depth < 32, 1)) u = utab[g * 32 + depth];
-                else u = uniform_search(T.seed, gid, T.step, SF.rollout, (uint32_t)depth);
-                // bestmove (:172-182) = number of running sums below u (the row is nondecreasing; +inf beyond A)
-                int cnt = 0;
-#pragma unroll
-                for (int j = 0; j < KPL; ++j) cnt += cum[j] < u ? 1 : 0;
-                int bestmove = grp_sum<G>(cnt);
-                if (__builtin_expect(__ballot(bestmove >= A) != 0, 0)) {
-                    // the row sums below u: the last positive action wins (:175-181)
-                    if (bestmove >= A) {
-                        const uint32_t lp = (T.aux4[(size_t)sl * V + node].z >> 24) & 0xffu;
-                        bestmove = lp == 0xffu ? -1 : (int)lp;
-                    }
-                }
-                if (lead) ++add_p;
-                if (bestmove < 0) {                                   // reference would index [-1]; leaf = node
-                    spnew = (uint32_t)depth << 16;
+                const int move = (int)(nx & 0xffu), child = (int)((nx >> 8) & 0xffu);
+                if (lead) ++C.add_p;
+                ++depth;
+                if (child == 0) {                                      // :183-191: a new child is never expanded -> the descent ends
+                    create_from = node; create_move = move;
+                    spnew = (uint32_t)node | ((uint32_t)move << 8) | ((uint32_t)depth << 16) | SP_VALID | SP_CREATED;
                     descending = false;
                 } else {
-                    const int idx = bestmove - k0;
-                    uint32_t byte = 0u;
-#pragma unroll
-                    for (int j = 0; j < KPL; ++j) byte = (j == idx) ? ((cw[j / 4] >> (8 * (j & 3))) & 0xffu) : byte;
-                    const int cv = grp_sum<G>((int)byte);
-                    const int child = cv & 0x7f;
-                    if (child == 0) {                                  // :183-191: a new child is never expanded -> the descent ends
-                        create_from = node; create_move = bestmove;
-                        spnew = (uint32_t)node | ((uint32_t)bestmove << 8) | ((uint32_t)(depth + 1) << 16) | SP_VALID | SP_CREATED;
-                        descending = false;
-                    } else if (cv & 0x80) {                            // expanded child: the descent goes on (:192)
-                        const uint64_t app = __ballot(lead);           // (only lanes of descending groups are here)
+                    const uint32_t nxc = T.aux4[(size_t)sl * V + child].y;     // (cleared when the child was created, set by its expansion)
+                    STAMPW(11);
+                    if (nxc & NX_VALID) {                              // expanded child: the descent goes on (:192)
+                        const uint64_t app = __ballot(lead);           // (only lanes of groups that go on are here)
                         if (lead) {
                             const uint32_t pos = wcount + (uint32_t)__popcll(app & ((1ull << lane) - 1ull));
-                            T.wl[wl_base + pos] = (uint32_t)node | ((uint32_t)bestmove << 8) | ((uint32_t)depth << 16) | ((uint32_t)g << 24);
+                            const uint32_t e = (uint32_t)node | ((uint32_t)move << 8) | ((uint32_t)(depth - 1) << 16) | ((uint32_t)g << 24);
+                            if (LEAN && pos < wl_cap_lds) wl_lds[pos] = e; else wl_g[pos] = e;
                         }
+                        node = child; nx = nxc;
+                    } else {                                           // existing child that was never expanded: a terminal position
+                        spnew = (uint32_t)node | ((uint32_t)move << 8) | ((uint32_t)depth << 16) | SP_VALID;
                         node = child;
-                    } else {                                           // existing child that is not expanded: a terminal position
-                        spnew = (uint32_t)node | ((uint32_t)bestmove << 8) | ((uint32_t)(depth + 1) << 16) | SP_VALID;
-                        node = child;
-                        at_leaf_known = true;
                         descending = false;
                     }
-                    ++depth;
                 }
             }
-            // entries appended this round (wave-uniform): lead lanes of groups that are still descending
-            wcount += (uint32_t)__popcll(__ballot(descending && lead));
+            wcount += (uint32_t)__popcll(__ballot(descending && lead));   // entries appended this round
             AGZ_WSYNC();
             STAMPW(12);
         }
-        if (lane == 0) T.wl_n[wl_block] = wcount;
-        if (live && lead) T.sp[slot] = spnew;
-        (void)at_leaf_known;
+        C.spw = spnew;
 
         WPos<NC> lst; bool have_state = false;   // PHASE create child (play, isOver)
         for (int i = 0; i < NC; ++i) { lst.p.c[i] = 0; lst.o.c[i] = 0; lst.lg.c[i] = 0; }
         lst.player = 1; lst.aux = 0;
+        uint32_t mn = 0u;
         if (live && create_from >= 0) {                                    // :183-191 node creation (at most one per rollout)
-            const uint32_t child = ncount; ncount += 1;
+            const uint32_t child = C.ncount; C.ncount += 1;
             const WPos<NC> ps = grp_load_pos<NC, REV>(T.states + (size_t)sl * V + create_from);
             lst = GM::play(P, ps, create_move);
             have_state = true;
@@ -527,12 +584,13 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
             uint32_t mc = (uint32_t)create_from | ((uint32_t)create_move << 8) | M_EXISTS | M_EVAL;
             if (f) mc |= M_TERM | ((uint32_t)(1 + lst.player * rr) << M_TV_SHIFT);
             if (lead) {
-                ++add_new;
+                ++C.add_new;
                 T.states[(size_t)sl * V + child] = pack(lst);
                 gmeta[child] = mc;
+                reinterpret_cast<uint32_t*>(T.aux4 + (size_t)sl * V + child)[1] = 0u;      // not expanded: no next word yet
             }
             mn = mc; node = (int)child;
-        } else if (live && node != 0) mn = gmeta[node];
+        } else if (live) mn = gmeta[node];
         if (live) {
             if (!(mn & M_EVAL)) {                                           // root on the first rollout
                 lst = grp_load_pos<NC, REV>(T.states + (size_t)sl * V + node); have_state = true;
@@ -584,17 +642,21 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
                 d[0] = make_float4(w[0], w[1], w[2], w[3]);
                 d[1] = make_float4(w[4], w[5], w[6], w[7]);
             }
-            leafn = (uint32_t)node;
+            C.leafn = (uint32_t)node;
         }
     }
 
     STAMPW(13);
-    // ---- bookkeeping ----------------------------------------------------------------------------------   // PHASE bookkeeping
-    if (live && lead) {
-        T.ncount[slot] = ncount;
-        T.leaf[slot] = leafn;
-        if (SF.do_reset) { T.cnt_p[slot] = add_p; T.cnt_new[slot] = add_new; }
-        else { T.cnt_p[slot] += add_p; T.cnt_new[slot] += add_new; }
+    // ---- bookkeeping: the stand-alone kernel hands the carry over through global memory; the whole-search kernel only at its end   // PHASE bookkeeping
+    if (!LEAN || !SF.do_select) {
+        if (live && lead) {
+            T.ncount[slot] = C.ncount;
+            T.leaf[slot] = C.leafn;
+            if constexpr (!LEAN) T.sp[slot] = C.spw;
+            if (LEAN || SF.do_reset) { T.cnt_p[slot] = C.add_p; T.cnt_new[slot] = C.add_new; }
+            else { T.cnt_p[slot] += C.add_p; T.cnt_new[slot] += C.add_new; }
+        }
+        if constexpr (!LEAN) { if (lane == 0) T.wl_n[wl_block] = wcount; }
     }
 #ifdef AGZ_STAMPS
     STAMPW(14);
@@ -603,11 +665,12 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
 #endif
 }
 
-template <int FAM, int NC, int KPL, int WV = AGZ_REG_WAVES>
+template <int FAM, int NC, int KPL, int WV = 4>
 __global__ __launch_bounds__(64, WV) void k_rollout_eager(const TreePar T) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_eager[];
     const StepFlags SF = {T.rollout, T.do_reset, T.do_expand, T.do_select, T.last, T.final_};
-    rollout_eager_body<FAM, NC, KPL, false>(T, SF, lds_eager, (int)blockIdx.x);
+    EagerCarry C; uint32_t wcount = 0;
+    rollout_eager_body<FAM, NC, KPL, false, (WV < 4 ? 2 : 1)>(T, SF, lds_eager, (int)blockIdx.x, C, nullptr, 0u, wcount);
 }
 
 }  // namespace agz

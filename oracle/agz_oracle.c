@@ -559,7 +559,7 @@ void agzo_forward_bf16(const agzo_net_bf16 *n, const float *planes, float *logit
  * the product's tree kernels evaluate the same fma chain (agz_device.hpp exp2_spec) */
 float agzo_exp2_spec(float x) {
     float t = x * 1.44269504088896341f;
-    if (!(t >= -125.0f)) return 0.0f;
+    if (!(t >= -60.0f)) return 0.0f;                                       /* priors below 2^-61 are exactly 0 */
     float n = rintf(t), f = t - n;
     float p = 1.5403530393381609e-4f;
     p = fmaf(p, f, 1.3333558146428443e-3f);
@@ -600,6 +600,8 @@ struct agzo_tree {
     float *batch;           /* [2VS][L] */
     /* vnodes (:42-53) */
     int *parent, *actionFromParent;   /* [V][L]; parent -1 = none */
+    float *unext;                     /* [V][L] the uniform the NEXT visit of the node samples with (see agzo_select) */
+    int *depth;                       /* [V][L] depth of the node (root 0) */
     agzo_pos *state;                  /* [V][L] */
     int8_t *expanded, *uptodate;      /* [V][L] */
     int *leaf, *newindex;             /* [L]; newindex = number of nodes in use */
@@ -620,6 +622,7 @@ agzo_tree *agzo_tree_create(const agzo_game *g, int Lmax, int V) {
     t->childnbr = calloc(n, sizeof(int));
     t->policy_final = calloc((size_t)g->A * Lmax, 4); t->batch = calloc((size_t)2 * g->VS * Lmax, 4);
     t->parent = malloc(n * sizeof(int)); t->actionFromParent = calloc(n, sizeof(int));
+    t->unext = calloc(n, 4); t->depth = calloc(n, sizeof(int));
     for (size_t i = 0; i < n; ++i) t->parent[i] = -1;                     /* :48 zeros == "no parent" */
     t->state = calloc(n, sizeof(agzo_pos));
     t->expanded = calloc(n, 1); t->uptodate = malloc(n); memset(t->uptodate, 1, n); /* :51 */
@@ -633,6 +636,7 @@ void agzo_tree_destroy(agzo_tree *t) {
     if (!t) return;
     free(t->prior); free(t->policy); free(t->q); free(t->visits); free(t->Achild); free(t->childID);
     free(t->childnbr); free(t->policy_final); free(t->batch); free(t->parent); free(t->actionFromParent);
+    free(t->unext); free(t->depth);
     free(t->state); free(t->expanded); free(t->uptodate); free(t->leaf); free(t->newindex);
     free(t->game_id); free(t->prior_tmp); free(t->v_tmp); free(t);
 }
@@ -640,6 +644,7 @@ void agzo_tree_set_roots(agzo_tree *t, const agzo_pos *positions, const uint32_t
     t->L = L;
     for (int i = 0; i < L; ++i) {
         t->state[ND(t, 0, i)] = positions[i];
+        t->depth[ND(t, 0, i)] = 0;
         t->game_id[i] = game_ids ? game_ids[i] : (uint32_t)i;
     }
     memset(t->expanded, 0, (size_t)t->V * t->Lmax);
@@ -660,7 +665,14 @@ static int32_t *g_trace = NULL; static long g_trace_cap = 0, g_trace_n = 0;
 void agzo_set_trace(int32_t *buf, long cap) { g_trace = buf; g_trace_cap = cap; g_trace_n = 0; }
 long agzo_trace_count(void) { return g_trace_n; }
 
+/* Randomness of the descent.  The reference draws prob = CUDA.rand(maxLengthGame, L) per rollout and uses prob[depth, game]
+ * at every node it passes (:397, :178): one fresh, independent uniform per node visit, unseeded.  Our definition keeps exactly
+ * that (one independent Philox uniform per node visit) but keys it by the event that PRODUCED the row the visit samples from:
+ * the expansion of the node, or the latest backup through it, in rollout k at depth d -> U(seed; game id, step, k, d).  A visit
+ * therefore samples with a number that was already fixed when its policy row was fixed — which is what lets the product
+ * compute the sampled action together with the row (agz_tree_eager.hpp) instead of storing the row. */
 void agzo_select(agzo_tree *t, uint64_t seed, uint32_t step, uint32_t rollout, float cpuct) { /* kdescendTree! :100-199 */
+    (void)seed; (void)step; (void)rollout;
     const int A_ = t->g.A;
     for (int i = 0; i < t->L; ++i) {
         int nindex = 0, cpt = 0;
@@ -713,7 +725,7 @@ void agzo_select(agzo_tree *t, uint64_t seed, uint32_t step, uint32_t rollout, f
                 int32_t *e = g_trace + 6 * g_trace_n++;
                 e[0] = i; e[1] = (int32_t)rollout; e[2] = cpt; e[3] = tr_stale; e[4] = tr_nch; e[5] = tr_it;
             }
-            float u = agzo_uniform_search(seed, t->game_id[i], step, rollout, (uint32_t)cpt);
+            float u = t->unext[ND(t, nindex, i)];                         /* prob[cpt,i] (:178): drawn when the row was made, see the note above */
             for (int k = 0; k < A_; ++k) {                                /* :172-182 */
                 float d = t->policy[ST(t, k, nindex, i)];
                 pr += d;
@@ -730,6 +742,7 @@ void agzo_select(agzo_tree *t, uint64_t seed, uint32_t step, uint32_t rollout, f
                 t->Achild[ST(t, bestmove, nindex, i)] = slot;
                 t->parent[ND(t, nn, i)] = nindex;
                 t->actionFromParent[ND(t, nn, i)] = bestmove;
+                t->depth[ND(t, nn, i)] = t->depth[ND(t, nindex, i)] + 1;
                 agzo_play(&t->g, &t->state[ND(t, nindex, i)], bestmove, &t->state[ND(t, nn, i)]);
                 t->sum_new++;
             }
@@ -745,10 +758,11 @@ void agzo_encode_leaves(agzo_tree *t, float *batch) {                     /* dec
         agzo_encode(&t->g, &t->state[ND(t, t->leaf[i], i)], batch + (size_t)i * 2 * t->g.VS);
 }
 
-void agzo_expand(agzo_tree *t, const float *prior, int training) {        /* expand :250-302; prior [L][A] */
+void agzo_expand(agzo_tree *t, const float *prior, int training, uint64_t seed, uint32_t step, uint32_t rollout) { /* expand :250-302; prior [L][A] */
     const int A_ = t->g.A;
     for (int i = 0; i < t->L; ++i) {
         int nindex = t->leaf[i], r;
+        t->unext[ND(t, nindex, i)] = agzo_uniform_search(seed, t->game_id[i], step, rollout, (uint32_t)t->depth[ND(t, nindex, i)]);
         const agzo_pos *st = &t->state[ND(t, nindex, i)];
         int f = agzo_is_over(&t->g, st, &r);
         t->expanded[ND(t, nindex, i)] = (int8_t)(1 - f);                  /* :256 */
@@ -785,9 +799,11 @@ void agzo_expand(agzo_tree *t, const float *prior, int training) {        /* exp
     }
 }
 
-void agzo_backup(agzo_tree *t, const float *v) {                          /* backUp :306-328 */
+void agzo_backup(agzo_tree *t, const float *v, uint64_t seed, uint32_t step, uint32_t rollout) { /* backUp :306-328 */
     for (int i = 0; i < t->L; ++i) {
         int lf = t->leaf[i], r;
+        for (int a = t->parent[ND(t, lf, i)]; a != -1; a = t->parent[ND(t, a, i)])     /* rows made stale (:321): their next visit's uniform */
+            t->unext[ND(t, a, i)] = agzo_uniform_search(seed, t->game_id[i], step, rollout, (uint32_t)t->depth[ND(t, a, i)]);
         int nindex = t->parent[ND(t, lf, i)];
         int move = t->actionFromParent[ND(t, lf, i)];
         const agzo_pos *st = &t->state[ND(t, lf, i)];
@@ -821,6 +837,14 @@ void agzo_backup(agzo_tree *t, const float *v) {                          /* bac
     }
 }
 
+static int omp_threads_for(int n) {                                       /* at least 4 leaves per thread: tiny teams, not 256 spinning threads */
+#ifdef _OPENMP
+    int m = omp_get_max_threads(), w = (n + 3) / 4;
+    return w < 1 ? 1 : (w < m ? w : m);
+#else
+    (void)n; return 1;
+#endif
+}
 void agzo_search(agzo_tree *t, const agzo_net *net, int V, float cpuct, int training,
                  uint64_t seed, uint32_t step,
                  const float *prior_inject, const float *v_inject,
@@ -834,7 +858,7 @@ void agzo_search(agzo_tree *t, const agzo_net *net, int V, float cpuct, int trai
         if (prior_inject) {
             pr = prior_inject + (size_t)k * L * A_; vv = v_inject + (size_t)k * L;
         } else {
-#pragma omp parallel for schedule(static) if (net->bf16)
+#pragma omp parallel for schedule(static) if (net->bf16 && L >= 8) num_threads(omp_threads_for(L))
             for (int i = 0; i < L; ++i) {
                 if (net->bf16) {                                          /* the product's bf16 mode, bit for bit */
                     agzo_forward_bf16(net->bf16, t->batch + (size_t)i * IN, t->prior_tmp + (size_t)i * A_, &t->v_tmp[i]);
@@ -848,8 +872,8 @@ void agzo_search(agzo_tree *t, const agzo_net *net, int V, float cpuct, int trai
         }
         if (prior_capture) memcpy(prior_capture + (size_t)k * L * A_, pr, (size_t)L * A_ * 4);
         if (v_capture) memcpy(v_capture + (size_t)k * L, vv, (size_t)L * 4);
-        agzo_expand(t, pr, training);
-        agzo_backup(t, vv);
+        agzo_expand(t, pr, training, seed, step, (uint32_t)k);
+        agzo_backup(t, vv, seed, step, (uint32_t)k);
     }
     for (int i = 0; i < L; ++i) {                                         /* decoder_roots :441, copy_pol :443 */
         agzo_encode(&t->g, &t->state[ND(t, 0, i)], t->batch + (size_t)i * IN);

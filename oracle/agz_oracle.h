@@ -99,8 +99,9 @@ void agzo_tree_set_roots(agzo_tree *t, const agzo_pos *positions, const uint32_t
 void agzo_search_reset(agzo_tree *t);                                                  /* :380-387 */
 void agzo_select(agzo_tree *t, uint64_t seed, uint32_t step, uint32_t rollout, float cpuct); /* :100-199 */
 void agzo_encode_leaves(agzo_tree *t, float *batch);                                   /* :202-223 */
-void agzo_expand(agzo_tree *t, const float *prior, int training);                      /* :250-302 */
-void agzo_backup(agzo_tree *t, const float *v);                                        /* :306-328 */
+/* expand / backup of rollout `rollout` also fix the uniform the next visit of every row they make samples with (see agzo_select) */
+void agzo_expand(agzo_tree *t, const float *prior, int training, uint64_t seed, uint32_t step, uint32_t rollout); /* :250-302 */
+void agzo_backup(agzo_tree *t, const float *v, uint64_t seed, uint32_t step, uint32_t rollout);                   /* :306-328 */
 /* mcts_single :376-462.  If prior_inject/v_inject are non-NULL they hold V x L x A / V x L teacher-forced
  * network outputs (softmaxed priors) and the net is not evaluated.  If prior_capture/v_capture are non-NULL
  * the evaluated (softmaxed) outputs are stored there. */

@@ -72,8 +72,8 @@ def lib():
         L.agzo_search_reset.argtypes = [C.c_void_p]
         L.agzo_select.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_float]
         L.agzo_encode_leaves.argtypes = [C.c_void_p, C.c_void_p]
-        L.agzo_expand.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
-        L.agzo_backup.argtypes = [C.c_void_p, C.c_void_p]
+        L.agzo_expand.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32]
+        L.agzo_backup.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32]
         L.agzo_search.argtypes = [C.c_void_p, C.POINTER(Net), C.c_int, C.c_float, C.c_int, C.c_uint64,
                                   C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         for n in ("policy", "root_planes", "root_visits", "root_q", "leaf", "newindex", "root_policy_row"):
@@ -280,13 +280,13 @@ class OracleTree:
         lib().agzo_encode_leaves(self.h, _p(out))
         return out
 
-    def expand(self, prior, training):
+    def expand(self, prior, training, seed, step, rollout):
         prior = np.ascontiguousarray(prior, np.float32)
-        lib().agzo_expand(self.h, _p(prior), int(training))
+        lib().agzo_expand(self.h, _p(prior), int(training), seed, step, rollout)
 
-    def backup(self, v):
+    def backup(self, v, seed, step, rollout):
         v = np.ascontiguousarray(v, np.float32)
-        lib().agzo_backup(self.h, _p(v))
+        lib().agzo_backup(self.h, _p(v), seed, step, rollout)
 
     def _get(self, name, shape, dtype=np.float32):
         out = np.zeros(shape, dtype)
