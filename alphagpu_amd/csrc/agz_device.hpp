@@ -75,10 +75,10 @@ AGZ_HD float exp_spec(float x) {
 }
 // exp of the bf16-mode softmax (argument <= 0): 2^(x log2 e) from a degree-6 polynomial on the fraction and an exact scaling
 // (v_ldexp_f32).  13 instructions; unlike v_exp_f32 it is a DEFINITION that a CPU restatement can follow, so the bf16
-// mode is reproducible bit for bit.  2^t with t < -60 is 0: a softmax numerator is 0 or at least 2^-61 (agz_fastdiv.hpp relies on it).
+// mode is reproducible bit for bit.  2^t with t < -125 is 0.
 AGZ_HD float exp2_spec(float x) {
     const float t = x * 1.44269504088896341f;
-    if (!(t >= -60.0f)) return 0.0f;
+    if (!(t >= -125.0f)) return 0.0f;
     const float n = __builtin_rintf(t), f = t - n;
     float p = 1.5403530393381609e-4f;
     p = fma_rn(p, f, 1.3333558146428443e-3f);

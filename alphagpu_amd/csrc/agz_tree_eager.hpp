@@ -30,7 +30,7 @@
 
 namespace agz {
 
-enum : uint32_t { SP_VALID = 1u << 24, SP_CREATED = 1u << 25, NX_VALID = 1u << 16 };
+enum : uint32_t { SP_VALID = 1u << 24, SP_CREATED = 1u << 25, NX_VALID = 1u << 16, AUX_SLOW = 1u << 24 };
 
 // bytes of a node record [prior f32 x A2][q f32 x A2][rank u8 x A2][cid u8 x A2][vis u8 x A2] (A2 is a multiple of 32)
 __host__ __device__ constexpr int eager_rec_bytes(int A2) { return 11 * A2; }
@@ -100,9 +100,11 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
     const bool exact = !LEAN && T.exact, planes_f32 = !LEAN && T.planes_f32;
     // FD: quotients by agz_fastdiv.hpp (same bits as '/', half the instructions) wherever the operands are inside its range by
     // construction — bf16 mode with cpuct in [2^-10, 2^10] (T.fastdiv), no injected priors:
-    //   softmax     x / s          x = exp2_spec(.) is 0 or in [2^-61, 1];  s in [1, 8 KPL]
-    //   normalize   x' / norm      x' in {0} U [2^-68, 1] (x / s, times 0.75 at the root);  norm = sum of those, checked >= 2^-100
-    //   policy      lambda p / (alpha - q):  p >= 2^-68 or 0, lambda in [2^-19, 2^10];  alpha - q >= 1e-4 for every action (alpha
+    // the logits of the leaf spread over at most 55 (checked at the expansion; a node that fails the check is flagged AUX_SLOW and
+    // keeps '/' for good):
+    //   softmax     x / s          x = exp2_spec(.) is 0 (padding) or in [2^-80, 1];  s in [1, 8 KPL]
+    //   normalize   x' / norm      x' in {0} U [2^-87, 1] (x / s, times 0.75 at the root);  norm = sum of those, checked >= 2^-100
+    //   policy      lambda p / (alpha - q):  p >= 2^-87 or 0, lambda in [2^-19, 2^10];  alpha - q >= 1e-4 for every action (alpha
     //               starts at max(q + max(lambda p, 1e-4)) and Newton only moves it up), <= 2^4
     //   Newton      top / bot, -top / bot^2: same bounds;  newerr / g: newerr in [1e-3, 2^25] and then |g| in [2^-10, 2^39]
     // The backup's own quotient (vis q + 1 - v) / (vis + 1) keeps '/': a value head output may be arbitrarily small.
@@ -240,6 +242,7 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
         float vleaf = 0.0f;
         const uint32_t spw = C.spw;
         float x[KPL]; int npos = 0;
+        bool wide = false, fdx = false;                               // (fdx is wave-uniform)
         if (doexp) {
             vleaf = T.v_eval[slot];
             const WPos<NC> st = grp_load_pos<NC, REV>(T.states + (size_t)sl * V + lf);
@@ -257,15 +260,17 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
                 for (int j = 0; j < KPL; ++j) x[j] = (k0 + j < A) ? src[k0 + j] : (inject ? 0.0f : -__builtin_inff());
             }
             if (!inject) {                                            // softmax!(prior) (:417), source-order sum   // PHASE expand: softmax
-                float mx = -__builtin_inff();
+                float mx = -__builtin_inff(), mnn = -__builtin_inff();         // mnn = max of -x = -min over the real actions
 #pragma unroll
-                for (int j = 0; j < KPL; ++j) mx = x[j] > mx ? x[j] : mx;
-                mx = grp_max<G>(mx);
+                for (int j = 0; j < KPL; ++j) { mx = x[j] > mx ? x[j] : mx; const float nx_ = (k0 + j < A) ? -x[j] : -__builtin_inff(); mnn = nx_ > mnn ? nx_ : mnn; }
+                mx = grp_max<G>(mx); mnn = grp_max<G>(mnn);
+                wide = !(mx + mnn <= 55.0f);                          // softmax numerators may fall below 2^-80: no fast quotients on this node
 #pragma unroll
                 for (int j = 0; j < KPL; ++j) x[j] = (k0 + j < A) ? (exact ? exp_spec(x[j] - mx) : exp2_spec(x[j] - mx)) : 0.0f;
                 float s;
                 (void)grp_ordered_start<KPL, true>(x, sub, s);
-                if (FD) {
+                fdx = FD && !__ballot(wide);
+                if (fdx) {
                     const float rs = fd_rcp(s);
 #pragma unroll
                     for (int j = 0; j < KPL; j += 2) fd_div2(x[j], s, rs, x[j + 1], s, rs, x[j], x[j + 1]);
@@ -291,7 +296,7 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
             const bool rootmix = lf == 0 && T.training;               // :270-275 vs :277-279, :292-294   // PHASE expand: mix / divide
             const float Af = (float)nl;
             float qn_[KPL];
-            if (FD && !__ballot(doexp && !(normalize >= 7.8886090522101181e-31f))) {        // 2^-100
+            if (fdx && !__ballot(doexp && !(normalize >= 7.8886090522101181e-31f))) {        // 2^-100
                 const float rn = fd_rcp(normalize);
 #pragma unroll
                 for (int j = 0; j < KPL; j += 2)
@@ -337,7 +342,7 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
             ml |= M_EXPANDED;                                         // :256
             if (lead) {
                 gmeta[lf] = ml;
-                T.aux4[(size_t)sl * V + lf] = make_uint4(__float_as_uint(total), nx, (uint32_t)npos, 0u);
+                T.aux4[(size_t)sl * V + lf] = make_uint4(__float_as_uint(total), nx, (uint32_t)npos | (wide ? AUX_SLOW : 0u), 0u);
             }
         } else if (__builtin_expect(live && lf == 0, 0)) {
 #pragma unroll
@@ -407,7 +412,8 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
                 rec[OFF_VIS + move] = (uint8_t)(R.vism + 1u);
                 if (created) { rec[OFF_RK + move] = (uint8_t)nch; rec[OFF_CID + move] = (uint8_t)ileaf; }   // creation rank + 1, node id (:183-191)
             }
-            const uint32_t auxz = npos | (nvis << 8) | (nch << 16);
+            const uint32_t auxz = npos | (nvis << 8) | (nch << 16) | (R.ax_z & AUX_SLOW);
+            const bool FDr = FD && !__ballot(valid && (R.ax_z & AUX_SLOW));      // (wave-uniform)
             if (!recompute) {
                 if (valid && lead) T.aux4[(size_t)islot * V + node] = make_uint4(__float_as_uint(prem_raw), 0u, auxz, 0u);
                 if constexpr (PF) { if (r + 1 < rounds) item_fetch(R, r + 1, nwl); }
@@ -430,7 +436,7 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
             // ---- :116-138   // PHASE items: lambda, alpha0
             const float nf = 1.0f + (float)nvis, Af = (float)npos;
             const float lnum = T.cpuct * __builtin_sqrtf(nf), lden = Af + nf;
-            const float lambda = FD ? fd_div(lnum, lden, fd_rcp(lden)) : lnum / lden;   // :132
+            const float lambda = FDr ? fd_div(lnum, lden, fd_rcp(lden)) : lnum / lden;   // :132
             const float prior_rem = prem_raw * lambda;               // :134
             float am = 0.0f;
 #pragma unroll
@@ -455,7 +461,7 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
                         float t = 0.0f, uu = 0.0f;
                         if (sub <= (int)nch) {
                             const float bot = alpha - qv_l;
-                            if (FD) fd_div_pair(top_l, bot, -top_l, bot * bot, t, uu); else div_pair(top_l, bot, -top_l, bot * bot, t, uu);
+                            if (FDr) fd_div_pair(top_l, bot, -top_l, bot * bot, t, uu); else div_pair(top_l, bot, -top_l, bot * bot, t, uu);
                         }
                         float a = t, b = uu;
 #define AGZ_PULL(d) { a += lane_shl<d>(t); b += lane_shl<d>(uu); }
@@ -471,7 +477,7 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
                                 float top = prior_rem, qv = 0.0f;
                                 if (c > 0) { top = lambda * tabp[c - 1]; qv = tabq[c - 1]; }
                                 const float bot = alpha - qv;
-                                if (FD) fd_div_pair(top, bot, -top, bot * bot, t, uu); else div_pair(top, bot, -top, bot * bot, t, uu);
+                                if (FDr) fd_div_pair(top, bot, -top, bot * bot, t, uu); else div_pair(top, bot, -top, bot * bot, t, uu);
                             }
                             if (j0 == 0) { a = t; b = uu; } else { a += t; b += uu; }
 #define AGZ_PULL(d) { a += lane_shl<d>(t); b += lane_shl<d>(uu); }
@@ -482,14 +488,14 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
                     }
                     const float newerr = S - 1.0f;
                     if (newerr < 0.001f || newerr == err) break;
-                    alpha -= FD ? fd_div(newerr, gg, fd_rcp(gg)) : newerr / gg;
+                    alpha -= FDr ? fd_div(newerr, gg, fd_rcp(gg)) : newerr / gg;
                     err = newerr;
                 }
             }
             STAMPW(6);
             // ---- the policy row (:165-169) and its running sums (:172-181)   // PHASE items: policy row
             float pol[KPL];
-            if (FD) {
+            if (FDr) {
 #pragma unroll
                 for (int j = 0; j < KPL; j += 2)
                     fd_div_pair(lambda * R.p[j], alpha - R.q[j], lambda * R.p[j + 1], alpha - R.q[j + 1], pol[j], pol[j + 1]);

@@ -559,7 +559,7 @@ void agzo_forward_bf16(const agzo_net_bf16 *n, const float *planes, float *logit
  * the product's tree kernels evaluate the same fma chain (agz_device.hpp exp2_spec) */
 float agzo_exp2_spec(float x) {
     float t = x * 1.44269504088896341f;
-    if (!(t >= -60.0f)) return 0.0f;                                       /* priors below 2^-61 are exactly 0 */
+    if (!(t >= -125.0f)) return 0.0f;
     float n = rintf(t), f = t - n;
     float p = 1.5403530393381609e-4f;
     p = fmaf(p, f, 1.3333558146428443e-3f);
