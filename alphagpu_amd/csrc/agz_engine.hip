@@ -24,6 +24,7 @@
 #include "agz_nn_wave.hpp"
 #include "agz_nn_big.hpp"
 #include "agz_search_small.hpp"
+#include "agz_search_big.hpp"
 #include "agz_selfplay.hpp"
 
 using namespace agz;
@@ -52,8 +53,9 @@ struct DevNet {
 
 typedef void (*rollout_fn)(const TreePar);
 typedef void (*small_fn)(const SmallPar);
+typedef void (*big_fn)(const BigSearchPar);
 namespace agz {
-#define X(F, C, K) AGZ_SMALL_VARIANTS(F, C, K, extern)
+#define X(F, C, K) AGZ_SMALL_VARIANTS(F, C, K, extern) AGZ_BIG_VARIANTS(F, C, K, extern)
 AGZ_SMALL_SHAPES(X)          // defined in agz_small_inst.hip
 #undef X
 }
@@ -106,6 +108,8 @@ struct agz_engine {
     double tree_ms = 0, nn_ms = 0, tree_busy_ms = 0; int64_t tree_launches = 0;
     hipEvent_t ev_ref = nullptr; bool ev_ref_live = false;
     advance_fn k_adv = nullptr; softmax_fn k_soft = nullptr;
+    big_fn k_big[2] = {nullptr, nullptr};   // whole-search kernel for 512-wide trunks (agz_search_big.hpp), 1 / 2 workgroups per CU
+    int big_maxl = 16384;        // ... used for batches up to this many games (AGZ_BIG_MAXL): 6.2 vs 8.0 ms per ply at 8192 games, 4.5 vs 7.3 at 1024, 9.9 vs 10.2 at 16384
     small_fn k_small4[3] = {nullptr, nullptr, nullptr};   // the same with 32 games per workgroup, register budgets for 2 / 3 / 4 workgroups per SIMD set
     std::string form_tree, form_nn;   // kernels of the last search (agz_get_search_form)
     int small4_occ = -1;         // >= 0: force the register budget k_small4[occ] (AGZ_SMALL4_OCC = 0, 1, 2)
@@ -142,7 +146,7 @@ static bool bind_kernels(agz_engine* h) {
     const int kpl = P.A <= 32 ? 4 : (P.A <= 64 ? 8 : (P.A <= 96 ? 12 : (P.A <= 128 ? 16 : (P.A <= 192 ? 24 : 0))));
 #define Z(F, C, K) if (P.fam == F && P.NC == C && kpl == K) { h->k_eager = k_rollout_eager<F, C, K, 4>; h->k_eager3 = k_rollout_eager<F, C, K, 3>; \
         h->k_small = k_search_small<F, C, K, 128, 2, 2>; h->k_small4[0] = k_search_small<F, C, K, 128, 4, 2>; h->k_small4[1] = k_search_small<F, C, K, 128, 4, 3>; \
-        h->k_small4[2] = k_search_small<F, C, K, 128, 4, 4>; h->reg_kpl = K; }
+        h->k_small4[2] = k_search_small<F, C, K, 128, 4, 4>; h->k_big[0] = k_search_big<F, C, K, 512, 1>; h->k_big[1] = k_search_big<F, C, K, 512, 2>; h->reg_kpl = K; }
     AGZ_SMALL_SHAPES(Z)
 #undef Z
     if (P.NR == 1) h->k_soft = k_softmax<1>; else if (P.NR == 2) h->k_soft = k_softmax<2>; else h->k_soft = k_softmax<3>;
@@ -298,6 +302,9 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
         if (e3 && (atoi(e3) == 1 || atoi(e3) == 2 || atoi(e3) == 4 || atoi(e3) == 8)) h->small_gpw = atoi(e3);
         e3 = getenv("AGZ_SMALL4_MAXL");
         if (e3) h->small4_maxl = atoi(e3);
+        e3 = getenv("AGZ_BIG_MAXL");
+        if (e3) h->big_maxl = atoi(e3);
+        for (int i = 0; i < 2; ++i) if (h->k_big[i]) hipFuncSetAttribute((const void*)h->k_big[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         e3 = getenv("AGZ_SMALL4_OCC");
         if (e3 && atoi(e3) >= 0 && atoi(e3) <= 2) h->small4_occ = atoi(e3);
         if (h->k_small) hipFuncSetAttribute((const void*)h->k_small, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -759,6 +766,43 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
             hipLaunchKernelGGL(kfn, dim3((unsigned)((h->L + S.T.gpw * tw - 1) / (S.T.gpw * tw))), dim3(64 * NW_WAVES), lds, h->stream, S);
             { char b[160]; snprintf(b, sizeof b, "k_search_small<KPL=%d,H=128,TW=%d,WV=%d> (whole mcts_single per launch, %d games per workgroup, %d per tree wave)",
                                     h->reg_kpl, tw, tw == 2 ? 2 : 2 + occ, S.T.gpw * tw, S.T.gpw); h->form_tree = b; h->form_nn = "inside k_search_small (mlp_wave_body<128>)"; }
+            if (ev) hipEventRecord(ev->second, h->stream);
+            HIPCHK(h, hipGetLastError());
+            h->cnt_live = true;
+            h->need_reset = true; h->injected = false;
+            if (h->prof_this) h->total_rollouts += (uint64_t)h->L * (uint64_t)V;
+            return AGZ_OK;
+        }
+    }
+    {   // wide trunk, batch small enough to be latency-bound in the two-kernel form: the whole search in one launch (agz_search_big.hpp)
+        DevNet& n = h->net[which];
+        const int big_rowb = 2 * std::max(n.H, 32 * n.k0r) + 16;
+        if (h->k_big[0] && h->cfg.nn_mode == AGZ_NN_BF16 && n.H == 512 && n.wbig && h->L > 0 && 8 * h->reg_kpl <= h->LGS &&
+            h->L <= std::min(h->big_maxl, 64 * h->cus) && !getenv("AGZ_NO_FUSED_NN")) {
+            BigSearchPar S;
+            S.T = h->tp;
+            S.T.L = h->L; S.T.slot0 = 0; S.T.step = h->step; S.T.cpuct = h->cpuct; S.T.training = h->training;
+            S.T.fastdiv = h->cpuct >= 0.0009765625f && h->cpuct <= 1024.0f && !getenv("AGZ_NO_FASTDIV");
+            S.T.inject = 0; S.T.capture = 0; S.T.rollout = 0; S.T.do_reset = 1; S.T.do_expand = 0; S.T.do_select = 1; S.T.last = 0;
+            BigPar& B = S.B;
+            B.planes = (const uint16_t*)h->planes; B.INP = n.INP; B.wh = n.wbig;
+            B.whead = n.w16 + (size_t)(n.INP / 32) * (n.H / 16) * 512 + (size_t)n.T * (n.H / 32) * (n.H / 16) * 512;
+            B.bias_head = n.bias_head; B.logits = h->logits; B.LGS = h->LGS; B.vout = h->v_eval;
+            B.L = h->L; B.T = n.T; B.A = h->G.A; B.AOP = n.AOP; B.K0R = n.k0r; B.ROWB = big_rowb;
+            const int gpw = h->L <= 4 * h->cus ? 1 : (h->L <= 8 * h->cus ? 2 : (h->L <= 16 * h->cus ? 4 : 8));   // sparse waves (see k_search_small)
+            S.T.gpw = h->small_gpw > 0 ? h->small_gpw : gpw;
+            const int wgs = (h->L + 4 * S.T.gpw - 1) / (4 * S.T.gpw);
+            const int occ = wgs <= h->cus ? 0 : 1;                 // 1 or 2 workgroups per CU
+            S.V = V; S.tree_lds = (int)h->reg_lds;
+            const size_t shared = (std::max((size_t)4 * h->reg_lds, (size_t)32 * big_rowb) + 15) & ~(size_t)15;
+            const size_t room = (size_t)(160 * 1024) / (size_t)(occ + 1) > shared ? (size_t)(160 * 1024) / (size_t)(occ + 1) - shared : 0;
+            S.wl_off = (int)shared; S.wl_bytes = (int)std::min((size_t)(8 * h->V * 4), (room / 4) & ~(size_t)15);
+            const size_t lds = shared + (size_t)4 * S.wl_bytes;
+            std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
+            if ((h->profiling & 1) && h->prof_this) { ev = next_events(h, h->ev_tree, h->ev_tree_used); hipEventRecord(ev->first, h->stream); }
+            hipLaunchKernelGGL(h->k_big[occ], dim3((unsigned)wgs), dim3(NB_THREADS), lds, h->stream, S);
+            { char b[160]; snprintf(b, sizeof b, "k_search_big<KPL=%d,H=512,WG=%d> (whole mcts_single per launch, %d games per workgroup, %d per tree wave)",
+                                    h->reg_kpl, occ + 1, 4 * S.T.gpw, S.T.gpw); h->form_tree = b; h->form_nn = "inside k_search_big (mlp_big_body<512,2>)"; }
             if (ev) hipEventRecord(ev->second, h->stream);
             HIPCHK(h, hipGetLastError());
             h->cnt_live = true;

@@ -29,16 +29,18 @@ struct BigPar {
 
 // MT = 16-leaf tiles per workgroup: 8 (128 leaves) when the batch fills the chip, 2 (32 leaves) below ~8192 leaves, where
 // the launch is bound by one workgroup's own chain of layers and a quarter of the work per workgroup is ~4x faster.
-template <int H, int MT>
-__global__ __launch_bounds__(NB_THREADS, 1) void k_mlp_big(const BigPar P) {
+// mlp_big_body: the 8-wave workgroup's forward for the leaves of tile rows 0 .. 16 MT - 1, slot_of(row) = leaf (game slot) of a
+// row or a value >= P.L (also called from k_search_big, agz_search_big.hpp); contains workgroup barriers.
+template <int H, int MT, typename SlotOf>
+__device__ __forceinline__ void mlp_big_body(const BigPar& P, uint8_t* const act, SlotOf slot_of) {
     constexpr int NT = H / 16, KTH = H / 32, NTW = NT / 8;       // neuron tiles per layer / k-rows per layer / neuron tiles per wave
     constexpr int MB = 16 * MT;                                  // leaves per workgroup
     const int ROWB = P.ROWB;
     static_assert(NTW >= 1 && KTH % 2 == 0, "H must be a multiple of 128");
-    extern __shared__ __attribute__((aligned(16))) uint8_t act[];   // [MB][ROWB]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int tid_ = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid_));                               // opaque per call (a caller may loop over rollouts)
+    const int tid = tid_ & (NB_THREADS - 1), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lrow = lane & 15, q4 = lane >> 4;
-    const int leaf0 = (int)blockIdx.x * MB;
     const AGZ_GLB v4u* wsrc = (const AGZ_GLB v4u*)P.wh + (size_t)wave * NTW * 64 + lane;   // this wave's tiles of k-row 0
 
     bf16x8 A0[NTW], A1[NTW];
@@ -53,7 +55,7 @@ __global__ __launch_bounds__(NB_THREADS, 1) void k_mlp_big(const BigPar P) {
         const int segs = P.K0R * 4, isegs = P.INP / 8;
         const AGZ_GLB uint16_t* gp = (const AGZ_GLB uint16_t*)P.planes;
         for (int c = tid; c < MB * segs; c += NB_THREADS) {
-            const int row = c / segs, seg = c - row * segs, mm = leaf0 + row;
+            const int row = c / segs, seg = c - row * segs, mm = slot_of(row);
             v4u v = {0u, 0u, 0u, 0u};
             if (mm < P.L && seg < isegs) v = *(const AGZ_GLB v4u*)(gp + (size_t)mm * P.INP + seg * 8);
             *reinterpret_cast<v4u*>(act + (size_t)row * ROWB + seg * 16) = v;
@@ -124,22 +126,31 @@ __global__ __launch_bounds__(NB_THREADS, 1) void k_mlp_big(const BigPar P) {
                     hacc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, w, hacc[mt], 0, 0, 0);
                 }
             }
-            // hacc[mt][r] = out[leaf = leaf0 + 16 mt + 4 q4 + r][n = 16 tile + (lane & 15)]
+            // hacc[mt][r] = out[leaf of tile row 16 mt + 4 q4 + r][n = 16 tile + (lane & 15)]
             const int n = 16 * tile + (lane & 15);
             const float bias = P.bias_head[n];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const int mw = leaf0 + 16 * mt + 4 * q4;
+                int mw[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mw[r] = slot_of(16 * mt + 4 * q4 + r);
                 if (n < P.A) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) if (mw + r < P.L) P.logits[(size_t)(mw + r) * P.LGS + n] = hacc[mt][r] + bias;
+                    for (int r = 0; r < 4; ++r) if (mw[r] < P.L) P.logits[(size_t)mw[r] * P.LGS + n] = hacc[mt][r] + bias;
                 } else if (n == P.A) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) if (mw + r < P.L) P.vout[mw + r] = sigmoid_ool(hacc[mt][r] + bias);
+                    for (int r = 0; r < 4; ++r) if (mw[r] < P.L) P.vout[mw[r]] = sigmoid_ool(hacc[mt][r] + bias);
                 }
             }
         }
     }
+}
+
+template <int H, int MT>
+__global__ __launch_bounds__(NB_THREADS, 1) void k_mlp_big(const BigPar P) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t act_big[];   // [16 MT][ROWB]
+    const int leaf0 = (int)blockIdx.x * 16 * MT;
+    mlp_big_body<H, MT>(P, act_big, [&](int row) { return leaf0 + row; });
 }
 
 }  // namespace agz

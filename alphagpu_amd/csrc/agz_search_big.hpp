@@ -1,0 +1,57 @@
+// agz_search_big.hpp — a whole mcts_single (mcts_gpu.jl:376-462) in ONE launch for the WIDE trunks the reference ships
+// (ressimplesf(..., 512, 4|6|8), main*.jl:123-128), for batches that leave the chip latency-bound.
+//
+// With a 512-wide network the two-kernel form (one tree launch + one k_mlp_big launch per rollout) costs ~100 us per rollout
+// whatever the batch below ~8192 games: two kernel boundaries and a global barrier per rollout, 37 of the 81 plies of a
+// generation.  Here an 8-wave workgroup owns 32 games for the whole search: waves 0-3 run the tree step (rollout_eager_body,
+// 8 games each), a workgroup barrier hands the 32 leaves to all eight waves for the forward (mlp_big_body<H, 2>: the 32 x H
+// activation tile resident in LDS, weights streamed from L2), a second barrier hands logits and values back.  The tree waves'
+// LDS windows lie over the activation tile (the phases alternate); work lists and the per-game carry survive the forward.
+// The two bodies are the functions the stand-alone kernels run: same bits (tested).
+#pragma once
+#include "agz_tree_eager.hpp"
+#include "agz_nn_big.hpp"
+
+namespace agz {
+
+struct BigSearchPar {
+    TreePar T;                // slot0 = 0, L = number of games
+    BigPar B;                 // k_mlp_big's parameters, L = number of games
+    int V;                    // rollouts
+    int tree_lds;             // bytes of LDS of one tree wave
+    int wl_off, wl_bytes;     // the tree waves' work lists live past the window the two phases share: offset, bytes per wave
+};
+
+// WG = workgroups per CU the register budget is cut for (1: 256 registers, 2: 128)
+template <int FAM, int NC, int KPL, int H, int WG>
+__global__ __launch_bounds__(NB_THREADS, 2 * WG) void k_search_big(const BigSearchPar S) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_bigs[];
+    constexpr int TW = 4;                                         // tree waves: 32 games = the 2 leaf tiles of mlp_big_body<H, 2>
+    const int wave = (int)threadIdx.x >> 6;
+    uint8_t* const tree_lds = lds_bigs + (size_t)(wave % TW) * S.tree_lds;
+    uint32_t* const wl_lds = reinterpret_cast<uint32_t*>(lds_bigs + S.wl_off + (size_t)(wave % TW) * S.wl_bytes);
+    EagerCarry C = {1u, 0u, 0u, 0u, 0u, 0u};
+    uint32_t wcount = 0;
+    for (int k = 0; k <= S.V; ++k) {
+        const StepFlags SF = {(uint32_t)k, k == 0, k > 0, k < S.V, k == S.V - 1, k == S.V};
+        int bx = (int)blockIdx.x;
+        asm volatile("" : "+s"(bx));                              // (see k_search_small)
+        if (wave < TW) rollout_eager_body<FAM, NC, KPL, true, (WG < 2 ? 2 : 1)>(S.T, SF, tree_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount);
+        if (k < S.V) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();                                      // the planes of the 32 leaves are written
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const int gpw = S.T.gpw, L = S.T.L;
+            mlp_big_body<H, 2>(S.B, lds_bigs, [&](int row) { return (row & 7) < gpw ? (bx * TW + (row >> 3)) * gpw + (row & 7) : L; });
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();                                      // logits and values are visible to the tree waves
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+    }
+}
+
+#define AGZ_BIG_VARIANTS(F, C, K, KW)                                        \
+    KW template __global__ void k_search_big<F, C, K, 512, 1>(const BigSearchPar); \
+    KW template __global__ void k_search_big<F, C, K, 512, 2>(const BigSearchPar);
+
+}  // namespace agz

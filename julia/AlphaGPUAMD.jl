@@ -26,15 +26,23 @@ mutable struct Engine
     L::Int
 end
 check(e::Engine, rc) = rc == 0 ? nothing : error(unsafe_string(ccall((:agz_last_error, libagz), Cstring, (Ptr{Cvoid},), e.h)))
+# an engine holds gigabytes of HBM the Julia GC cannot see: release it explicitly (the finalizer is only a safety net)
+function destroy!(e::Engine)
+    e.h == C_NULL || ccall((:agz_destroy, libagz), Cvoid, (Ptr{Cvoid},), e.h)
+    e.h = C_NULL
+end
+# the reference draws unseeded CUDA.rand / StatsBase randomness on every call (mcts_gpu.jl:397,520): a fresh Philox key per call
+fresh_seed() = rand(UInt64) >> 1 | UInt64(1)
+set_seed!(e::Engine, seed) = check(e, ccall((:agz_set_seed, libagz), Cint, (Ptr{Cvoid}, UInt64), e.h, seed))
 
 # game ids: 0 Gobang, 1 Connect4, 2 Hex, 3 Reversi 8x8, 4 Reversi 6x6 — set by the main*.jl that includes the plugin
-function init(positions::Vector{Position}, visits; game::Integer, N::Integer=0, Nvict::Integer=0, device=0, seed=1, nn_mode=0)
+function init(positions::Vector{Position}, visits; game::Integer, N::Integer=0, Nvict::Integer=0, device=0, seed=fresh_seed(), nn_mode=0)
     cfg = Ref(AgzConfig(game, N, Nvict, length(positions), visits, device, seed, 0, nn_mode, 0, (0, 0, 0)))
     h = Ref{Ptr{Cvoid}}(C_NULL)
     rc = ccall((:agz_create, libagz), Cint, (Ref{AgzConfig}, Ref{Ptr{Cvoid}}), cfg, h)
     rc == 0 || error(unsafe_string(ccall((:agz_last_error, libagz), Cstring, (Ptr{Cvoid},), C_NULL)))
     e = Engine(h[], 0)
-    finalizer(x -> ccall((:agz_destroy, libagz), Cvoid, (Ptr{Cvoid},), x.h), e)
+    finalizer(destroy!, e)
     re_init(positions, e)
     e
 end
@@ -66,8 +74,9 @@ function mcts_single(actor, visits, e::Engine; training=true, cpuct=2f0, step=0)
     policy, batch                                  # == Array(vnodesStats.policy_final), Array(vnodesStats.batch)
 end
 
-function mcts(actor, visits, ngames, buffer::PoolSample; θ=1, cpuct=2.0, noise=Float32(1 / maxActions), game, N=0, Nvict=0)
-    e = init(ngames, visits; game=game, N=N, Nvict=Nvict)
+function mcts(actor, visits, ngames, buffer::PoolSample; θ=1, cpuct=2.0, noise=Float32(1 / maxActions), game, N=0, Nvict=0, seed=fresh_seed())
+    e = init(ngames, visits; game=game, N=N, Nvict=Nvict, seed=seed)
+    try
     set_network!(e, actor)
     st = Ref{AgzStats}()
     rc = ccall((:agz_selfplay, libagz), Cint, (Ptr{Cvoid}, Cint, Cint, Cfloat, Cint, Ref{AgzStats}), e.h, ngames, visits, cpuct, 25, st)
@@ -84,20 +93,27 @@ function mcts(actor, visits, ngames, buffer::PoolSample; θ=1, cpuct=2.0, noise=
         buffer.pool[idx].value = value[i]; buffer.pool[idx].fstate .= @view fstate[:, i]
     end
     println("victoires,nul,défaites", [st[].wins, st[].draws, st[].losses])
-    (data=[], valid=true)
+    return (data=[], valid=true)
+    finally
+        destroy!(e)
+    end
 end
 
-function duelnetwork(actor1, actor2, visits, ngames, conv=2; game, N=0, Nvict=0)
+function duelnetwork(actor1, actor2, visits, ngames, conv=2; game, N=0, Nvict=0, seed=fresh_seed())
     half = div(ngames, 2)
-    function half_duel(a, b)
-        e = init(half, visits; game=game, N=N, Nvict=Nvict)
-        set_network!(e, a; slot=0); set_network!(e, b; slot=1)
-        wdl = zeros(Int64, 3)
-        check(e, ccall((:agz_duel, libagz), Cint, (Ptr{Cvoid}, Cint, Cint, Cfloat, Cint, Cint, Ptr{Int64}), e.h, half, visits, 2f0, 15, 0, wdl))
-        wdl
+    function half_duel(a, b, sd)
+        e = init(half, visits; game=game, N=N, Nvict=Nvict, seed=sd)
+        try
+            set_network!(e, a; slot=0); set_network!(e, b; slot=1)
+            wdl = zeros(Int64, 3)
+            check(e, ccall((:agz_duel, libagz), Cint, (Ptr{Cvoid}, Cint, Cint, Cfloat, Cint, Cint, Ptr{Int64}), e.h, half, visits, 2f0, 15, 0, wdl))
+            return wdl
+        finally
+            destroy!(e)
+        end
     end
-    v1, n1, d1 = half_duel(actor1, actor2)
-    d2, n2, v2 = half_duel(actor2, actor1)
+    v1, n1, d1 = half_duel(actor1, actor2, seed)
+    d2, n2, v2 = half_duel(actor2, actor1, seed + 1)
     v1 + v2, n1 + n2, d1 + d2
 end
 

@@ -12,3 +12,5 @@ namespace agz {
 template __global__ void k_search_small<F_LINE, 2, 12, 128, 4, WVV>(const SmallPar);
 }
 namespace agz { template __global__ void k_rollout_eager<F_LINE, 2, 12, WVV>(const TreePar); }
+#include "../alphagpu_amd/csrc/agz_search_big.hpp"
+namespace agz { template __global__ void k_search_big<F_LINE, 2, 12, 512, 1>(const BigSearchPar); template __global__ void k_search_big<F_LINE, 2, 12, 512, 2>(const BigSearchPar); }

@@ -610,6 +610,34 @@ def test_whole_search_kernel_agrees_bitwise(name, L, V, monkeypatch):
             assert_same_bits(a, b, what + " " + str(env))
 
 
+@pytest.mark.parametrize("name,L,V,T", [("gobang9", 300, 24, 2), ("hex9", 70, 128, 1), ("reversi8", 1100, 16, 1), ("connect4", 2100, 12, 1)])
+def test_whole_search_kernel_for_wide_trunks_agrees_bitwise(name, L, V, T, monkeypatch):
+    """k_search_big (512-wide trunk, one launch per mcts_single, 32 games per 8-wave workgroup; sparse waves at these sizes) runs the
+    same tree step and network bodies as k_rollout_eager + k_mlp_big: identical bits, ragged last workgroup, V = 128 trees."""
+    g, _ = spec(name)
+    net = ag.SNetwork2.random(g, 512, T)
+
+    def run():
+        with M.Engine(g, L, V, seed=11, nn_mode=M.NN_BF16) as e:
+            e.set_network(net)
+            e.set_roots(None, L=L)
+            e.search(V, cpuct=1.5, training=True, step=2)
+            return e.root_visits().copy(), e.policy().copy(), e.root_q().copy(), e.leaf().copy(), e.node_count().copy(), e.search_form()[0]
+
+    monkeypatch.setenv("AGZ_BIG_MAXL", "0")
+    ref = run()                                     # two kernels per rollout
+    assert ref[5].startswith("k_rollout_eager")
+    monkeypatch.delenv("AGZ_BIG_MAXL")
+    for env in ({}, {"AGZ_SMALL_GPW": "8"}, {"AGZ_SMALL_GPW": "2"}):
+        monkeypatch.delenv("AGZ_SMALL_GPW", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        got = run()
+        assert got[5].startswith("k_search_big")
+        for a, b, what in zip(got[:5], ref[:5], ("visits", "policy", "q", "leaf", "node_count")):
+            assert_same_bits(a, b, what + " " + str(env))
+
+
 def test_duel_with_two_different_128_wide_networks_is_deterministic_and_symmetric():
     """mcts(actor1, actor2, ...) on the whole-search kernel (H = 128): two different weight slots alternate by ply parity.
     Same seeds -> same result; swapping who moves first swaps the roles (W/L mirror when the nets are swapped too)."""
