@@ -107,6 +107,8 @@ struct agz_engine {
     size_t ev_tree_used = 0, ev_nn_used = 0;
     double tree_ms = 0, nn_ms = 0, tree_busy_ms = 0; int64_t tree_launches = 0;
     hipEvent_t ev_ref = nullptr; bool ev_ref_live = false;
+    hipEvent_t ev_ply0 = nullptr, ev_ply1 = nullptr; uint32_t* hcount = nullptr;   // ply loop: search timing, pinned alive count
+    uint64_t nn_leaves = 0;    // leaves sent through stand-alone network launches of the instrumented searches
     advance_fn k_adv = nullptr; softmax_fn k_soft = nullptr;
     big_fn k_big[2] = {nullptr, nullptr};   // whole-search kernel for 512-wide trunks (agz_search_big.hpp), 1 / 2 workgroups per CU
     int big_maxl = 16384;        // ... used for batches up to this many games (AGZ_BIG_MAXL): 6.2 vs 8.0 ms per ply at 8192 games, 4.5 vs 7.3 at 1024, 9.9 vs 10.2 at 16384
@@ -225,6 +227,9 @@ void agz_destroy(agz_engine* h) {
     for (auto& e : h->ev_tree) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto& e : h->ev_nn) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     if (h->ev_ref) hipEventDestroy(h->ev_ref);
+    if (h->ev_ply0) hipEventDestroy(h->ev_ply0);
+    if (h->ev_ply1) hipEventDestroy(h->ev_ply1);
+    if (h->hcount) hipHostFree(h->hcount);
     for (int c = 0; c < agz_engine::KCH - 1; ++c) { if (h->aux[c]) hipStreamDestroy(h->aux[c]); if (h->ev_join[c]) hipEventDestroy(h->ev_join[c]); }
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -265,22 +270,26 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     const GamePar& P = h->G;
     h->Lmax = cfg->max_games; h->V = cfg->max_visits;
     if (!bind_kernels(h)) { h->fail("no kernel instantiation for this game shape"); return bail(AGZ_ERR_UNSUPPORTED); }
-    hipFuncSetAttribute((const void*)k_mlp_wave<128, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)k_mlp_wave<128, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)k_mlp_wave<128, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)k_mlp_wave<128, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)k_mlp_wave<64, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)k_mlp_wave<64, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)k_mlp_big<512, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)k_mlp_big<256, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)k_mlp_big<512, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)k_mlp_big<256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)k_layer_exact<EX_RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)k_layer_exact<EX_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)k_layer_exact<EX_POLICY>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)k_layer_exact<EX_VALUE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)k_mlp_fused3<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)k_mlp_fused3<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (hipEventCreate(&h->ev_ply0) != hipSuccess || hipEventCreate(&h->ev_ply1) != hipSuccess ||
+        hipHostMalloc((void**)&h->hcount, 4, 0) != hipSuccess) { h->fail("cannot create the ply-loop events / pinned counter"); return bail(AGZ_ERR_HIP); }
+    hipError_t fa = hipSuccess;                                     // first failure of the attribute / memset calls below
+#define FA_(call) do { hipError_t r_ = (call); if (fa == hipSuccess) fa = r_; } while (0)
+    FA_(hipFuncSetAttribute((const void*)k_mlp_wave<128, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    FA_(hipFuncSetAttribute((const void*)k_mlp_wave<128, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    FA_(hipFuncSetAttribute((const void*)k_mlp_wave<128, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    FA_(hipFuncSetAttribute((const void*)k_mlp_wave<128, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    FA_(hipFuncSetAttribute((const void*)k_mlp_wave<64, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    FA_(hipFuncSetAttribute((const void*)k_mlp_wave<64, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    FA_(hipFuncSetAttribute((const void*)k_mlp_big<512, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    FA_(hipFuncSetAttribute((const void*)k_mlp_big<256, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    FA_(hipFuncSetAttribute((const void*)k_mlp_big<512, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    FA_(hipFuncSetAttribute((const void*)k_mlp_big<256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    FA_(hipFuncSetAttribute((const void*)k_layer_exact<EX_RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    FA_(hipFuncSetAttribute((const void*)k_layer_exact<EX_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    FA_(hipFuncSetAttribute((const void*)k_layer_exact<EX_POLICY>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    FA_(hipFuncSetAttribute((const void*)k_layer_exact<EX_VALUE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    FA_(hipFuncSetAttribute((const void*)k_mlp_fused3<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    FA_(hipFuncSetAttribute((const void*)k_mlp_fused3<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     // node record: [prior f32 x A2][q f32 x A2][rank u8 x A2][cid u8 x A2][vis u8 x A2], A2 = 8 lanes x KPL actions
     // (agz_tree_eager.hpp)
     h->reg_lds = (size_t)eager_lds_layout(h->V).total;
@@ -290,8 +299,8 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     const uint32_t A2 = (uint32_t)(8 * h->reg_kpl);
     const uint32_t rec_bytes = (uint32_t)eager_rec_bytes((int)A2);
     {
-        hipFuncSetAttribute((const void*)h->k_eager, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->reg_lds);
-        hipFuncSetAttribute((const void*)h->k_eager3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->reg_lds);
+        FA_(hipFuncSetAttribute((const void*)h->k_eager, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->reg_lds));
+        FA_(hipFuncSetAttribute((const void*)h->k_eager3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->reg_lds));
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) { h->reg3_max_waves = 12 * prop.multiProcessorCount; h->cus = prop.multiProcessorCount; }   // 3 waves x 4 SIMDs per CU
         const char* e3 = getenv("AGZ_REG3_MAX_WAVES");
@@ -304,11 +313,11 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
         if (e3) h->small4_maxl = atoi(e3);
         e3 = getenv("AGZ_BIG_MAXL");
         if (e3) h->big_maxl = atoi(e3);
-        for (int i = 0; i < 2; ++i) if (h->k_big[i]) hipFuncSetAttribute((const void*)h->k_big[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        for (int i = 0; i < 2; ++i) if (h->k_big[i]) FA_(hipFuncSetAttribute((const void*)h->k_big[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         e3 = getenv("AGZ_SMALL4_OCC");
         if (e3 && atoi(e3) >= 0 && atoi(e3) <= 2) h->small4_occ = atoi(e3);
-        if (h->k_small) hipFuncSetAttribute((const void*)h->k_small, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        for (int i = 0; i < 3; ++i) if (h->k_small4[i]) hipFuncSetAttribute((const void*)h->k_small4[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (h->k_small) FA_(hipFuncSetAttribute((const void*)h->k_small, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        for (int i = 0; i < 3; ++i) if (h->k_small4[i]) FA_(hipFuncSetAttribute((const void*)h->k_small4[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     const size_t Lm = (size_t)h->Lmax, V = (size_t)h->V;
     h->INP = round_up(2 * P.VS, 32);
@@ -333,21 +342,21 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     A_(dmalloc(&h->prior_eval, Lm * P.A + 64)); A_(dmalloc(&h->v_eval, Lm)); A_(dmalloc(&h->policy_final, Lm * P.A));
     A_(dmalloc(&h->newpos, Lm)); A_(dmalloc(&h->alive, Lm)); A_(dmalloc(&h->newslot, Lm)); A_(dmalloc(&h->d_count, 4));
     A_(dmalloc(&h->d_stats, 8)); A_(dmalloc(&h->d_acc, 2));
-    hipMemset(h->d_acc, 0, 16);
+    FA_(hipMemset(h->d_acc, 0, 16));
     A_(dmalloc(&h->scratch_f, Lm * (size_t)((P.A > 2 * P.VS) ? P.A : 2 * P.VS)));
     h->sample_games = cfg->sample_capacity_games > 0 ? cfg->sample_capacity_games : h->Lmax;
     const size_t SG = (size_t)h->sample_games, MP = (size_t)P.max_plies;
     A_(dmalloc(&h->s_boards, SG * MP * 6)); A_(dmalloc(&h->s_policy, SG * MP * P.A)); A_(dmalloc(&h->s_move, SG * MP));
     A_(dmalloc(&h->g_nplies, SG)); A_(dmalloc(&h->g_result, SG)); A_(dmalloc(&h->g_final, SG));
     if (e != hipSuccess) { h->fail("device allocation failed: %s", hipGetErrorString(e)); return bail(AGZ_ERR_NOMEM); }
-    hipMemsetAsync(h->meta, 0, Lm * V * 4, h->stream);
-    hipMemsetAsync(h->policy_final, 0, Lm * P.A * 4, h->stream);
-    hipMemsetAsync(h->planes, 0, Lm * h->INP * (cfg->nn_mode == AGZ_NN_BF16 ? 2 : 4), h->stream);
-    hipMemsetAsync(h->logits, 0, Lm * h->LGS * 4, h->stream);
-    hipMemsetAsync(h->prior_eval, 0, Lm * P.A * 4, h->stream);
-    hipMemsetAsync(h->v_eval, 0, Lm * 4, h->stream);
-    hipMemsetAsync(h->cnt_p, 0, Lm * 4, h->stream); hipMemsetAsync(h->cnt_new, 0, Lm * 4, h->stream);
-    hipMemsetAsync(h->g_nplies, 0, SG * 4, h->stream);
+    FA_(hipMemsetAsync(h->meta, 0, Lm * V * 4, h->stream));
+    FA_(hipMemsetAsync(h->policy_final, 0, Lm * P.A * 4, h->stream));
+    FA_(hipMemsetAsync(h->planes, 0, Lm * h->INP * (cfg->nn_mode == AGZ_NN_BF16 ? 2 : 4), h->stream));
+    FA_(hipMemsetAsync(h->logits, 0, Lm * h->LGS * 4, h->stream));
+    FA_(hipMemsetAsync(h->prior_eval, 0, Lm * P.A * 4, h->stream));
+    FA_(hipMemsetAsync(h->v_eval, 0, Lm * 4, h->stream));
+    FA_(hipMemsetAsync(h->cnt_p, 0, Lm * 4, h->stream)); hipMemsetAsync(h->cnt_new, 0, Lm * 4, h->stream);
+    FA_(hipMemsetAsync(h->g_nplies, 0, SG * 4, h->stream));
 
     TreePar& T = h->tp;
     memset(&T, 0, sizeof T);
@@ -357,10 +366,12 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     T.logits = h->logits; T.LGS = h->LGS; T.prior_eval = h->prior_eval; T.v_eval = h->v_eval; T.policy_final = h->policy_final;
     T.seed = cfg->seed; T.exact = cfg->nn_mode == AGZ_NN_EXACT;
     T.aux4 = h->aux4; T.wl = h->wl; T.wl_n = h->wl_n; T.sp = h->sp; T.wl_cap = h->wl_cap;
-    hipMemsetAsync(h->wl_n, 0, wl_blocks * 4, h->stream); hipMemsetAsync(h->sp, 0, Lm * 4, h->stream);
+    FA_(hipMemsetAsync(h->wl_n, 0, wl_blocks * 4, h->stream)); hipMemsetAsync(h->sp, 0, Lm * 4, h->stream);
 #ifdef AGZ_STAMPS
     { unsigned long long* d = nullptr; hipMalloc((void**)&d, (size_t)65536 * 16 * 8); hipMemset(d, 0, (size_t)65536 * 16 * 8); T.dbg = d; }
 #endif
+#undef FA_
+    if (fa != hipSuccess) { h->fail("device setup failed: %s", hipGetErrorString(fa)); return bail(AGZ_ERR_HIP); }
     if (hipStreamSynchronize(h->stream) != hipSuccess) { h->fail("device init failed"); return bail(AGZ_ERR_HIP); }
     *out = h;
     return AGZ_OK;
@@ -627,7 +638,7 @@ static int launch_network(agz_engine* h, int which, int s0 = 0, int s1 = -1, hip
     const uint8_t* const planes = (const uint8_t*)h->planes + (size_t)s0 * h->INP * pe;
     float* const logits = h->logits + (size_t)s0 * h->LGS; float* const v_eval = h->v_eval + s0;
     std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
-    if ((h->profiling & 2) && h->prof_this) { ev = next_events(h, h->ev_nn, h->ev_nn_used); hipEventRecord(ev->first, stream); }
+    if ((h->profiling & 2) && h->prof_this) { ev = next_events(h, h->ev_nn, h->ev_nn_used); hipEventRecord(ev->first, stream); h->nn_leaves += (uint64_t)L; }
     size_t f3_lds = 0;
     if (h->cfg.nn_mode == AGZ_NN_BF16 && (n.H == 64 || n.H == 128) && n.w16 && n.AOP / 16 <= n.H / 16 && !getenv("AGZ_NO_FUSED_NN")) {
         f3_lds = (size_t)F3_M * (n.H * 2 + 16) + F3_WCHUNK + (size_t)F3_M * (n.INP * 2 + 16);
@@ -998,10 +1009,15 @@ int agz_get_kernel_times(agz_engine* h, double* tree_ms, double* nn_ms, int64_t*
     if (tree_ms) *tree_ms = h->tree_ms;
     if (nn_ms) *nn_ms = h->nn_ms;
     if (tree_launches) *tree_launches = h->tree_launches;
-    if (reset) { h->tree_ms = h->nn_ms = h->tree_busy_ms = 0; h->tree_launches = 0; h->acc_p = h->acc_new = 0; h->total_rollouts = 0; hipMemsetAsync(h->d_acc, 0, 16, h->stream); }
+    if (reset) { h->nn_leaves = 0; h->tree_ms = h->nn_ms = h->tree_busy_ms = 0; h->tree_launches = 0; h->acc_p = h->acc_new = 0; h->total_rollouts = 0; hipMemsetAsync(h->d_acc, 0, 16, h->stream); }
     return AGZ_OK;
 }
 
+int agz_get_nn_leaves(agz_engine* h, uint64_t* leaves) {
+    if (!h || !leaves) return AGZ_ERR_ARG;
+    *leaves = h->nn_leaves;
+    return AGZ_OK;
+}
 int agz_get_tree_busy_ms(agz_engine* h, double* busy_ms) {
     if (!h || !busy_ms) return AGZ_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device));
@@ -1031,15 +1047,14 @@ static int run_games(agz_engine* h, int ngames, int V, float cpuct, int tau_plie
     HIPCHK(h, hipMemsetAsync(h->d_stats, 0, 8 * sizeof(unsigned long long), h->stream));
     HIPCHK(h, hipMemsetAsync(h->g_nplies, 0, (size_t)h->sample_games * 4, h->stream));
     h->sp_games = ngames;
-    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const hipEvent_t e0 = h->ev_ply0, e1 = h->ev_ply1;
     double search_ms = 0; int64_t rollouts = 0; int ply = 0;
-    uint32_t* hcount = nullptr;
-    HIPCHK(h, hipHostMalloc((void**)&hcount, 4, 0));
+    uint32_t* const hcount = h->hcount;
     while (h->L > 0) {                                                          // :494
         const int which = duel ? ((ply & 1) == 0 ? duel_first : 1 - duel_first) : 0;   // :592-596
-        hipEventRecord(e0, h->stream);
+        if (hipEventRecord(e0, h->stream) != hipSuccess) { h->fail("hipEventRecord failed"); rc = AGZ_ERR_HIP; break; }
         rc = agz_search_actor(h, which, V, cpuct, training, (uint32_t)ply); if (rc) break;      // :503
-        hipEventRecord(e1, h->stream);
+        if (hipEventRecord(e1, h->stream) != hipSuccess) { h->fail("hipEventRecord failed"); rc = AGZ_ERR_HIP; break; }
         rollouts += (int64_t)h->L * V;
         PlyPar T; fill_plypar(h, T, ply, tau_plies, duel);
         hipLaunchKernelGGL(h->k_adv, dim3((unsigned)((h->L + 3) / 4)), dim3(256), 0, h->stream, T);          // :513-549
@@ -1060,7 +1075,6 @@ static int run_games(agz_engine* h, int ngames, int V, float cpuct, int tau_plie
         ++ply;
         if (ply > 255) { h->fail("game exceeded 255 plies"); rc = AGZ_ERR_STATE; break; }
     }
-    hipHostFree(hcount); hipEventDestroy(e0); hipEventDestroy(e1);
     if (rc) return rc;
     unsigned long long hs[8];
     HIPCHK(h, hipMemcpy(hs, h->d_stats, sizeof hs, hipMemcpyDeviceToHost));

@@ -87,5 +87,6 @@ def load_library():
     L.agz_get_kernel_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]
     L.agz_set_profiling.argtypes = [vp, C.c_int]
     L.agz_get_tree_busy_ms.argtypes = [vp, C.POINTER(C.c_double)]
+    L.agz_get_nn_leaves.argtypes = [vp, C.POINTER(C.c_uint64)]
     _LIB = L
     return L

@@ -205,6 +205,12 @@ class Engine:
         self._chk(self.L.agz_get_tree_busy_ms(self.h, C.byref(t)))
         return t.value
 
+    def nn_leaves(self):
+        """Leaves evaluated by the stand-alone network launches that kernel_times()'s nn_ms covers."""
+        n = C.c_uint64(0)
+        self._chk(self.L.agz_get_nn_leaves(self.h, C.byref(n)))
+        return n.value
+
     def synchronize(self):
         self._chk(self.L.agz_synchronize(self.h))
 

@@ -176,7 +176,7 @@ def main():
         eng.set_roots(None, L=G)
         eng.search(V, cpuct=args.cpuct, training=True, step=0)
     form_tree, form_nn = eng.search_form()
-    whole = form_tree.startswith("k_search_small")
+    whole = form_tree.startswith("k_search_small")       # (the form of the LAST search; big batches of wide trunks use two kernels)
     eng.set_profiling(1 if whole else 7)
     eng.kernel_times(reset=True)
     fence()
@@ -196,6 +196,7 @@ def main():
     tree_ms, nn_ms, launches = eng.kernel_times()
     busy_ms = eng.tree_busy_ms()      # union of the launch intervals: sub-batch chains run launches side by side
     sum_p, sum_new, r_cnt = eng.counters()
+    nn_leaves = eng.nn_leaves()
     form_tree, form_nn = eng.search_form()
 
     # host delivery (SURVEY §8d "end-to-end"): the reference's generation ends with the samples in the host PoolSample
@@ -239,13 +240,16 @@ def main():
         except Exception:
             traffic = None
         hbm_achieved = alg / (busy_ms * 1e-3) / 1e9 if busy_ms > 0 else 0.0   # aggregate over the launches in flight together
-        flops = nn_flops_per_leaf(game, args.filters, args.towers) * r_cnt
-        if whole:
+        if whole or nn_leaves == 0:
             # the network forward runs inside the search kernel: its time is not separable, the fraction is taken against the
             # whole launch (a lower bound of the MFMA pipe's rate while the network phase runs)
-            nn_t_ms, nn_note = busy_ms, "network inside k_search_small: flops / whole-launch time (lower bound)"
+            flops = nn_flops_per_leaf(game, args.filters, args.towers) * r_cnt
+            nn_t_ms, nn_note = busy_ms, "network inside the whole-search kernel: flops / whole-launch time (lower bound)"
         else:
-            nn_t_ms, nn_note = nn_ms, "HIP events around the network launches of the instrumented searches"
+            # plies of the two-kernel form only (big batches): leaves and HIP-event time of the stand-alone network launches; the
+            # small-batch plies of the same generation run the network inside k_search_big / k_search_small
+            flops = nn_flops_per_leaf(game, args.filters, args.towers) * nn_leaves
+            nn_t_ms, nn_note = nn_ms, "stand-alone network launches of the instrumented searches (leaves and HIP-event time of those launches only)"
         mfma_achieved = flops / (nn_t_ms * 1e-3) / 1e12 if nn_t_ms > 0 else 0.0
         tree_obj = {"kernel": form_tree, "bound": "hbm", "achieved": hbm_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": hbm_achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -257,7 +261,8 @@ def main():
                             + "; algorithmic bytes are the tree path's (SURVEY 8d)"}
         nn_obj = {"kernel": form_nn, "bound": "mfma", "achieved": mfma_achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                   "frac": mfma_achieved / MFMA_PEAK_TFLOPS, "traffic": None,
-                  "flops_per_leaf": nn_flops_per_leaf(game, args.filters, args.towers), "leaves": r_cnt, "time_ms": nn_t_ms, "note": nn_note}
+                  "flops_per_leaf": nn_flops_per_leaf(game, args.filters, args.towers), "leaves": (r_cnt if (whole or nn_leaves == 0) else nn_leaves),
+                  "time_ms": nn_t_ms, "note": nn_note}
         # the dominant kernel of the configuration: the network when its launches take longer than the tree kernel's
         nn_dominant = (not whole) and nn_ms > busy_ms
         out = {

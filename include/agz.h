@@ -147,11 +147,28 @@ int  agz_get_kernel_times(agz_engine *h, double *tree_ms, double *nn_ms, int64_t
 /* with sub-batch chains several tree-kernel launches run side by side: busy time (ms) = length of the union of the
  * launch intervals since the last reset of agz_get_kernel_times (== tree_ms when launches never overlap) */
 int  agz_get_tree_busy_ms(agz_engine *h, double *busy_ms);
+/* leaves evaluated by the stand-alone network launches that agz_get_kernel_times' nn_ms covers (since its last reset) */
+int  agz_get_nn_leaves(agz_engine *h, uint64_t *leaves);
 /* names of the kernels the last search ran (the engine picks the execution form by batch size and network width) */
 int  agz_get_search_form(agz_engine *h, char *tree_kernel, char *nn_kernel, int cap);
 int  agz_set_profiling(agz_engine *h, int mode);       /* HIP events per launch: bit 0 tree kernel, bit 1 network kernel;
                                                           bit 2: instrument (events and agz_get_counters) every 4th search only */
 
+/*
+ * Environment switches read by agz_create (all optional; results never depend on them, the tests use them to reach every
+ * kernel build at small sizes):
+ *   AGZ_SMALL_MAXL=n       128-wide trunk: 16 games per workgroup of the one-launch search up to n games (default 8192), 32 above;
+ *                          0 together with AGZ_SMALL4_MAXL=0 disables the one-launch form (two kernels per rollout)
+ *   AGZ_SMALL4_MAXL=n      largest batch of the 32-games-per-workgroup one-launch search
+ *   AGZ_SMALL4_OCC=0|1|2   force the 2 / 3 / 4 workgroups-per-CU register budget of that kernel
+ *   AGZ_SMALL_GPW=1|2|4|8  games per tree wave of the one-launch forms (sparse waves for small batches)
+ *   AGZ_BIG_MAXL=n         512-wide trunk: one-launch search (k_search_big) up to n games (default 16384; 0 disables)
+ *   AGZ_CHAINS=k           two-kernel form: k sub-batches on parallel streams (default 2-3 from 12000 games)
+ *   AGZ_REG3_MAX_WAVES=n   two-kernel form: largest grid that uses the 3-waves-per-SIMD build of the tree kernel
+ *   AGZ_NN_WAVE_LT, AGZ_NN_WAVE_DEPTH, AGZ_NN_WAVE_MAXL   tile count / prefetch depth / batch limit of k_mlp_wave
+ *   AGZ_NO_FUSED_NN=1      per-layer network kernels (k_layer_bf16) and no one-launch search
+ *   AGZ_NO_FASTDIV=1       IEEE '/' everywhere in the tree kernel (agz_fastdiv.hpp off)
+ */
 #ifdef __cplusplus
 }
 #endif
