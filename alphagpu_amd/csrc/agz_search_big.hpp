@@ -30,7 +30,7 @@ __global__ __launch_bounds__(NB_THREADS, 2 * WG) void k_search_big(const BigSear
     const int wave = (int)threadIdx.x >> 6;
     uint8_t* const tree_lds = lds_bigs + (size_t)(wave % TW) * S.tree_lds;
     uint32_t* const wl_lds = reinterpret_cast<uint32_t*>(lds_bigs + S.wl_off + (size_t)(wave % TW) * S.wl_bytes);
-    EagerCarry C = {1u, 0u, 0u, 0u, 0u, 0u};
+    EagerCarry C = {1u, 0u, 0u, 0u, 0u, 0u, 0u};
     uint32_t wcount = 0;
     for (int k = 0; k <= S.V; ++k) {
         const StepFlags SF = {(uint32_t)k, k == 0, k > 0, k < S.V, k == S.V - 1, k == S.V};

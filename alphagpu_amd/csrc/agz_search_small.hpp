@@ -32,7 +32,7 @@ __global__ __launch_bounds__(64 * NW_WAVES, WV) void k_search_small(const SmallP
     uint8_t* const nn_lds = lds_small;                            // the two phases never overlap and the tree step keeps nothing
                                                                   // in this window from one rollout to the next: same memory
     uint32_t* const wl_lds = reinterpret_cast<uint32_t*>(lds_small + S.wl_off + (size_t)(wave % TW) * S.wl_bytes);
-    EagerCarry C = {1u, 0u, 0u, 0u, 0u, 0u};                      // what a game carries from rollout to rollout: in registers
+    EagerCarry C = {1u, 0u, 0u, 0u, 0u, 0u, 0u};                      // what a game carries from rollout to rollout: in registers
     uint32_t wcount = 0;
     for (int k = 0; k <= S.V; ++k) {
         const StepFlags SF = {(uint32_t)k, k == 0, k > 0, k < S.V, k == S.V - 1, k == S.V};

@@ -50,7 +50,7 @@ __host__ __device__ inline EagerLds eager_lds_layout(int V) {
 
 // what a game carries from one rollout to the next.  The stand-alone kernel keeps it in global memory (T.ncount, T.leaf, T.sp,
 // T.cnt_*); the whole-search kernel (agz_search_small.hpp) keeps it in registers across its rollout loop.
-struct EagerCarry { uint32_t ncount, leafn, spw, add_p, add_new, root_exp; };
+struct EagerCarry { uint32_t ncount, leafn, spw, add_p, add_new, root_exp, leaf_meta; };   // leaf_meta: the leaf's meta word (whole-search kernels)
 
 // rows of one work item, loaded one round ahead of their use
 template <int KPL> struct ItemRows {
@@ -118,7 +118,7 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
     AGZ_WSYNC();
 #endif
     if (SF.do_reset) {
-        C.ncount = 1; C.leafn = 0; C.spw = 0; C.add_p = 0; C.add_new = 0; C.root_exp = 0;
+        C.ncount = 1; C.leafn = 0; C.spw = 0; C.add_p = 0; C.add_new = 0; C.root_exp = 0; C.leaf_meta = M_EXISTS;
         wcount = 0;
         if (live && lead) gmeta[0] = M_EXISTS;
     } else if constexpr (!LEAN) {
@@ -236,7 +236,7 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
         if constexpr (PFM == 1) sink = item_touch(0, nwl);           // the first item's record starts travelling towards L2 now
         // ---------------------------------------------------------------------------- expand (lane-group g = game g)
         const int lf = (int)C.leafn;
-        uint32_t ml = live ? gmeta[lf] : (uint32_t)M_TERM;
+        uint32_t ml = live ? (LEAN ? C.leaf_meta : gmeta[lf]) : (uint32_t)M_TERM;   // (one memory round trip less on the rollout's chain)
         const bool term = (ml & M_TERM) != 0;
         const bool doexp = live && !term;
         float vleaf = 0.0f;
@@ -648,7 +648,7 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
                 d[0] = make_float4(w[0], w[1], w[2], w[3]);
                 d[1] = make_float4(w[4], w[5], w[6], w[7]);
             }
-            C.leafn = (uint32_t)node;
+            C.leafn = (uint32_t)node; C.leaf_meta = mn;
         }
     }
 
