@@ -172,11 +172,12 @@ def main():
     eng.set_profiling(1)
     for _ in range(max(args.warmup, 0)):
         step()
-    if args.warmup == 0:                        # the form is needed before the timed region: one probe search of the first ply
-        eng.set_roots(None, L=G)
-        eng.search(V, cpuct=args.cpuct, training=True, step=0)
+    # the kernel the roofline object names is the one the FIRST ply (all G games alive) dispatches to -- the plies of the tail
+    # run smaller-batch variants of the same kernel (agz_get_search_form reports the last search): one untimed probe search
+    eng.set_roots(None, L=G)
+    eng.search(V, cpuct=args.cpuct, training=True, step=0)
     form_tree, form_nn = eng.search_form()
-    whole = form_tree.startswith("k_search_small")       # (the form of the LAST search; big batches of wide trunks use two kernels)
+    whole = form_tree.startswith("k_search_small")
     eng.set_profiling(1 if whole else 7)
     eng.kernel_times(reset=True)
     fence()
@@ -197,7 +198,6 @@ def main():
     busy_ms = eng.tree_busy_ms()      # union of the launch intervals: sub-batch chains run launches side by side
     sum_p, sum_new, r_cnt = eng.counters()
     nn_leaves = eng.nn_leaves()
-    form_tree, form_nn = eng.search_form()
 
     # host delivery (SURVEY §8d "end-to-end"): the reference's generation ends with the samples in the host PoolSample
     # (mcts_gpu.jl:515, mainGobang.jl:54-80).  One extra generation, outside the timed region: generation + packed records D2H
