@@ -742,7 +742,7 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
         // then times that launch (it counts as one "tree launch" of agz_get_kernel_times)
         DevNet& n = h->net[which];
         if (h->k_small && h->cfg.nn_mode == AGZ_NN_BF16 && n.H == 128 && n.w16w && h->L > 0 &&
-            h->V <= 64 && (h->V & 3) == 0 && 8 * h->reg_kpl <= h->LGS &&   // the lean build of the tree step (rollout_eager_body<..., LEAN>)
+            h->V <= 128 && (h->V & 3) == 0 && 8 * h->reg_kpl <= h->LGS &&   // the lean build of the tree step (rollout_eager_body<..., LEAN>)
             h->L <= std::min(std::max(h->small_maxl, h->small4_maxl), 128 * h->cus) && !getenv("AGZ_NO_FUSED_NN")) {
             // 16 games per workgroup up to small_maxl; beyond, 32 games per workgroup with the loosest register budget that still
             // keeps every workgroup resident (2 / 3 / 4 workgroups per CU = 64 / 96 / 128 games per CU)

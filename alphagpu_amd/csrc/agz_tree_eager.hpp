@@ -60,7 +60,7 @@ template <int KPL> struct ItemRows {
     uint32_t ent; int gi; bool valid;
 };
 
-// LEAN: the caller is the whole-search kernel: V <= 64 (a multiple of 4), bf16 network mode, no inject / capture, the carry
+// LEAN: the caller is a whole-search kernel: V a multiple of 4 (<= 128 in the engine's dispatch), bf16 network mode, no inject / capture, the carry
 // lives in registers (C) and the wave's work list in LDS (wl_lds, wcount); otherwise both live in global memory.
 // PFM = 2: the rows of the next work item are requested while the running sums of the current one are computed, and those of
 // the first item before the leaf's rows are written (35 more live registers: only where the register budget has room for them

@@ -17,4 +17,7 @@ done
 if [ -f scratch/libagz_dbg.so ]; then
   for L in 32768 4096 512; do echo "## $L games" >> $out/stamps.txt; LL=$L python scratch/stamps.py >> $out/stamps.txt 2>&1; done
 fi
+# per-ply search time by batch size (default dispatch), 128x6 and 512x8
+for L in 256 1024 2048 4096 8192 16384 24576 32768; do echo "128x6 L=$L $(python scratch/prof_search.py 64 $L 3 | tail -1)" >> $out/per_ply_by_batch.txt; done
+for L in 256 1024 4096 8192 16384 32768; do echo "512x8 L=$L $(NH=512 NT=8 python scratch/prof_search.py 64 $L 3 | tail -1)" >> $out/per_ply_by_batch.txt; done
 ls $out

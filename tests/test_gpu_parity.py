@@ -575,10 +575,10 @@ def test_wide_trunk_128_leaf_tiles_agree_bitwise(monkeypatch):
         assert_same_bits(a, b, what)
 
 
-@pytest.mark.parametrize("name,L,V", [("gobang9", 300, 24), ("connect4", 77, 36), ("hex9", 40, 64)])
+@pytest.mark.parametrize("name,L,V", [("gobang9", 300, 24), ("connect4", 77, 36), ("hex9", 40, 64), ("hex9", 44, 128)])
 def test_whole_search_kernel_agrees_bitwise(name, L, V, monkeypatch):
     """k_search_small (one launch per mcts_single, 16 or 32 games per workgroup, default up to 16384 games) runs the same
-    tree step and network bodies as the two stand-alone kernels (trees of up to 64 nodes, a multiple of 4): identical bits,
+    tree step and network bodies as the two stand-alone kernels (trees of up to 128 nodes, a multiple of 4): identical bits,
     ragged last workgroup."""
     g, _ = spec(name)
     net = ag.SNetwork2.random(g, 128, 2)
