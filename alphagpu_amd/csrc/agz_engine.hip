@@ -765,7 +765,12 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
             S.F.gpw = S.T.gpw < 8 ? S.T.gpw : 0; S.F.tw = tw;
             S.V = V; S.tree_lds = (int)h->reg_lds;
             const int kth = n.H / 32, g0 = (n.INP / 32 + kth - 1) / kth;
-            const size_t shared = (std::max((size_t)tw * h->reg_lds, (size_t)8 * tw * (2 * (n.H * 2 + 16) + (g0 * kth * 64 + 16))) + 15) & ~(size_t)15;   // tree and network phases share it
+            // the tree waves' tables and the network's two activation strips share one window (the phases never overlap); the hand-over
+            // window behind it carries planes (tree -> network) and logits (network -> tree), one block of 8 rows per tree wave
+            const int prowb = g0 * kth * 64 + 16;
+            S.io_prowb = prowb; S.io_lgs = n.AOP; S.io_bw = (8 * std::max(prowb, 4 * n.AOP) + 15) & ~15;
+            S.io_off = (int)((std::max((size_t)tw * h->reg_lds, (size_t)8 * tw * 2 * (n.H * 2 + 16)) + 15) & ~(size_t)15);
+            const size_t shared = (size_t)S.io_off + (size_t)tw * S.io_bw;
             // + the tree waves' work lists (kept across the network phase): what the CU's LDS leaves when every workgroup of the launch
             // must be resident (4 per CU at 32768 games); entries beyond the region, rare, go to the global list
             const int wgs_per_cu = tw == 2 ? 2 : 2 + occ;

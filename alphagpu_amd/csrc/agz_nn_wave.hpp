@@ -31,8 +31,9 @@ __host__ __device__ inline int nw_hidden_groups(int INP, int H, int T) {
 // larger LT when the batch is big enough for the L2 weight stream to become the bound).
 // DEPTH = groups (layers) of weight fragments in flight per wave: 4 hides the whole L2 latency behind one workgroup's own
 // work, 2 halves the registers so that twice as many workgroups share a CU (throughput mode for big batches).
-template <int H, int LT, int DEPTH, bool PRE_BARRIER = false>
-__device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const smem, const int bidx);
+template <int H, int LT, int DEPTH, bool PRE_BARRIER = false, bool IO = false>
+__device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const smem, const int bidx, uint8_t* const io = nullptr,
+                                              const int io_bw = 0, const int io_lgs = 0);
 
 template <int H, int LT, int DEPTH>
 __global__ __launch_bounds__(64 * NW_WAVES) void k_mlp_wave(const Fused3Par P) {
@@ -43,8 +44,12 @@ __global__ __launch_bounds__(64 * NW_WAVES) void k_mlp_wave(const Fused3Par P) {
 // The 4-wave workgroup's forward for the leaves [bidx*16*LT, +16*LT) (also called from k_search_small); contains
 // workgroup barriers: every wave of the workgroup must call it.  PRE_BARRIER: the input planes are being written by other
 // waves of this workgroup; the barrier that publishes them is taken AFTER the first weight fragments have been requested.
-template <int H, int LT, int DEPTH, bool PRE_BARRIER>
-__device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const smem, const int bidx) {
+// IO (whole-search kernel): planes and logits are handed over through LDS instead of a round trip through L2 — the tree wave that
+// owns tile rows 8 w .. 8 w + 7 has left their planes in block w of `io` (io_bw bytes per block, rows of PROWB bytes, zero padded),
+// and the head leaves logits (and the value in column A) in the same block, rows of io_lgs floats.  Global logits are still written.
+template <int H, int LT, int DEPTH, bool PRE_BARRIER, bool IO>
+__device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const smem, const int bidx, uint8_t* const io, const int io_bw,
+                                              const int io_lgs) {
     constexpr int NTH = H / 16, KTH = H / 32, TPW = NTH / NW_WAVES;
     constexpr int ROWB = H * 2 + 16;
     static_assert(TPW >= 1, "at least one neuron tile per wave");
@@ -80,7 +85,7 @@ __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const
     if constexpr (DEPTH == 4) { NW_LOADGROUP(2); NW_LOADGROUP(3); }
     if constexpr (PRE_BARRIER) __syncthreads();
 
-    {   // the ML rows of input planes -> LDS (coalesced 16-B loads), zero beyond INP
+    if constexpr (!IO) {   // the ML rows of input planes -> LDS (coalesced 16-B loads), zero beyond INP
         const int segs = G0 * KTH * 4, isegs = P.INP / 8;
         const AGZ_GLB uint16_t* gp = (const AGZ_GLB uint16_t*)P.planes;
         constexpr int TPR = 64 * NW_WAVES / ML;                   // threads per tile row (a power of two): no division by segs
@@ -90,8 +95,11 @@ __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const
             if (mm < P.L && seg < isegs) v = *(const AGZ_GLB v4u*)(gp + (size_t)mm * P.INP + seg * 8);
             *reinterpret_cast<v4u*>(pl + (size_t)row * PROWB + seg * 16) = v;
         }
+        __syncthreads();
     }
-    __syncthreads();
+    // tile row lrow of tile 0 of the input planes; the next 16-leaf tile is pstride bytes further
+    const uint8_t* const prow0 = IO ? io + (size_t)(lrow >> 3) * io_bw + (size_t)(lrow & 7) * PROWB : pl + (size_t)lrow * PROWB;
+    const int pstride = IO ? 2 * io_bw : 16 * PROWB;
 
     f32x4 acc[LT][TPW];
 #pragma unroll
@@ -103,9 +111,9 @@ __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const
 #define NW_GROUP(d, g)                                                                                  \
     do {                                                                                                \
         const int g_ = (g);                                                                             \
-        const uint8_t* const brow_ = g_ < G0 ? pl + (size_t)lrow * PROWB + (size_t)g_ * KTH * 64         \
+        const uint8_t* const brow_ = g_ < G0 ? prow0 + (size_t)g_ * KTH * 64                             \
                                              : act0 + (size_t)cur * ML * ROWB + (size_t)lrow * ROWB;    \
-        const int bstride_ = 16 * (g_ < G0 ? PROWB : ROWB);       /* next 16-leaf tile */               \
+        const int bstride_ = g_ < G0 ? pstride : 16 * ROWB;       /* next 16-leaf tile */               \
         _Pragma("unroll") for (int k = 0; k < KTH; ++k)                                                 \
             _Pragma("unroll") for (int lt = 0; lt < LT; ++lt) {                                         \
                 const bf16x8 b_ = *reinterpret_cast<const bf16x8*>(brow_ + (size_t)lt * bstride_ + k * 64 + q4 * 16); \
@@ -173,12 +181,22 @@ __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const
                     const float bias = P.bias_head[n];
 #pragma unroll
                     for (int lt = 0; lt < LT; ++lt) {
+                        // (IO) rows 16 lt + 4 q4 + r sit in block 2 lt + q4 / 2, rows 4 (q4 & 1) + r of it
+                        float* const lrow_ = IO ? reinterpret_cast<float*>(io + (size_t)(2 * lt + (q4 >> 1)) * io_bw) + (size_t)(4 * (q4 & 1)) * io_lgs + n : nullptr;
                         if (n < P.A) {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) { const int m = mrow[lt][r]; if (m < P.L) P.logits[(size_t)m * P.LGS + n] = acc[lt][t][r] + bias; }
+                            for (int r = 0; r < 4; ++r) {
+                                const int m = mrow[lt][r]; const float o = acc[lt][t][r] + bias;
+                                if (m < P.L) P.logits[(size_t)m * P.LGS + n] = o;
+                                if constexpr (IO) lrow_[(size_t)r * io_lgs] = o;
+                            }
                         } else if (n == P.A) {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) { const int m = mrow[lt][r]; if (m < P.L) P.vout[m] = sigmoid_ool(acc[lt][t][r] + bias); }
+                            for (int r = 0; r < 4; ++r) {
+                                const int m = mrow[lt][r]; const float o = sigmoid_ool(acc[lt][t][r] + bias);
+                                if (m < P.L) P.vout[m] = o;
+                                if constexpr (IO) lrow_[(size_t)r * io_lgs] = o;
+                            }
                         }
                     }
                 }

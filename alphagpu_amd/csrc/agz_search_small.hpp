@@ -18,6 +18,8 @@ struct SmallPar {
     int V;                    // rollouts
     int tree_lds;             // bytes of LDS of one tree wave
     int wl_off, wl_bytes;     // the tree waves' work lists live past the window the two phases share: offset, bytes per wave
+    int io_off, io_bw;        // hand-over window (planes to the network, logits back): offset, bytes per tree wave (8 rows)
+    int io_prowb, io_lgs;     // ... bytes of a row of planes, floats of a row of logits
 };
 
 // TW = tree waves per workgroup (2 or 4): the workgroup owns 8*TW games and runs the network with TW/2 leaf tiles.
@@ -40,13 +42,14 @@ __global__ __launch_bounds__(64 * NW_WAVES, WV) void k_search_small(const SmallP
         // of this loop and kept alive across them (hundreds of registers, spills)
         int bx = (int)blockIdx.x;
         asm volatile("" : "+s"(bx));
-        if (wave < TW) rollout_eager_body<FAM, NC, KPL, true, (WV < 4 ? 2 : 1)>(S.T, SF, tree_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount);
+        if (wave < TW) rollout_eager_body<FAM, NC, KPL, true, (WV < 4 ? 2 : 1)>(S.T, SF, tree_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
+                                                                               lds_small + S.io_off + (size_t)wave * S.io_bw, S.io_prowb, S.io_lgs);
 #ifdef AGZ_STAMPS
         const unsigned long long t_nn0 = __builtin_amdgcn_s_memtime();
 #endif
         if (k < S.V) {
             // (the barrier that publishes the planes of the leaves sits inside, after the first weight fragments are requested)
-            mlp_wave_body<H, TW / 2, 2, true>(S.F, nn_lds, bx);
+            mlp_wave_body<H, TW / 2, 2, true, true>(S.F, nn_lds, bx, lds_small + S.io_off, S.io_bw, S.io_lgs);
             __syncthreads();                                      // logits and values are visible to the tree waves
         }
 #ifdef AGZ_STAMPS

@@ -68,9 +68,13 @@ template <int KPL> struct ItemRows {
 // PFM = 1: the next item's record is only TOUCHED a round ahead (each of the 8 lanes of the group reads one dword of one of the
 // record's 8 cache lines into a scratch register), so that the real loads find it in L2 instead of paying an HBM miss.
 // wl_cap_lds: entries of the work list that fit the LDS region (the rest, rare, goes to the global list).
+// io_blk (LEAN, may be null): this wave's block of the LDS hand-over window of k_search_small — the network body left the logits
+// of game g in row g (io_lgs floats, the value in column A) and takes the leaf's planes from row g (io_prowb bytes, zero padded to
+// whole k-rows): one round trip through L2 less in each direction on the rollout's chain.  The global arrays are still written.
 template <int FAM, int NC, int KPL, bool LEAN, int PFM>
 __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepFlags SF, uint8_t* const lds, const int bidx,
-                                                   EagerCarry& C, uint32_t* const wl_lds, const uint32_t wl_cap_lds, uint32_t& wcount) {
+                                                   EagerCarry& C, uint32_t* const wl_lds, const uint32_t wl_cap_lds, uint32_t& wcount,
+                                                   uint8_t* const io_blk = nullptr, const int io_prowb = 0, const int io_lgs = 0) {
     using GM = Game<FAM, NC>;
     constexpr bool REV = FAM == F_REV;
     constexpr int G = 8, NG = 8;
@@ -244,9 +248,11 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
         float x[KPL]; int npos = 0;
         bool wide = false, fdx = false;                               // (fdx is wave-uniform)
         if (doexp) {
-            vleaf = T.v_eval[slot];
+            const bool lio = LEAN && io_blk != nullptr;
+            const float* src = inject ? T.prior_eval + (size_t)slot * A
+                                      : (lio ? reinterpret_cast<const float*>(io_blk) + (size_t)g * io_lgs : T.logits + (size_t)slot * T.LGS);
+            vleaf = lio ? src[A] : T.v_eval[slot];
             const WPos<NC> st = grp_load_pos<NC, REV>(T.states + (size_t)sl * V + lf);
-            const float* src = inject ? T.prior_eval + (size_t)slot * A : T.logits + (size_t)slot * T.LGS;
             if constexpr (LEAN) {
 #pragma unroll
                 for (int j = 0; j < KPL; j += 4) {
@@ -622,15 +628,17 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
                     if (sw == NC - 1) { W[i + NC - 1] |= oc << sb; W[i + NC] |= sb ? oc >> (64 - sb) : 0ull; }
                     else W[i + NC] |= oc;
                 }
+                const bool lio = LEAN && io_blk != nullptr;          // (the hand-over rows are NC * 128 columns wide: every k is written)
 #pragma unroll
                 for (int k = 0; k < NW; ++k) {
                     const int j0 = 64 * k + 8 * sub;
-                    if (j0 < T.INP) {
+                    if (j0 < T.INP || lio) {
                         const uint32_t f = (uint32_t)(W[k] >> (8 * sub)) & 0xffu;
                         uint4 o;
                         o.x = ((f & 1u) ? 0x3F80u : 0u) | ((f & 2u) ? 0x3F800000u : 0u); o.y = ((f & 4u) ? 0x3F80u : 0u) | ((f & 8u) ? 0x3F800000u : 0u);
                         o.z = ((f & 16u) ? 0x3F80u : 0u) | ((f & 32u) ? 0x3F800000u : 0u); o.w = ((f & 64u) ? 0x3F80u : 0u) | ((f & 128u) ? 0x3F800000u : 0u);
-                        *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(T.planes) + (size_t)slot * T.INP + j0) = o;
+                        if (j0 < T.INP) *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(T.planes) + (size_t)slot * T.INP + j0) = o;
+                        if (lio) *reinterpret_cast<uint4*>(io_blk + (size_t)g * io_prowb + (size_t)j0 * 2) = o;
                     }
                 }
             } else
