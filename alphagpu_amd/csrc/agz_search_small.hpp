@@ -49,8 +49,13 @@ __global__ __launch_bounds__(64 * NW_WAVES, WV) void k_search_small(const SmallP
 #endif
         if (k < S.V) {
             // (the barrier that publishes the planes of the leaves sits inside, after the first weight fragments are requested)
+            // wave priorities: the phases that wait on latencies with little arithmetic (network: barriers, LDS, MFMA chain; descent
+            // and child creation in the tree step: dependent loads) go first, so that the waves get back to the arithmetic of the
+            // work items sooner (measured -1.6 % per generation)
+            __builtin_amdgcn_s_setprio(3);
             mlp_wave_body<H, TW / 2, 2, true, true>(S.F, nn_lds, bx, lds_small + S.io_off, S.io_bw, S.io_lgs);
             __syncthreads();                                      // logits and values are visible to the tree waves
+            __builtin_amdgcn_s_setprio(0);
         }
 #ifdef AGZ_STAMPS
         if ((threadIdx.x & 63) == 0 && wave < TW && S.T.dbg) S.T.dbg[(size_t)(bx * TW + wave) * 16 + 15] += __builtin_amdgcn_s_memtime() - t_nn0;

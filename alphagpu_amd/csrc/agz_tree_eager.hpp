@@ -542,6 +542,7 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
     // kdescendTree! (mcts_gpu.jl:100-199) over the stored running sums + decoder (:202-223)
     // =============================================================================================
     if (SF.do_select) {   // PHASE descent: rounds
+        if constexpr (LEAN) __builtin_amdgcn_s_setprio(2);
         // every expanded node carries the action its next visit samples and the child under it: the descent follows the words
         int node = 0, depth = 0;
         uint32_t nx = (live && C.root_exp) ? T.aux4[(size_t)sl * V].y : 0u;

@@ -5,7 +5,8 @@ import alphagpu_amd as ag
 from alphagpu_amd import mcts_gpu as M
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 cfgs = [("connect4", 0, 0, 64, 128, 6), ("gobang", 9, 5, 64, 512, 8), ("hex", 9, 0, 128, 512, 8), ("reversi8", 0, 0, 64, 512, 8),
-        ("reversi6", 0, 0, 64, 128, 6), ("gobang", 13, 5, 64, 256, 4), ("gobang", 3, 3, 16, 128, 6)]
+        ("reversi6", 0, 0, 64, 128, 6), ("gobang", 13, 5, 64, 256, 4), ("gobang", 3, 3, 16, 128, 6),
+        ("hex", 9, 0, 128, 128, 6), ("gobang", 13, 5, 64, 128, 6), ("reversi8", 0, 0, 64, 128, 6), ("gobang", 9, 5, 64, 128, 6)]
 for kind, n, nv, V, H, T in cfgs:
     g = ag.GameSpec(kind, n, nv)
     net = ag.SNetwork2.random(g, H, T)

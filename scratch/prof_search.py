@@ -5,7 +5,7 @@ from alphagpu_amd import mcts_gpu as M
 V = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 32768
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
-g = ag.GameSpec('gobang', 9, 5)
+g = ag.GameSpec(os.environ.get('GK', 'gobang'), int(os.environ.get('GN', '9')), int(os.environ.get('GV', '5')))
 net = ag.SNetwork2.random(g, int(os.environ.get('NH', '128')), int(os.environ.get('NT', '6')))
 e = M.Engine(g, L, V, seed=1, nn_mode=M.NN_BF16)
 e.set_network(net)

@@ -14,7 +14,7 @@ e.L.agz_debug_stamps(e.h, out, 1)
 e.set_roots(None, L=L); e.search(V, cpuct=1.5, training=True, step=0); e.synchronize()
 e.L.agz_debug_stamps(e.h, out, 1)
 names_reg = ['0 meta stage', '1 newton: fast branch', '2 expand', '3 newton: slow branch', '4 backup', '5 fence', '6 newton: step+loop', '7 round: row load+philox', '8 round: stats/prior_rem/alpha0', '9 round: child table compaction', '10 round: newton', '11 round: policy', '12 round: child lookup/end', '13 round: sampling', '14 tail: create+planes', '15 writeback']
-names = ['0 prologue', '1 expand (+ sampling of the first visit)', '2 values', '3 item: fetch + row loads (wait)', '4 item: edge backup, q patch, re-sum', '5 item: scatter, lambda, alpha0', '6 item: Newton', '7 item: policy row', '8 item: running sums + sampling + store', '9 fence after items', '10 descent: root word', '11 descent: child word (wait)', '12 descent: step', '13 create + encode', '14 bookkeeping', '15 network phase + barriers']
+names = ['0 prologue', '1 expand (+ sampling of the first visit)', '2 values', '3 item: fetch + row loads (wait)', '4 item: edge backup, q patch, re-sum', '5 item: scatter, lambda, alpha0', '6 item: Newton', '7 item: policy row', '8 item: running sums + sampling + store', '9 fence after items', '10 descent: root word', '11 descent: child word (wait)', '12 descent: step', '13 create + encode', '14 bookkeeping + wait for the other tree waves (first barrier)', '15 network + last barrier']
 tot = sum(out)
 G = 8; waves = (L * G // 64) * 65
 for n, v in zip(names, out):
