@@ -111,6 +111,7 @@ struct agz_engine {
     uint64_t nn_leaves = 0;    // leaves sent through stand-alone network launches of the instrumented searches
     advance_fn k_adv = nullptr; softmax_fn k_soft = nullptr;
     big_fn k_big[2] = {nullptr, nullptr};   // whole-search kernel for 512-wide trunks (agz_search_big.hpp), 1 / 2 workgroups per CU
+    int wl_lds_max = 1 << 30;    // cap (bytes per tree wave) of the LDS part of the work lists (AGZ_WL_LDS_BYTES; tests: the global overflow path)
     int big_maxl = 16384;        // ... used for batches up to this many games (AGZ_BIG_MAXL): 6.2 vs 8.0 ms per ply at 8192 games, 4.5 vs 7.3 at 1024, 9.9 vs 10.2 at 16384
     small_fn k_small4[3] = {nullptr, nullptr, nullptr};   // the same with 32 games per workgroup, register budgets for 2 / 3 / 4 workgroups per SIMD set
     std::string form_tree, form_nn;   // kernels of the last search (agz_get_search_form)
@@ -313,6 +314,8 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
         if (e3) h->small4_maxl = atoi(e3);
         e3 = getenv("AGZ_BIG_MAXL");
         if (e3) h->big_maxl = atoi(e3);
+        e3 = getenv("AGZ_WL_LDS_BYTES");
+        if (e3 && atoi(e3) >= 0) h->wl_lds_max = atoi(e3) & ~15;
         for (int i = 0; i < 2; ++i) if (h->k_big[i]) FA_(hipFuncSetAttribute((const void*)h->k_big[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         e3 = getenv("AGZ_SMALL4_OCC");
         if (e3 && atoi(e3) >= 0 && atoi(e3) <= 2) h->small4_occ = atoi(e3);
@@ -775,7 +778,7 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
             // must be resident (4 per CU at 32768 games); entries beyond the region, rare, go to the global list
             const int wgs_per_cu = tw == 2 ? 2 : 2 + occ;
             const size_t room = (size_t)(160 * 1024) / (size_t)wgs_per_cu > shared ? (size_t)(160 * 1024) / (size_t)wgs_per_cu - shared : 0;
-            S.wl_off = (int)shared; S.wl_bytes = (int)std::min((size_t)(8 * h->V * 4), (room / (size_t)tw) & ~(size_t)15);
+            S.wl_off = (int)shared; S.wl_bytes = (int)std::min({(size_t)(8 * h->V * 4), (room / (size_t)tw) & ~(size_t)15, (size_t)h->wl_lds_max});
             const size_t lds = shared + (size_t)tw * S.wl_bytes;
             std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
             if ((h->profiling & 1) && h->prof_this) { ev = next_events(h, h->ev_tree, h->ev_tree_used); hipEventRecord(ev->first, h->stream); }
@@ -812,7 +815,7 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
             S.V = V; S.tree_lds = (int)h->reg_lds;
             const size_t shared = (std::max((size_t)4 * h->reg_lds, (size_t)32 * big_rowb) + 15) & ~(size_t)15;
             const size_t room = (size_t)(160 * 1024) / (size_t)(occ + 1) > shared ? (size_t)(160 * 1024) / (size_t)(occ + 1) - shared : 0;
-            S.wl_off = (int)shared; S.wl_bytes = (int)std::min((size_t)(8 * h->V * 4), (room / 4) & ~(size_t)15);
+            S.wl_off = (int)shared; S.wl_bytes = (int)std::min({(size_t)(8 * h->V * 4), (room / 4) & ~(size_t)15, (size_t)h->wl_lds_max});
             const size_t lds = shared + (size_t)4 * S.wl_bytes;
             std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
             if ((h->profiling & 1) && h->prof_this) { ev = next_events(h, h->ev_tree, h->ev_tree_used); hipEventRecord(ev->first, h->stream); }

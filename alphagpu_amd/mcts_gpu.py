@@ -180,15 +180,20 @@ class Engine:
         return a.value.decode(), b.value.decode()
 
     def samples_packed_host(self):
-        """Packed sample records of the last selfplay (agz.h layout) copied to host memory: uint8 array [n, rec_bytes]."""
+        """Packed sample records of the last selfplay (agz.h layout) copied to host memory: uint8 array [n, rec_bytes].
+        The device staging buffer and the pinned host buffer are kept and reused by the next call (a host loop pays for their
+        allocation once, not per generation): the returned array is a view that stays valid until then."""
         import torch
         n = self.num_samples()
         rb = self.game.rec_bytes
-        dev = torch.empty(max(n, 1) * rb, dtype=torch.uint8, device=f"cuda:{self.device}")
-        self.samples_packed_into(dev.data_ptr(), n)
-        host = torch.empty(n * rb, dtype=torch.uint8, pin_memory=True)
-        host.copy_(dev[: n * rb])
-        return host.numpy().reshape(n, rb)
+        need = max(n, 1) * rb
+        if getattr(self, "_pk_dev", None) is None or self._pk_dev.numel() < need:
+            cap = need + need // 8
+            self._pk_dev = torch.empty(cap, dtype=torch.uint8, device=f"cuda:{self.device}")
+            self._pk_host = torch.empty(cap, dtype=torch.uint8, pin_memory=True)
+        self.samples_packed_into(self._pk_dev.data_ptr(), n)
+        self._pk_host[: n * rb].copy_(self._pk_dev[: n * rb])
+        return self._pk_host[: n * rb].numpy().reshape(n, rb)
 
     def set_profiling(self, on):
         self._chk(self.L.agz_set_profiling(self.h, 3 if on is True else int(on)))

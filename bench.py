@@ -206,6 +206,7 @@ def main():
     if world == 1 and not args.no_host_delivery:
         eng.set_profiling(0)
         buf = ag.PoolSample(game, 2_000_000)               # mainGobang.jl:130
+        eng.samples_packed_host()                          # (staging buffers of the delivery path are allocated once per run, not per generation)
         eng.synchronize()
         h0 = time.perf_counter()
         st = step()

@@ -597,12 +597,15 @@ def test_whole_search_kernel_agrees_bitwise(name, L, V, monkeypatch):
     monkeypatch.delenv("AGZ_SMALL4_MAXL")
     # 16 games per workgroup (default: sparse waves at these sizes), dense waves, 4 games per wave, 32 games per workgroup
     # ... and every register budget of the 32-game build (launch bounds for 2 / 3 / 4 workgroups per CU: k_search_small<..,4,2|3|4>)
+    # ... and work lists that overflow their LDS part into global memory (16 bytes = 4 entries, and no LDS part at all)
     for env in ({}, {"AGZ_SMALL_GPW": "8"}, {"AGZ_SMALL_GPW": "4"}, {"AGZ_SMALL_MAXL": "0"},
                 {"AGZ_SMALL_MAXL": "0", "AGZ_SMALL4_OCC": "0"}, {"AGZ_SMALL_MAXL": "0", "AGZ_SMALL4_OCC": "1"},
-                {"AGZ_SMALL_MAXL": "0", "AGZ_SMALL4_OCC": "2"}):
+                {"AGZ_SMALL_MAXL": "0", "AGZ_SMALL4_OCC": "2"}, {"AGZ_SMALL_GPW": "8", "AGZ_WL_LDS_BYTES": "16"},
+                {"AGZ_SMALL_MAXL": "0", "AGZ_WL_LDS_BYTES": "0"}):
         monkeypatch.delenv("AGZ_SMALL_GPW", raising=False)
         monkeypatch.delenv("AGZ_SMALL_MAXL", raising=False)
         monkeypatch.delenv("AGZ_SMALL4_OCC", raising=False)
+        monkeypatch.delenv("AGZ_WL_LDS_BYTES", raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         got = run()
@@ -628,8 +631,9 @@ def test_whole_search_kernel_for_wide_trunks_agrees_bitwise(name, L, V, T, monke
     ref = run()                                     # two kernels per rollout
     assert ref[5].startswith("k_rollout_eager")
     monkeypatch.delenv("AGZ_BIG_MAXL")
-    for env in ({}, {"AGZ_SMALL_GPW": "8"}, {"AGZ_SMALL_GPW": "2"}):
+    for env in ({}, {"AGZ_SMALL_GPW": "8"}, {"AGZ_SMALL_GPW": "2"}, {"AGZ_SMALL_GPW": "8", "AGZ_WL_LDS_BYTES": "16"}):
         monkeypatch.delenv("AGZ_SMALL_GPW", raising=False)
+        monkeypatch.delenv("AGZ_WL_LDS_BYTES", raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         got = run()
