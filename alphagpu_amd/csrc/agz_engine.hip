@@ -112,6 +112,7 @@ struct agz_engine {
     advance_fn k_adv = nullptr; softmax_fn k_soft = nullptr;
     big_fn k_big[2] = {nullptr, nullptr};   // whole-search kernel for 512-wide trunks (agz_search_big.hpp), 1 / 2 workgroups per CU
     int wl_lds_max = 1 << 30;    // cap (bytes per tree wave) of the LDS part of the work lists (AGZ_WL_LDS_BYTES; tests: the global overflow path)
+    int big_mt = 0;              // != 0: force the leaf tiles per workgroup of the stand-alone wide-trunk network (AGZ_BIG_MT = 2, 4, 8)
     int big_maxl = 16384;        // ... used for batches up to this many games (AGZ_BIG_MAXL): 6.2 vs 8.0 ms per ply at 8192 games, 4.5 vs 7.3 at 1024, 9.9 vs 10.2 at 16384
     small_fn k_small4[3] = {nullptr, nullptr, nullptr};   // the same with 32 games per workgroup, register budgets for 2 / 3 / 4 workgroups per SIMD set
     std::string form_tree, form_nn;   // kernels of the last search (agz_get_search_form)
@@ -284,6 +285,8 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     FA_(hipFuncSetAttribute((const void*)k_mlp_big<512, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     FA_(hipFuncSetAttribute((const void*)k_mlp_big<256, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     FA_(hipFuncSetAttribute((const void*)k_mlp_big<512, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    FA_(hipFuncSetAttribute((const void*)k_mlp_big<512, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    FA_(hipFuncSetAttribute((const void*)k_mlp_big<256, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     FA_(hipFuncSetAttribute((const void*)k_mlp_big<256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     FA_(hipFuncSetAttribute((const void*)k_layer_exact<EX_RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     FA_(hipFuncSetAttribute((const void*)k_layer_exact<EX_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -314,6 +317,8 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
         if (e3) h->small4_maxl = atoi(e3);
         e3 = getenv("AGZ_BIG_MAXL");
         if (e3) h->big_maxl = atoi(e3);
+        e3 = getenv("AGZ_BIG_MT");
+        if (e3 && (atoi(e3) == 2 || atoi(e3) == 4 || atoi(e3) == 8)) h->big_mt = atoi(e3);
         e3 = getenv("AGZ_WL_LDS_BYTES");
         if (e3 && atoi(e3) >= 0) h->wl_lds_max = atoi(e3) & ~15;
         for (int i = 0; i < 2; ++i) if (h->k_big[i]) FA_(hipFuncSetAttribute((const void*)h->k_big[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -654,12 +659,16 @@ static int launch_network(agz_engine* h, int which, int s0 = 0, int s1 = -1, hip
         B.whead = n.w16 + (size_t)(n.INP / 32) * (n.H / 16) * 512 + (size_t)n.T * (n.H / 32) * (n.H / 16) * 512;
         B.bias_head = n.bias_head; B.logits = logits; B.LGS = h->LGS; B.vout = v_eval;
         B.L = L; B.T = n.T; B.A = h->G.A; B.AOP = n.AOP; B.K0R = n.k0r; B.ROWB = big_rowb;
-        const int mt = L <= 8192 ? 2 : 8;                       // 32 or 128 leaves per workgroup
+        // 32, 64 or 128 leaves per workgroup.  Measured per ply (512x8, V = 64): sub-batch chains of 10923 leaves (32768 games) 14.4 ms
+        // with 64, 17.1 with 128, 17.4 with 32; one chain of 16384 leaves 10.0 with 64, 11.0 with 32; of 8192 leaves 8.0 with 32, 8.8 with 64
+        // (sub-batch chains: what counts is the whole batch in flight — chains of 8192 leaves, 24576 games: 12.2 ms with 64, 13.5 with 32)
+        int mt = h->L <= 8192 ? 2 : (L <= 20000 ? 4 : 8);
+        if (h->big_mt) mt = h->big_mt;
         { char b[96]; snprintf(b, sizeof b, "k_mlp_big<H=%d,MT=%d> (%d leaves per workgroup, one launch)", n.H, mt, 16 * mt); h->form_nn = b; }
         const size_t lds = (size_t)16 * mt * big_rowb;
         dim3 grid((unsigned)((L + 16 * mt - 1) / (16 * mt))), block(NB_THREADS);
-        if (n.H == 512) { if (mt == 8) hipLaunchKernelGGL((k_mlp_big<512, 8>), grid, block, lds, stream, B); else hipLaunchKernelGGL((k_mlp_big<512, 2>), grid, block, lds, stream, B); }
-        else { if (mt == 8) hipLaunchKernelGGL((k_mlp_big<256, 8>), grid, block, lds, stream, B); else hipLaunchKernelGGL((k_mlp_big<256, 2>), grid, block, lds, stream, B); }
+        if (n.H == 512) { if (mt == 8) hipLaunchKernelGGL((k_mlp_big<512, 8>), grid, block, lds, stream, B); else if (mt == 4) hipLaunchKernelGGL((k_mlp_big<512, 4>), grid, block, lds, stream, B); else hipLaunchKernelGGL((k_mlp_big<512, 2>), grid, block, lds, stream, B); }
+        else { if (mt == 8) hipLaunchKernelGGL((k_mlp_big<256, 8>), grid, block, lds, stream, B); else if (mt == 4) hipLaunchKernelGGL((k_mlp_big<256, 4>), grid, block, lds, stream, B); else hipLaunchKernelGGL((k_mlp_big<256, 2>), grid, block, lds, stream, B); }
     } else if (f3_lds && n.w16w && L <= h->nn_wave_maxl) {   // one wave per 16 leaves, weights streamed from L2: lowest latency
         Fused3Par F;
         F.planes = (const uint16_t*)planes; F.INP = n.INP; F.w16 = n.w16w; F.bias_head = n.bias_head;

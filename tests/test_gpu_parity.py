@@ -562,17 +562,30 @@ def test_sub_batch_chains_do_not_change_results(monkeypatch):
         assert_same_bits(a, b, what)
 
 
-def test_wide_trunk_128_leaf_tiles_agree_bitwise(monkeypatch):
-    """Above 8192 leaves k_mlp_big runs 128 leaves per workgroup (32 below): same bits as the per-layer kernels, ragged last tile."""
+def test_wide_trunk_leaf_tiles_agree_bitwise(monkeypatch):
+    """The stand-alone wide-trunk network k_mlp_big runs 32, 64 or 128 leaves per workgroup depending on the launch size (forced
+    here with AGZ_BIG_MT): each build gives the same bits as the per-layer kernels, ragged last tile."""
     g, _ = spec("connect4")
     net = ag.SNetwork2.random(g, 512, 1)
     L, V = 8400, 3
     monkeypatch.setenv("AGZ_CHAINS", "1")
-    ref = _bf16_search_bits(g, net, L, V, 512)
+    monkeypatch.setenv("AGZ_BIG_MAXL", "0")               # two kernels per rollout (no k_search_big)
     monkeypatch.setenv("AGZ_NO_FUSED_NN", "1")
-    got = _bf16_search_bits(g, net, L, V, 512)
-    for a, b, what in zip(got, ref, ("visits", "policy", "q")):
-        assert_same_bits(a, b, what)
+    ref = _bf16_search_bits(g, net, L, V, 512)
+    monkeypatch.delenv("AGZ_NO_FUSED_NN")
+    for mt in ("2", "4", "8", None):
+        if mt is None:
+            monkeypatch.delenv("AGZ_BIG_MT")
+        else:
+            monkeypatch.setenv("AGZ_BIG_MT", mt)
+        with M.Engine(g, L, V, seed=5, nn_mode=M.NN_BF16) as e:
+            e.set_network(net)
+            e.set_roots(None, L=L)
+            e.search(V, cpuct=1.5, training=True, step=0)
+            assert e.search_form()[1].startswith("k_mlp_big<H=512,MT=" + (mt or "4"))
+        got = _bf16_search_bits(g, net, L, V, 512)
+        for a, b, what in zip(got, ref, ("visits", "policy", "q")):
+            assert_same_bits(a, b, what + f" MT={mt}")
 
 
 @pytest.mark.parametrize("name,L,V", [("gobang9", 300, 24), ("connect4", 77, 36), ("hex9", 40, 64), ("hex9", 44, 128)])
