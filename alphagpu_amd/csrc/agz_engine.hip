@@ -1073,6 +1073,10 @@ static int run_games(agz_engine* h, int ngames, int V, float cpuct, int tau_plie
         rc = agz_search_actor(h, which, V, cpuct, training, (uint32_t)ply); if (rc) break;      // :503
         if (hipEventRecord(e1, h->stream) != hipSuccess) { h->fail("hipEventRecord failed"); rc = AGZ_ERR_HIP; break; }
         rollouts += (int64_t)h->L * V;
+        const bool fold = h->profiling && h->prof_this;                         // descent counters of this search -> d_acc (queued before the
+        if (fold)                                                               // ply kernels: nothing is launched between the sync and the next search)
+            hipLaunchKernelGGL(k_fold_counters, dim3((unsigned)std::min(64, (h->L + 255) / 256)), dim3(256), 0, h->stream, (const uint32_t*)h->cnt_p,
+                               (const uint32_t*)h->cnt_new, h->L, h->d_acc);
         PlyPar T; fill_plypar(h, T, ply, tau_plies, duel);
         hipLaunchKernelGGL(h->k_adv, dim3((unsigned)((h->L + 3) / 4)), dim3(256), 0, h->stream, T);          // :513-549
         hipLaunchKernelGGL(k_scan_alive, dim3(1), dim3(1024), 0, h->stream, (const uint32_t*)h->alive, h->newslot, h->L, h->d_count);
@@ -1081,12 +1085,7 @@ static int run_games(agz_engine* h, int ngames, int V, float cpuct, int tau_plie
         if (hipMemcpyAsync(hcount, h->d_count, 4, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
             hipStreamSynchronize(h->stream) != hipSuccess) { h->fail("ply loop failed: %s", hipGetErrorString(hipGetLastError())); rc = AGZ_ERR_HIP; break; }
         float ms = 0; hipEventElapsedTime(&ms, e0, e1); search_ms += ms;
-        if (h->profiling && h->prof_this) {                                     // (L is still the size of the search just done)
-            hipLaunchKernelGGL(k_fold_counters, dim3((unsigned)std::min(64, (h->L + 255) / 256)), dim3(256), 0, h->stream, (const uint32_t*)h->cnt_p,
-                               (const uint32_t*)h->cnt_new, h->L, h->d_acc);
-            h->cnt_live = false;
-            drain_events(h);
-        }
+        if (fold) { h->cnt_live = false; drain_events(h); }
         { uint32_t* s = h->game_id; h->game_id = h->game_id2; h->game_id2 = s; h->tp.game_id = h->game_id; }
         h->L = (int)*hcount;
         ++ply;

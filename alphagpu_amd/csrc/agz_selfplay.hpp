@@ -124,25 +124,41 @@ __global__ __launch_bounds__(256) void k_fold_counters(const uint32_t* cnt_p, co
     if ((threadIdx.x & 63) == 0) { atomicAdd(&acc[0], a); atomicAdd(&acc[1], b); }
 }
 
-// exclusive scan of alive[0..L) by one workgroup of 1024 threads -> newslot[], total -> *count
+// exclusive scan of the 0/1 flags alive[0..L) by one workgroup of 1024 threads -> newslot[], total -> *count.  Wave w owns a
+// contiguous segment and walks it 64 flags at a time (coalesced loads, counts by ballot): one pass for the segment totals, a
+// 16-entry scan of them, one pass for the slots.
 __global__ __launch_bounds__(1024) void k_scan_alive(const uint32_t* alive, uint32_t* newslot, int L, uint32_t* count) {
-    __shared__ uint32_t part[1024];
-    const int t = threadIdx.x;
-    const int per = (L + 1023) / 1024;
-    const int b = t * per, e = (b + per < L) ? b + per : L;
+    __shared__ uint32_t part[16];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int seg = ((L + 1023) / 1024) * 64;                    // flags per wave (a multiple of 64)
+    const int b = w * seg, e = (b + seg < L) ? b + seg : L;
+    const uint64_t below = (1ull << lane) - 1ull;
     uint32_t s = 0;
-    for (int i = b; i < e; ++i) s += alive[i];
-    part[t] = s;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        uint32_t v = t >= off ? part[t - off] : 0;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
+    for (int i = b; i < e; i += 256) {                            // four chunks per turn: their loads are in flight together
+        uint32_t a[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int k = i + 64 * j + lane; a[j] = k < e ? alive[k] : 0u; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += (uint32_t)__popcll(__ballot(a[j] != 0u));
     }
-    uint32_t base = part[t] - s;
-    for (int i = b; i < e; ++i) { newslot[i] = base; base += alive[i]; }
-    if (t == 1023) *count = part[1023];
+    if (lane == 0) part[w] = s;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { const uint32_t v = part[j]; base += j < w ? v : 0u; total += v; }
+    for (int i = b; i < e; i += 256) {
+        uint32_t a[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int k = i + 64 * j + lane; a[j] = k < e ? alive[k] : 0u; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint64_t m = __ballot(a[j] != 0u);
+            const int k = i + 64 * j + lane;
+            if (k < e) newslot[k] = base + (uint32_t)__popcll(m & below);
+            base += (uint32_t)__popcll(m);
+        }
+    }
+    if (t == 0) *count = total;
 }
 
 // re_init (:359-373): move surviving games to their compacted slots

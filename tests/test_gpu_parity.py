@@ -117,6 +117,7 @@ def test_exact_search_matches_oracle(name, L, V, H, T):
 
 @pytest.mark.parametrize("name,L,V,H,T", [
     ("gobang9", 48, 64, 128, 6), ("connect4", 64, 64, 128, 6), ("tictactoe", 64, 16, 128, 6), ("hex9", 24, 128, 128, 2), ("reversi8", 40, 64, 64, 3),
+    ("reversi8", 40, 32, 128, 2), ("reversi6", 40, 24, 128, 2),          # (whole-search kernel with passes)
     # BASELINE configs 3-5 with the trunk the reference ships (512 wide, 8 towers): k_rollout_reg + k_mlp_big
     ("gobang9", 136, 32, 512, 8), ("hex9", 40, 128, 512, 8), ("reversi8", 136, 24, 512, 8), ("gobang9", 40, 16, 256, 3)])
 def test_bf16_search_matches_oracle_bitwise(name, L, V, H, T):
@@ -588,7 +589,8 @@ def test_wide_trunk_leaf_tiles_agree_bitwise(monkeypatch):
             assert_same_bits(a, b, what + f" MT={mt}")
 
 
-@pytest.mark.parametrize("name,L,V", [("gobang9", 300, 24), ("connect4", 77, 36), ("hex9", 40, 64), ("hex9", 44, 128)])
+@pytest.mark.parametrize("name,L,V", [("gobang9", 300, 24), ("connect4", 77, 36), ("hex9", 40, 64), ("hex9", 44, 128), ("reversi8", 130, 32),
+                                      ("reversi6", 90, 20), ("tictactoe", 500, 8)])
 def test_whole_search_kernel_agrees_bitwise(name, L, V, monkeypatch):
     """k_search_small (one launch per mcts_single, 16 or 32 games per workgroup, default up to 16384 games) runs the same
     tree step and network bodies as the two stand-alone kernels (trees of up to 128 nodes, a multiple of 4): identical bits,
