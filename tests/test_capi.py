@@ -126,3 +126,17 @@ def test_snetwork2_accepts_flux_matrices_in_column_major_order():
 def test_wrappers_draw_a_fresh_seed_per_call():
     seeds = {M.fresh_seed() for _ in range(64)}
     assert len(seeds) == 64 and all(0 < s < 2 ** 63 for s in seeds)
+
+
+def test_every_environment_switch_is_documented_in_the_header():
+    """agz_create reads debug / A-B switches from the environment; include/agz.h lists every one of them (and nothing stale)."""
+    csrc = os.path.join(ROOT, "alphagpu_amd", "csrc")
+    used = set()
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".hpp")):
+            used |= set(re.findall(r'getenv\("(AGZ_[A-Z0-9_]+)"\)', open(os.path.join(csrc, f)).read()))
+    header = open(os.path.join(ROOT, "include", "agz.h")).read()
+    block = header[header.index("Environment switches read by agz_create"):]
+    documented = set(re.findall(r"\b(AGZ_[A-Z0-9_]+)\b", block))
+    assert used and used <= documented, sorted(used - documented)
+    assert documented <= used, sorted(documented - used)
