@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 #include <algorithm>
 
@@ -108,6 +109,7 @@ struct agz_engine {
     double tree_ms = 0, nn_ms = 0, tree_busy_ms = 0; int64_t tree_launches = 0;
     hipEvent_t ev_ref = nullptr; bool ev_ref_live = false;
     hipEvent_t ev_ply0 = nullptr, ev_ply1 = nullptr; uint32_t* hcount = nullptr;   // ply loop: search timing, pinned alive count
+    uint8_t *stage_dev = nullptr, *stage_host = nullptr; size_t stage_cap = 0;     // agz_get_samples: packed records on the device / in pinned host memory (kept)
     uint64_t nn_leaves = 0;    // leaves sent through stand-alone network launches of the instrumented searches
     advance_fn k_adv = nullptr; softmax_fn k_soft = nullptr;
     big_fn k_big[2] = {nullptr, nullptr};   // whole-search kernel for 512-wide trunks (agz_search_big.hpp), 1 / 2 workgroups per CU
@@ -225,6 +227,7 @@ void agz_destroy(agz_engine* h) {
     hipFree(h->s_boards); hipFree(h->s_policy); hipFree(h->s_move); hipFree(h->g_nplies); hipFree(h->g_result);
     hipFree(h->g_final); hipFree(h->d_stats); hipFree(h->d_acc); hipFree(h->scratch_f);
     hipFree(h->aux4); hipFree(h->wl); hipFree(h->wl_n); hipFree(h->sp);
+    hipFree(h->stage_dev); if (h->stage_host) hipHostFree(h->stage_host);
     free_net(h->net[0]); free_net(h->net[1]);
     for (auto& e : h->ev_tree) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto& e : h->ev_nn) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
@@ -1168,24 +1171,41 @@ int agz_get_samples(agz_engine* h, int8_t* state, float* policy, int8_t* player,
     int rc = agz_get_samples_packed(h, nullptr, 0, &n); if (rc) return rc;
     if (n == 0) return AGZ_OK;
     const size_t rb = (size_t)h->info.rec_bytes;
-    uint8_t* dev = nullptr;
-    HIPCHK(h, dmalloc(&dev, (size_t)n * rb));
-    rc = agz_get_samples_packed(h, dev, n, &n);
-    std::vector<uint8_t> host((size_t)n * rb);
-    if (!rc && hipMemcpy(host.data(), dev, host.size(), hipMemcpyDeviceToHost) != hipSuccess) { h->fail("sample D2H failed"); rc = AGZ_ERR_HIP; }
-    hipFree(dev);
-    if (rc) return rc;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    if ((size_t)n * rb > h->stage_cap) {                 // staging buffers are kept: a host loop allocates them once, not per generation
+        hipFree(h->stage_dev); h->stage_dev = nullptr;
+        if (h->stage_host) { hipHostFree(h->stage_host); h->stage_host = nullptr; }
+        h->stage_cap = 0;
+        const size_t cap = (size_t)n * rb + (size_t)n * rb / 8;
+        HIPCHK(h, dmalloc(&h->stage_dev, cap));
+        HIPCHK(h, hipHostMalloc((void**)&h->stage_host, cap, hipHostMallocDefault));
+        h->stage_cap = cap;
+    }
+    rc = agz_get_samples_packed(h, h->stage_dev, n, &n); if (rc) return rc;
+    if (hipMemcpyAsync(h->stage_host, h->stage_dev, (size_t)n * rb, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        hipStreamSynchronize(h->stream) != hipSuccess) { h->fail("sample D2H failed"); return AGZ_ERR_HIP; }
     const int A = h->G.A, VS = h->G.VS, FS = h->G.FS;
-    for (int64_t s = 0; s < n; ++s) {
-        const uint8_t* r = host.data() + (size_t)s * rb;
-        if (game_id) memcpy(&game_id[s], r, 4);
-        if (ply) memcpy(&ply[s], r + 4, 4);
-        if (move) memcpy(&move[s], r + 8, 4);
-        if (value) memcpy(&value[s], r + 12, 4);
-        if (player) player[s] = (int8_t)r[16];
-        if (policy) memcpy(policy + (size_t)s * A, r + 20, (size_t)A * 4);
-        if (state) memcpy(state + (size_t)s * 2 * VS, r + 20 + 4 * A, (size_t)2 * VS);
-        if (fstate) memcpy(fstate + (size_t)s * FS, r + 20 + 4 * A + 2 * VS, (size_t)FS);
+    const uint8_t* const host = h->stage_host;
+    auto unpack = [=](int64_t s0, int64_t s1) {          // records [s0, s1) -> the caller's arrays (PoolSample layout)
+        for (int64_t s = s0; s < s1; ++s) {
+            const uint8_t* r = host + (size_t)s * rb;
+            if (game_id) memcpy(&game_id[s], r, 4);
+            if (ply) memcpy(&ply[s], r + 4, 4);
+            if (move) memcpy(&move[s], r + 8, 4);
+            if (value) memcpy(&value[s], r + 12, 4);
+            if (player) player[s] = (int8_t)r[16];
+            if (policy) memcpy(policy + (size_t)s * A, r + 20, (size_t)A * 4);
+            if (state) memcpy(state + (size_t)s * 2 * VS, r + 20 + 4 * A, (size_t)2 * VS);
+            if (fstate) memcpy(fstate + (size_t)s * FS, r + 20 + 4 * A + 2 * VS, (size_t)FS);
+        }
+    };
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int nt = (int)std::min<int64_t>(std::max(1u, std::min(hw, 16u)), (n + 65535) / 65536);   // one thread per 64 K records, at most 16
+    if (nt <= 1) unpack(0, n);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; ++t) th.emplace_back(unpack, n * t / nt, n * (t + 1) / nt);
+        for (auto& x : th) x.join();
     }
     return AGZ_OK;
 }

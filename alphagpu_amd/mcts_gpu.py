@@ -251,6 +251,16 @@ class Engine:
                                          _p(out["fstate"]), _p(out["game_id"]), _p(out["ply"]), _p(out["move"])))
         return out
 
+    def samples_into(self, state, policy, player, value, fstate):
+        """Samples of the last selfplay written into caller-owned C-contiguous arrays (PoolSample layout and dtypes); any may be None."""
+        g, n = self.game, self.num_samples()
+        for a, shape, dt in ((state, (n, 2 * g.VS), np.int8), (policy, (n, g.A), np.float32), (player, (n,), np.int8),
+                             (value, (n,), np.float32), (fstate, (n, g.FS), np.int8)):
+            if a is not None and (a.shape != shape or a.dtype != dt or not a.flags["C_CONTIGUOUS"]):
+                raise ValueError(f"samples_into: expected a C-contiguous {dt.__name__}{shape} array, got {a.dtype}{a.shape}")
+        self._chk(self.L.agz_get_samples(self.h, _p(state), _p(policy), _p(player), _p(value), _p(fstate), None, None, None))
+        return n
+
     def samples_packed_into(self, dev_ptr, capacity_records):
         """Write packed sample records to DEVICE memory (for the RCCL all-gather); returns the record count."""
         n = C.c_int64(0)
@@ -309,7 +319,7 @@ def mcts(actor, visits, ngames, buffer, game=None, cpuct=2.0, engine=None, tau_p
             engine.set_network(actor, 0)
         stats = engine.selfplay(ngames, visits, cpuct=cpuct, tau_plies=tau_plies)
         if stats["valid"] and buffer is not None:
-            buffer.push_generation(engine.samples())
+            buffer.push_from_engine(engine)
         return stats, stats["valid"]
     finally:
         if own:

@@ -48,12 +48,31 @@ class PoolSample:
         order) — equivalent to the reference's interleaved push_buffer/update_buffer calls."""
         n = len(s["player"])
         idx = (self.currentIndex - 1 + np.arange(n)) % self.length
-        self.state[idx], self.policy[idx], self.player[idx] = s["state"], s["policy"], s["player"]
-        self.value[idx], self.fstate[idx] = s["value"], s["fstate"]
+        start = self.currentIndex - 1
+        if n <= self.length - start:                                      # no wrap: plain slice copies (memcpy speed)
+            for name in ("state", "policy", "player", "value", "fstate"):
+                getattr(self, name)[start:start + n] = s[name]
+        else:
+            self.state[idx], self.policy[idx], self.player[idx] = s["state"], s["policy"], s["player"]
+            self.value[idx], self.fstate[idx] = s["value"], s["fstate"]
         if self.currentIndex - 1 + n >= self.length:
             self.full = True
         self.currentIndex = int((self.currentIndex - 1 + n) % self.length) + 1
         return idx + 1
+
+    def push_from_engine(self, eng):
+        """The samples of the engine's last self-play generation straight into the ring (agz_get_samples unpacks the records into
+        this buffer's arrays at the write position: no intermediate copies).  Same result as push_generation(eng.samples())."""
+        n = eng.num_samples()
+        start = self.currentIndex - 1
+        if n > self.length - start:                                       # the write would wrap: the general path
+            return self.push_generation(eng.samples())
+        eng.samples_into(self.state[start:start + n], self.policy[start:start + n], self.player[start:start + n],
+                         self.value[start:start + n], self.fstate[start:start + n])
+        if start + n >= self.length:
+            self.full = True
+        self.currentIndex = int((start + n) % self.length) + 1
+        return start + 1 + np.arange(n)
 
     def length_buffer(self):                                              # mainGobang.jl:82
         return self.length if self.full else self.currentIndex - 1

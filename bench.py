@@ -206,19 +206,21 @@ def main():
     if world == 1 and not args.no_host_delivery:
         eng.set_profiling(0)
         buf = ag.PoolSample(game, 2_000_000)               # mainGobang.jl:130
-        eng.samples_packed_host()                          # (staging buffers of the delivery path are allocated once per run, not per generation)
+        eng.samples_packed_host(); eng.samples_into(None, None, None, None, None)   # (staging buffers of the delivery paths are allocated once per run, not per generation)
         eng.synchronize()
         h0 = time.perf_counter()
         st = step()
         h1 = time.perf_counter()
         recs = eng.samples_packed_host()
         h2 = time.perf_counter()
-        buf.push_generation(shard.unpack_records(recs.reshape(-1), recs.shape[0], game))
+        # ... and into the PoolSample arrays: agz_get_samples (D2H into the engine's pinned staging buffer + unpack on the host
+        # cores) followed by the ring-buffer push
+        buf.push_from_engine(eng)
         h3 = time.perf_counter()
-        host = {"generation_s": h1 - h0, "packed_records_to_pinned_host_s": h2 - h1, "push_into_PoolSample_s": h3 - h2,
+        host = {"generation_s": h1 - h0, "packed_records_to_pinned_host_s": h2 - h1, "samples_into_PoolSample_s": h3 - h2,
                 "bytes": int(recs.size), "samples": int(recs.shape[0]),
                 "rollouts_per_s_with_host_delivery": st["rollouts"] / (h2 - h0),
-                "rollouts_per_s_with_host_delivery_and_PoolSample": st["rollouts"] / (h3 - h0)}
+                "rollouts_per_s_with_delivery_into_PoolSample": st["rollouts"] / (h1 - h0 + h3 - h2)}
 
     cdev = "cuda" if args.backend == "nccl" else "cpu"
     tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)

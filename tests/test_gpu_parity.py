@@ -311,6 +311,26 @@ def test_mcts_module_api_fills_pool_like_reference():
     assert np.array_equal(buf.value[:ref["n"]], ref["value"])
 
 
+def test_samples_go_straight_into_the_pool_and_wrap_like_the_reference_ring():
+    """PoolSample.push_from_engine (agz_get_samples unpacking into the ring's own arrays) == push_generation(samples()), also when
+    the write wraps around the end of the ring (mainGobang.jl:54-68 newindex logic)."""
+    g, _ = spec("connect4")
+    net = ag.SNetwork2.random(g, 64, 1)
+    with M.Engine(g, 200, 8, seed=4, nn_mode=M.NN_BF16) as e:
+        e.set_network(net)
+        st = e.selfplay(200, 8, cpuct=1.5, tau_plies=25)
+        n = st["nsamples"]
+        for length in (3 * n, n + n // 2):                 # second generation wraps in the smaller ring
+            a, b = ag.PoolSample(g, length), ag.PoolSample(g, length)
+            for _ in range(2):
+                ia = a.push_from_engine(e)
+                ib = b.push_generation(e.samples())
+                assert np.array_equal(ia, ib)
+            assert (a.currentIndex, a.full) == (b.currentIndex, b.full)
+            for name in ("state", "policy", "player", "value", "fstate"):
+                assert np.array_equal(getattr(a, name), getattr(b, name)), name
+
+
 def test_julia_position_image_roundtrip_through_set_roots():
     g, og = spec("reversi8")
     net, onet = nets(g, og, 32, 1)
