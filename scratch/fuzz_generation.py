@@ -1,0 +1,44 @@
+# Larger randomized parity runs than the pytest suite affords: whole self-play generations in the benchmarked bf16 mode against the
+# oracle's generation (bf16 MFMA model), bit for bit, for several games / seeds / network sizes.  Test infrastructure (uses oracle/).
+import sys, os, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import alphagpu_amd as ag
+from alphagpu_amd import mcts_gpu as M
+import common, oracle_lib as O
+
+cases = [("gobang9", 640, 64, 128, 6, 11), ("gobang9", 320, 64, 128, 6, 12), ("connect4", 1200, 64, 128, 6, 13), ("hex9", 200, 128, 128, 2, 14),
+         ("reversi8", 400, 64, 128, 2, 15), ("reversi6", 600, 48, 128, 3, 16), ("gobang9", 96, 64, 512, 8, 17), ("reversi8", 96, 32, 512, 8, 18),
+         ("hex9", 64, 128, 512, 4, 19), ("tictactoe", 3000, 16, 128, 6, 20)]
+if len(sys.argv) > 1:
+    cases = [c for c in cases if str(c[5]) in sys.argv[1:] or c[0] in sys.argv[1:]]
+bad = 0
+for name, n, V, H, T, seed in cases:
+    kind, nn, k = common.GAMES[name]
+    g, og = ag.GameSpec(kind, nn, k), O.make_game(kind, nn, k)
+    net, onet = ag.SNetwork2.random(g, H, T, 0x5EED + seed), O.OracleNet(og, H, T, 0x5EED + seed)
+    t0 = time.perf_counter()
+    ref = O.selfplay(og, onet.bf16(), n, V, 1.5, 25, seed, 1000 * seed)
+    t1 = time.perf_counter()
+    with M.Engine(g, n, V, seed=seed, game_id_base=1000 * seed, nn_mode=M.NN_BF16) as e:
+        e.set_network(net)
+        st = e.selfplay(n, V, cpuct=1.5, tau_plies=25)
+        s = e.samples()
+    ok = st["valid"] and ref["rc"] == 0 and st["nsamples"] == ref["n"]
+    diff = {}
+    if ok:
+        for key in ("game_id", "ply", "move", "player", "state", "fstate", "policy", "value"):
+            a, b = np.ascontiguousarray(s[key]), np.ascontiguousarray(ref[key])
+            same = a.shape == b.shape and np.array_equal(a.view(np.uint8), b.view(np.uint8))
+            if not same:
+                diff[key] = int((a.view(np.uint8) != b.view(np.uint8)).sum()) if a.shape == b.shape else -1
+                if a.shape == b.shape and a.ndim == 2:
+                    for i, j in np.argwhere(a.view(np.uint32 if a.dtype == np.float32 else a.dtype) != b.view(np.uint32 if b.dtype == np.float32 else b.dtype))[:8]:
+                        print(f"   {key}[{i},{j}]: gpu {a[i, j]!r} ({a[i, j].view(np.uint32) if a.dtype == np.float32 else ''})  oracle {b[i, j]!r} "
+                              f"({b[i, j].view(np.uint32) if b.dtype == np.float32 else ''})  game {s['game_id'][i]} ply {s['ply'][i]} move {s['move'][i]}")
+    bad += (not ok) or bool(diff)
+    print(f"{name} n={n} V={V} {H}x{T} seed={seed}: samples {st['nsamples']} vs {ref['n']}  W/D/L {st['wins']}/{st['draws']}/{st['losses']}  "
+          f"{'IDENTICAL' if ok and not diff else 'DIFFERENT ' + str(diff)}  (oracle {t1 - t0:.1f}s)", flush=True)
+print("fuzz:", "all identical" if not bad else f"{bad} case(s) differ")
+sys.exit(1 if bad else 0)
