@@ -11,6 +11,8 @@ import common, oracle_lib as O
 cases = [("gobang9", 640, 64, 128, 6, 11), ("gobang9", 320, 64, 128, 6, 12), ("connect4", 1200, 64, 128, 6, 13), ("hex9", 200, 128, 128, 2, 14),
          ("reversi8", 400, 64, 128, 2, 15), ("reversi6", 600, 48, 128, 3, 16), ("gobang9", 96, 64, 512, 8, 17), ("reversi8", 96, 32, 512, 8, 18),
          ("hex9", 64, 128, 512, 4, 19), ("tictactoe", 3000, 16, 128, 6, 20)]
+off = int(os.environ.get("FUZZ_SEED_OFFSET", "0"))             # other seeds (networks, roots, uniforms): FUZZ_SEED_OFFSET=100 ...
+cases = [(a, b, c, d, e, f + off) for a, b, c, d, e, f in cases]
 if len(sys.argv) > 1:
     cases = [c for c in cases if str(c[5]) in sys.argv[1:] or c[0] in sys.argv[1:]]
 bad = 0
