@@ -11,6 +11,9 @@ import common, oracle_lib as O
 cases = [("gobang9", 640, 64, 128, 6, 11), ("gobang9", 320, 64, 128, 6, 12), ("connect4", 1200, 64, 128, 6, 13), ("hex9", 200, 128, 128, 2, 14),
          ("reversi8", 400, 64, 128, 2, 15), ("reversi6", 600, 48, 128, 3, 16), ("gobang9", 96, 64, 512, 8, 17), ("reversi8", 96, 32, 512, 8, 18),
          ("hex9", 64, 128, 512, 4, 19), ("tictactoe", 3000, 16, 128, 6, 20)]
+if os.environ.get("FUZZ_SET") == "2":                          # other shapes: V = 128 on Gobang, 256-wide trunks, 13x13, Hex 11x11, wide Connect4
+    cases = [("gobang9", 200, 128, 128, 6, 41), ("gobang13", 96, 64, 256, 3, 42), ("hex11", 120, 40, 128, 2, 43), ("connect4", 200, 64, 512, 8, 44),
+             ("reversi6", 200, 64, 512, 2, 45), ("gobang9", 160, 64, 256, 4, 46), ("hex5", 1500, 24, 128, 1, 47), ("gobang13", 64, 64, 128, 2, 48)]
 off = int(os.environ.get("FUZZ_SEED_OFFSET", "0"))             # other seeds (networks, roots, uniforms): FUZZ_SEED_OFFSET=100 ...
 cases = [(a, b, c, d, e, f + off) for a, b, c, d, e, f in cases]
 if len(sys.argv) > 1:
