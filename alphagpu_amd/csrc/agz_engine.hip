@@ -518,14 +518,17 @@ int agz_set_network_slot(agz_engine* h, int which, int H, int T, const float* W0
             }
             // agz_nn_wave.hpp: groups of KThb k-rows x NTb tiles: layer 0 padded with zero rows to whole groups, zero-weight
             // residual groups (identity) up to a multiple of NW_DEPTH, the head padded with zero tiles, NW_DEPTH groups of slack
-            if (NTheadb <= NTb && NTb % NW_WAVES == 0) {
-                const int G0 = (KT0b + KThb - 1) / KThb, NGH = nw_hidden_groups(n.INP, H, T);
+            // (a head of up to 2 H outputs takes two groups: Gobang 13x13 / Hex 12x12 on a 128-wide trunk)
+            if (NTheadb <= 2 * NTb && NTb % NW_WAVES == 0) {
+                const int G0 = (KT0b + KThb - 1) / KThb, NGH = nw_hidden_groups(n.INP, H, T), HG = (NTheadb + NTb - 1) / NTb;
                 const size_t s0p = (size_t)G0 * sr;
-                std::vector<uint16_t> bw((size_t)(NGH + 1 + NW_DEPTH) * sr, 0);
+                std::vector<uint16_t> bw((size_t)(NGH + 2 + NW_DEPTH) * sr, 0);
                 std::copy(b16.begin(), b16.begin() + s0, bw.begin());
                 std::copy(b16.begin() + s0, b16.begin() + (s0 + sr * T), bw.begin() + s0p);
-                tile_weights16(Wp, P.A, H, NTb, KThb, bw.data() + (size_t)NGH * sr);
-                tile_weights16(Wv, 1, H, NTb, KThb, bw.data() + (size_t)NGH * sr, P.A, 1);
+                for (int hg = 0; hg < HG; ++hg) {                  // head group hg: output rows 16 NTb hg ...
+                    tile_weights16(Wp, P.A, H, NTb, KThb, bw.data() + (size_t)(NGH + hg) * sr, -16 * NTb * hg);
+                    tile_weights16(Wv, 1, H, NTb, KThb, bw.data() + (size_t)(NGH + hg) * sr, P.A - 16 * NTb * hg, 1);
+                }
                 HIPCHK(h, dmalloc(&n.w16w, bw.size()));
                 HIPCHK(h, hipMemcpy(n.w16w, bw.data(), bw.size() * 2, hipMemcpyHostToDevice));
             }
@@ -672,7 +675,7 @@ static int launch_network(agz_engine* h, int which, int s0 = 0, int s1 = -1, hip
         dim3 grid((unsigned)((L + 16 * mt - 1) / (16 * mt))), block(NB_THREADS);
         if (n.H == 512) { if (mt == 8) hipLaunchKernelGGL((k_mlp_big<512, 8>), grid, block, lds, stream, B); else if (mt == 4) hipLaunchKernelGGL((k_mlp_big<512, 4>), grid, block, lds, stream, B); else hipLaunchKernelGGL((k_mlp_big<512, 2>), grid, block, lds, stream, B); }
         else { if (mt == 8) hipLaunchKernelGGL((k_mlp_big<256, 8>), grid, block, lds, stream, B); else if (mt == 4) hipLaunchKernelGGL((k_mlp_big<256, 4>), grid, block, lds, stream, B); else hipLaunchKernelGGL((k_mlp_big<256, 2>), grid, block, lds, stream, B); }
-    } else if (f3_lds && n.w16w && L <= h->nn_wave_maxl) {   // one wave per 16 leaves, weights streamed from L2: lowest latency
+    } else if (h->cfg.nn_mode == AGZ_NN_BF16 && (n.H == 64 || n.H == 128) && n.w16w && L <= h->nn_wave_maxl && !getenv("AGZ_NO_FUSED_NN")) {   // one wave per 16 leaves, weights streamed from L2: lowest latency
         Fused3Par F;
         F.planes = (const uint16_t*)planes; F.INP = n.INP; F.w16 = n.w16w; F.bias_head = n.bias_head;
         F.logits = logits; F.LGS = h->LGS; F.vout = v_eval; F.L = L; F.T = n.T; F.A = h->G.A; F.AOP = n.AOP; F.gpw = 0; F.tw = 0;

@@ -152,56 +152,61 @@ __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const
 #undef NW_GROUP
 #undef NW_LOADGROUP
 
-    {   // head: D = X * W^T (logits leave row-major); its fragments sit in buffer 0 (NGH is a multiple of DEPTH)
+    {   // head: D = X * W^T (logits leave row-major); its fragments sit in buffer 0 (NGH is a multiple of DEPTH).  A head wider than
+        // the trunk (A + 1 > H, up to 2 H outputs: Gobang 13x13 on a 128-wide trunk) has a second group of tiles, which the group
+        // loop above has already brought into buffer 1
         const uint8_t* const brow = act0 + (size_t)cur * ML * ROWB + (size_t)lrow * ROWB;
         const int NT = P.AOP / 16;
-        if (wave * TPW < NT) {
+        int mrow[LT][4];                                            // game slot of tile row 16 lt + 4 q4 + r (once, not per tile)
 #pragma unroll
-            for (int k = 0; k < KTH; ++k)
+        for (int lt = 0; lt < LT; ++lt) {                          // rows 16 lt + 4 q4 + r: tree wave 2 lt + q4/2, game 4 (q4 & 1) + r of it
+            const int gq = 4 * (q4 & 1);
+            const int base = P.gpw == 0 ? leaf0 + 16 * lt + 4 * q4 : (bidx * P.tw + 2 * lt + (q4 >> 1)) * P.gpw + gq;
 #pragma unroll
-                for (int lt = 0; lt < LT; ++lt) {
-                    const bf16x8 b = *reinterpret_cast<const bf16x8*>(brow + (size_t)lt * 16 * ROWB + k * 64 + q4 * 16);
-#pragma unroll
-                    for (int t = 0; t < TPW; ++t) acc[lt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, A[0][k][t], acc[lt][t], 0, 0, 0);
-                }
-            // acc[lt][t][r] = out[leaf = leaf0 + 16 lt + 4 q4 + r][n = 16 tile + (lane & 15)]
-            int mrow[LT][4];                                        // game slot of tile row 16 lt + 4 q4 + r (once, not per tile)
-#pragma unroll
-            for (int lt = 0; lt < LT; ++lt) {                      // rows 16 lt + 4 q4 + r: tree wave 2 lt + q4/2, game 4 (q4 & 1) + r of it
-                const int gq = 4 * (q4 & 1);
-                const int base = P.gpw == 0 ? leaf0 + 16 * lt + 4 * q4 : (bidx * P.tw + 2 * lt + (q4 >> 1)) * P.gpw + gq;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) mrow[lt][r] = (P.gpw == 0 || gq + r < P.gpw) ? base + r : P.L;
-            }
-#pragma unroll
-            for (int t = 0; t < TPW; ++t) {
-                const int tile = wave * TPW + t;
-                if (tile < NT) {
-                    const int n = 16 * tile + (lane & 15);
-                    const float bias = P.bias_head[n];
-#pragma unroll
-                    for (int lt = 0; lt < LT; ++lt) {
-                        // (IO) rows 16 lt + 4 q4 + r sit in block 2 lt + q4 / 2, rows 4 (q4 & 1) + r of it
-                        float* const lrow_ = IO ? reinterpret_cast<float*>(io + (size_t)(2 * lt + (q4 >> 1)) * io_bw) + (size_t)(4 * (q4 & 1)) * io_lgs + n : nullptr;
-                        if (n < P.A) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int m = mrow[lt][r]; const float o = acc[lt][t][r] + bias;
-                                if (m < P.L) P.logits[(size_t)m * P.LGS + n] = o;
-                                if constexpr (IO) lrow_[(size_t)r * io_lgs] = o;
-                            }
-                        } else if (n == P.A) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int m = mrow[lt][r]; const float o = sigmoid_ool(acc[lt][t][r] + bias);
-                                if (m < P.L) P.vout[m] = o;
-                                if constexpr (IO) lrow_[(size_t)r * io_lgs] = o;
-                            }
-                        }
-                    }
-                }
-            }
+            for (int r = 0; r < 4; ++r) mrow[lt][r] = (P.gpw == 0 || gq + r < P.gpw) ? base + r : P.L;
         }
+#define NW_HEAD(buf, tile0)                                                                             \
+        if ((tile0) + wave * TPW < NT) {                                                                \
+            _Pragma("unroll") for (int k = 0; k < KTH; ++k)                                             \
+                _Pragma("unroll") for (int lt = 0; lt < LT; ++lt) {                                     \
+                    const bf16x8 b = *reinterpret_cast<const bf16x8*>(brow + (size_t)lt * 16 * ROWB + k * 64 + q4 * 16); \
+                    _Pragma("unroll") for (int t = 0; t < TPW; ++t) acc[lt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, A[buf][k][t], acc[lt][t], 0, 0, 0); \
+                }                                                                                       \
+            /* acc[lt][t][r] = out[leaf = leaf0 + 16 lt + 4 q4 + r][n = 16 tile + (lane & 15)] */        \
+            _Pragma("unroll") for (int t = 0; t < TPW; ++t) {                                           \
+                const int tile = (tile0) + wave * TPW + t;                                              \
+                if (tile < NT) {                                                                        \
+                    const int n = 16 * tile + (lane & 15);                                              \
+                    const float bias = P.bias_head[n];                                                  \
+                    _Pragma("unroll") for (int lt = 0; lt < LT; ++lt) {                                 \
+                        /* (IO) rows 16 lt + 4 q4 + r sit in block 2 lt + q4 / 2, rows 4 (q4 & 1) + r of it */ \
+                        float* const lrow_ = IO ? reinterpret_cast<float*>(io + (size_t)(2 * lt + (q4 >> 1)) * io_bw) + (size_t)(4 * (q4 & 1)) * io_lgs + n : nullptr; \
+                        if (n < P.A) {                                                                  \
+                            _Pragma("unroll") for (int r = 0; r < 4; ++r) {                             \
+                                const int m = mrow[lt][r]; const float o = acc[lt][t][r] + bias;        \
+                                if (m < P.L) P.logits[(size_t)m * P.LGS + n] = o;                       \
+                                if constexpr (IO) lrow_[(size_t)r * io_lgs] = o;                        \
+                            }                                                                           \
+                        } else if (n == P.A) {                                                          \
+                            _Pragma("unroll") for (int r = 0; r < 4; ++r) {                             \
+                                const int m = mrow[lt][r]; const float o = sigmoid_ool(acc[lt][t][r] + bias); \
+                                if (m < P.L) P.vout[m] = o;                                             \
+                                if constexpr (IO) lrow_[(size_t)r * io_lgs] = o;                        \
+                            }                                                                           \
+                        }                                                                               \
+                    }                                                                                   \
+                }                                                                                       \
+            }                                                                                           \
+        }
+        NW_HEAD(0, 0)
+        if (NT > NTH) {                                             // (wave-uniform, rare)
+#pragma unroll
+            for (int lt = 0; lt < LT; ++lt)
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) { acc[lt][t][0] = 0.0f; acc[lt][t][1] = 0.0f; acc[lt][t][2] = 0.0f; acc[lt][t][3] = 0.0f; }
+            NW_HEAD(1, NTH)
+        }
+#undef NW_HEAD
     }
 }
 
