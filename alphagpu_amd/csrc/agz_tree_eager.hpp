@@ -165,9 +165,10 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
     // one work item's rows -> registers (zeros for a lane-group without an item).  entry: node | move << 8 | depth << 16 | game << 24
     auto item_fetch = [&](ItemRows<KPL>& R, const int r, const uint32_t nwl) {
         R.ent = 0u; R.gi = g; R.valid = false;
-        if (r == 0) { R.ent = C.spw; R.valid = live && (C.spw & SP_VALID); }
+        // round 0: the lane-groups that own a game take its special item, the others (sparse waves: g >= GPW) already take list entries
+        if (r == 0 && g < GPW) { R.ent = C.spw; R.valid = live && (C.spw & SP_VALID); }
         else {
-            const uint32_t idx = 8u * (uint32_t)(r - 1) + (uint32_t)g;
+            const uint32_t idx = r == 0 ? (uint32_t)(g - GPW) : (uint32_t)(8 - GPW) + 8u * (uint32_t)(r - 1) + (uint32_t)g;
             if (idx < nwl) {
                 if (LEAN && idx < wl_cap_lds) R.ent = wl_lds[idx]; else R.ent = wl_g[idx];
                 R.valid = true; R.gi = (int)(R.ent >> 24) & 7;
@@ -204,9 +205,9 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
     // touch the record (and the aux word) of the item of round r: one dword per cache line
     auto item_touch = [&](const int r, const uint32_t nwl) -> uint32_t {
         uint32_t ent = 0u; int gi = g; bool valid = false;
-        if (r == 0) { ent = C.spw; valid = live && (C.spw & SP_VALID); }
+        if (r == 0 && g < GPW) { ent = C.spw; valid = live && (C.spw & SP_VALID); }
         else {
-            const uint32_t idx = 8u * (uint32_t)(r - 1) + (uint32_t)g;
+            const uint32_t idx = r == 0 ? (uint32_t)(g - GPW) : (uint32_t)(8 - GPW) + 8u * (uint32_t)(r - 1) + (uint32_t)g;
             if (idx < nwl) {
                 if (LEAN && idx < wl_cap_lds) ent = wl_lds[idx]; else ent = wl_g[idx];
                 valid = true; gi = (int)(ent >> 24) & 7;
@@ -227,7 +228,8 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
     // =============================================================================================
     if (SF.do_expand) {   // PHASE expand: load logits
         const uint32_t nwl = wcount;
-        const int rounds = 1 + (int)((nwl + 7u) >> 3);
+        const uint32_t free0 = (uint32_t)(8 - GPW);                  // list entries that round 0 already takes (sparse waves)
+        const int rounds = 1 + (nwl > free0 ? (int)((nwl - free0 + 7u) >> 3) : 0);
         ItemRows<KPL> R;
         const uint32_t gid = live ? T.game_id[slot] : 0u;
         {   // the uniforms of the rows this call makes: U(seed; game, step, rollout whose leaf is expanded / backed up, depth);
@@ -376,7 +378,7 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
                 asm volatile("" :: "v"(sink));                        // (keeps the touch loads alive; they completed long ago)
                 if (r + 1 < rounds) sink = item_touch(r + 1, nwl);
             }
-            const bool valid = R.valid, special = r == 0;
+            const bool valid = R.valid, special = r == 0 && g < GPW;
             const int gi = R.gi;   // PHASE items: fetch item
             const int node = (int)(R.ent & 0xffu), move = (int)((R.ent >> 8) & 0xffu), dpt_e = (int)((R.ent >> 16) & 0xffu);
             const bool created = special && (R.ent & SP_CREATED);
