@@ -315,7 +315,7 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
         e3 = getenv("AGZ_SMALL_MAXL");
         if (e3) h->small_maxl = atoi(e3);
         e3 = getenv("AGZ_SMALL_GPW");
-        if (e3 && (atoi(e3) == 1 || atoi(e3) == 2 || atoi(e3) == 4 || atoi(e3) == 8)) h->small_gpw = atoi(e3);
+        if (e3 && atoi(e3) >= 1 && atoi(e3) <= 8) h->small_gpw = atoi(e3);
         e3 = getenv("AGZ_SMALL4_MAXL");
         if (e3) h->small4_maxl = atoi(e3);
         e3 = getenv("AGZ_BIG_MAXL");
@@ -781,8 +781,13 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
             // few games: sparse waves — a rollout lasts as long as the deepest descent among the games of a workgroup, and with
             // <= 2 workgroups per CU idle lanes cost nothing: 1 / 2 games per tree wave up to 4 / 8 games per CU (measured per ply:
             // 2.9 vs 4.0 ms at 256 games, 3.1 vs 3.9 at 1024, 3.5 vs 3.9 at 2048; no gain from 4 games per wave at 4096)
-            const int gpw = tw == 4 ? 8 : (h->L <= 4 * h->cus ? 1 : (h->L <= 8 * h->cus ? 2 : (h->L <= 16 * h->cus ? 4 : 8)));   // (4096 games: 2.30 vs 2.56 ms with 4 per wave)
-            S.T.gpw = h->small_gpw > 0 && tw == 2 ? h->small_gpw : gpw;
+            // the fewest games per tree wave that keep every workgroup resident (4 tree waves per CU): 1 .. 8
+            // (16-game workgroups: 2 tree waves x 2 workgroups per CU; 32-game workgroups at 2 per CU: 8 tree waves per CU)
+            const int res_waves = (tw == 4 ? 4 * (2 + occ) : 4) * h->cus;      // tree waves resident at once
+            // sparse waves up to 64 games per CU (measured per ply: 2.40 vs 2.82 ms at 5120 games, 2.90 vs 3.43 at 10240); with 3 and 4
+            // workgroups per CU (more than 16384 games) 7 games per wave are not reliably faster than 8 (3.8 vs 4.2 ms at 17408, 6.8 vs 6.2 at 26624)
+            const int gpw = (tw == 4 && occ > 0) ? 8 : std::min(8, std::max(1, (h->L + res_waves - 1) / res_waves));
+            S.T.gpw = h->small_gpw > 0 && (tw == 2 || occ == 0) ? h->small_gpw : gpw;
             S.F.gpw = S.T.gpw < 8 ? S.T.gpw : 0; S.F.tw = tw;
             S.V = V; S.tree_lds = (int)h->reg_lds;
             const int kth = n.H / 32, g0 = (n.INP / 32 + kth - 1) / kth;
@@ -826,7 +831,7 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
             B.whead = n.w16 + (size_t)(n.INP / 32) * (n.H / 16) * 512 + (size_t)n.T * (n.H / 32) * (n.H / 16) * 512;
             B.bias_head = n.bias_head; B.logits = h->logits; B.LGS = h->LGS; B.vout = h->v_eval;
             B.L = h->L; B.T = n.T; B.A = h->G.A; B.AOP = n.AOP; B.K0R = n.k0r; B.ROWB = big_rowb;
-            const int gpw = h->L <= 4 * h->cus ? 1 : (h->L <= 8 * h->cus ? 2 : (h->L <= 16 * h->cus ? 4 : 8));   // sparse waves (see k_search_small)
+            const int gpw = std::min(8, std::max(1, (h->L + 4 * h->cus - 1) / (4 * h->cus)));   // sparse waves (see k_search_small)
             S.T.gpw = h->small_gpw > 0 ? h->small_gpw : gpw;
             const int wgs = (h->L + 4 * S.T.gpw - 1) / (4 * S.T.gpw);
             const int occ = wgs <= h->cus ? 0 : 1;                 // 1 or 2 workgroups per CU

@@ -161,7 +161,7 @@ int  agz_set_profiling(agz_engine *h, int mode);       /* HIP events per launch:
  *                          0 together with AGZ_SMALL4_MAXL=0 disables the one-launch form (two kernels per rollout)
  *   AGZ_SMALL4_MAXL=n      largest batch of the 32-games-per-workgroup one-launch search
  *   AGZ_SMALL4_OCC=0|1|2   force the 2 / 3 / 4 workgroups-per-CU register budget of that kernel
- *   AGZ_SMALL_GPW=1|2|4|8  games per tree wave of the one-launch forms (sparse waves for small batches)
+ *   AGZ_SMALL_GPW=1..8    games per tree wave of the one-launch forms (sparse waves for small batches)
  *   AGZ_BIG_MAXL=n         512-wide trunk: one-launch search (k_search_big) up to n games (default 16384; 0 disables)
  *   AGZ_CHAINS=k           two-kernel form: k sub-batches on parallel streams (default 2-3 from 12000 games)
  *   AGZ_REG3_MAX_WAVES=n   two-kernel form: largest grid that uses the 3-waves-per-SIMD build of the tree kernel

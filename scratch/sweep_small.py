@@ -1,7 +1,7 @@
 # per-ply search time of the whole-search kernel for several batch sizes and dispatch overrides
 import sys, os, time, subprocess
 sizes = [int(x) for x in sys.argv[1].split(",")]
-envs = [{}, {"AGZ_SMALL_GPW": "1"}, {"AGZ_SMALL_GPW": "2"}, {"AGZ_SMALL_GPW": "4"}, {"AGZ_SMALL_GPW": "8"}, {"AGZ_SMALL_MAXL": "0"}, {"AGZ_SMALL_MAXL": "0", "AGZ_SMALL4_OCC": "0"}]
+envs = [{}] + [{"AGZ_SMALL_GPW": str(k)} for k in (os.environ.get("GPWS", "1,2,4,8").split(","))] + [{"AGZ_SMALL_MAXL": "0"}]
 for L in sizes:
     row = []
     for e in envs:
