@@ -122,7 +122,7 @@ struct agz_engine {
     int small4_maxl = 1 << 30;   // ... used for batches in (small_maxl, small4_maxl] that fit the chip at once (AGZ_SMALL4_MAXL)
     int cus = 256;
     int small_gpw = 0;           // games per tree wave of the 16-game variant: 0 = by batch size (AGZ_SMALL_GPW = 1, 2, 4, 8)
-    small_fn k_small = nullptr; int small_maxl = 8192;   // whole-search kernel (agz_search_small.hpp) for batches up to small_maxl games (AGZ_SMALL_MAXL)
+    small_fn k_small = nullptr; int small_maxl = 5120;   // 16-game workgroups of the whole-search kernel up to small_maxl games (AGZ_SMALL_MAXL): 2.60 vs 2.45 ms per ply at 6144 games, 2.90 vs 2.72 at 8192 with 32-game workgroups and sparse waves
     int reg3_max_waves = 0;      // largest grid the 3-waves-per-SIMD build of the stand-alone tree kernel is used for
     rollout_fn k_eager = nullptr, k_eager3 = nullptr;   // the tree kernel (agz_tree_eager.hpp), register budgets for 4 / 3 waves per SIMD
     uint4* aux4 = nullptr; uint32_t *wl = nullptr, *wl_n = nullptr, *sp = nullptr; uint32_t wl_cap = 0;
