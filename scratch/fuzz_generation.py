@@ -14,6 +14,8 @@ cases = [("gobang9", 640, 64, 128, 6, 11), ("gobang9", 320, 64, 128, 6, 12), ("c
 if os.environ.get("FUZZ_SET") == "2":                          # other shapes: V = 128 on Gobang, 256-wide trunks, 13x13, Hex 11x11, wide Connect4
     cases = [("gobang9", 200, 128, 128, 6, 41), ("gobang13", 96, 64, 256, 3, 42), ("hex11", 120, 40, 128, 2, 43), ("connect4", 200, 64, 512, 8, 44),
              ("reversi6", 200, 64, 512, 2, 45), ("gobang9", 160, 64, 256, 4, 46), ("hex5", 1500, 24, 128, 1, 47), ("gobang13", 64, 64, 128, 2, 48)]
+if os.environ.get("FUZZ_SET") == "3":                          # thousands of games with cheap searches: every sparse-wave shape (1..8 games per wave,
+    cases = [("connect4", 7000, 16, 128, 1, 51), ("tictactoe", 12000, 8, 128, 1, 52), ("reversi6", 3000, 12, 128, 1, 53)]   # 16- and 32-game workgroups) on the way down
 off = int(os.environ.get("FUZZ_SEED_OFFSET", "0"))             # other seeds (networks, roots, uniforms): FUZZ_SEED_OFFSET=100 ...
 cases = [(a, b, c, d, e, f + off) for a, b, c, d, e, f in cases]
 if len(sys.argv) > 1:
