@@ -109,6 +109,7 @@ struct agz_engine {
     double tree_ms = 0, nn_ms = 0, tree_busy_ms = 0; int64_t tree_launches = 0;
     hipEvent_t ev_ref = nullptr; bool ev_ref_live = false;
     hipEvent_t ev_ply0 = nullptr, ev_ply1 = nullptr; uint32_t* hcount = nullptr;   // ply loop: search timing, pinned alive count
+    unsigned long long* hflag = nullptr; unsigned long long* hflag_dev = nullptr; uint32_t ply_seq = 0;   // ... host-visible (seq, count) word the scan kernel publishes
     uint8_t *stage_dev = nullptr, *stage_host = nullptr; size_t stage_cap = 0;     // agz_get_samples: packed records on the device / in pinned host memory (kept)
     uint64_t nn_leaves = 0;    // leaves sent through stand-alone network launches of the instrumented searches
     advance_fn k_adv = nullptr; softmax_fn k_soft = nullptr;
@@ -235,6 +236,7 @@ void agz_destroy(agz_engine* h) {
     if (h->ev_ply0) hipEventDestroy(h->ev_ply0);
     if (h->ev_ply1) hipEventDestroy(h->ev_ply1);
     if (h->hcount) hipHostFree(h->hcount);
+    if (h->hflag) hipHostFree(h->hflag);
     for (int c = 0; c < agz_engine::KCH - 1; ++c) { if (h->aux[c]) hipStreamDestroy(h->aux[c]); if (h->ev_join[c]) hipEventDestroy(h->ev_join[c]); }
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -277,6 +279,10 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     if (!bind_kernels(h)) { h->fail("no kernel instantiation for this game shape"); return bail(AGZ_ERR_UNSUPPORTED); }
     if (hipEventCreate(&h->ev_ply0) != hipSuccess || hipEventCreate(&h->ev_ply1) != hipSuccess ||
         hipHostMalloc((void**)&h->hcount, 4, 0) != hipSuccess) { h->fail("cannot create the ply-loop events / pinned counter"); return bail(AGZ_ERR_HIP); }
+    if (!getenv("AGZ_NO_HOST_FLAG") && hipHostMalloc((void**)&h->hflag, 8, hipHostMallocMapped) == hipSuccess) {
+        *h->hflag = 0;
+        if (hipHostGetDevicePointer((void**)&h->hflag_dev, h->hflag, 0) != hipSuccess) { hipHostFree(h->hflag); h->hflag = nullptr; h->hflag_dev = nullptr; }
+    }
     hipError_t fa = hipSuccess;                                     // first failure of the attribute / memset calls below
 #define FA_(call) do { hipError_t r_ = (call); if (fa == hipSuccess) fa = r_; } while (0)
     FA_(hipFuncSetAttribute((const void*)k_mlp_wave<128, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1093,11 +1099,27 @@ static int run_games(agz_engine* h, int ngames, int V, float cpuct, int tau_plie
                                (const uint32_t*)h->cnt_new, h->L, h->d_acc);
         PlyPar T; fill_plypar(h, T, ply, tau_plies, duel);
         hipLaunchKernelGGL(h->k_adv, dim3((unsigned)((h->L + 3) / 4)), dim3(256), 0, h->stream, T);          // :513-549
-        hipLaunchKernelGGL(k_scan_alive, dim3(1), dim3(1024), 0, h->stream, (const uint32_t*)h->alive, h->newslot, h->L, h->d_count);
+        const uint32_t seq = ++h->ply_seq ? h->ply_seq : ++h->ply_seq;        // (never 0)
+        hipLaunchKernelGGL(k_scan_alive, dim3(1), dim3(1024), 0, h->stream, (const uint32_t*)h->alive, h->newslot, h->L, h->d_count, h->hflag_dev, seq);
         hipLaunchKernelGGL(k_compact, dim3((unsigned)((h->L + 255) / 256)), dim3(256), 0, h->stream, T, (const uint32_t*)h->newslot,
                            (const uint32_t*)h->game_id, h->game_id2);           // :550-561
-        if (hipMemcpyAsync(hcount, h->d_count, 4, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
-            hipStreamSynchronize(h->stream) != hipSuccess) { h->fail("ply loop failed: %s", hipGetErrorString(hipGetLastError())); rc = AGZ_ERR_HIP; break; }
+        bool have = false;
+        if (h->hflag_dev) {
+            // the number of games left, as soon as the scan kernel has it: polled from host-visible memory while the compaction still runs
+            // (the next search is queued behind it on the stream); a stream that ends without the word falls back to the copy below
+            volatile unsigned long long* const f = h->hflag;
+            for (uint32_t spin = 0;; ++spin) {
+                const unsigned long long w = __atomic_load_n(f, __ATOMIC_ACQUIRE);
+                if ((uint32_t)(w >> 32) == seq) { *hcount = (uint32_t)w; have = true; break; }
+                if ((spin & 1023u) == 1023u) {
+                    const hipError_t q = hipStreamQuery(h->stream);
+                    if (q != hipErrorNotReady) { (void)hipGetLastError(); break; }
+                }
+            }
+            if (have && hipEventSynchronize(e1) != hipSuccess) have = false;   // (the search's end event is long past)
+        }
+        if (!have && (hipMemcpyAsync(hcount, h->d_count, 4, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+                      hipStreamSynchronize(h->stream) != hipSuccess)) { h->fail("ply loop failed: %s", hipGetErrorString(hipGetLastError())); rc = AGZ_ERR_HIP; break; }
         float ms = 0; hipEventElapsedTime(&ms, e0, e1); search_ms += ms;
         if (fold) { h->cnt_live = false; drain_events(h); }
         { uint32_t* s = h->game_id; h->game_id = h->game_id2; h->game_id2 = s; h->tp.game_id = h->game_id; }

@@ -127,7 +127,10 @@ __global__ __launch_bounds__(256) void k_fold_counters(const uint32_t* cnt_p, co
 // exclusive scan of the 0/1 flags alive[0..L) by one workgroup of 1024 threads -> newslot[], total -> *count.  Wave w owns a
 // contiguous segment and walks it 64 flags at a time (coalesced loads, counts by ballot): one pass for the segment totals, a
 // 16-entry scan of them, one pass for the slots.
-__global__ __launch_bounds__(1024) void k_scan_alive(const uint32_t* alive, uint32_t* newslot, int L, uint32_t* count) {
+// hostflag (may be null): a 64-bit word in host-visible memory that receives (seq << 32 | total) — the host polls it instead of
+// waiting for a copy and a stream synchronisation (the ply loop's only round trip to the host)
+__global__ __launch_bounds__(1024) void k_scan_alive(const uint32_t* alive, uint32_t* newslot, int L, uint32_t* count,
+                                                     unsigned long long* hostflag, uint32_t seq) {
     __shared__ uint32_t part[16];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int seg = ((L + 1023) / 1024) * 64;                    // flags per wave (a multiple of 64)
@@ -158,7 +161,10 @@ __global__ __launch_bounds__(1024) void k_scan_alive(const uint32_t* alive, uint
             base += (uint32_t)__popcll(m);
         }
     }
-    if (t == 0) *count = total;
+    if (t == 0) {
+        *count = total;
+        if (hostflag) __hip_atomic_store(hostflag, ((unsigned long long)seq << 32) | total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // re_init (:359-373): move surviving games to their compacted slots

@@ -168,6 +168,8 @@ int  agz_set_profiling(agz_engine *h, int mode);       /* HIP events per launch:
  *   AGZ_NN_WAVE_LT, AGZ_NN_WAVE_DEPTH, AGZ_NN_WAVE_MAXL   tile count / prefetch depth / batch limit of k_mlp_wave
  *   AGZ_NO_FUSED_NN=1      per-layer network kernels (k_layer_bf16) and no one-launch search
  *   AGZ_NO_FASTDIV=1       IEEE '/' everywhere in the tree kernel (agz_fastdiv.hpp off)
+ *   AGZ_NO_HOST_FLAG=1     ply loop: fetch the number of games left with a copy + stream synchronisation instead of polling the
+ *                          host-visible word the scan kernel publishes
  *   AGZ_BIG_MT=2|4|8       256 / 512-wide trunk, stand-alone network launches: 16-leaf tiles per workgroup (default by launch size)
  *   AGZ_WL_LDS_BYTES=n     one-launch forms: at most n bytes of LDS per tree wave for the work list of a rollout (the rest of
  *                          the list lives in global memory; default: what the resident workgroups leave free)
