@@ -632,15 +632,18 @@ def test_whole_search_kernel_agrees_bitwise(name, L, V, monkeypatch):
     monkeypatch.delenv("AGZ_SMALL4_MAXL")
     # 16 games per workgroup (default: sparse waves at these sizes), dense waves, 4 games per wave, 32 games per workgroup
     # ... and every register budget of the 32-game build (launch bounds for 2 / 3 / 4 workgroups per CU: k_search_small<..,4,2|3|4>)
-    # ... and work lists that overflow their LDS part into global memory (16 bytes = 4 entries, and no LDS part at all)
+    # ... and work lists that overflow their LDS part into global memory (16 bytes = 4 entries, and no LDS part at all), odd numbers
+    # of games per wave, IEEE '/' instead of the guarded fast divisions
     for env in ({}, {"AGZ_SMALL_GPW": "8"}, {"AGZ_SMALL_GPW": "4"}, {"AGZ_SMALL_MAXL": "0"},
                 {"AGZ_SMALL_MAXL": "0", "AGZ_SMALL4_OCC": "0"}, {"AGZ_SMALL_MAXL": "0", "AGZ_SMALL4_OCC": "1"},
                 {"AGZ_SMALL_MAXL": "0", "AGZ_SMALL4_OCC": "2"}, {"AGZ_SMALL_GPW": "8", "AGZ_WL_LDS_BYTES": "16"},
-                {"AGZ_SMALL_MAXL": "0", "AGZ_WL_LDS_BYTES": "0"}):
+                {"AGZ_SMALL_MAXL": "0", "AGZ_WL_LDS_BYTES": "0"}, {"AGZ_SMALL_GPW": "3"}, {"AGZ_SMALL_GPW": "5", "AGZ_SMALL_MAXL": "0"},
+                {"AGZ_NO_FASTDIV": "1"}):
         monkeypatch.delenv("AGZ_SMALL_GPW", raising=False)
         monkeypatch.delenv("AGZ_SMALL_MAXL", raising=False)
         monkeypatch.delenv("AGZ_SMALL4_OCC", raising=False)
         monkeypatch.delenv("AGZ_WL_LDS_BYTES", raising=False)
+        monkeypatch.delenv("AGZ_NO_FASTDIV", raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         got = run()
