@@ -26,9 +26,10 @@ for name, n, V, H, T, seed in cases:
     g, og = ag.GameSpec(kind, nn, k), O.make_game(kind, nn, k)
     net, onet = ag.SNetwork2.random(g, H, T, 0x5EED + seed), O.OracleNet(og, H, T, 0x5EED + seed)
     t0 = time.perf_counter()
-    ref = O.selfplay(og, onet.bf16(), n, V, 1.5, 25, seed, 1000 * seed)
+    exact = os.environ.get("FUZZ_EXACT") == "1"                # the bit-exact fp32 mode instead of the benchmarked bf16 mode
+    ref = O.selfplay(og, onet if exact else onet.bf16(), n, V, 1.5, 25, seed, 1000 * seed)
     t1 = time.perf_counter()
-    with M.Engine(g, n, V, seed=seed, game_id_base=1000 * seed, nn_mode=M.NN_BF16) as e:
+    with M.Engine(g, n, V, seed=seed, game_id_base=1000 * seed, nn_mode=M.NN_EXACT if exact else M.NN_BF16) as e:
         e.set_network(net)
         st = e.selfplay(n, V, cpuct=1.5, tau_plies=25)
         s = e.samples()
