@@ -1,10 +1,12 @@
-// agz_search_small.hpp — a whole mcts_single (mcts_gpu.jl:376-462: V x {select, network, expand, backup}) in ONE launch,
-// for the long tail of a generation where few games are alive.
+// agz_search_small.hpp — a whole mcts_single (mcts_gpu.jl:376-462: V x {select, network, expand, backup}) in ONE launch, for
+// 128-wide trunks and every batch that fits the chip at once (up to 128 games per CU).
 //
-// With < ~2000 games every launch is bound by its own dependency chain, and a rollout pays two kernel boundaries
-// (dispatch, ramp-up, drain, the round trip of planes / logits through L2).  Here a 4-wave workgroup owns 16 games for the
-// whole search: waves 0-1 run the eager-policy tree step (rollout_eager_body, 8 games each), a workgroup barrier hands the
-// 16 leaves to all four waves for the network forward (mlp_wave_body), a second barrier hands logits and values back.
+// One tree kernel and one network kernel per rollout put a global barrier after every rollout and two kernel boundaries on the
+// critical path of every game.  Here a 4-wave workgroup owns its games for the whole search: TW of its waves run the eager-policy
+// tree step (rollout_eager_body, up to 8 games each), a workgroup barrier hands the leaves to all four waves for the network
+// forward (mlp_wave_body; planes and logits change hands through LDS), a second barrier hands logits and values back.
+// TW = 2 (16 games per workgroup) up to 5120 games, TW = 4 (32 games) above; up to 64 games per CU the waves are sparse (the
+// fewest games per wave that keep every workgroup resident; lane-groups without a game take work items of the wave's games).
 // The two bodies are the very functions the stand-alone kernels run — same arithmetic, same bits (tested).
 #pragma once
 #include "agz_tree_eager.hpp"
