@@ -34,11 +34,13 @@ AGZ_HD float uniform_search(uint64_t seed, uint32_t game, uint32_t step, uint32_
     const uint32_t w = depth & 3u;
     return w == 0 ? u[0] : (w == 1 ? u[1] : (w == 2 ? u[2] : u[3]));
 }
-// uniform in [0,1) standing for rand() inside StatsBase.sample (mcts_gpu.jl:520)
+// uniform in (0,1] standing for rand() inside StatsBase.sample (mcts_gpu.jl:520): (24 random bits + 1/2) 2^-24.  Never 0: the
+// reference's Float64 rand() is 0 with probability 2^-53 — never in practice — whereas a 24-bit draw that could be 0 would stop the
+// duel's all-actions walk (:606) at action 1 whatever its weight once in 2^24 draws
 AGZ_HD float uniform_move(uint64_t seed, uint32_t game, uint32_t step) {
     uint32_t o[4];
     philox4x32_10(game, step, 0u, 0x80000000u, (uint32_t)seed, (uint32_t)(seed >> 32), o);
-    return (float)(o[0] >> 8) * 5.9604644775390625e-8f;
+    return ((float)(o[0] >> 8) + 0.5f) * 5.9604644775390625e-8f;
 }
 
 // ---------------------------------------------------------------------------------------------------

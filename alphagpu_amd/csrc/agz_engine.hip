@@ -21,7 +21,6 @@
 #include "agz_small_kernels.hpp"
 #include "agz_tree_eager.hpp"
 #include "agz_nn.hpp"
-#include "agz_nn_fused3.hpp"
 #include "agz_nn_wave.hpp"
 #include "agz_nn_big.hpp"
 #include "agz_search_small.hpp"
@@ -47,7 +46,7 @@ struct DevNet {
     uint16_t *t0 = nullptr, *tres = nullptr, *thead = nullptr;
     uint16_t* w16w = nullptr;      // uniform k-rows for agz_nn_wave.hpp
     uint16_t* wbig = nullptr; int k0r = 0;   // hidden k-rows for agz_nn_big.hpp (layer 0 padded to k0r rows)
-    uint16_t* w16 = nullptr;       // the same three sections tiled for v_mfma_f32_16x16x32_bf16 (agz_nn_fused3.hpp)
+    uint16_t* w16 = nullptr;       // the same three sections tiled for v_mfma_f32_16x16x32_bf16 (the head section feeds agz_nn_big.hpp)
     float* bias_head = nullptr;
     int NT_h = 0, NT_head = 0;
 };
@@ -75,7 +74,8 @@ struct agz_engine {
     int chains = 0;                     // 0 = automatic (AGZ_CHAINS overrides)
     int nn_wave_depth = 0;              // layers of weights in flight: 0 = by batch size (AGZ_NN_WAVE_DEPTH = 2, 4)
     int nn_wave_lt = 0;                 // 16-leaf tiles per workgroup of that kernel: 0 = by batch size (AGZ_NN_WAVE_LT = 1, 2, 4, 8)
-    int nn_wave_maxl = 1 << 30;         // batches up to this size use agz_nn_wave.hpp, larger ones k_mlp_fused3 (AGZ_NN_WAVE_MAXL); the wave kernel wins at every size measured
+    bool no_fastdiv = false;            // AGZ_NO_FASTDIV: the tree keeps the compiler's division everywhere (A/B, tests)
+    bool no_fused_nn = false;           // AGZ_NO_FUSED_NN: one network launch per layer (k_layer_bf16) and the two-kernel search form (tests)
     int L = 0;                 // active slots
     int Lmax = 0, V = 0;
     TreePar tp;                // template of kernel arguments
@@ -110,6 +110,7 @@ struct agz_engine {
     hipEvent_t ev_ref = nullptr; bool ev_ref_live = false;
     hipEvent_t ev_ply0 = nullptr, ev_ply1 = nullptr; uint32_t* hcount = nullptr;   // ply loop: search timing, pinned alive count
     unsigned long long* hflag = nullptr; unsigned long long* hflag_dev = nullptr; uint32_t ply_seq = 0;   // ... host-visible (seq, count) word the scan kernel publishes
+    uint32_t* d_order = nullptr; int64_t sp_nsamples = 0; int sp_maxplies = 0;   // PoolSample order of the last generation (device), its length, its longest game
     uint8_t *stage_dev = nullptr, *stage_host = nullptr; size_t stage_cap = 0;     // agz_get_samples: packed records on the device / in pinned host memory (kept)
     uint64_t nn_leaves = 0;    // leaves sent through stand-alone network launches of the instrumented searches
     advance_fn k_adv = nullptr; softmax_fn k_soft = nullptr;
@@ -228,6 +229,7 @@ void agz_destroy(agz_engine* h) {
     hipFree(h->s_boards); hipFree(h->s_policy); hipFree(h->s_move); hipFree(h->g_nplies); hipFree(h->g_result);
     hipFree(h->g_final); hipFree(h->d_stats); hipFree(h->d_acc); hipFree(h->scratch_f);
     hipFree(h->aux4); hipFree(h->wl); hipFree(h->wl_n); hipFree(h->sp);
+    hipFree(h->d_order);
     hipFree(h->stage_dev); if (h->stage_host) hipHostFree(h->stage_host);
     free_net(h->net[0]); free_net(h->net[1]);
     for (auto& e : h->ev_tree) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
@@ -262,8 +264,8 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     {
         const char* e = getenv("AGZ_CHAINS");
         h->chains = e ? atoi(e) : 0;
-        e = getenv("AGZ_NN_WAVE_MAXL");
-        if (e) h->nn_wave_maxl = atoi(e);
+        h->no_fastdiv = getenv("AGZ_NO_FASTDIV") != nullptr;        // every switch is read here, once: no getenv on a launch path
+        h->no_fused_nn = getenv("AGZ_NO_FUSED_NN") != nullptr;
         e = getenv("AGZ_NN_WAVE_DEPTH");
         if (e && (atoi(e) == 2 || atoi(e) == 4)) h->nn_wave_depth = atoi(e);
         e = getenv("AGZ_NN_WAVE_LT");
@@ -279,7 +281,7 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     if (!bind_kernels(h)) { h->fail("no kernel instantiation for this game shape"); return bail(AGZ_ERR_UNSUPPORTED); }
     if (hipEventCreate(&h->ev_ply0) != hipSuccess || hipEventCreate(&h->ev_ply1) != hipSuccess ||
         hipHostMalloc((void**)&h->hcount, 4, 0) != hipSuccess) { h->fail("cannot create the ply-loop events / pinned counter"); return bail(AGZ_ERR_HIP); }
-    if (!getenv("AGZ_NO_HOST_FLAG") && hipHostMalloc((void**)&h->hflag, 8, hipHostMallocMapped) == hipSuccess) {
+    if (!getenv("AGZ_NO_HOST_FLAG") && hipHostMalloc((void**)&h->hflag, 8, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
         *h->hflag = 0;
         if (hipHostGetDevicePointer((void**)&h->hflag_dev, h->hflag, 0) != hipSuccess) { hipHostFree(h->hflag); h->hflag = nullptr; h->hflag_dev = nullptr; }
     }
@@ -301,8 +303,6 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     FA_(hipFuncSetAttribute((const void*)k_layer_exact<EX_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     FA_(hipFuncSetAttribute((const void*)k_layer_exact<EX_POLICY>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     FA_(hipFuncSetAttribute((const void*)k_layer_exact<EX_VALUE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    FA_(hipFuncSetAttribute((const void*)k_mlp_fused3<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    FA_(hipFuncSetAttribute((const void*)k_mlp_fused3<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     // node record: [prior f32 x A2][q f32 x A2][rank u8 x A2][cid u8 x A2][vis u8 x A2], A2 = 8 lanes x KPL actions
     // (agz_tree_eager.hpp)
     h->reg_lds = (size_t)eager_lds_layout(h->V).total;
@@ -349,7 +349,7 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     size_t wl_blocks = 0;
     {
         h->wl_cap = (uint32_t)(8 * h->V);
-        wl_blocks = std::max((size_t)(h->Lmax / 8 + 64), (size_t)(8 * std::max(h->cus, 256)));   // sparse waves: up to 8 cus one-game blocks
+        wl_blocks = (size_t)h->Lmax + 64;                  // one block per tree wave; a forced AGZ_SMALL_GPW = 1 makes every game a wave
         A_(dmalloc(&h->aux4, Lm * V));
         A_(dmalloc(&h->wl, wl_blocks * h->wl_cap)); A_(dmalloc(&h->wl_n, wl_blocks)); A_(dmalloc(&h->sp, Lm));
     }
@@ -365,6 +365,7 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     const size_t SG = (size_t)h->sample_games, MP = (size_t)P.max_plies;
     A_(dmalloc(&h->s_boards, SG * MP * 6)); A_(dmalloc(&h->s_policy, SG * MP * P.A)); A_(dmalloc(&h->s_move, SG * MP));
     A_(dmalloc(&h->g_nplies, SG)); A_(dmalloc(&h->g_result, SG)); A_(dmalloc(&h->g_final, SG));
+    A_(dmalloc(&h->d_order, SG * MP));
     if (e != hipSuccess) { h->fail("device allocation failed: %s", hipGetErrorString(e)); return bail(AGZ_ERR_NOMEM); }
     FA_(hipMemsetAsync(h->meta, 0, Lm * V * 4, h->stream));
     FA_(hipMemsetAsync(h->policy_final, 0, Lm * P.A * 4, h->stream));
@@ -603,7 +604,7 @@ static std::pair<hipEvent_t, hipEvent_t>* next_events(agz_engine* h, std::vector
     }
     return &pool[used++];
 }
-static void drain_events(agz_engine* h) {     // stream must be idle
+static void drain_events(agz_engine* h) {     // every recorded event has completed
     // tree kernels: sum of the launch durations, and the BUSY time = length of the union of the launch intervals (with
     // sub-batch chains several launches run side by side; the union is the time during which the kernel type was active)
     std::vector<std::pair<float, float>> iv;
@@ -626,6 +627,10 @@ static void drain_events(agz_engine* h) {     // stream must be idle
     h->ev_ref_live = false;
 }
 
+// agz_fastdiv.hpp's operand range: lambda p >= 2^-100 needs lambda = cpuct sqrt(n) / (A + n) >= 2^-13 (p >= 2^-87), i.e. cpuct >= 2^-4
+// for every A + n <= 512
+static inline bool fastdiv_range(const agz_engine* h) { return !h->no_fastdiv && h->cpuct >= 0.0625f && h->cpuct <= 1024.0f; }
+
 static int launch_rollout(agz_engine* h, uint32_t rollout, int do_reset, int do_expand, int do_select, int last, int inject, int capture,
                           int s0 = 0, int s1 = -1, hipStream_t stream = nullptr, int final_ = 0) {
     if (h->L == 0) return AGZ_OK;
@@ -636,7 +641,7 @@ static int launch_rollout(agz_engine* h, uint32_t rollout, int do_reset, int do_
     T.L = s1; T.slot0 = s0; T.gpw = 8; T.step = h->step; T.rollout = rollout; T.cpuct = h->cpuct; T.training = h->training;
     T.do_reset = do_reset; T.do_expand = do_expand; T.do_select = do_select; T.last = last; T.inject = inject; T.capture = capture;
     T.final_ = final_;
-    T.fastdiv = h->cfg.nn_mode == AGZ_NN_BF16 && h->cpuct >= 0.0009765625f && h->cpuct <= 1024.0f && !getenv("AGZ_NO_FASTDIV");
+    T.fastdiv = h->cfg.nn_mode == AGZ_NN_BF16 && fastdiv_range(h);
     dim3 grid((unsigned)((n + 7) / 8)), block(64);                // 8 games per wavefront
     std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
     if ((h->profiling & 1) && h->prof_this) { ev = next_events(h, h->ev_tree, h->ev_tree_used); hipEventRecord(ev->first, stream); }
@@ -659,13 +664,8 @@ static int launch_network(agz_engine* h, int which, int s0 = 0, int s1 = -1, hip
     float* const logits = h->logits + (size_t)s0 * h->LGS; float* const v_eval = h->v_eval + s0;
     std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
     if ((h->profiling & 2) && h->prof_this) { ev = next_events(h, h->ev_nn, h->ev_nn_used); hipEventRecord(ev->first, stream); h->nn_leaves += (uint64_t)L; }
-    size_t f3_lds = 0;
-    if (h->cfg.nn_mode == AGZ_NN_BF16 && (n.H == 64 || n.H == 128) && n.w16 && n.AOP / 16 <= n.H / 16 && !getenv("AGZ_NO_FUSED_NN")) {
-        f3_lds = (size_t)F3_M * (n.H * 2 + 16) + F3_WCHUNK + (size_t)F3_M * (n.INP * 2 + 16);
-        if (f3_lds > 160 * 1024) f3_lds = 0;
-    }
     const int big_rowb = 2 * std::max(n.H, 32 * n.k0r) + 16;
-    if (h->cfg.nn_mode == AGZ_NN_BF16 && n.wbig && (size_t)NB_M * big_rowb <= 160 * 1024 && !getenv("AGZ_NO_FUSED_NN")) {   // wide trunk: activations resident in LDS, weights streamed from L2
+    if (h->cfg.nn_mode == AGZ_NN_BF16 && n.wbig && (size_t)NB_M * big_rowb <= 160 * 1024 && !h->no_fused_nn) {   // wide trunk: activations resident in LDS, weights streamed from L2
         BigPar B;
         B.planes = (const uint16_t*)planes; B.INP = n.INP; B.wh = n.wbig;
         B.whead = n.w16 + (size_t)(n.INP / 32) * (n.H / 16) * 512 + (size_t)n.T * (n.H / 32) * (n.H / 16) * 512;
@@ -681,7 +681,7 @@ static int launch_network(agz_engine* h, int which, int s0 = 0, int s1 = -1, hip
         dim3 grid((unsigned)((L + 16 * mt - 1) / (16 * mt))), block(NB_THREADS);
         if (n.H == 512) { if (mt == 8) hipLaunchKernelGGL((k_mlp_big<512, 8>), grid, block, lds, stream, B); else if (mt == 4) hipLaunchKernelGGL((k_mlp_big<512, 4>), grid, block, lds, stream, B); else hipLaunchKernelGGL((k_mlp_big<512, 2>), grid, block, lds, stream, B); }
         else { if (mt == 8) hipLaunchKernelGGL((k_mlp_big<256, 8>), grid, block, lds, stream, B); else if (mt == 4) hipLaunchKernelGGL((k_mlp_big<256, 4>), grid, block, lds, stream, B); else hipLaunchKernelGGL((k_mlp_big<256, 2>), grid, block, lds, stream, B); }
-    } else if (h->cfg.nn_mode == AGZ_NN_BF16 && (n.H == 64 || n.H == 128) && n.w16w && L <= h->nn_wave_maxl && !getenv("AGZ_NO_FUSED_NN")) {   // one wave per 16 leaves, weights streamed from L2: lowest latency
+    } else if (h->cfg.nn_mode == AGZ_NN_BF16 && (n.H == 64 || n.H == 128) && n.w16w && !h->no_fused_nn) {   // one wave per 16 leaves, weights streamed from L2: lowest latency
         Fused3Par F;
         F.planes = (const uint16_t*)planes; F.INP = n.INP; F.w16 = n.w16w; F.bias_head = n.bias_head;
         F.logits = logits; F.LGS = h->LGS; F.vout = v_eval; F.L = L; F.T = n.T; F.A = h->G.A; F.AOP = n.AOP; F.gpw = 0; F.tw = 0;
@@ -696,16 +696,8 @@ static int launch_network(agz_engine* h, int which, int s0 = 0, int s1 = -1, hip
         if (n.H == 128) { if (lt == 1) NW_LAUNCH(128, 1); else if (lt == 2) NW_LAUNCH(128, 2); else if (lt == 4) NW_LAUNCH(128, 4); else NW_LAUNCH(128, 8); }
         else { if (lt == 1) NW_LAUNCH(64, 1); else if (lt == 2) NW_LAUNCH(64, 2); else if (lt == 4) NW_LAUNCH(64, 4); else NW_LAUNCH(64, 8); }
 #undef NW_LAUNCH
-    } else if (f3_lds) {                // 16x16x32 tiles, 8 waves per workgroup
-        Fused3Par F;
-        F.planes = (const uint16_t*)planes; F.INP = n.INP; F.w16 = n.w16; F.bias_head = n.bias_head;
-        F.logits = logits; F.LGS = h->LGS; F.vout = v_eval; F.L = L; F.T = n.T; F.A = h->G.A; F.AOP = n.AOP; F.gpw = 0; F.tw = 0;
-        dim3 grid((unsigned)((L + F3_M - 1) / F3_M)), block(F3_THREADS);
-        h->form_nn = "k_mlp_fused3 (one launch)";
-        if (n.H == 128) hipLaunchKernelGGL(k_mlp_fused3<128>, grid, block, f3_lds, stream, F);
-        else hipLaunchKernelGGL(k_mlp_fused3<64>, grid, block, f3_lds, stream, F);
     } else if (h->cfg.nn_mode == AGZ_NN_BF16) {
-        h->form_nn = "k_layer_bf16 (one launch per layer)";
+        h->form_nn = "k_layer_bf16 (one launch per layer)";   // any trunk width (H = 32, 96, 1024 ...): the generic path
         dim3 block(256);
         dim3 gh((unsigned)((L + GB_M - 1) / GB_M), (unsigned)((n.H + GB_N - 1) / GB_N));
         const uint16_t* x = (const uint16_t*)planes;
@@ -770,7 +762,7 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
             // (rows of 16+ actions per lane — 13x13 boards, Hex 11x11 — spill in the 3- and 4-workgroups-per-CU builds: two kernels per
             //  rollout are faster there, 13.1 vs 16.6 ms per ply at 24576 games of Gobang 13x13; up to 64 games per CU the one-launch
             //  form wins, 6.6 vs 10.2 ms at 16384)
-            h->L <= std::min(std::max(h->small_maxl, h->small4_maxl), (h->reg_kpl >= 16 ? 64 : 128) * h->cus) && !getenv("AGZ_NO_FUSED_NN")) {
+            h->L <= std::min(std::max(h->small_maxl, h->small4_maxl), (h->reg_kpl >= 16 ? 64 : 128) * h->cus) && !h->no_fused_nn) {
             // 16 games per workgroup up to small_maxl; beyond, 32 games per workgroup with the loosest register budget that still
             // keeps every workgroup resident (2 / 3 / 4 workgroups per CU = 64 / 96 / 128 games per CU)
             const int tw = h->L <= h->small_maxl ? 2 : 4;
@@ -780,7 +772,7 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
             SmallPar S;
             S.T = h->tp;
             S.T.L = h->L; S.T.slot0 = 0; S.T.step = h->step; S.T.cpuct = h->cpuct; S.T.training = h->training;
-            S.T.fastdiv = h->cpuct >= 0.0009765625f && h->cpuct <= 1024.0f && !getenv("AGZ_NO_FASTDIV");
+            S.T.fastdiv = fastdiv_range(h);
             S.T.inject = 0; S.T.capture = 0; S.T.rollout = 0; S.T.do_reset = 1; S.T.do_expand = 0; S.T.do_select = 1; S.T.last = 0;
             S.F.planes = (const uint16_t*)h->planes; S.F.INP = n.INP; S.F.w16 = n.w16w; S.F.bias_head = n.bias_head;
             S.F.logits = h->logits; S.F.LGS = h->LGS; S.F.vout = h->v_eval; S.F.L = h->L; S.F.T = n.T; S.F.A = h->G.A; S.F.AOP = n.AOP;
@@ -826,11 +818,12 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
         DevNet& n = h->net[which];
         const int big_rowb = 2 * std::max(n.H, 32 * n.k0r) + 16;
         if (h->k_big[0] && h->cfg.nn_mode == AGZ_NN_BF16 && n.H == 512 && n.wbig && h->L > 0 && 8 * h->reg_kpl <= h->LGS &&
-            h->L <= std::min(h->big_maxl, 64 * h->cus) && !getenv("AGZ_NO_FUSED_NN")) {
+            h->V <= 128 && (h->V & 3) == 0 &&                    // (the shapes the lean build of the tree step is tested at, as for k_search_small)
+            h->L <= std::min(h->big_maxl, 64 * h->cus) && !h->no_fused_nn) {
             BigSearchPar S;
             S.T = h->tp;
             S.T.L = h->L; S.T.slot0 = 0; S.T.step = h->step; S.T.cpuct = h->cpuct; S.T.training = h->training;
-            S.T.fastdiv = h->cpuct >= 0.0009765625f && h->cpuct <= 1024.0f && !getenv("AGZ_NO_FASTDIV");
+            S.T.fastdiv = fastdiv_range(h);
             S.T.inject = 0; S.T.capture = 0; S.T.rollout = 0; S.T.do_reset = 1; S.T.do_expand = 0; S.T.do_select = 1; S.T.last = 0;
             BigPar& B = S.B;
             B.planes = (const uint16_t*)h->planes; B.INP = n.INP; B.wh = n.wbig;
@@ -1083,7 +1076,7 @@ static int run_games(agz_engine* h, int ngames, int V, float cpuct, int tau_plie
     rc = agz_set_roots(h, nullptr, 0, nullptr, ngames); if (rc) return rc;       // Position() for every game (:479)
     HIPCHK(h, hipMemsetAsync(h->d_stats, 0, 8 * sizeof(unsigned long long), h->stream));
     HIPCHK(h, hipMemsetAsync(h->g_nplies, 0, (size_t)h->sample_games * 4, h->stream));
-    h->sp_games = ngames;
+    h->sp_games = ngames; h->sp_nsamples = 0; h->sp_maxplies = 0;
     const hipEvent_t e0 = h->ev_ply0, e1 = h->ev_ply1;
     double search_ms = 0; int64_t rollouts = 0; int ply = 0;
     uint32_t* const hcount = h->hcount;
@@ -1111,6 +1104,7 @@ static int run_games(agz_engine* h, int ngames, int V, float cpuct, int tau_plie
             for (uint32_t spin = 0;; ++spin) {
                 const unsigned long long w = __atomic_load_n(f, __ATOMIC_ACQUIRE);
                 if ((uint32_t)(w >> 32) == seq) { *hcount = (uint32_t)w; have = true; break; }
+                __builtin_ia32_pause();                                            // (a polite spin: the core is shared with the host's other threads)
                 if ((spin & 1023u) == 1023u) {
                     const hipError_t q = hipStreamQuery(h->stream);
                     if (q != hipErrorNotReady) { (void)hipGetLastError(); break; }
@@ -1130,16 +1124,18 @@ static int run_games(agz_engine* h, int ngames, int V, float cpuct, int tau_plie
     if (rc) return rc;
     unsigned long long hs[8];
     HIPCHK(h, hipMemcpy(hs, h->d_stats, sizeof hs, hipMemcpyDeviceToHost));
+    {   // nsamples = sum of plies per game; kept (with the longest game) for agz_get_samples_packed
+        std::vector<int32_t> np((size_t)(ngames < h->sample_games ? ngames : h->sample_games));
+        HIPCHK(h, hipMemcpy(np.data(), h->g_nplies, np.size() * 4, hipMemcpyDeviceToHost));
+        int64_t n = 0; int mx = 0; for (int32_t x : np) { n += x; mx = x > mx ? x : mx; }
+        h->sp_nsamples = n; h->sp_maxplies = mx;
+    }
     if (st) {
         memset(st, 0, sizeof *st);
         st->wins = (int64_t)hs[0]; st->draws = (int64_t)hs[1]; st->losses = (int64_t)hs[2]; st->total_plies = (int64_t)hs[3];
         st->faults = (int32_t)hs[4]; st->rollouts = rollouts; st->plies = ply; st->search_seconds = search_ms * 1e-3;
         st->total_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        // nsamples = sum of plies per game
-        std::vector<int32_t> np((size_t)(ngames < h->sample_games ? ngames : h->sample_games));
-        HIPCHK(h, hipMemcpy(np.data(), h->g_nplies, np.size() * 4, hipMemcpyDeviceToHost));
-        int64_t n = 0; for (int32_t x : np) n += x;
-        st->nsamples = n;
+        st->nsamples = h->sp_nsamples;
     }
     if (hs[4]) { h->fail("%llu illegal sampled move(s) (\"faute\", mcts_gpu.jl:526-529)", hs[4]); return AGZ_ERR_ILLEGAL_MOVE; }
     return AGZ_OK;
@@ -1163,37 +1159,27 @@ int agz_duel(agz_engine* h, int ngames, int V, float cpuct, int tau_plies, int f
 }
 
 // ---- samples ----------------------------------------------------------------------------------------
-static int build_order(agz_engine* h, std::vector<uint32_t>& order) {
-    const int G = h->sp_games < h->sample_games ? h->sp_games : h->sample_games;
-    std::vector<int32_t> np((size_t)G);
-    if (G > 0) HIPCHK(h, hipMemcpy(np.data(), h->g_nplies, (size_t)G * 4, hipMemcpyDeviceToHost));
-    int maxp = 0; for (int g = 0; g < G; ++g) maxp = np[g] > maxp ? np[g] : maxp;
-    order.clear();
-    for (int p = 0; p < maxp; ++p)                      // PoolSample order: ply-major, then slot (= game id) order
-        for (int g = 0; g < G; ++g) if (np[g] > p) order.push_back(((uint32_t)g << 8) | (uint32_t)p);
-    return AGZ_OK;
-}
 int agz_get_samples_packed(agz_engine* h, void* dev_out, int64_t capacity_records, int64_t* n_out) {
     if (!h || !n_out) return AGZ_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    std::vector<uint32_t> order;
-    int rc = build_order(h, order); if (rc) return rc;
-    *n_out = (int64_t)order.size();
+    // the number of samples and the longest game are known since the generation ended (run_games); the order table is built on the
+    // device into a buffer the engine keeps: no allocation, no copy of the per-game ply counts per call
+    const int64_t n = h->sp_games > 0 ? h->sp_nsamples : 0;
+    *n_out = n;
     if (!dev_out) return AGZ_OK;                         // size query
-    if ((int64_t)order.size() > capacity_records) { h->fail("sample buffer too small: %zu > %lld", order.size(), (long long)capacity_records); return AGZ_ERR_ARG; }
-    if (order.empty()) return AGZ_OK;
-    uint32_t* d_order = nullptr;
-    HIPCHK(h, dmalloc(&d_order, order.size()));
-    HIPCHK(h, hipMemcpy(d_order, order.data(), order.size() * 4, hipMemcpyHostToDevice));
+    if (n > capacity_records) { h->fail("sample buffer too small: %lld > %lld", (long long)n, (long long)capacity_records); return AGZ_ERR_ARG; }
+    if (n == 0) return AGZ_OK;
+    const int G = h->sp_games < h->sample_games ? h->sp_games : h->sample_games;
+    hipLaunchKernelGGL(k_sample_order, dim3((unsigned)h->sp_maxplies), dim3(1024), 0, h->stream, (const int32_t*)h->g_nplies, G, h->d_order,
+                       (unsigned long long*)nullptr);
     PackPar T;
     T.A = h->G.A; T.VS = h->G.VS; T.FS = h->G.FS; T.max_plies = h->G.max_plies; T.rec_bytes = h->info.rec_bytes;
     T.game_id_base = h->cfg.game_id_base; T.s_boards = h->s_boards; T.s_policy = h->s_policy; T.s_move = h->s_move;
-    T.g_nplies = h->g_nplies; T.g_result = h->g_result; T.g_final = h->g_final; T.order = d_order; T.n = (int64_t)order.size();
+    T.g_nplies = h->g_nplies; T.g_result = h->g_result; T.g_final = h->g_final; T.order = h->d_order; T.n = n;
     T.out = (uint8_t*)dev_out;
-    hipLaunchKernelGGL(k_pack_samples, dim3((unsigned)order.size()), dim3(64), 0, h->stream, T);
-    hipError_t e = hipStreamSynchronize(h->stream);
-    hipFree(d_order);
+    hipLaunchKernelGGL(k_pack_samples, dim3((unsigned)n), dim3(64), 0, h->stream, T);
+    HIPCHK(h, hipGetLastError());
+    const hipError_t e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) { h->fail("k_pack_samples failed: %s", hipGetErrorString(e)); return AGZ_ERR_HIP; }
     return AGZ_OK;
 }

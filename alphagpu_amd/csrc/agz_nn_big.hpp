@@ -10,7 +10,7 @@
 // flight ahead of the matrix core, across layer boundaries.  One workgroup per CU: a 32768-leaf batch is one round.
 // 2 * 128 * (INP*H + T*H*H + AOP*H) flop per workgroup; 512x8 on Gobang 9x9: 4.44 MFLOP / leaf, 146 GFLOP / launch.
 #pragma once
-#include "agz_nn_fused3.hpp"
+#include "agz_nn_wave.hpp"
 
 namespace agz {
 

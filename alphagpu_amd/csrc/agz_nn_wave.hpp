@@ -1,23 +1,45 @@
 // agz_nn_wave.hpp — the snetwork2 forward (DenseNet.jl:294-304), latency-first: one 4-wave workgroup per 16 leaves.
 //
-// The LDS-shared layout (agz_nn_fused3.hpp) spends its time waiting: every layer is "weights chunk arrives -> commit to
-// LDS -> barrier -> 32 MFMAs -> epilogue -> barrier", ~7.6 K cycles per layer for ~0.5 K cycles of matrix work, and a
-// search with few games left (the long tail of a self-play generation) pays that latency on every rollout.
+// A layout that stages the weights through LDS (tried first, removed) spends its time waiting: every layer is "weights chunk
+// arrives -> commit to LDS -> barrier -> 32 MFMAs -> epilogue -> barrier", ~7.6 K cycles per layer for ~0.5 K cycles of matrix
+// work, and a search with few games left (the long tail of a self-play generation) pays that latency on every rollout.
 // Here the pre-tiled weight fragments (1 KiB per 16x32 tile, lane l's 16 bytes at +16 l) go from L2 straight into the MFMA
 // A operand.  Wave w of the workgroup owns the neuron tiles {w*TPW .. w*TPW+TPW-1} of every layer, so it streams only a
 // quarter of the weights and can keep NW_DEPTH = 4 whole layers of its fragments in flight in registers (weights do not
 // depend on activations: the prefetch runs across layer boundaries and the matrix core never waits for memory).
 // The activations of the 16 leaves ping-pong between two 4 KiB LDS strips, one workgroup barrier per layer.
-// Same MFMA instruction, operand order and k order as k_mlp_fused3 -> bit-identical logits and values.
+// Same MFMA instruction, operand order and k order as the per-layer kernels (agz_nn.hpp) -> bit-identical logits and values.
 //
 // P.w16 is the UNIFORM tiling built by agz_set_network: the network is a sequence of GROUPS of KTH = H/32 k-rows of
 // NTH = H/16 tiles: layer 0 = G0 = ceil((INP/32)/KTH) groups (zero rows pad it), the T residual layers one group each,
 // zero-weight residual groups (the identity on post-ReLU activations: relu(b + relu(0)) = b) up to a multiple of
 // NW_DEPTH, the head (zero tiles pad it to NTH), then NW_DEPTH groups of slack so that the prefetch needs no bounds test.
 #pragma once
-#include "agz_nn_fused3.hpp"
+#include "agz_nn.hpp"
 
 namespace agz {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+#define AGZ_GLB __attribute__((address_space(1)))
+
+// arguments of the fused forward kernels (k_mlp_wave, and the network phase of k_search_small)
+struct Fused3Par {
+    const uint16_t* planes; int INP;      // [L][INP] bf16, INP % 32 == 0
+    const uint16_t* w16;                  // [layer 0 | T residual layers | head] fragments (16x16x32 tiling)
+    const float* bias_head;
+    float* logits; int LGS; float* vout;
+    int L, T, A, AOP;
+    int gpw, tw;                          // k_search_small with sparse waves: row r of a workgroup's tile is game slot
+                                          // (bidx*tw + r/8)*gpw + r%8 if r%8 < gpw (gpw = 0: rows are consecutive leaves)
+};
+
+__device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __attribute__((noinline)) float sigmoid_ool(float x) { return sigmoid_spec(x); }
 
 constexpr int NW_WAVES = 4;               // waves per workgroup (= per 16-leaf tile)
 constexpr int NW_DEPTH = 4;               // hidden groups are padded to a multiple of this (the deepest prefetch)
@@ -46,7 +68,8 @@ __global__ __launch_bounds__(64 * NW_WAVES) void k_mlp_wave(const Fused3Par P) {
 // waves of this workgroup; the barrier that publishes them is taken AFTER the first weight fragments have been requested.
 // IO (whole-search kernel): planes and logits are handed over through LDS instead of a round trip through L2 — the tree wave that
 // owns tile rows 8 w .. 8 w + 7 has left their planes in block w of `io` (io_bw bytes per block, rows of PROWB bytes, zero padded),
-// and the head leaves logits (and the value in column A) in the same block, rows of io_lgs floats.  Global logits are still written.
+// and the head leaves logits (and the value in column A) in the same block, rows of io_lgs floats; the global arrays are not
+// written (agz_get_logits reads what the stepwise API's network launch left).
 template <int H, int LT, int DEPTH, bool PRE_BARRIER, bool IO>
 __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const smem, const int bidx, uint8_t* const io, const int io_bw,
                                               const int io_lgs) {
@@ -184,13 +207,13 @@ __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const
                         if (n < P.A) {                                                                  \
                             _Pragma("unroll") for (int r = 0; r < 4; ++r) {                             \
                                 const int m = mrow[lt][r]; const float o = acc[lt][t][r] + bias;        \
-                                if (m < P.L) P.logits[(size_t)m * P.LGS + n] = o;                       \
+                                if (!IO && m < P.L) P.logits[(size_t)m * P.LGS + n] = o;                \
                                 if constexpr (IO) lrow_[(size_t)r * io_lgs] = o;                        \
                             }                                                                           \
                         } else if (n == P.A) {                                                          \
                             _Pragma("unroll") for (int r = 0; r < 4; ++r) {                             \
                                 const int m = mrow[lt][r]; const float o = sigmoid_ool(acc[lt][t][r] + bias); \
-                                if (m < P.L) P.vout[m] = o;                                             \
+                                if (!IO && m < P.L) P.vout[m] = o;                                      \
                                 if constexpr (IO) lrow_[(size_t)r * io_lgs] = o;                        \
                             }                                                                           \
                         }                                                                               \

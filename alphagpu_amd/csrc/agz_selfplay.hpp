@@ -67,8 +67,8 @@ __global__ __launch_bounds__(256) void k_advance(const PlyPar T) {
         const float u = ufirst(uniform_move(T.seed, gid, (uint32_t)T.ply));
         const float tt = u * total;
         // duel (:606): sample(1:maxActions, Weights(policy)) walks ALL actions, zero weights included — the same index as the
-        // nonzero-list walk of self-play (:519-520) except for tt == 0, where the walk stops at action 1 whatever its weight
-        if (T.all_actions && !(tt > 0.0f)) c = 0;
+        // nonzero-list walk of self-play (:519-520) whenever tt > 0, and u is never 0 (uniform_move): a zero-weight action is never
+        // chosen
         float carry = 0.0f; bool stopped = false; int last = -1;
         for (int r = 0; r < NR; ++r) {
             if (!nzm[r]) continue;
@@ -180,6 +180,38 @@ __global__ void k_compact(const PlyPar T, const uint32_t* newslot, const uint32_
 // packed sample records (Sample, mainGobang.jl:34-43 + update_buffer :70-80 + decode mcts_gpu.jl:464-474)
 //   {u32 game_id, i32 ply, i32 move, f32 value, i8 player, i8 pad[3], f32 policy[A], i8 state[2VS], i8 fstate[FS]}
 // ---------------------------------------------------------------------------------------------------
+// PoolSample order of the generation's samples (mcts_gpu.jl:513-516: one push per ply and per game still running, ply-major, games
+// in slot = game-id order) built on the device: block p takes ply p — its first record is the number of samples of earlier plies,
+// sum over games of min(nplies, p), then the games with nplies > p in order (ballot ranks).  order[s] = game << 8 | ply.
+__global__ __launch_bounds__(1024) void k_sample_order(const int32_t* nplies, int G, uint32_t* order, unsigned long long* total) {
+    __shared__ unsigned long long red[16];
+    __shared__ uint32_t part[16];
+    const int p = (int)blockIdx.x, t = (int)threadIdx.x, lane = t & 63, w = t >> 6;
+    unsigned long long b = 0;
+    for (int g = t; g < G; g += 1024) { const int n = nplies[g]; b += (unsigned long long)(n < p ? n : p); }
+    for (int o = 32; o > 0; o >>= 1) b += __shfl_down(b, o, 64);
+    if (lane == 0) red[w] = b;
+    __syncthreads();
+    unsigned long long base = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) base += red[j];
+    const uint64_t below = (1ull << lane) - 1ull;
+    for (int g0 = 0; g0 < G; g0 += 1024) {
+        const int g = g0 + t;
+        const bool in = g < G && nplies[g] > p;
+        const uint64_t m = __ballot(in);
+        __syncthreads();                                           // (part of the previous chunk has been read)
+        if (lane == 0) part[w] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t before = 0, all = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { const uint32_t v = part[j]; before += j < w ? v : 0u; all += v; }
+        if (in) order[base + before + (uint32_t)__popcll(m & below)] = ((uint32_t)g << 8) | (uint32_t)p;
+        base += all;
+    }
+    if (total && p == (int)gridDim.x - 1 && t == 0) *total = base;   // (the last ply's block ends at the number of samples)
+}
+
 struct PackPar {
     int32_t A, VS, FS, max_plies, rec_bytes;
     uint32_t game_id_base;

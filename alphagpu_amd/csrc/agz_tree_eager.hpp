@@ -70,7 +70,7 @@ template <int KPL> struct ItemRows {
 // wl_cap_lds: entries of the work list that fit the LDS region (the rest, rare, goes to the global list).
 // io_blk (LEAN, may be null): this wave's block of the LDS hand-over window of k_search_small — the network body left the logits
 // of game g in row g (io_lgs floats, the value in column A) and takes the leaf's planes from row g (io_prowb bytes, zero padded to
-// whole k-rows): one round trip through L2 less in each direction on the rollout's chain.  The global arrays are still written.
+// whole k-rows): one round trip through L2 less in each direction on the rollout's chain.  The global arrays are not written then.
 template <int FAM, int NC, int KPL, bool LEAN, int PFM>
 __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepFlags SF, uint8_t* const lds, const int bidx,
                                                    EagerCarry& C, uint32_t* const wl_lds, const uint32_t wl_cap_lds, uint32_t& wcount,
@@ -640,7 +640,7 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
                         uint4 o;
                         o.x = ((f & 1u) ? 0x3F80u : 0u) | ((f & 2u) ? 0x3F800000u : 0u); o.y = ((f & 4u) ? 0x3F80u : 0u) | ((f & 8u) ? 0x3F800000u : 0u);
                         o.z = ((f & 16u) ? 0x3F80u : 0u) | ((f & 32u) ? 0x3F800000u : 0u); o.w = ((f & 64u) ? 0x3F80u : 0u) | ((f & 128u) ? 0x3F800000u : 0u);
-                        if (j0 < T.INP) *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(T.planes) + (size_t)slot * T.INP + j0) = o;
+                        if (j0 < T.INP && !lio) *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(T.planes) + (size_t)slot * T.INP + j0) = o;
                         if (lio) *reinterpret_cast<uint4*>(io_blk + (size_t)g * io_prowb + (size_t)j0 * 2) = o;
                     }
                 }

@@ -165,7 +165,7 @@ int  agz_set_profiling(agz_engine *h, int mode);       /* HIP events per launch:
  *   AGZ_BIG_MAXL=n         512-wide trunk: one-launch search (k_search_big) up to n games (default 16384; 0 disables)
  *   AGZ_CHAINS=k           two-kernel form: k sub-batches on parallel streams (default 2-3 from 12000 games)
  *   AGZ_REG3_MAX_WAVES=n   two-kernel form: largest grid that uses the 3-waves-per-SIMD build of the tree kernel
- *   AGZ_NN_WAVE_LT, AGZ_NN_WAVE_DEPTH, AGZ_NN_WAVE_MAXL   tile count / prefetch depth / batch limit of k_mlp_wave
+ *   AGZ_NN_WAVE_LT, AGZ_NN_WAVE_DEPTH   tile count / prefetch depth of k_mlp_wave
  *   AGZ_NO_FUSED_NN=1      per-layer network kernels (k_layer_bf16) and no one-launch search
  *   AGZ_NO_FASTDIV=1       IEEE '/' everywhere in the tree kernel (agz_fastdiv.hpp off)
  *   AGZ_NO_HOST_FLAG=1     ply loop: fetch the number of games left with a copy + stream synchronisation instead of polling the

@@ -351,11 +351,12 @@ float agzo_uniform_search(uint64_t seed, uint32_t game_id, uint32_t step, uint32
     agzo_philox4x32_10(ctr, key, o);
     return (float)((o[depth & 3u] >> 8) + 1u) * 5.9604644775390625e-8f;           /* 2^-24 */
 }
-/* move uniform in [0,1): stands for rand() inside StatsBase.sample (mcts_gpu.jl:520) */
+/* move uniform in (0,1] = (24 random bits + 1/2) 2^-24: stands for rand() inside StatsBase.sample (mcts_gpu.jl:520); never 0
+ * (Julia's Float64 rand() is 0 with probability 2^-53), so the all-actions walk of the duel never stops on a zero weight */
 float agzo_uniform_move(uint64_t seed, uint32_t game_id, uint32_t step) {
     uint32_t ctr[4] = { game_id, step, 0u, 0x80000000u }, key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) }, o[4];
     agzo_philox4x32_10(ctr, key, o);
-    return (float)(o[0] >> 8) * 5.9604644775390625e-8f;
+    return ((float)(o[0] >> 8) + 0.5f) * 5.9604644775390625e-8f;
 }
 /* Flux 0.12 Dense default init: glorot_uniform weights, zero bias (DenseNet.jl:195-197) */
 static void glorot(uint64_t seed, uint32_t tensor, int out, int in, float *W) {
@@ -1020,7 +1021,8 @@ done:
  * ========================================================================================== */
 /* sample(1:maxActions, Weights(policy[:,i])) (:606): StatsBase's cumulative walk over ALL actions
  * (t = rand()*sum(w); i=1; cw=w[1]; while cw<t && i<n: i+=1; cw+=w[i]); zero weights are walked over, so
- * the only difference from the nonzero-list form of self-play (:519-520) is u == 0, which returns action 1. */
+ * the only difference from the nonzero-list form of self-play (:519-520) would be u == 0 (the walk stops at action 1 whatever its
+ * weight) — which agzo_uniform_move never returns. */
 static int choose_move_all(const float *pol, int A, float u) {
     float total = 0.0f;
     for (int c = 0; c < A; ++c) total += pol[c];

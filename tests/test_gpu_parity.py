@@ -118,7 +118,7 @@ def test_exact_search_matches_oracle(name, L, V, H, T):
 @pytest.mark.parametrize("name,L,V,H,T", [
     ("gobang9", 48, 64, 128, 6), ("connect4", 64, 64, 128, 6), ("tictactoe", 64, 16, 128, 6), ("hex9", 24, 128, 128, 2), ("reversi8", 40, 64, 64, 3),
     ("reversi8", 40, 32, 128, 2), ("reversi6", 40, 24, 128, 2),          # (whole-search kernel with passes)
-    # BASELINE configs 3-5 with the trunk the reference ships (512 wide, 8 towers): k_rollout_reg + k_mlp_big
+    # BASELINE configs 3-5 with the trunk the reference ships (512 wide, 8 towers): k_rollout_eager + k_mlp_big
     ("gobang9", 136, 32, 512, 8), ("hex9", 40, 128, 512, 8), ("reversi8", 136, 24, 512, 8), ("gobang9", 40, 16, 256, 3)])
 def test_bf16_search_matches_oracle_bitwise(name, L, V, H, T):
     """The BENCHMARKED mode (bf16 MFMA network, fp32 tree arithmetic), whole mcts_single, no teacher forcing: the oracle evaluates
@@ -381,7 +381,7 @@ def test_full_size_properties_and_sharding_invariance():
 @pytest.mark.parametrize("L", [20000, 32768])
 def test_whole_search_kernel_at_scale_equals_two_kernel_form(L, monkeypatch):
     """The register budgets the big batches actually run (k_search_small<..,4,3> for 16384 < L <= 24576, <..,4,4> above) against
-    the two-kernel form (k_rollout_reg + k_mlp_wave per rollout) on the same 2000 game ids: visits, q, policy, leaf, node count."""
+    the two-kernel form (k_rollout_eager + k_mlp_wave per rollout) on the same 2000 game ids: visits, q, policy, leaf, node count."""
     g, _ = spec("gobang9")
     net = ag.SNetwork2.random(g, 128, 6)
     V = 64
@@ -545,9 +545,9 @@ def _bf16_search_bits(g, net, L, V, H):
 
 @pytest.mark.parametrize("H,T", [(128, 6), (64, 3), (128, 1), (512, 2), (256, 3)])
 def test_bf16_network_kernels_agree_bitwise(H, T, monkeypatch):
-    """The latency-first network kernel (agz_nn_wave.hpp, the default) at other tile counts / prefetch depths, the LDS-shared one
-    (agz_nn_fused3.hpp) and the per-layer MFMA kernels run the same MFMA sequence: identical bits, also for a ragged
-    last tile and for layer counts that need identity padding groups."""
+    """The latency-first network kernel (agz_nn_wave.hpp, the default) at other tile counts / prefetch depths and the per-layer
+    MFMA kernels (agz_nn.hpp) run the same MFMA sequence: identical bits, also for a ragged last tile and for layer counts that
+    need identity padding groups."""
     g, _ = spec("gobang9")
     net = ag.SNetwork2.random(g, H, T)
     L, V = 300, 24
@@ -557,9 +557,8 @@ def test_bf16_network_kernels_agree_bitwise(H, T, monkeypatch):
     got = _bf16_search_bits(g, net, L, V, H)
     for a, b, what in zip(got, ref, ("visits", "policy", "q")):
         assert_same_bits(a, b, what + " two-kernel form")
-    for env in ({"AGZ_NN_WAVE_LT": "4", "AGZ_NN_WAVE_DEPTH": "4"}, {"AGZ_NN_WAVE_LT": "2"}, {"AGZ_NN_WAVE_MAXL": "0"},
-                {"AGZ_NN_WAVE_MAXL": "0", "AGZ_NO_FUSED_NN": "1"}):
-        for k in ("AGZ_NN_WAVE_LT", "AGZ_NN_WAVE_DEPTH", "AGZ_NN_WAVE_MAXL", "AGZ_NO_FUSED_NN"):
+    for env in ({"AGZ_NN_WAVE_LT": "4", "AGZ_NN_WAVE_DEPTH": "4"}, {"AGZ_NN_WAVE_LT": "2"}, {"AGZ_NN_WAVE_LT": "8"}, {"AGZ_NO_FUSED_NN": "1"}):
+        for k in ("AGZ_NN_WAVE_LT", "AGZ_NN_WAVE_DEPTH", "AGZ_NO_FUSED_NN"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
