@@ -14,6 +14,7 @@ GAMES = {
     "hex5": ("hex", 5, 0),
     "hex9": ("hex", 9, 0),
     "hex11": ("hex", 11, 0),
+    "hex12": ("hex", 12, 0),
     "reversi8": ("reversi8", 0, 0),
     "reversi6": ("reversi6", 0, 0),
 }

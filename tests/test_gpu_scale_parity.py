@@ -1,0 +1,253 @@
+"""GPU parity at the sizes and in the execution forms the benchmark actually runs (-m gpu).
+
+Results are keyed by game id, never by slot, rank or launch shape, so a slice of the game ids of a FULL-SIZE launch can be checked
+against the CPU oracle at the cost of a few dozen oracle searches:
+
+  * every BASELINE.json configuration at its full size (32768 games, the default dispatch — the one-launch search for the 128-wide
+    trunk, three sub-batch chains of tree + network launches for the 512-wide trunks), first ply: game ids from the start, the
+    middle (across a chain / workgroup boundary) and the ragged end, bit for bit against OracleTree.search with the oracle's
+    bf16 MFMA model (visits, Q, policy_final, leaves, node counts);
+  * k_search_big at its largest batch; boards whose head is wider than the trunk (Gobang 13x13, Hex 11x11 / 12x12 on 128-wide
+    trunks: second head group of the fused network, 16 / 24 actions per lane in the one-launch search);
+  * the two-actor duel in the benchmarked bf16 mode, move for move (mcts_gpu.jl:581-651);
+  * the multi-GPU exchange path with REAL engines: two processes (gloo), one engine each on game-id shards, packed records
+    all-gathered and merged == one un-sharded engine run == the oracle; and the same code over RCCL ("nccl") with one rank.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import alphagpu_amd as ag
+from alphagpu_amd import mcts_gpu as M
+import common
+import oracle_lib as O
+import parity
+
+pytestmark = pytest.mark.gpu
+
+
+def spec(name):
+    kind, n, k = common.GAMES[name]
+    return ag.GameSpec(kind, n, k), O.make_game(kind, n, k)
+
+
+def slice_ids(L, n_each):
+    """game ids from the start, the middle (odd offset: straddles workgroup / chain boundaries) and the ragged end of [0, L)"""
+    mid = L // 2 - n_each // 2 - 3
+    return np.unique(np.concatenate([np.arange(0, n_each), np.arange(mid, mid + n_each), np.arange(L - n_each, L)])).astype(np.uint32)
+
+
+def run_slice_case(name, H, T, V, L, n_each, form_prefix, nn_prefix=None, step=0, seed=1, cpuct=1.5):
+    g, og = spec(name)
+    net, onet = ag.SNetwork2.random(g, H, T), O.OracleNet(og, H, T)
+    ids = slice_ids(L, n_each)
+    with M.Engine(g, L, V, seed=seed, nn_mode=M.NN_BF16) as e:
+        e.set_network(net)
+        e.set_roots(None, L=L)                                     # Position() for every game, ids 0 .. L-1 (mcts_gpu.jl:479)
+        e.search(V, cpuct=cpuct, training=True, step=step)
+        form = e.search_form()
+        got = parity.engine_result(e, ids.astype(np.int64))
+        vis = e.root_visits()
+    assert form[0].startswith(form_prefix), form                   # the kernel bench.py's roofline object names
+    if nn_prefix:
+        assert form[1].startswith(nn_prefix), form
+    assert (vis.sum(1) == V - 1).all()                             # every game of the launch searched (rollout 1 expands the root)
+    roots = [O.pos_init(og)] * len(ids)
+    t = O.OracleTree(og, len(ids), V)
+    t.set_roots(roots, ids)
+    t.search(onet.bf16(), V, cpuct, True, seed, step)
+    ref = parity.oracle_result(t)
+
+    def fallback(rows):
+        def mk(Ls, Vs):
+            e2 = M.Engine(g, Ls, Vs, seed=seed, nn_mode=M.NN_BF16)
+            e2.set_network(net)
+            return e2
+        return parity.teacher_forced_check(mk, og, onet, [roots[i] for i in rows], ids[rows], V, cpuct, True, seed, step, name)
+
+    parity.assert_bf16_search_matches(got, ref, fallback, f"{name} {H}x{T} L={L} V={V}")
+    return form
+
+
+# BASELINE.json: the metric configuration and configs[1..4], each at its full size and default dispatch
+@pytest.mark.parametrize("label,name,H,T,V,n_each,form,nn", [
+    ("headline", "gobang9", 128, 6, 64, 24, "k_search_small<KPL=12,H=128,TW=4,WV=4>", "inside k_search_small"),
+    ("config2", "connect4", 128, 6, 64, 24, "k_search_small<KPL=4,H=128,TW=4,WV=4>", "inside k_search_small"),
+    ("config3", "gobang9", 512, 8, 64, 16, None, None),
+    ("config4", "hex9", 512, 8, 128, 8, None, None),
+    ("config5", "reversi8", 512, 8, 64, 16, None, None)])
+def test_full_size_first_ply_slice_matches_oracle(label, name, H, T, V, n_each, form, nn):
+    L = 32768
+    if form is None:
+        # the wide-trunk form of a 32768-game ply (whatever the engine's dispatch makes it) must be the one bench.py reports
+        got = run_slice_case(name, H, T, V, L, n_each, "k_", None)
+        assert ("k_search_big" in got[0]) or ("k_rollout_eager" in got[0] and "k_mlp_big" in got[1]), got
+    else:
+        run_slice_case(name, H, T, V, L, n_each, form, nn)
+
+
+@pytest.mark.parametrize("name,L,V,n_each", [("gobang9", 16384, 64, 12), ("reversi8", 8192, 64, 12), ("gobang9", 136, 64, 16)])
+def test_wide_trunk_one_launch_search_slice_matches_oracle(name, L, V, n_each):
+    """k_search_big (512x8, whole mcts_single per launch) at its largest batches and at V = 64 on a small one."""
+    run_slice_case(name, 512, 8, V, L, n_each, "k_search_big", "inside k_search_big", step=3)
+
+
+@pytest.mark.parametrize("name,L,V,H,T,form", [
+    # heads wider than the trunk: A + 1 > H -> second head group of mlp_wave_body; 16 / 24 actions per lane in the tree step
+    ("gobang13", 40, 32, 128, 2, "k_search_small<KPL=24"), ("hex12", 40, 32, 128, 2, "k_search_small<KPL=24"),
+    ("hex11", 48, 32, 128, 3, "k_search_small<KPL=16"), ("gobang13", 24, 24, 64, 2, None)])
+def test_wide_head_bf16_search_matches_oracle(name, L, V, H, T, form):
+    g, og = spec(name)
+    net, onet = ag.SNetwork2.random(g, H, T), O.OracleNet(og, H, T)
+    roots = common.diverse_roots(og, L, seed=4, max_prefix=20)
+    ids = (700 + 5 * np.arange(L)).astype(np.uint32)
+    t = O.OracleTree(og, L, V)
+    t.set_roots(roots, ids)
+    t.search(onet.bf16(), V, 1.5, True, 21, 9)
+    with M.Engine(g, L, V, seed=21, nn_mode=M.NN_BF16) as e:
+        e.set_network(net)
+        e.set_roots(common.pos_bytes(roots), game_ids=ids)
+        e.search(V, cpuct=1.5, training=True, step=9)
+        if form:
+            assert e.search_form()[0].startswith(form), e.search_form()
+        got = parity.engine_result(e)
+
+    def fallback(rows):
+        def mk(Ls, Vs):
+            e2 = M.Engine(g, Ls, Vs, seed=21, nn_mode=M.NN_BF16)
+            e2.set_network(net)
+            return e2
+        return parity.teacher_forced_check(mk, og, onet, [roots[i] for i in rows], ids[rows], V, 1.5, True, 21, 9, name)
+
+    parity.assert_bf16_search_matches(got, parity.oracle_result(t), fallback, f"{name} {H}x{T}")
+
+
+@pytest.mark.parametrize("name,n,V,H,T", [("gobang13", 6, 12, 128, 1), ("hex11", 6, 12, 128, 1)])
+def test_wide_head_bf16_generation_matches_oracle(name, n, V, H, T):
+    """whole self-play generations on the big boards (README.md:6 of the reference: boards up to 13x13) in the benchmarked mode"""
+    g, og = spec(name)
+    net, onet = ag.SNetwork2.random(g, H, T), O.OracleNet(og, H, T)
+    ref = O.selfplay(og, onet.bf16(), n, V, 1.5, 25, 13, 40)
+    assert ref["rc"] == 0
+    with M.Engine(g, n, V, seed=13, game_id_base=40, nn_mode=M.NN_BF16) as e:
+        e.set_network(net)
+        st = e.selfplay(n, V, cpuct=1.5, tau_plies=25)
+        s = e.samples()
+    assert st["valid"] and st["nsamples"] == ref["n"]
+    for key in ("game_id", "ply", "move", "player", "state", "fstate", "value", "policy"):
+        assert parity.same_bits(s[key], ref[key]), key
+
+
+@pytest.mark.parametrize("name,n,V,H,T,tau", [
+    ("tictactoe", 96, 16, 128, 2, 15), ("connect4", 40, 16, 128, 2, 15), ("gobang9", 24, 12, 128, 1, 6), ("reversi6", 24, 12, 64, 1, 15),
+    ("gobang9", 12, 8, 512, 2, 4)])
+@pytest.mark.parametrize("first", [0, 1])
+def test_bf16_duel_matches_oracle(name, n, V, H, T, tau, first):
+    """mcts(actor1, actor2, visits, ngames) (mcts_gpu.jl:581-651) in the BENCHMARKED mode: W/D/L and every move of every game equal the
+    oracle's duel with its bf16 MFMA model of both networks, both orders."""
+    g, og = spec(name)
+    a, oa = ag.SNetwork2.random(g, H, T, 11), O.OracleNet(og, H, T, 11)
+    b, ob = ag.SNetwork2.random(g, H, T, 22), O.OracleNet(og, H, T, 22)
+    ref = O.duel(og, oa.bf16(), ob.bf16(), n, V, 2.0, tau, 31, 200, first)
+    assert ref["rc"] == 0
+    with M.Engine(g, n, V, seed=31, game_id_base=200, nn_mode=M.NN_BF16) as e:
+        e.set_network(a, 0)
+        e.set_network(b, 1)
+        wdl = e.duel(n, V, cpuct=2.0, tau_plies=tau, first=first)
+        s = e.samples()
+    moves = np.full_like(ref["moves"], -1)
+    moves[s["game_id"].astype(np.int64) - 200, s["ply"]] = s["move"]
+    assert wdl == ref["wdl"] and sum(wdl) == n, (wdl, ref["wdl"])
+    assert np.array_equal(moves, ref["moves"])
+    assert np.array_equal(np.bincount(s["game_id"] - 200, minlength=n), ref["nplies"])
+
+
+# ---- the exchange step with real engines -------------------------------------------------------------
+SHARD_CASE = dict(game=("gobang", 3, 3), H=32, T=1, G=24, V=12, seed=5)
+
+
+def _engine_shard_worker(rank, world, port, backend, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    from alphagpu_amd import shard
+    c = SHARD_CASE
+    torch.cuda.set_device(0)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = ag.GameSpec(*c["game"])
+    net = ag.SNetwork2.random(g, c["H"], c["T"])
+    G, V, rb = c["G"], c["V"], g.rec_bytes
+    with M.Engine(g, G, V, device=0, seed=c["seed"], game_id_base=shard.shard_base(rank, G), nn_mode=M.NN_BF16) as e:
+        e.set_network(net)
+        st = e.selfplay(G, V, cpuct=1.5, tau_plies=25)
+        assert st["valid"]
+        buf = torch.empty(G * g.max_plies * rb, dtype=torch.uint8, device="cuda")
+        n = e.samples_packed_into(buf.data_ptr(), G * g.max_plies)
+        assert n == st["nsamples"]
+        local = buf if backend == "nccl" else buf[: n * rb].cpu()
+        out, counts = shard.allgather_records_async(local, n, rb).wait()
+        parts = [shard.unpack_records(out[r].cpu().numpy(), int(counts[r]), g) for r in range(world)]
+        merged = shard.merge_poolsample_order(parts)
+    if rank == 0:
+        q.put(merged)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_workers(world, backend):
+    import torch.multiprocessing as mp
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_engine_shard_worker, args=(r, world, port, backend, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        merged = q.get(timeout=300)
+    finally:
+        for p in procs:
+            p.join(120)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    return merged
+
+
+def _unsharded_reference(world):
+    c = SHARD_CASE
+    g, og = ag.GameSpec(*c["game"]), O.make_game(*c["game"])
+    net, onet = ag.SNetwork2.random(g, c["H"], c["T"]), O.OracleNet(og, c["H"], c["T"])
+    n = world * c["G"]
+    with M.Engine(g, n, c["V"], seed=c["seed"], game_id_base=0, nn_mode=M.NN_BF16) as e:
+        e.set_network(net)
+        assert e.selfplay(n, c["V"], cpuct=1.5, tau_plies=25)["valid"]
+        one = e.samples()
+    ref = O.selfplay(og, onet.bf16(), n, c["V"], 1.5, 25, c["seed"], 0)
+    return one, ref
+
+
+def test_two_engines_on_game_id_shards_allgather_to_the_unsharded_run():
+    """rank r owns game ids [r G, (r+1) G); agz_selfplay -> agz_get_samples_packed -> all-gather (gloo, two processes on
+    this GPU) -> PoolSample-order merge == ONE engine running all 2 G games == the oracle, record for record."""
+    merged = _run_workers(2, "gloo")
+    one, ref = _unsharded_reference(2)
+    assert len(merged["ply"]) == ref["n"] == len(one["ply"])
+    for k in ("game_id", "ply", "move", "player", "state", "fstate", "value", "policy"):
+        assert parity.same_bits(merged[k], one[k]), k + " (sharded vs one engine)"
+        assert parity.same_bits(merged[k], ref[k]), k + " (sharded vs oracle)"
+
+
+def test_exchange_over_rccl_with_one_rank():
+    """the same code path over torch.distributed "nccl" (= RCCL): device buffers, asynchronous all_gather_into_tensor"""
+    merged = _run_workers(1, "nccl")
+    one, ref = _unsharded_reference(1)
+    for k in ("game_id", "ply", "move", "player", "state", "fstate", "value", "policy"):
+        assert parity.same_bits(merged[k], one[k]), k
+        assert parity.same_bits(merged[k], ref[k]), k
