@@ -96,7 +96,7 @@ def test_wide_trunk_one_launch_search_slice_matches_oracle(name, L, V, n_each):
 
 @pytest.mark.parametrize("name,L,V,H,T,form", [
     # heads wider than the trunk: A + 1 > H -> second head group of mlp_wave_body; 16 / 24 actions per lane in the tree step
-    ("gobang13", 40, 32, 128, 2, "k_search_small<KPL=24"), ("hex12", 40, 32, 128, 2, "k_search_small<KPL=24"),
+    ("gobang13", 40, 32, 128, 2, "k_search_small<KPL=24"), ("hex12", 40, 32, 128, 2, "k_rollout_eager"),
     ("hex11", 48, 32, 128, 3, "k_search_small<KPL=16"), ("gobang13", 24, 24, 64, 2, None)])
 def test_wide_head_bf16_search_matches_oracle(name, L, V, H, T, form):
     g, og = spec(name)
