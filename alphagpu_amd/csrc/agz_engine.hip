@@ -342,6 +342,7 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     hipError_t e = hipSuccess;
     auto A_ = [&](hipError_t r) { if (e == hipSuccess) e = r; };
     A_(dmalloc(&h->recs, Lm * V * rec_bytes));
+    if (h->recs) FA_(hipMemsetAsync(h->recs, 0, Lm * V * rec_bytes, h->stream));   // a lane-group without a work item reads its game's root record: finite numbers from the start
     A_(dmalloc(&h->states, Lm * V));
     A_(dmalloc(&h->meta, Lm * V));
     A_(dmalloc(&h->ncount, Lm)); A_(dmalloc(&h->leaf, Lm)); A_(dmalloc(&h->game_id, Lm)); A_(dmalloc(&h->game_id2, Lm));

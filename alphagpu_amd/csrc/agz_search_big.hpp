@@ -27,7 +27,7 @@ template <int FAM, int NC, int KPL, int H, int WG>
 __global__ __launch_bounds__(NB_THREADS, 2 * WG) void k_search_big(const BigSearchPar S) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_bigs[];
     constexpr int TW = 4;                                         // tree waves: 32 games = the 2 leaf tiles of mlp_big_body<H, 2>
-    const int wave = (int)threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     uint8_t* const tree_lds = lds_bigs + (size_t)(wave % TW) * S.tree_lds;
     uint32_t* const wl_lds = reinterpret_cast<uint32_t*>(lds_bigs + S.wl_off + (size_t)(wave % TW) * S.wl_bytes);
     EagerCarry C = {1u, 0u, 0u, 0u, 0u, 0u, 0u};

@@ -30,7 +30,7 @@ struct SmallPar {
 template <int FAM, int NC, int KPL, int H, int TW, int WV>
 __global__ __launch_bounds__(64 * NW_WAVES, WV) void k_search_small(const SmallPar S) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_small[];
-    const int wave = (int)threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);   // (scalar: the tree step's addresses are scalar base + offset)
     static_assert(TW == 2 || TW == 4, "tree waves per workgroup");
     uint8_t* const tree_lds = lds_small + (size_t)(wave % TW) * S.tree_lds;
     uint8_t* const nn_lds = lds_small;                            // the two phases never overlap and the tree step keeps nothing
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(64 * NW_WAVES, WV) void k_search_small(const SmallP
         // of this loop and kept alive across them (hundreds of registers, spills)
         int bx = (int)blockIdx.x;
         asm volatile("" : "+s"(bx));
-        if (wave < TW) rollout_eager_body<FAM, NC, KPL, true, (WV < 4 ? 2 : 1)>(S.T, SF, tree_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
+        if (wave < TW) rollout_eager_body<FAM, NC, KPL, true, (WV < 4 ? 2 : 1), true>(S.T, SF, tree_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
                                                                                lds_small + S.io_off + (size_t)wave * S.io_bw, S.io_prowb, S.io_lgs);
 #ifdef AGZ_STAMPS
         const unsigned long long t_nn0 = __builtin_amdgcn_s_memtime();

@@ -68,10 +68,10 @@ template <int KPL> struct ItemRows {
 // PFM = 1: the next item's record is only TOUCHED a round ahead (each of the 8 lanes of the group reads one dword of one of the
 // record's 8 cache lines into a scratch register), so that the real loads find it in L2 instead of paying an HBM miss.
 // wl_cap_lds: entries of the work list that fit the LDS region (the rest, rare, goes to the global list).
-// io_blk (LEAN, may be null): this wave's block of the LDS hand-over window of k_search_small — the network body left the logits
+// io_blk (LIO builds): this wave's block of the LDS hand-over window of k_search_small — the network body left the logits
 // of game g in row g (io_lgs floats, the value in column A) and takes the leaf's planes from row g (io_prowb bytes, zero padded to
 // whole k-rows): one round trip through L2 less in each direction on the rollout's chain.  The global arrays are not written then.
-template <int FAM, int NC, int KPL, bool LEAN, int PFM>
+template <int FAM, int NC, int KPL, bool LEAN, int PFM, bool LIO = false>
 __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepFlags SF, uint8_t* const lds, const int bidx,
                                                    EagerCarry& C, uint32_t* const wl_lds, const uint32_t wl_cap_lds, uint32_t& wcount,
                                                    uint8_t* const io_blk = nullptr, const int io_prowb = 0, const int io_lgs = 0) {
@@ -84,7 +84,7 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
     asm volatile("" : "+v"(lane_));                              // opaque per call (see rollout_reg_body)   // PHASE setup
     const int lane = lane_ & 63, g = lane / G, sub = lane % G;
     const int GPW = T.gpw;
-    const int slot_base = T.slot0 + bidx * GPW;
+    const int slot_base = T.slot0 + __builtin_amdgcn_readfirstlane(bidx) * GPW;   // (wave-uniform: the wave's arrays get scalar bases)
     const int slot = slot_base + g;
     const bool live = g < GPW && slot < T.L;
     const bool lead = sub == 0;
@@ -100,6 +100,7 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
     float* const utab = reinterpret_cast<float*>(lds + LO.utab);
     const int sl = live ? slot : 0;
     const int k0 = sub * KPL;
+    const int nval = A - k0 < 0 ? 0 : (A - k0 > KPL ? KPL : A - k0);   // real actions in this lane's block (padding sits at the end of the last blocks)
     const bool inject = !LEAN && T.inject, capture = !LEAN && T.capture;
     const bool exact = !LEAN && T.exact, planes_f32 = !LEAN && T.planes_f32;
     // FD: quotients by agz_fastdiv.hpp (same bits as '/', half the instructions) wherever the operands are inside its range by
@@ -113,9 +114,20 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
     //   Newton      top / bot, -top / bot^2: same bounds;  newerr / g: newerr in [1e-3, 2^25] and then |g| in [2^-10, 2^39]
     // The backup's own quotient (vis q + 1 - v) / (vis + 1) keeps '/': a value head output may be arbitrarily small.
     const bool FD = T.fastdiv && !inject && !exact;
-    const int wl_block = T.slot0 / NG + bidx;
+    const int wl_block = T.slot0 / NG + __builtin_amdgcn_readfirstlane(bidx);
     uint32_t* const wl_g = T.wl + (size_t)wl_block * (size_t)T.wl_cap;            // this wave's work list (global form)
-    uint32_t* const gmeta = T.meta + (size_t)sl * V;
+    // the wave's 8 games lie next to each other in every per-node array: ONE wave-uniform base per array (scalar registers) and
+    // 32-bit offsets (game-in-wave, node) from it — every load / store of the item loop is base + 32-bit offset + immediate,
+    // without 64-bit vector address arithmetic
+    // (a wave of the ragged last workgroup may own no game at all: its idle loads then go to the launch's first game)
+    const int mem_base = slot_base < T.L ? slot_base : T.slot0;
+    uint8_t* const wrecs = T.recs + (size_t)mem_base * (size_t)V * ROWS;
+    uint4* const waux = T.aux4 + (size_t)mem_base * (size_t)V;
+    uint32_t* const wmeta = T.meta + (size_t)mem_base * (size_t)V;
+    Pos* const wstates = T.states + (size_t)mem_base * (size_t)V;
+    const int gl = live ? g : 0;                                                  // this group's game inside the wave (0 when it has none)
+    const uint32_t gnode0 = (uint32_t)(gl * V);                                   // index of its root in the wave's node arrays
+    uint32_t* const gmeta = wmeta + gnode0;
 #ifdef AGZ_STAMPS
     unsigned long long* const stamp_lds = reinterpret_cast<unsigned long long*>(lds + LO.total);
     if (lane < 17) stamp_lds[lane] = lane == 16 ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -141,8 +153,7 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
         float c = st; int cnt = 0;
 #pragma unroll
         for (int j = 0; j < KPL; ++j) { c += pol[j]; cnt += c < u ? 1 : 0; }
-        const int nvalid = A - k0 < 0 ? 0 : (A - k0 > KPL ? KPL : A - k0);     // padded actions (k >= A) sit at the end of the last blocks
-        cnt = cnt < nvalid ? cnt : nvalid;
+        cnt = cnt < nval ? cnt : nval;                                         // (padded actions never count)
         int bestmove = grp_sum<G>(cnt);
         if (__builtin_expect(__ballot(bestmove >= A) != 0, 0)) {               // the row sums below u: the last positive action wins (:175-181)
             int lastpos = -1;
@@ -174,30 +185,27 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
                 R.valid = true; R.gi = (int)(R.ent >> 24) & 7;
             }
         }
-        const int node = (int)(R.ent & 0xffu), move = (int)((R.ent >> 8) & 0xffu);
-        const int islot = R.valid ? slot_base + R.gi : sl;
-        const uint8_t* const rec = T.recs + ((size_t)islot * V + node) * ROWS;
-        if (R.valid) {
-            const uint4 ax = T.aux4[(size_t)islot * V + node];
-            R.ax_x = ax.x; R.ax_z = ax.z;
+        const uint32_t node = R.ent & 0xffu, move = (R.ent >> 8) & 0xffu;
+        // a lane-group without an item reads the root record of its own game (ent == 0: node 0, move 0) — finite numbers, the engine
+        // clears the records once at creation — with prior_rem = 0 and no children: its Newton loop ends in the first iteration and
+        // nothing it computes is stored.  The loads are unconditional (no branch, no zero fill of 30 registers per round).
+        const uint32_t nd = (uint32_t)((R.valid ? R.gi : gl) * V) + node;
+        const uint8_t* const rec = wrecs + nd * (uint32_t)ROWS;
+        {
+            const uint4 ax = waux[nd];
+            R.ax_x = R.valid ? ax.x : 0u; R.ax_z = R.valid ? ax.z : 0u;
 #pragma unroll
             for (int j = 0; j < KPL; j += 4) {
-                const float4 a = *reinterpret_cast<const float4*>(rec + (size_t)(k0 + j) * 4);
+                const float4 a = *reinterpret_cast<const float4*>(rec + (uint32_t)(k0 + j) * 4u);
                 R.p[j] = a.x; R.p[j + 1] = a.y; R.p[j + 2] = a.z; R.p[j + 3] = a.w;
-                const float4 b = *reinterpret_cast<const float4*>(rec + OFF_Q + (size_t)(k0 + j) * 4);
+                const float4 b = *reinterpret_cast<const float4*>(rec + OFF_Q + (uint32_t)(k0 + j) * 4u);
                 R.q[j] = b.x; R.q[j + 1] = b.y; R.q[j + 2] = b.z; R.q[j + 3] = b.w;
-                R.rk[j / 4] = *reinterpret_cast<const uint32_t*>(rec + OFF_RK + (size_t)(k0 + j));
-                R.cd[j / 4] = *reinterpret_cast<const uint32_t*>(rec + OFF_CID + (size_t)(k0 + j));
+                R.rk[j / 4] = *reinterpret_cast<const uint32_t*>(rec + OFF_RK + (uint32_t)(k0 + j));
+                R.cd[j / 4] = *reinterpret_cast<const uint32_t*>(rec + OFF_CID + (uint32_t)(k0 + j));
             }
             R.pm = reinterpret_cast<const float*>(rec)[move];
             R.qm = reinterpret_cast<const float*>(rec + OFF_Q)[move];
             R.vism = rec[OFF_VIS + move];
-        } else {
-            R.ax_x = 0u; R.ax_z = 0u; R.pm = 0.0f; R.qm = 0.0f; R.vism = 0u;
-#pragma unroll
-            for (int j = 0; j < KPL; ++j) { R.p[j] = 0.0f; R.q[j] = 0.0f; }
-#pragma unroll
-            for (int j = 0; j < KPL / 4; ++j) { R.rk[j] = 0u; R.cd[j] = 0u; }
         }
     };
 
@@ -215,9 +223,9 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
         }
         uint32_t v = 0u;
         if (valid) {
-            const size_t nd = (size_t)(slot_base + gi) * V + (ent & 0xffu);
-            v = *reinterpret_cast<const uint32_t*>(T.recs + nd * ROWS + (size_t)sub * 128);
-            if (sub == 0) v ^= reinterpret_cast<const uint32_t*>(T.aux4 + nd)[0];
+            const uint32_t nd = (uint32_t)(gi * V) + (ent & 0xffu);
+            v = *reinterpret_cast<const uint32_t*>(wrecs + nd * (uint32_t)ROWS + (uint32_t)sub * 128u);
+            if (sub == 0) v ^= reinterpret_cast<const uint32_t*>(waux + nd)[0];
         }
         return v;
     };
@@ -250,11 +258,11 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
         float x[KPL]; int npos = 0;
         bool wide = false, fdx = false;                               // (fdx is wave-uniform)
         if (doexp) {
-            const bool lio = LEAN && io_blk != nullptr;
+            constexpr bool lio = LEAN && LIO;
             const float* src = inject ? T.prior_eval + (size_t)slot * A
                                       : (lio ? reinterpret_cast<const float*>(io_blk) + (size_t)g * io_lgs : T.logits + (size_t)slot * T.LGS);
             vleaf = lio ? src[A] : T.v_eval[slot];
-            const WPos<NC> st = grp_load_pos<NC, REV>(T.states + (size_t)sl * V + lf);
+            const WPos<NC> st = grp_load_pos<NC, REV>(wstates + (gnode0 + (uint32_t)lf));
             if constexpr (LEAN) {
 #pragma unroll
                 for (int j = 0; j < KPL; j += 4) {
@@ -262,19 +270,19 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
                     x[j] = a.x; x[j + 1] = a.y; x[j + 2] = a.z; x[j + 3] = a.w;
                 }
 #pragma unroll
-                for (int j = 0; j < KPL; ++j) x[j] = (k0 + j < A) ? x[j] : -__builtin_inff();
+                for (int j = 0; j < KPL; ++j) x[j] = (j < nval) ? x[j] : -__builtin_inff();
             } else {
 #pragma unroll
-                for (int j = 0; j < KPL; ++j) x[j] = (k0 + j < A) ? src[k0 + j] : (inject ? 0.0f : -__builtin_inff());
+                for (int j = 0; j < KPL; ++j) x[j] = (j < nval) ? src[k0 + j] : (inject ? 0.0f : -__builtin_inff());
             }
             if (!inject) {                                            // softmax!(prior) (:417), source-order sum   // PHASE expand: softmax
                 float mx = -__builtin_inff(), mnn = -__builtin_inff();         // mnn = max of -x = -min over the real actions
 #pragma unroll
-                for (int j = 0; j < KPL; ++j) { mx = x[j] > mx ? x[j] : mx; const float nx_ = (k0 + j < A) ? -x[j] : -__builtin_inff(); mnn = nx_ > mnn ? nx_ : mnn; }
+                for (int j = 0; j < KPL; ++j) { mx = x[j] > mx ? x[j] : mx; const float nx_ = (j < nval) ? -x[j] : -__builtin_inff(); mnn = nx_ > mnn ? nx_ : mnn; }
                 mx = grp_max<G>(mx); mnn = grp_max<G>(mnn);
                 wide = !(mx + mnn <= 55.0f);                          // softmax numerators may fall below 2^-80: no fast quotients on this node
 #pragma unroll
-                for (int j = 0; j < KPL; ++j) x[j] = (k0 + j < A) ? (exact ? exp_spec(x[j] - mx) : exp2_spec(x[j] - mx)) : 0.0f;
+                for (int j = 0; j < KPL; ++j) x[j] = (j < nval) ? (exact ? exp_spec(x[j] - mx) : exp2_spec(x[j] - mx)) : 0.0f;
                 float s;
                 (void)grp_ordered_start<KPL, true>(x, sub, s);
                 fdx = FD && !__ballot(wide);
@@ -288,13 +296,13 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
                 }
                 if (capture) {
 #pragma unroll
-                    for (int j = 0; j < KPL; ++j) if (k0 + j < A) T.prior_eval[(size_t)slot * A + k0 + j] = x[j];
+                    for (int j = 0; j < KPL; ++j) if (j < nval) T.prior_eval[(size_t)slot * A + k0 + j] = x[j];
                 }
             }
             bool lg[KPL]; int nl = 0;                                 // legal mask; masked priors (:260-268 / :284-290)   // PHASE expand: legal mask + normalize sum
 #pragma unroll
             for (int j = 0; j < KPL; ++j) {
-                lg[j] = (k0 + j < A) && GM::canPlay(P, st, k0 + j);
+                lg[j] = (j < nval) && GM::canPlay(P, st, k0 + j);
                 x[j] = lg[j] ? x[j] : 0.0f;
                 nl += lg[j] ? 1 : 0;
             }
@@ -317,13 +325,13 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
 #pragma unroll
             for (int j = 0; j < KPL; ++j) {
                 float pr = rootmix ? (lg[j] ? qn_[j] + 0.25f / Af : 0.0f) : qn_[j];
-                if (k0 + j >= A) pr = 0.0f;
+                if (j >= nval) pr = 0.0f;
                 x[j] = pr;
                 npos += pr > 0.0f ? 1 : 0;
             }
             if (__builtin_expect(lf == 0, 0)) {                       // root expansion: policy == prior is what copy_pol sees for V <= 2
 #pragma unroll
-                for (int j = 0; j < KPL; ++j) if (k0 + j < A) T.policy_final[(size_t)slot * A + k0 + j] = x[j];
+                for (int j = 0; j < KPL; ++j) if (j < nval) T.policy_final[(size_t)slot * A + k0 + j] = x[j];
                 C.root_exp = 1u;
             }
             npos = grp_sum<G>(npos);                                  // "A" of :125-131 never changes after the expansion
@@ -338,7 +346,7 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
             const float ul = Dl < 32 ? utab[g * 32 + Dl] : uniform_search(T.seed, gid, T.step, SF.rollout - 1u, (uint32_t)Dl);
             const uint32_t nocd[KPL / 4] = {};
             const uint32_t nx = sample_next(x, st0, ul, nocd, -1, 0u);
-            uint8_t* rec = T.recs + ((size_t)sl * V + lf) * ROWS;
+            uint8_t* rec = wrecs + (gnode0 + (uint32_t)lf) * (uint32_t)ROWS;
 #pragma unroll
             for (int j = 0; j < KPL; j += 4) {
                 *reinterpret_cast<float4*>(rec + (size_t)(k0 + j) * 4) = make_float4(x[j], x[j + 1], x[j + 2], x[j + 3]);
@@ -350,11 +358,11 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
             ml |= M_EXPANDED;                                         // :256
             if (lead) {
                 gmeta[lf] = ml;
-                T.aux4[(size_t)sl * V + lf] = make_uint4(__float_as_uint(total), nx, (uint32_t)npos | (wide ? AUX_SLOW : 0u), 0u);
+                waux[gnode0 + (uint32_t)lf] = make_uint4(__float_as_uint(total), nx, (uint32_t)npos | (wide ? AUX_SLOW : 0u), 0u);
             }
         } else if (__builtin_expect(live && lf == 0, 0)) {
 #pragma unroll
-            for (int j = 0; j < KPL; ++j) if (k0 + j < A) T.policy_final[(size_t)slot * A + k0 + j] = 0.0f;   // terminal root
+            for (int j = 0; j < KPL; ++j) if (j < nval) T.policy_final[(size_t)slot * A + k0 + j] = 0.0f;   // terminal root
         }
         STAMPW(1);
         // ---- what the backup adds at the ancestors (:312-324): value_1 = 1 - v at even levels (the parent is level 0), value_2 =   // PHASE values of the backup
@@ -382,7 +390,7 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
             const int gi = R.gi;   // PHASE items: fetch item
             const int node = (int)(R.ent & 0xffu), move = (int)((R.ent >> 8) & 0xffu), dpt_e = (int)((R.ent >> 16) & 0xffu);
             const bool created = special && (R.ent & SP_CREATED);
-            const int islot = valid ? slot_base + gi : sl;
+            const uint32_t ind = (uint32_t)((valid ? gi : gl) * V) + (uint32_t)(R.ent & 0xffu);   // the item's node in the wave's arrays
             const float4 vt = valtab[gi];
             const uint32_t vflags = __float_as_uint(vt.z);
             const bool iterm = vflags & 1u;
@@ -390,7 +398,7 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
             const int dpt = special ? D - 1 : dpt_e;                  // depth of the item's node
             const int level = D - 1 - dpt;
             const float w = (level & 1) ? vt.y : vt.x;                // 1 - value at this level
-            uint8_t* const rec = T.recs + ((size_t)islot * V + node) * ROWS;
+            uint8_t* const rec = wrecs + ind * (uint32_t)ROWS;
             STAMPW(3);
             // ---- backUp of this edge (:319-320)   // PHASE items: backUp of the edge, prior_rem re-sum, q patch
             const float vis = (float)R.vism;
@@ -423,7 +431,7 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
             const uint32_t auxz = npos | (nvis << 8) | (nch << 16) | (R.ax_z & AUX_SLOW);
             const bool FDr = FD && !__ballot(valid && (R.ax_z & AUX_SLOW));      // (wave-uniform)
             if (!recompute) {
-                if (valid && lead) T.aux4[(size_t)islot * V + node] = make_uint4(__float_as_uint(prem_raw), 0u, auxz, 0u);
+                if (valid && lead) waux[ind] = make_uint4(__float_as_uint(prem_raw), 0u, auxz, 0u);
                 if constexpr (PF) { if (r + 1 < rounds) item_fetch(R, r + 1, nwl); }
                 continue;
             }
@@ -522,16 +530,16 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
             if (__builtin_expect(__ballot(valid && node == 0 && SF.last) != 0, 0)) {     // copy_pol (:330-339): the row the last descent samples from
                 if (valid && node == 0) {
 #pragma unroll
-                    for (int j = 0; j < KPL; ++j) if (k0 + j < A) T.policy_final[(size_t)islot * A + k0 + j] = pol[j];
+                    for (int j = 0; j < KPL; ++j) if (j < nval) T.policy_final[(size_t)(slot_base + gi) * A + k0 + j] = pol[j];
                 }
             }
             // the child bytes are needed past the prefetch of the next item: kept aside   // PHASE items: running sums + sampling
             STAMPW(7);
             float dummy;
             const float st = grp_ordered_start<KPL, false>(pol, sub, dummy);
-            const float u = dpt < 32 ? utab[gi * 32 + dpt] : uniform_search(T.seed, T.game_id[islot], T.step, SF.rollout - 1u, (uint32_t)dpt);
+            const float u = dpt < 32 ? utab[gi * 32 + dpt] : uniform_search(T.seed, T.game_id[valid ? slot_base + gi : sl], T.step, SF.rollout - 1u, (uint32_t)dpt);
             const uint32_t nx = sample_next(pol, st, u, cdk, created ? move : -1, (uint32_t)ileaf);
-            if (valid && lead) T.aux4[(size_t)islot * V + node] = make_uint4(__float_as_uint(prem_raw), nx, auxz, 0u);
+            if (valid && lead) waux[ind] = make_uint4(__float_as_uint(prem_raw), nx, auxz, 0u);
             STAMPW(8);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");        // rows written by one lane-group are read by the descent of another
@@ -547,7 +555,7 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
         if constexpr (LEAN) __builtin_amdgcn_s_setprio(2);
         // every expanded node carries the action its next visit samples and the child under it: the descent follows the words
         int node = 0, depth = 0;
-        uint32_t nx = (live && C.root_exp) ? T.aux4[(size_t)sl * V].y : 0u;
+        uint32_t nx = (live && C.root_exp) ? waux[gnode0].y : 0u;
         bool descending = (nx & NX_VALID) != 0;
         int create_from = -1, create_move = 0;
         uint32_t spnew = 0u;
@@ -563,7 +571,7 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
                     spnew = (uint32_t)node | ((uint32_t)move << 8) | ((uint32_t)depth << 16) | SP_VALID | SP_CREATED;
                     descending = false;
                 } else {
-                    const uint32_t nxc = T.aux4[(size_t)sl * V + child].y;     // (cleared when the child was created, set by its expansion)
+                    const uint32_t nxc = waux[gnode0 + (uint32_t)child].y;     // (cleared when the child was created, set by its expansion)
                     STAMPW(11);
                     if (nxc & NX_VALID) {                              // expanded child: the descent goes on (:192)
                         const uint64_t app = __ballot(lead);           // (only lanes of groups that go on are here)
@@ -592,7 +600,7 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
         uint32_t mn = 0u;
         if (live && create_from >= 0) {                                    // :183-191 node creation (at most one per rollout)
             const uint32_t child = C.ncount; C.ncount += 1;
-            const WPos<NC> ps = grp_load_pos<NC, REV>(T.states + (size_t)sl * V + create_from);
+            const WPos<NC> ps = grp_load_pos<NC, REV>(wstates + (gnode0 + (uint32_t)create_from));
             lst = GM::play(P, ps, create_move);
             have_state = true;
             int rr; const bool f = GM::isOver(P, lst, rr);
@@ -600,21 +608,21 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
             if (f) mc |= M_TERM | ((uint32_t)(1 + lst.player * rr) << M_TV_SHIFT);
             if (lead) {
                 ++C.add_new;
-                T.states[(size_t)sl * V + child] = pack(lst);
+                wstates[gnode0 + child] = pack(lst);
                 gmeta[child] = mc;
-                reinterpret_cast<uint32_t*>(T.aux4 + (size_t)sl * V + child)[1] = 0u;      // not expanded: no next word yet
+                reinterpret_cast<uint32_t*>(waux + (gnode0 + child))[1] = 0u;      // not expanded: no next word yet
             }
             mn = mc; node = (int)child;
         } else if (live) mn = gmeta[node];
         if (live) {
             if (!(mn & M_EVAL)) {                                           // root on the first rollout
-                lst = grp_load_pos<NC, REV>(T.states + (size_t)sl * V + node); have_state = true;
+                lst = grp_load_pos<NC, REV>(wstates + (gnode0 + (uint32_t)node)); have_state = true;
                 int rr; const bool f = GM::isOver(P, lst, rr);
                 mn |= M_EVAL;
                 if (f) mn |= M_TERM | ((uint32_t)(1 + lst.player * rr) << M_TV_SHIFT);
                 if (lead) gmeta[node] = mn;
             }
-            if (!have_state) lst = grp_load_pos<NC, REV>(T.states + (size_t)sl * V + node);
+            if (!have_state) lst = grp_load_pos<NC, REV>(wstates + (gnode0 + (uint32_t)node));
             // decoder (:202-223)   // PHASE encode planes
             if (!planes_f32) {
                 constexpr int NW = 2 * NC;
@@ -631,7 +639,7 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
                     if (sw == NC - 1) { W[i + NC - 1] |= oc << sb; W[i + NC] |= sb ? oc >> (64 - sb) : 0ull; }
                     else W[i + NC] |= oc;
                 }
-                const bool lio = LEAN && io_blk != nullptr;          // (the hand-over rows are NC * 128 columns wide: every k is written)
+                constexpr bool lio = LEAN && LIO;                    // (the hand-over rows are NC * 128 columns wide: every k is written)
 #pragma unroll
                 for (int k = 0; k < NW; ++k) {
                     const int j0 = 64 * k + 8 * sub;
