@@ -99,7 +99,7 @@ __device__ __forceinline__ void mlp_big_body(const BigPar& P, uint8_t* const act
                     const uint2 o = *dst;
                     x0 += __uint_as_float(o.x << 16); x1 += __uint_as_float(o.x & 0xffff0000u);
                     x2 += __uint_as_float(o.y << 16); x3 += __uint_as_float(o.y & 0xffff0000u);
-                    x0 = x0 > 0.0f ? x0 : 0.0f; x1 = x1 > 0.0f ? x1 : 0.0f; x2 = x2 > 0.0f ? x2 : 0.0f; x3 = x3 > 0.0f ? x3 : 0.0f;
+                    // (no second relu: b >= 0 and relu(W b) >= 0, so the sum is its own relu, bit for bit)
                 }
                 *dst = make_uint2(pk_bf16(x0, x1), pk_bf16(x2, x3));
             }

@@ -40,6 +40,9 @@ __device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {
     return r;
 }
 __device__ __attribute__((noinline)) float sigmoid_ool(float x) { return sigmoid_spec(x); }
+// relu of an MFMA accumulator element (x > 0 ? x : 0 for every non-NaN x, -0 included) as ONE integer instruction: the bits of a
+// non-negative float order like the integer, those of a negative one are a negative integer
+__device__ __forceinline__ float relu_bits(float x) { const int b = __float_as_int(x); return __int_as_float(b > 0 ? b : 0); }
 
 constexpr int NW_WAVES = 4;               // waves per workgroup (= per 16-leaf tile)
 constexpr int NW_DEPTH = 4;               // hidden groups are padded to a multiple of this (the deepest prefetch)
@@ -92,7 +95,8 @@ __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const
     uint8_t* const act0 = smem;                                   // [ML][ROWB] x 2 (ping-pong), then [ML][PROWB] input planes
     uint8_t* const pl = smem + 2 * ML * ROWB;
     const int lrow = lane & 15, q4 = lane >> 4;
-    const AGZ_GLB v4u* wsrc = (const AGZ_GLB v4u*)P.w16 + (size_t)wave * TPW * 64 + lane;   // advances one group at a time
+    // this wave's fragments of the running group: a scalar base that advances one group at a time + the lane's 16 bytes
+    const AGZ_GLB v4u* wsrc = (const AGZ_GLB v4u*)P.w16 + (size_t)wave * TPW * 64 + lane;
 
     static_assert(DEPTH == 2 || DEPTH == 4, "the group loop below is unrolled by hand");
     bf16x8 A[DEPTH][KTH][TPW];
@@ -125,10 +129,11 @@ __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const
     const int pstride = IO ? 2 * io_bw : 16 * PROWB;
 
     f32x4 acc[LT][TPW];
+    const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int lt = 0; lt < LT; ++lt)
 #pragma unroll
-        for (int t = 0; t < TPW; ++t) { acc[lt][t][0] = 0.0f; acc[lt][t][1] = 0.0f; acc[lt][t][2] = 0.0f; acc[lt][t][3] = 0.0f; }
+        for (int t = 0; t < TPW; ++t) acc[lt][t] = zero4;
     int cur = 0;                                                  // activation strip holding the current layer's input
     // one group: KTH k-rows of this wave's TPW tiles; closes a layer unless it is an inner group of layer 0
 #define NW_GROUP(d, g)                                                                                  \
@@ -151,16 +156,16 @@ __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const
                 uint8_t* const new_ = act0 + (size_t)(cur ^ 1) * ML * ROWB + (size_t)(lt * 16 + lrow) * ROWB; \
                 _Pragma("unroll") for (int t = 0; t < TPW; ++t) {                                       \
                     const int n = 16 * (wave * TPW + t) + 4 * q4;  /* acc[lt][t][r] = out[neuron n + r][leaf 16 lt + lrow] */ \
-                    float x0 = acc[lt][t][0] > 0.0f ? acc[lt][t][0] : 0.0f, x1 = acc[lt][t][1] > 0.0f ? acc[lt][t][1] : 0.0f; \
-                    float x2 = acc[lt][t][2] > 0.0f ? acc[lt][t][2] : 0.0f, x3 = acc[lt][t][3] > 0.0f ? acc[lt][t][3] : 0.0f; \
+                    float x0 = relu_bits(acc[lt][t][0]), x1 = relu_bits(acc[lt][t][1]);                 \
+                    float x2 = relu_bits(acc[lt][t][2]), x3 = relu_bits(acc[lt][t][3]);                 \
                     if (res_) {                                    /* b = relu(b + relu(W b)) */        \
                         const uint2 o = *reinterpret_cast<const uint2*>(old_ + n * 2);                  \
                         x0 += __uint_as_float(o.x << 16); x1 += __uint_as_float(o.x & 0xffff0000u);     \
                         x2 += __uint_as_float(o.y << 16); x3 += __uint_as_float(o.y & 0xffff0000u);     \
-                        x0 = x0 > 0.0f ? x0 : 0.0f; x1 = x1 > 0.0f ? x1 : 0.0f; x2 = x2 > 0.0f ? x2 : 0.0f; x3 = x3 > 0.0f ? x3 : 0.0f; \
+                        /* (no second relu: b >= 0 and relu(W b) >= 0, so the sum is its own relu, bit for bit) */ \
                     }                                                                                   \
                     *reinterpret_cast<uint2*>(new_ + n * 2) = make_uint2(pk_bf16(x0, x1), pk_bf16(x2, x3)); \
-                    acc[lt][t][0] = 0.0f; acc[lt][t][1] = 0.0f; acc[lt][t][2] = 0.0f; acc[lt][t][3] = 0.0f; \
+                    acc[lt][t] = zero4;                                                                 \
                 }                                                                                       \
             }                                                                                           \
             cur ^= 1;                                                                                   \
@@ -193,7 +198,7 @@ __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const
             _Pragma("unroll") for (int k = 0; k < KTH; ++k)                                             \
                 _Pragma("unroll") for (int lt = 0; lt < LT; ++lt) {                                     \
                     const bf16x8 b = *reinterpret_cast<const bf16x8*>(brow + (size_t)lt * 16 * ROWB + k * 64 + q4 * 16); \
-                    _Pragma("unroll") for (int t = 0; t < TPW; ++t) acc[lt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, A[buf][k][t], acc[lt][t], 0, 0, 0); \
+                    _Pragma("unroll") for (int t = 0; t < TPW; ++t) acc[lt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, A[buf][k][t], k == 0 ? zero4 : acc[lt][t], 0, 0, 0); \
                 }                                                                                       \
             /* acc[lt][t][r] = out[leaf = leaf0 + 16 lt + 4 q4 + r][n = 16 tile + (lane & 15)] */        \
             _Pragma("unroll") for (int t = 0; t < TPW; ++t) {                                           \
@@ -222,13 +227,7 @@ __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const
             }                                                                                           \
         }
         NW_HEAD(0, 0)
-        if (NT > NTH) {                                             // (wave-uniform, rare)
-#pragma unroll
-            for (int lt = 0; lt < LT; ++lt)
-#pragma unroll
-                for (int t = 0; t < TPW; ++t) { acc[lt][t][0] = 0.0f; acc[lt][t][1] = 0.0f; acc[lt][t][2] = 0.0f; acc[lt][t][3] = 0.0f; }
-            NW_HEAD(1, NTH)
-        }
+        if (NT > NTH) { NW_HEAD(1, NTH) }                           // (wave-uniform, rare)
 #undef NW_HEAD
     }
 }

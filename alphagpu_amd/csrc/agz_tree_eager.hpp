@@ -32,6 +32,47 @@ namespace agz {
 
 enum : uint32_t { SP_VALID = 1u << 24, SP_CREATED = 1u << 25, NX_VALID = 1u << 16, AUX_SLOW = 1u << 24 };
 
+// correctly rounded sqrt of a float in [1, 2^24] (here: 1 + the visit count of a node): v_sqrt_f32 is within 1 ulp, and the two
+// residual tests are the compiler's own correction steps — without its scaling for tiny arguments and its inf / 0 test (8 instead
+// of 20 instructions, same result)
+__device__ __forceinline__ float sqrt_count(const float x) {
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float sm = __int_as_float(__float_as_int(s) - 1), sp = __int_as_float(__float_as_int(s) + 1);
+    const float rm = __builtin_fmaf(-sm, s, x), rp = __builtin_fmaf(-sp, s, x);
+    s = rm <= 0.0f ? sm : s;
+    s = rp > 0.0f ? sp : s;
+    return s;
+}
+// bits [bit0, bit0 + 32) of a bitboard (zeros beyond its end), bit0 per lane: two 32-bit words picked by the lane, one v_alignbit
+template <int NC> __device__ __forceinline__ uint32_t bb_field32(const BB<NC>& b, const int bit0) {
+    uint32_t w[2 * NC + 2];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) { w[2 * i] = (uint32_t)b.c[i]; w[2 * i + 1] = (uint32_t)(b.c[i] >> 32); }
+    w[2 * NC] = 0u; w[2 * NC + 1] = 0u;
+    const int i = bit0 >> 5;
+    uint32_t lo = w[0], hi = w[1];
+#pragma unroll
+    for (int k = 1; k <= 2 * NC; ++k) { lo = i == k ? w[k] : lo; hi = i == k ? w[k + 1] : hi; }
+    return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(bit0 & 31));
+}
+// canPlay of the lane's block of KPL <= 24 actions k0 .. k0 + nval - 1 as a bit mask (mcts_gpu.jl:262, :286 call canPlay per action).
+// Games whose action k is cell k (Gobang.jl:25-27: the cell is empty; Reversi8x8.jl:84-90: bit k of the cached legal set, the pass
+// action = no legal move) read the block as one bit field; the others (Connect4's top cells, Hex's padded board) ask per action.
+template <int FAM, int NC, int KPL>
+__device__ __forceinline__ uint32_t legal_block(const GamePar& P, const WPos<NC>& st, const int k0, const int nval) {
+    uint32_t m = 0u;
+    if constexpr (FAM == F_LINE) m = ~bb_field32<NC>(bb_or(st.p, st.o), k0);
+    else if constexpr (FAM == F_REV) {
+        m = bb_field32<NC>(st.lg, k0);
+        const int pj = P.pass_action - k0;
+        if (pj >= 0 && pj < KPL && !bb_any(st.lg)) m |= 1u << pj;
+    } else {
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) m |= Game<FAM, NC>::canPlay(P, st, k0 + j) ? 1u << j : 0u;
+    }
+    return m & ((1u << nval) - 1u);
+}
+
 // bytes of a node record [prior f32 x A2][q f32 x A2][rank u8 x A2][cid u8 x A2][vis u8 x A2] (A2 is a multiple of 32)
 __host__ __device__ constexpr int eager_rec_bytes(int A2) { return 11 * A2; }
 
@@ -39,9 +80,11 @@ struct EagerLds { int tabp, tabq, tstride, val, utab, total; };
 __host__ __device__ inline EagerLds eager_lds_layout(int V) {
     EagerLds o;
     auto up16 = [](int x) { return (x + 15) & ~15; };
-    o.tabp = 0;                                                  // per lane-group: Newton inputs in creation order
-    o.tabq = up16(V * 4);
-    o.tstride = 2 * up16(V * 4);
+    // per lane-group: Newton inputs in creation order, [16 bytes][tabp: V floats][16 bytes][tabq: V floats] — the slot in front of
+    // each table takes the writes of the actions that have no child (rank 0)
+    o.tabp = 16;
+    o.tabq = 16 + up16(V * 4) + 16;
+    o.tstride = 2 * (up16(V * 4) + 16);
     o.val = 8 * o.tstride;                                       // per game: {value_1, value_2, flags, -}
     o.utab = o.val + 8 * 16;                                     // per game: 32 uniforms (depths 0..31)
     o.total = o.utab + 8 * 128;
@@ -100,6 +143,7 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
     float* const utab = reinterpret_cast<float*>(lds + LO.utab);
     const int sl = live ? slot : 0;
     const int k0 = sub * KPL;
+    const int nlanes = (A + KPL - 1) / KPL;                            // lanes of a group whose block holds real actions (wave-uniform)
     const int nval = A - k0 < 0 ? 0 : (A - k0 > KPL ? KPL : A - k0);   // real actions in this lane's block (padding sits at the end of the last blocks)
     const bool inject = !LEAN && T.inject, capture = !LEAN && T.capture;
     const bool exact = !LEAN && T.exact, planes_f32 = !LEAN && T.planes_f32;
@@ -284,7 +328,7 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
 #pragma unroll
                 for (int j = 0; j < KPL; ++j) x[j] = (j < nval) ? (exact ? exp_spec(x[j] - mx) : exp2_spec(x[j] - mx)) : 0.0f;
                 float s;
-                (void)grp_ordered_start<KPL, true>(x, sub, s);
+                (void)grp_ordered_start<KPL, true>(x, sub, s, nlanes);
                 fdx = FD && !__ballot(wide);
                 if (fdx) {
                     const float rs = fd_rcp(s);
@@ -299,16 +343,16 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
                     for (int j = 0; j < KPL; ++j) if (j < nval) T.prior_eval[(size_t)slot * A + k0 + j] = x[j];
                 }
             }
-            bool lg[KPL]; int nl = 0;                                 // legal mask; masked priors (:260-268 / :284-290)   // PHASE expand: legal mask + normalize sum
+            bool lg[KPL];                                             // legal mask; masked priors (:260-268 / :284-290)   // PHASE expand: legal mask + normalize sum
+            const uint32_t lmask = legal_block<FAM, NC, KPL>(P, st, k0, nval);
 #pragma unroll
             for (int j = 0; j < KPL; ++j) {
-                lg[j] = (j < nval) && GM::canPlay(P, st, k0 + j);
+                lg[j] = (lmask >> j) & 1u;
                 x[j] = lg[j] ? x[j] : 0.0f;
-                nl += lg[j] ? 1 : 0;
             }
-            nl = grp_sum<G>(nl);
+            const int nl = grp_sum<G>(__builtin_popcount(lmask));
             float normalize;
-            (void)grp_ordered_start<KPL, true>(x, sub, normalize);
+            (void)grp_ordered_start<KPL, true>(x, sub, normalize, nlanes);
             const bool rootmix = lf == 0 && T.training;               // :270-275 vs :277-279, :292-294   // PHASE expand: mix / divide
             const float Af = (float)nl;
             float qn_[KPL];
@@ -341,7 +385,7 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
             // policy = prior (:297-299): the first revisit samples from these running sums; their total is prior_rem (:120-124, no   // PHASE expand: running sums + write rows
             // child yet)
             float total;
-            const float st0 = grp_ordered_start<KPL, true>(x, sub, total);
+            const float st0 = grp_ordered_start<KPL, true>(x, sub, total, nlanes);
             const int Dl = (int)((spw >> 16) & 0xffu);                // depth of the leaf = expanded nodes above it
             const float ul = Dl < 32 ? utab[g * 32 + Dl] : uniform_search(T.seed, gid, T.step, SF.rollout - 1u, (uint32_t)Dl);
             const uint32_t nocd[KPL / 4] = {};
@@ -420,7 +464,7 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
                     m[j] = (created && rk == 0 && k0 + j != move) ? R.p[j] : 0.0f;
                 }
                 float tot;
-                (void)grp_ordered_start<KPL, true>(m, sub, tot);
+                (void)grp_ordered_start<KPL, true>(m, sub, tot, nlanes);
                 prem_raw = created ? tot : prem_raw;
             }
             if (valid && lead) {
@@ -441,17 +485,18 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
             }
             STAMPW(4);
             // ---- Newton inputs in creation order (:144-148): the rank stored with the child id is the place   // PHASE items: Newton inputs (rank scatter)
+            // (no branch: an action without a child, rank byte 0, writes the unused slot in front of the table)
 #pragma unroll
             for (int j = 0; j < KPL; ++j) {
-                const uint32_t rk = (R.rk[j / 4] >> (8 * (j & 3))) & 0xffu;
-                if (rk != 0) { tabp[rk - 1] = R.p[j]; tabq[rk - 1] = R.q[j]; }
+                const int rk = (int)((R.rk[j / 4] >> (8 * (j & 3))) & 0xffu);
+                tabp[rk - 1] = R.p[j]; tabq[rk - 1] = R.q[j];
             }
             AGZ_WSYNC();
             if (created && lead) { tabp[nch - 1] = R.pm; tabq[nch - 1] = nq; }
             AGZ_WSYNC();
             // ---- :116-138   // PHASE items: lambda, alpha0
             const float nf = 1.0f + (float)nvis, Af = (float)npos;
-            const float lnum = T.cpuct * __builtin_sqrtf(nf), lden = Af + nf;
+            const float lnum = T.cpuct * sqrt_count(nf), lden = Af + nf;
             const float lambda = FDr ? fd_div(lnum, lden, fd_rcp(lden)) : lnum / lden;   // :132
             const float prior_rem = prem_raw * lambda;               // :134
             float am = 0.0f;
@@ -460,48 +505,40 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
                 const float lp = lambda * R.p[j];
                 const float gap = lp > 1e-4f ? lp : 1e-4f;
                 const float c = R.q[j] + gap;
-                am = c > am ? c : am;
+                am = __builtin_fmaxf(c, am);                          // (no NaN can occur: one v_max_f32)
             }
             float alpha = grp_max<G>(am);
             STAMPW(5);
             // ---- Newton (:141-162): element 0 is the prior_rem term, elements 1..nch the children in creation order   // PHASE items: Newton
             {
                 float err = __builtin_inff();
-                const bool fast = (int)nch < G;
-                float top_l = 0.0f, qv_l = 0.0f;
-                if (sub == 0) top_l = prior_rem;
-                else if (sub <= (int)nch && fast) { top_l = lambda * tabp[sub - 1]; qv_l = tabq[sub - 1]; }
+                // block 0 (the prior_rem term and the first 7 children) stays in registers for every iteration; further blocks of 8
+                // children are read from the group's table as long as ANY group of the wave still has children left (a wave-uniform
+                // loop: groups with fewer children add zeros)
+                const bool v0 = sub <= (int)nch;
+                float top0 = 0.0f, qv0 = 0.0f;
+                if (sub == 0) top0 = prior_rem;
+                else if (v0) { top0 = lambda * tabp[sub - 1]; qv0 = tabq[sub - 1]; }
                 for (int it = 0; it < 100; ++it) {
-                    float S, gg;
-                    if (fast) {
-                        float t = 0.0f, uu = 0.0f;
-                        if (sub <= (int)nch) {
-                            const float bot = alpha - qv_l;
-                            if (FDr) fd_div_pair(top_l, bot, -top_l, bot * bot, t, uu); else div_pair(top_l, bot, -top_l, bot * bot, t, uu);
-                        }
-                        float a = t, b = uu;
-#define AGZ_PULL(d) { a += lane_shl<d>(t); b += lane_shl<d>(uu); }
-                        AGZ_PULL(1) AGZ_PULL(2) AGZ_PULL(3) AGZ_PULL(4) AGZ_PULL(5) AGZ_PULL(6) AGZ_PULL(7)
-#undef AGZ_PULL
-                        S = grp_bcast<G>(a); gg = grp_bcast<G>(b);
-                    } else {
-                        float a = 0.0f, b = 0.0f;
-                        for (int j0 = 0; j0 <= (int)nch; j0 += G) {
-                            const int c = j0 + sub;
-                            float t = 0.0f, uu = 0.0f;
-                            if (c <= (int)nch) {
-                                float top = prior_rem, qv = 0.0f;
-                                if (c > 0) { top = lambda * tabp[c - 1]; qv = tabq[c - 1]; }
-                                const float bot = alpha - qv;
-                                if (FDr) fd_div_pair(top, bot, -top, bot * bot, t, uu); else div_pair(top, bot, -top, bot * bot, t, uu);
-                            }
-                            if (j0 == 0) { a = t; b = uu; } else { a += t; b += uu; }
-#define AGZ_PULL(d) { a += lane_shl<d>(t); b += lane_shl<d>(uu); }
-                            AGZ_PULL(1) AGZ_PULL(2) AGZ_PULL(3) AGZ_PULL(4) AGZ_PULL(5) AGZ_PULL(6) AGZ_PULL(7)
-#undef AGZ_PULL
-                        }
-                        S = grp_bcast<G>(a); gg = grp_bcast<G>(b);
+                    float t, uu;
+                    {
+                        const float bot = alpha - qv0;
+                        if (FDr) fd_div_pair(top0, bot, -top0, bot * bot, t, uu); else div_pair(top0, bot, -top0, bot * bot, t, uu);
+                        t = v0 ? t : 0.0f; uu = v0 ? uu : 0.0f;
                     }
+                    float a = t, b = uu;
+                    grp_pull_sums(a, t, b, uu);
+                    for (int j0 = G; __ballot(j0 <= (int)nch) != 0; j0 += G) {
+                        const int c = j0 + sub;
+                        const bool vc = c <= (int)nch;
+                        const int ci = vc ? c - 1 : 0;
+                        const float top = lambda * tabp[ci], bot = alpha - tabq[ci];
+                        if (FDr) fd_div_pair(top, bot, -top, bot * bot, t, uu); else div_pair(top, bot, -top, bot * bot, t, uu);
+                        t = vc ? t : 0.0f; uu = vc ? uu : 0.0f;
+                        a += t; b += uu;
+                        grp_pull_sums(a, t, b, uu);
+                    }
+                    const float S = grp_bcast<G>(a), gg = grp_bcast<G>(b);
                     const float newerr = S - 1.0f;
                     if (newerr < 0.001f || newerr == err) break;
                     alpha -= FDr ? fd_div(newerr, gg, fd_rcp(gg)) : newerr / gg;
@@ -536,7 +573,7 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
             // the child bytes are needed past the prefetch of the next item: kept aside   // PHASE items: running sums + sampling
             STAMPW(7);
             float dummy;
-            const float st = grp_ordered_start<KPL, false>(pol, sub, dummy);
+            const float st = grp_ordered_start<KPL, false>(pol, sub, dummy, nlanes);
             const float u = dpt < 32 ? utab[gi * 32 + dpt] : uniform_search(T.seed, T.game_id[valid ? slot_base + gi : sl], T.step, SF.rollout - 1u, (uint32_t)dpt);
             const uint32_t nx = sample_next(pol, st, u, cdk, created ? move : -1, (uint32_t)ileaf);
             if (valid && lead) waux[ind] = make_uint4(__float_as_uint(prem_raw), nx, auxz, 0u);

@@ -61,28 +61,39 @@ template <int G> __device__ __forceinline__ float grp_bcast_last(float xf) {   /
     if (G >= 4) x = dpp_mov<DPP_QUAD_B3, 0xF>(x, x);
     return __int_as_float(x);
 }
+// Group reductions with the lane exchange FUSED into the arithmetic instruction (v_add_u32_dpp / v_max_*_dpp: one instruction per
+// step; a v_mov_b32_dpp + compare + select sequence is six).  A DPP operand written by the preceding VALU instruction needs two
+// wait states: the s_nop 1 in front of every step.  (v_max_f32 and `y > x ? y : x` agree on every non-NaN pair.)
+#define AGZ_DPP_STEP(op, ctrl, x) asm("s_nop 1\n\t" op " %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf" : "+v"(x))
 template <int G> __device__ __forceinline__ int grp_sum(int x) {
-    if (G >= 2) x += dpp_mov<DPP_XOR1, 0xF>(0, x);
-    if (G >= 4) x += dpp_mov<DPP_XOR2, 0xF>(0, x);
-    if (G >= 8) x += dpp_mov<DPP_HALF_MIRROR, 0xF>(0, x);
-    if (G >= 16) x += dpp_mov<DPP_MIRROR, 0xF>(0, x);
+    static_assert(G == 8, "lane-groups of 8");
+    AGZ_DPP_STEP("v_add_u32_dpp", "quad_perm:[1,0,3,2]", x);
+    AGZ_DPP_STEP("v_add_u32_dpp", "quad_perm:[2,3,0,1]", x);
+    AGZ_DPP_STEP("v_add_u32_dpp", "row_half_mirror", x);
     return x;
 }
-template <int G> __device__ __forceinline__ int grp_max_i(int x) {            // (-1 = "none")
-    int y;
-    if (G >= 2) { y = dpp_mov<DPP_XOR1, 0xF>(-1, x); x = y > x ? y : x; }
-    if (G >= 4) { y = dpp_mov<DPP_XOR2, 0xF>(-1, x); x = y > x ? y : x; }
-    if (G >= 8) { y = dpp_mov<DPP_HALF_MIRROR, 0xF>(-1, x); x = y > x ? y : x; }
-    if (G >= 16) { y = dpp_mov<DPP_MIRROR, 0xF>(-1, x); x = y > x ? y : x; }
+template <int G> __device__ __forceinline__ int grp_max_i(int x) {
+    static_assert(G == 8, "lane-groups of 8");
+    AGZ_DPP_STEP("v_max_i32_dpp", "quad_perm:[1,0,3,2]", x);
+    AGZ_DPP_STEP("v_max_i32_dpp", "quad_perm:[2,3,0,1]", x);
+    AGZ_DPP_STEP("v_max_i32_dpp", "row_half_mirror", x);
     return x;
 }
 template <int G> __device__ __forceinline__ float grp_max(float x) {
-    float y;
-    if (G >= 2) { y = __int_as_float(dpp_mov<DPP_XOR1, 0xF>(0, __float_as_int(x))); x = y > x ? y : x; }
-    if (G >= 4) { y = __int_as_float(dpp_mov<DPP_XOR2, 0xF>(0, __float_as_int(x))); x = y > x ? y : x; }
-    if (G >= 8) { y = __int_as_float(dpp_mov<DPP_HALF_MIRROR, 0xF>(0, __float_as_int(x))); x = y > x ? y : x; }
-    if (G >= 16) { y = __int_as_float(dpp_mov<DPP_MIRROR, 0xF>(0, __float_as_int(x))); x = y > x ? y : x; }
+    static_assert(G == 8, "lane-groups of 8");
+    AGZ_DPP_STEP("v_max_f32_dpp", "quad_perm:[1,0,3,2]", x);
+    AGZ_DPP_STEP("v_max_f32_dpp", "quad_perm:[2,3,0,1]", x);
+    AGZ_DPP_STEP("v_max_f32_dpp", "row_half_mirror", x);
     return x;
+}
+// a += t[lane + d], b += u[lane + d] for d = 1 .. 7, in that order (the source-order sum of 8 consecutive lanes' values ends up
+// in the first of them; lanes whose source lies past the 16-lane row add 0 — only a group's first lane is read afterwards)
+__device__ __forceinline__ void grp_pull_sums(float& a, const float t, float& b, const float u) {
+#define AGZ_PULL2(d) "v_add_f32_dpp %0, %2, %0 row_shl:" #d " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+                     "v_add_f32_dpp %1, %3, %1 row_shl:" #d " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    asm("s_nop 1\n\t" AGZ_PULL2(1) AGZ_PULL2(2) AGZ_PULL2(3) AGZ_PULL2(4) AGZ_PULL2(5) AGZ_PULL2(6) AGZ_PULL2(7)
+        : "+&v"(a), "+&v"(b) : "v"(t), "v"(u));   // (early clobber: a starts as a copy of t and must not share its register)
+#undef AGZ_PULL2
 }
 template <int D> __device__ __forceinline__ float lane_shl(float x) {      // value of lane + D (same 16-lane row), own value past the row's end
     return __int_as_float(dpp_mov<0x100 + D, 0xF>(__float_as_int(x), __float_as_int(x)));
@@ -91,12 +102,16 @@ __device__ __forceinline__ float lane_shr1(float x) { return __int_as_float(dpp_
 
 // Source-order running sums over the group's 8*KPL values (lane sub holds block sub): returns the sum of everything BEFORE the
 // lane's own block — the lanes take turns, lane t adds its KPL values to what lane t-1 ended with (one DPP row_shr:1 per turn),
-// bit-identical to the source-order loop.  The last lane's start needs no turn of its own; its end (the total) does.
+// bit-identical to the source-order loop.  nl = lanes whose block holds real actions (ceil(A / KPL), wave-uniform): the blocks
+// of the lanes behind them are all +0 padding, which a sum passes through unchanged, so their turns are not taken — the total is
+// handed down the remaining lanes by one move per lane.  The start of lane nl - 1 needs no turn of its own; its end (the total)
+// does.  (Connect4: 2 turns instead of 8, Gobang 9x9: 7 / 6 instead of 8 / 7.)
 template <int KPL, bool WANT_TOTAL>
-__device__ __forceinline__ float grp_ordered_start(const float (&x)[KPL], int sub, float& total) {
+__device__ __forceinline__ float grp_ordered_start(const float (&x)[KPL], int sub, float& total, int nl = 8) {
     float a = 0.0f, st = 0.0f;
+    const int turns = WANT_TOTAL ? nl : nl - 1;
 #pragma unroll 1
-    for (int t = 0; t < (WANT_TOTAL ? 8 : 7); ++t) {
+    for (int t = 0; t < turns; ++t) {
         const float carry = lane_shr1(a);                       // what the previous lane ended with
         const float s0 = sub == 0 ? 0.0f : carry;
         if (sub == t) st = s0;
@@ -104,8 +119,11 @@ __device__ __forceinline__ float grp_ordered_start(const float (&x)[KPL], int su
 #pragma unroll
         for (int j = 0; j < KPL; ++j) a += x[j];                // only lane t's result is final in turn t
     }
-    if (WANT_TOTAL) total = grp_bcast_last<8>(a);
-    else { const float carry = lane_shr1(a); if (sub == 7) st = carry; }
+    if (WANT_TOTAL) {
+#pragma unroll 1
+        for (int t = nl; t < 8; ++t) { const float carry = lane_shr1(a); a = sub == t ? carry : a; }   // padding lanes pass the total on
+        total = grp_bcast_last<8>(a);
+    } else { const float carry = lane_shr1(a); if (sub == nl - 1) st = carry; }
     return st;
 }
 
