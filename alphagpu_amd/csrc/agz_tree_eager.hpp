@@ -96,6 +96,7 @@ __host__ __device__ inline EagerLds eager_lds_layout(int V) {
 struct EagerCarry { uint32_t ncount, leafn, spw, add_p, add_new, root_exp, leaf_meta; };   // leaf_meta: the leaf's meta word (whole-search kernels)
 
 // rows of one work item, loaded one round ahead of their use
+template <int KPL> struct ChildWords { uint32_t w[KPL / 4]; };       // child-id bytes of a lane's block, passed by value (registers)
 template <int KPL> struct ItemRows {
     float p[KPL], q[KPL]; uint32_t rk[KPL / 4], cd[KPL / 4];      // rank + 1 / child id bytes of the lane's KPL actions
     uint32_t ax_x, ax_z;                                          // aux: prior_rem bits, npos | nvis << 8 | nch << 16
@@ -192,7 +193,7 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
     // The action the next visit of a row samples (:172-182), given the row pol[] (block sub of the group), the running sum st before
     // the block, the visit's uniform u and the child bytes of the block: the number of running sums below u — the row of sums is
     // nondecreasing — or, when the whole row sums below u, the last positive action.  Returns the next word.
-    auto sample_next = [&](const float (&pol)[KPL], const float st, const float u, const uint32_t (&cd)[KPL / 4], const int fix_move,
+    auto sample_next = [&](const float (&pol)[KPL], const float st, const float u, const ChildWords<KPL> cdw, const int fix_move,
                            const uint32_t fix_child) -> uint32_t {
         float c = st; int cnt = 0;
 #pragma unroll
@@ -208,9 +209,9 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
         }
         if (bestmove < 0) return 0u;                                           // (the reference would index [-1]: the visit ends here)
         const uint32_t idx = (uint32_t)(bestmove - k0);
-        uint32_t wsel = cd[0];
+        uint32_t wsel = cdw.w[0];
 #pragma unroll
-        for (int j = 1; j < KPL / 4; ++j) wsel = (idx >> 2) == (uint32_t)j ? cd[j] : wsel;
+        for (int j = 1; j < KPL / 4; ++j) wsel = (idx >> 2) == (uint32_t)j ? cdw.w[j] : wsel;
         const uint32_t byte = idx < (uint32_t)KPL ? __builtin_amdgcn_ubfe(wsel, (idx & 3u) * 8u, 8u) : 0u;
         uint32_t child = (uint32_t)grp_sum<G>((int)byte);
         if (bestmove == fix_move) child = fix_child;                           // the child registered by this very item
@@ -388,7 +389,9 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
             const float st0 = grp_ordered_start<KPL, true>(x, sub, total, nlanes);
             const int Dl = (int)((spw >> 16) & 0xffu);                // depth of the leaf = expanded nodes above it
             const float ul = Dl < 32 ? utab[g * 32 + Dl] : uniform_search(T.seed, gid, T.step, SF.rollout - 1u, (uint32_t)Dl);
-            const uint32_t nocd[KPL / 4] = {};
+            ChildWords<KPL> nocd;
+#pragma unroll
+            for (int j = 0; j < KPL / 4; ++j) nocd.w[j] = 0u;
             const uint32_t nx = sample_next(x, st0, ul, nocd, -1, 0u);
             uint8_t* rec = wrecs + (gnode0 + (uint32_t)lf) * (uint32_t)ROWS;
 #pragma unroll
@@ -557,9 +560,9 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
                 for (int j = 0; j < KPL; j += 2)
                     div_pair(lambda * R.p[j], alpha - R.q[j], lambda * R.p[j + 1], alpha - R.q[j + 1], pol[j], pol[j + 1]);
             }
-            uint32_t cdk[KPL / 4];
+            ChildWords<KPL> cdk;
 #pragma unroll
-            for (int j = 0; j < KPL / 4; ++j) cdk[j] = R.cd[j];
+            for (int j = 0; j < KPL / 4; ++j) cdk.w[j] = R.cd[j];
             // the rows of this item are dead: the next item's start travelling now (its table entries are written after the
             // AGZ_WSYNC below)
             AGZ_WSYNC();
