@@ -103,7 +103,7 @@ AGZ_HD float sigmoid_spec(float x) {      // NNlib sigma (DenseNet.jl:197, :301)
 // ---------------------------------------------------------------------------------------------------
 // Tree layout in HBM (per slot = one game tree, one wavefront works on it):
 //   meta  [L][V]   u32   : node word  (parent | action<<8 | flags<<16)            256 B/slot at V=64
-//   recs  [L][V]   rec   : [prior f32 x A2][q f32 x A2][rank u8 x A2][cid u8 x A2][vis u8 x A2]   (agz_tree_eager.hpp)
+//   recs  [L][V]   rec   : [prior f32 x A2][rank u8 x A2][cid u8 x A2][edge {q, prior} x VL][visits u8 x VL]   (agz_tree_eager.hpp)
 //   states[L][V]   Pos   : 80 B positions
 // A2 = 8 lanes x KPL actions >= A.  Node 0 is the root.  No array is ever re-zeroed: a record is fully written
 // when its node is expanded and only read while the node's EXPANDED bit is set.

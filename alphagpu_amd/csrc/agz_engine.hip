@@ -310,7 +310,7 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     h->reg_lds += 256;
 #endif
     const uint32_t A2 = (uint32_t)(8 * h->reg_kpl);
-    const uint32_t rec_bytes = (uint32_t)eager_rec_bytes((int)A2);
+    const uint32_t rec_bytes = (uint32_t)eager_rec_bytes((int)A2, h->V);
     {
         FA_(hipFuncSetAttribute((const void*)h->k_eager, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->reg_lds));
         FA_(hipFuncSetAttribute((const void*)h->k_eager3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->reg_lds));
@@ -379,7 +379,7 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
 
     TreePar& T = h->tp;
     memset(&T, 0, sizeof T);
-    T.G = P; T.V = h->V; T.rec_bytes = rec_bytes; T.off_q = A2 * 4; T.off_vis = A2 * 10; T.A2 = A2;
+    T.G = P; T.V = h->V; T.rec_bytes = rec_bytes; T.off_q = A2 * 6; T.off_vis = A2 * 6 + 8 * (uint32_t)eager_vl(h->V); T.A2 = A2;   // (off_q: the edge list {q, prior} by rank)
     T.recs = h->recs; T.states = h->states; T.meta = h->meta; T.ncount = h->ncount; T.leaf = h->leaf; T.game_id = h->game_id;
     T.cnt_p = h->cnt_p; T.cnt_new = h->cnt_new; T.planes = h->planes; T.INP = h->INP; T.planes_f32 = cfg->nn_mode == AGZ_NN_EXACT;
     T.logits = h->logits; T.LGS = h->LGS; T.prior_eval = h->prior_eval; T.v_eval = h->v_eval; T.policy_final = h->policy_final;
@@ -983,7 +983,7 @@ static int stats_getter(agz_engine* h, float* out, int want_q) {
     HIPCHK(h, hipSetDevice(h->cfg.device));
     if (h->L == 0) return AGZ_OK;
     hipLaunchKernelGGL(k_root_stats, dim3((unsigned)h->L), dim3(128), 0, h->stream, (const uint8_t*)h->recs, (const uint32_t*)h->meta, h->V,
-                       h->tp.rec_bytes, h->tp.off_q, h->tp.off_vis, h->G.A, h->L, want_q ? (float*)nullptr : h->scratch_f,
+                       h->tp.rec_bytes, h->tp.A2 * 4, h->tp.off_q, h->tp.off_vis, h->G.A, h->L, want_q ? (float*)nullptr : h->scratch_f,
                        want_q ? h->scratch_f : (float*)nullptr);
     HIPCHK(h, hipGetLastError());
     return fetch(h, out, h->scratch_f, (size_t)h->L * h->G.A * 4);

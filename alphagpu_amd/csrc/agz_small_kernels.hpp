@@ -40,18 +40,20 @@ static __global__ void k_planes(const Pos* states, const uint32_t* leaf, int use
     }
 }
 
-// visits[:,1,:] and q[:,1,:] of the root as fp32 [L][A] (record layout of agz_tree_eager.hpp)
-static __global__ void k_root_stats(const uint8_t* recs, const uint32_t* meta, int V, uint32_t rec_bytes, uint32_t off_q, uint32_t off_vis,
-                                    int A, int L, float* visits, float* q) {
+// visits[:,1,:] and q[:,1,:] of the root as fp32 [L][A] (record layout of agz_tree_eager.hpp: the rank byte of an action leads to
+// the edge's entry in the node's list)
+static __global__ void k_root_stats(const uint8_t* recs, const uint32_t* meta, int V, uint32_t rec_bytes, uint32_t off_rk, uint32_t off_el,
+                                    uint32_t off_vis, int A, int L, float* visits, float* q) {
     int slot = blockIdx.x;
     if (slot >= L) return;
     const uint8_t* rec = recs + (size_t)slot * V * rec_bytes;
     bool expanded = (meta[(size_t)slot * V] & M_EXPANDED) != 0;
     for (int k = threadIdx.x; k < A; k += blockDim.x) {
         float vv = 0.0f, qq = 0.0f;
-        if (expanded) {
-            vv = (float)rec[off_vis + k];
-            qq = reinterpret_cast<const float*>(rec + off_q)[k];
+        const uint32_t rk = expanded ? rec[off_rk + k] : 0u;
+        if (rk != 0u) {
+            vv = (float)rec[off_vis + rk - 1u];
+            qq = reinterpret_cast<const float*>(rec + off_el)[2 * (rk - 1u)];
         }
         if (visits) visits[(size_t)slot * A + k] = vv;
         if (q) q[(size_t)slot * A + k] = qq;

@@ -17,9 +17,12 @@
 //   * the descent follows those words: one 4-byte load per level, no arithmetic.
 // Same arithmetic, same order of every fp32 operation as the reference restated by the oracle; only the time at which a row is
 // computed changes.  Layout (A2 = 8 KPL >= A):
-//   rec[L][V]  [prior f32 x A2][q f32 x A2][rank u8 x A2][cid u8 x A2][vis u8 x A2]: creation rank + 1 and node id of the child
-//              under each action (0 = none), visits of the edge
-//   aux[L][V]  {prior_rem before lambda (:120-124), next word, npos | nvis << 8 | nch << 16, -}
+//   rec[L][V]  [prior f32 x A2][rank u8 x A2][cid u8 x A2] by action: creation rank + 1 and node id of the child under each action
+//              (0 = none); [edge {q, prior} f32x2 x VL][visits u8 x VL] by creation rank (VL = V rounded up to 16): the running
+//              mean and the visit count of the edge to the child — only as many entries as the node has children are ever
+//              read, and an expansion writes the per-action rows only (a fresh node has no edge)
+//   aux[L][V]  {prior_rem before lambda (:120-124), next word (action | child << 8 | valid << 16 | rank + 1 of the child << 17),
+//              npos | nvis << 8 | nch << 16, -}
 //   wl[block][8 V] work list of the wave (in LDS inside the whole-search kernel): one word per expanded node passed below which
 //   the descent went on; sp[slot]: the last expanded node of the path (the parent of the leaf) — these 8 items are processed
 //   together in the first round because they alone may have a new child to register (rank, cid, re-summed prior_rem).
@@ -73,18 +76,18 @@ __device__ __forceinline__ uint32_t legal_block(const GamePar& P, const WPos<NC>
     return m & ((1u << nval) - 1u);
 }
 
-// bytes of a node record [prior f32 x A2][q f32 x A2][rank u8 x A2][cid u8 x A2][vis u8 x A2] (A2 is a multiple of 32)
-__host__ __device__ constexpr int eager_rec_bytes(int A2) { return 11 * A2; }
+// bytes of a node record [prior f32 x A2][rank u8 x A2][cid u8 x A2][edge f32x2 x VL][visits u8 x VL] (A2 a multiple of 32)
+__host__ __device__ constexpr int eager_vl(int V) { return (V + 15) & ~15; }
+__host__ __device__ constexpr int eager_rec_bytes(int A2, int V) { return 6 * A2 + 9 * eager_vl(V); }
 
-struct EagerLds { int tabp, tabq, tstride, val, utab, total; };
+struct EagerLds { int tab, tstride, val, utab, total; };
 __host__ __device__ inline EagerLds eager_lds_layout(int V) {
     EagerLds o;
     auto up16 = [](int x) { return (x + 15) & ~15; };
-    // per lane-group: Newton inputs in creation order, [16 bytes][tabp: V floats][16 bytes][tabq: V floats] — the slot in front of
-    // each table takes the writes of the actions that have no child (rank 0)
-    o.tabp = 16;
-    o.tabq = 16 + up16(V * 4) + 16;
-    o.tstride = 2 * (up16(V * 4) + 16);
+    // per lane-group: the edges {q, prior} of the item's node in creation order, a zero pair in front of them (what an action
+    // without a child reads)
+    o.tab = 16;
+    o.tstride = 16 + up16(V * 8);
     o.val = 8 * o.tstride;                                       // per game: {value_1, value_2, flags, -}
     o.utab = o.val + 8 * 16;                                     // per game: 32 uniforms (depths 0..31)
     o.total = o.utab + 8 * 128;
@@ -98,9 +101,10 @@ struct EagerCarry { uint32_t ncount, leafn, spw, add_p, add_new, root_exp, leaf_
 // rows of one work item, loaded one round ahead of their use
 template <int KPL> struct ChildWords { uint32_t w[KPL / 4]; };       // child-id bytes of a lane's block, passed by value (registers)
 template <int KPL> struct ItemRows {
-    float p[KPL], q[KPL]; uint32_t rk[KPL / 4], cd[KPL / 4];      // rank + 1 / child id bytes of the lane's KPL actions
+    float p[KPL]; uint32_t rk[KPL / 4], cd[KPL / 4];              // priors; rank + 1 / child id bytes of the lane's KPL actions
     uint32_t ax_x, ax_z;                                          // aux: prior_rem bits, npos | nvis << 8 | nch << 16
-    float pm, qm; uint32_t vism;                                  // the edge taken: prior, q, visits
+    float pm, qm; uint32_t vism;                                  // the edge taken: prior of its action (a new edge), q, visits
+    float2 e0, e1, e2, e3;                                        // edges sub, 8 + sub .. of the node's list (e1.. only for a root: the node with many children)
     uint32_t ent; int gi; bool valid;
 };
 
@@ -134,12 +138,12 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
     const bool lead = sub == 0;
     // the row geometry follows from KPL alone (the engine lays the records out with the same formulas): compile-time offsets,
     // so that every load / store of a row is one base address + an immediate
-    constexpr int A2 = G * KPL, ROWS = eager_rec_bytes(A2);
-    constexpr int OFF_Q = 4 * A2, OFF_RK = 8 * A2, OFF_CID = 9 * A2, OFF_VIS = 10 * A2;
+    constexpr int A2 = G * KPL;
+    constexpr int OFF_RK = 4 * A2, OFF_CID = 5 * A2, OFF_EL = 6 * A2;   // per-action rows, then the edge list by rank ...
     const int A = P.A, V = T.V;
+    const uint32_t OFF_VIS = (uint32_t)(OFF_EL + 8 * eager_vl(V)), ROWS = (uint32_t)eager_rec_bytes(A2, V);   // ... and the visit bytes by rank
     const EagerLds LO = eager_lds_layout(V);
-    float* const tabp = reinterpret_cast<float*>(lds + (size_t)g * LO.tstride + LO.tabp);
-    float* const tabq = reinterpret_cast<float*>(lds + (size_t)g * LO.tstride + LO.tabq);
+    float2* const tab = reinterpret_cast<float2*>(lds + (size_t)g * LO.tstride + LO.tab);   // tab[-1] = {0, 0}
     float4* const valtab = reinterpret_cast<float4*>(lds + LO.val);
     float* const utab = reinterpret_cast<float*>(lds + LO.utab);
     const int sl = live ? slot : 0;
@@ -178,6 +182,7 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
     if (lane < 17) stamp_lds[lane] = lane == 16 ? __builtin_amdgcn_s_memtime() : 0ull;
     AGZ_WSYNC();
 #endif
+    if (lead) tab[-1] = make_float2(0.0f, 0.0f);
     if (SF.do_reset) {
         C.ncount = 1; C.leafn = 0; C.spw = 0; C.add_p = 0; C.add_new = 0; C.root_exp = 0; C.leaf_meta = M_EXISTS;
         wcount = 0;
@@ -193,8 +198,9 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
     // The action the next visit of a row samples (:172-182), given the row pol[] (block sub of the group), the running sum st before
     // the block, the visit's uniform u and the child bytes of the block: the number of running sums below u — the row of sums is
     // nondecreasing — or, when the whole row sums below u, the last positive action.  Returns the next word.
-    auto sample_next = [&](const float (&pol)[KPL], const float st, const float u, const ChildWords<KPL> cdw, const int fix_move,
-                           const uint32_t fix_child) -> uint32_t {
+    // next word: action | child << 8 | NX_VALID | creation rank + 1 of the child << 17 (0: no child yet)
+    auto sample_next = [&](const float (&pol)[KPL], const float st, const float u, const ChildWords<KPL> cdw, const ChildWords<KPL> rkw,
+                           const int fix_move, const uint32_t fix_child) -> uint32_t {
         float c = st; int cnt = 0;
 #pragma unroll
         for (int j = 0; j < KPL; ++j) { c += pol[j]; cnt += c < u ? 1 : 0; }
@@ -209,13 +215,16 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
         }
         if (bestmove < 0) return 0u;                                           // (the reference would index [-1]: the visit ends here)
         const uint32_t idx = (uint32_t)(bestmove - k0);
-        uint32_t wsel = cdw.w[0];
+        uint32_t wsel = cdw.w[0], rsel = rkw.w[0];
 #pragma unroll
-        for (int j = 1; j < KPL / 4; ++j) wsel = (idx >> 2) == (uint32_t)j ? cdw.w[j] : wsel;
-        const uint32_t byte = idx < (uint32_t)KPL ? __builtin_amdgcn_ubfe(wsel, (idx & 3u) * 8u, 8u) : 0u;
-        uint32_t child = (uint32_t)grp_sum<G>((int)byte);
+        for (int j = 1; j < KPL / 4; ++j) { wsel = (idx >> 2) == (uint32_t)j ? cdw.w[j] : wsel; rsel = (idx >> 2) == (uint32_t)j ? rkw.w[j] : rsel; }
+        // (child id in bits 0..7, rank in bits 8..15 of one sum: both are 0 in every lane but the one that owns the action)
+        const uint32_t both = idx < (uint32_t)KPL ? __builtin_amdgcn_ubfe(wsel, (idx & 3u) * 8u, 8u) | (__builtin_amdgcn_ubfe(rsel, (idx & 3u) * 8u, 8u) << 8) : 0u;
+        const uint32_t cr = (uint32_t)grp_sum<G>((int)both);
+        uint32_t child = cr & 0xffu;
+        const uint32_t rank = cr >> 8;                                         // (the rank bytes of this item's own new edge are already in rkw)
         if (bestmove == fix_move) child = fix_child;                           // the child registered by this very item
-        return (uint32_t)bestmove | (child << 8) | NX_VALID;
+        return (uint32_t)bestmove | (child << 8) | NX_VALID | (rank << 17);
     };
 
     // one work item's rows -> registers (zeros for a lane-group without an item).  entry: node | move << 8 | depth << 16 | game << 24
@@ -230,27 +239,40 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
                 R.valid = true; R.gi = (int)(R.ent >> 24) & 7;
             }
         }
-        const uint32_t node = R.ent & 0xffu, move = (R.ent >> 8) & 0xffu;
-        // a lane-group without an item reads the root record of its own game (ent == 0: node 0, move 0) — finite numbers, the engine
+        // entry: node | mr << 8 | ...: mr = the ACTION of a new edge (special item with SP_CREATED), else the creation rank + 1 of
+        // the edge taken
+        const uint32_t node = R.ent & 0xffu, mr = (R.ent >> 8) & 0xffu;
+        const bool crt = r == 0 && g < GPW && (R.ent & SP_CREATED);
+        // a lane-group without an item reads the root record of its own game (ent == 0: node 0) — finite numbers, the engine
         // clears the records once at creation — with prior_rem = 0 and no children: its Newton loop ends in the first iteration and
         // nothing it computes is stored.  The loads are unconditional (no branch, no zero fill of 30 registers per round).
         const uint32_t nd = (uint32_t)((R.valid ? R.gi : gl) * V) + node;
-        const uint8_t* const rec = wrecs + nd * (uint32_t)ROWS;
+        const uint8_t* const rec = wrecs + __umul24(nd, ROWS);
         {
             const uint4 ax = waux[nd];
-            R.ax_x = R.valid ? ax.x : 0u; R.ax_z = R.valid ? ax.z : 0u;
+            R.ax_x = ax.x; R.ax_z = ax.z;                             // (raw: nothing here may wait for a load — the item body masks them)
 #pragma unroll
             for (int j = 0; j < KPL; j += 4) {
                 const float4 a = *reinterpret_cast<const float4*>(rec + (uint32_t)(k0 + j) * 4u);
                 R.p[j] = a.x; R.p[j + 1] = a.y; R.p[j + 2] = a.z; R.p[j + 3] = a.w;
-                const float4 b = *reinterpret_cast<const float4*>(rec + OFF_Q + (uint32_t)(k0 + j) * 4u);
-                R.q[j] = b.x; R.q[j + 1] = b.y; R.q[j + 2] = b.z; R.q[j + 3] = b.w;
                 R.rk[j / 4] = *reinterpret_cast<const uint32_t*>(rec + OFF_RK + (uint32_t)(k0 + j));
                 R.cd[j / 4] = *reinterpret_cast<const uint32_t*>(rec + OFF_CID + (uint32_t)(k0 + j));
             }
-            R.pm = reinterpret_cast<const float*>(rec)[move];
-            R.qm = reinterpret_cast<const float*>(rec + OFF_Q)[move];
-            R.vism = rec[OFF_VIS + move];
+            // the edge taken: an existing one is entry mr - 1 of the list; a new one has q = 0, no visit, and the prior of its action
+            const uint32_t er = (crt || mr == 0u) ? 0u : mr - 1u;
+            const float2 em = *reinterpret_cast<const float2*>(rec + OFF_EL + er * 8u);
+            const uint32_t vm = rec[OFF_VIS + er];
+            R.pm = reinterpret_cast<const float*>(rec)[crt ? mr : 0u];
+            R.qm = em.x; R.vism = vm;                                 // (raw: a new edge ignores them)
+            // the node's edges for the Newton sums and the per-action q: entry sub of every item; a root (node 0: the node that collects
+            // children) also entries 8 + sub, 16 + sub, 24 + sub — what lies beyond is fetched when the item is processed
+            R.e0 = *reinterpret_cast<const float2*>(rec + OFF_EL + (uint32_t)sub * 8u);
+            R.e1 = R.e2 = R.e3 = make_float2(0.0f, 0.0f);
+            if (node == 0u) {
+                R.e1 = *reinterpret_cast<const float2*>(rec + OFF_EL + (uint32_t)(8 + sub) * 8u);
+                if (V > 16) R.e2 = *reinterpret_cast<const float2*>(rec + OFF_EL + (uint32_t)(16 + sub) * 8u);
+                if (V > 24) R.e3 = *reinterpret_cast<const float2*>(rec + OFF_EL + (uint32_t)(24 + sub) * 8u);
+            }
         }
     };
 
@@ -269,7 +291,9 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
         uint32_t v = 0u;
         if (valid) {
             const uint32_t nd = (uint32_t)(gi * V) + (ent & 0xffu);
-            v = *reinterpret_cast<const uint32_t*>(wrecs + nd * (uint32_t)ROWS + (uint32_t)sub * 128u);
+            // the per-action rows and the head of the edge list (6 A2 + 128 bytes), then the line of the visit bytes
+            const uint32_t toff = (uint32_t)sub * 128u < (uint32_t)OFF_EL + 128u ? (uint32_t)sub * 128u : OFF_VIS;
+            v = *reinterpret_cast<const uint32_t*>(wrecs + __umul24(nd, ROWS) + toff);
             if (sub == 0) v ^= reinterpret_cast<const uint32_t*>(waux + nd)[0];
         }
         return v;
@@ -392,15 +416,13 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
             ChildWords<KPL> nocd;
 #pragma unroll
             for (int j = 0; j < KPL / 4; ++j) nocd.w[j] = 0u;
-            const uint32_t nx = sample_next(x, st0, ul, nocd, -1, 0u);
-            uint8_t* rec = wrecs + (gnode0 + (uint32_t)lf) * (uint32_t)ROWS;
+            const uint32_t nx = sample_next(x, st0, ul, nocd, nocd, -1, 0u);
+            uint8_t* rec = wrecs + __umul24(gnode0 + (uint32_t)lf, ROWS);
 #pragma unroll
-            for (int j = 0; j < KPL; j += 4) {
+            for (int j = 0; j < KPL; j += 4) {                        // (the per-action rows only: a fresh node has no edge)
                 *reinterpret_cast<float4*>(rec + (size_t)(k0 + j) * 4) = make_float4(x[j], x[j + 1], x[j + 2], x[j + 3]);
-                *reinterpret_cast<float4*>(rec + OFF_Q + (size_t)(k0 + j) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
                 *reinterpret_cast<uint32_t*>(rec + OFF_RK + (size_t)(k0 + j)) = 0u;
                 *reinterpret_cast<uint32_t*>(rec + OFF_CID + (size_t)(k0 + j)) = 0u;
-                *reinterpret_cast<uint32_t*>(rec + OFF_VIS + (size_t)(k0 + j)) = 0u;
             }
             ml |= M_EXPANDED;                                         // :256
             if (lead) {
@@ -435,8 +457,9 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
             }
             const bool valid = R.valid, special = r == 0 && g < GPW;
             const int gi = R.gi;   // PHASE items: fetch item
-            const int node = (int)(R.ent & 0xffu), move = (int)((R.ent >> 8) & 0xffu), dpt_e = (int)((R.ent >> 16) & 0xffu);
+            const int node = (int)(R.ent & 0xffu), mr = (int)((R.ent >> 8) & 0xffu), dpt_e = (int)((R.ent >> 16) & 0xffu);
             const bool created = special && (R.ent & SP_CREATED);
+            const int move = created ? mr : -1;                       // the action of a NEW edge (an old one is known by its rank)
             const uint32_t ind = (uint32_t)((valid ? gi : gl) * V) + (uint32_t)(R.ent & 0xffu);   // the item's node in the wave's arrays
             const float4 vt = valtab[gi];
             const uint32_t vflags = __float_as_uint(vt.z);
@@ -445,58 +468,89 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
             const int dpt = special ? D - 1 : dpt_e;                  // depth of the item's node
             const int level = D - 1 - dpt;
             const float w = (level & 1) ? vt.y : vt.x;                // 1 - value at this level
-            uint8_t* const rec = wrecs + ind * (uint32_t)ROWS;
+            uint8_t* const rec = wrecs + __umul24(ind, ROWS);
             STAMPW(3);
-            // ---- backUp of this edge (:319-320)   // PHASE items: backUp of the edge, prior_rem re-sum, q patch
-            const float vis = (float)R.vism;
+            // ---- backUp of this edge (:319-320)   // PHASE items: backUp of the edge, prior_rem re-sum
+            const uint32_t ax_z = valid ? R.ax_z : 0u;                // (a group without an item: no visits, no children, prior_rem 0)
+            const uint32_t vism = created ? 0u : R.vism;              // a new edge: q = 0, no visit yet
+            const float qm = created ? 0.0f : R.qm;
+            const float vis = (float)vism;
             float nq;
             if (__builtin_expect(__ballot(valid && iterm) != 0, 0)) {
-                const float nqf = (vis * R.qm + w) / (vis + 1.0f);
-                const float nqd = (float)(((double)(vis * R.qm) + (double)w) / (double)(vis + 1.0f));
+                const float nqf = (vis * qm + w) / (vis + 1.0f);
+                const float nqd = (float)(((double)(vis * qm) + (double)w) / (double)(vis + 1.0f));
                 nq = iterm ? nqd : nqf;
-            } else nq = (vis * R.qm + w) / (vis + 1.0f);
-            const uint32_t npos = R.ax_z & 0xffu, nvis = ((R.ax_z >> 8) & 0xffu) + 1u, nch_old = (R.ax_z >> 16) & 0xffu;
+            } else nq = (vis * qm + w) / (vis + 1.0f);
+            const uint32_t npos = ax_z & 0xffu, nvis = ((ax_z >> 8) & 0xffu) + 1u, nch_old = (ax_z >> 16) & 0xffu;
             const uint32_t nch = nch_old + (created ? 1u : 0u);
-            float prem_raw = __uint_as_float(R.ax_x);                 // sum of the priors of childless actions, before lambda
+            const uint32_t rank1 = created ? nch : (uint32_t)mr;      // creation rank + 1 of the edge taken (:183-191 for a new one)
+            ChildWords<KPL> rkw;                                      // rank bytes of the block, the new edge registered
+            {   const uint32_t idx = (uint32_t)(move - k0);
+#pragma unroll
+                for (int j = 0; j < KPL / 4; ++j) rkw.w[j] = (created && (idx >> 2) == (uint32_t)j) ? (R.rk[j] | (nch << ((idx & 3u) * 8u))) : R.rk[j];
+            }
+            float prem_raw = valid ? __uint_as_float(R.ax_x) : 0.0f;   // sum of the priors of childless actions, before lambda
             if (__builtin_expect(__ballot(valid && created) != 0, 0)) {
                 // the node loses one childless action: re-sum prior_rem in source order (:120-124), once per rollout
                 float m[KPL];
 #pragma unroll
                 for (int j = 0; j < KPL; ++j) {
-                    const uint32_t rk = (R.rk[j / 4] >> (8 * (j & 3))) & 0xffu;
-                    m[j] = (created && rk == 0 && k0 + j != move) ? R.p[j] : 0.0f;
+                    const uint32_t rk = (rkw.w[j / 4] >> (8 * (j & 3))) & 0xffu;
+                    m[j] = (created && rk == 0) ? R.p[j] : 0.0f;
                 }
                 float tot;
                 (void)grp_ordered_start<KPL, true>(m, sub, tot, nlanes);
                 prem_raw = created ? tot : prem_raw;
             }
             if (valid && lead) {
-                reinterpret_cast<float*>(rec + OFF_Q)[move] = nq;
-                rec[OFF_VIS + move] = (uint8_t)(R.vism + 1u);
-                if (created) { rec[OFF_RK + move] = (uint8_t)nch; rec[OFF_CID + move] = (uint8_t)ileaf; }   // creation rank + 1, node id (:183-191)
+                float2* const el = reinterpret_cast<float2*>(rec + OFF_EL) + (rank1 - 1u);
+                if (created) {
+                    *el = make_float2(nq, R.pm);                      // the new edge: q, prior of its action
+                    rec[OFF_RK + move] = (uint8_t)nch; rec[OFF_CID + move] = (uint8_t)ileaf;   // creation rank + 1, node id (:183-191)
+                } else el->x = nq;
+                rec[OFF_VIS + (rank1 - 1u)] = (uint8_t)(vism + 1u);
             }
-            const uint32_t auxz = npos | (nvis << 8) | (nch << 16) | (R.ax_z & AUX_SLOW);
-            const bool FDr = FD && !__ballot(valid && (R.ax_z & AUX_SLOW));      // (wave-uniform)
+            const uint32_t auxz = npos | (nvis << 8) | (nch << 16) | (ax_z & AUX_SLOW);
+            const bool FDr = FD && !__ballot(ax_z & AUX_SLOW);      // (wave-uniform)
             if (!recompute) {
                 if (valid && lead) waux[ind] = make_uint4(__float_as_uint(prem_raw), 0u, auxz, 0u);
                 if constexpr (PF) { if (r + 1 < rounds) item_fetch(R, r + 1, nwl); }
                 continue;
             }
-            {   const int idx = move - k0;                            // the row in registers follows the update
-#pragma unroll
-                for (int j = 0; j < KPL; ++j) R.q[j] = (j == idx) ? nq : R.q[j];
-            }
             STAMPW(4);
-            // ---- Newton inputs in creation order (:144-148): the rank stored with the child id is the place   // PHASE items: Newton inputs (rank scatter)
-            // (no branch: an action without a child, rank byte 0, writes the unused slot in front of the table)
+            // ---- the node's edges in creation order -> the group's table (Newton's sums :144-148 read them by rank, the per-action   // PHASE items: edge table
+            // q by the rank byte of the action)
+            {
+                const uint32_t no = valid ? nch_old : 0u;              // (a group without an item has no edge)
+                tab[sub] = (uint32_t)sub < no ? R.e0 : make_float2(0.0f, 0.0f);
+                if (__builtin_expect(__ballot(no > 8u) != 0, 0)) {
+                    // a root's entries 8 .. 31 arrived with the item; any other node with more than 8 children, and a root's
+                    // entries from 32 on, are read here (rare)
+                    const bool pre = node == 0;
+                    float2 e[3] = {R.e1, R.e2, R.e3};
+#pragma unroll
+                    for (int b = 1; b < 4; ++b) {
+                        const uint32_t i = (uint32_t)(8 * b + sub);
+                        if (__ballot(no > (uint32_t)(8 * b)) == 0) break;
+                        float2 ev = e[b - 1];
+                        if (!pre && i < no) ev = *reinterpret_cast<const float2*>(rec + OFF_EL + i * 8u);
+                        if (i < no) tab[i] = ev;
+                    }
+                    for (uint32_t b8 = 32u; __ballot(no > b8) != 0; b8 += 8u) {
+                        const uint32_t i = b8 + (uint32_t)sub;
+                        if (i < no) tab[i] = *reinterpret_cast<const float2*>(rec + OFF_EL + i * 8u);
+                    }
+                }
+            }
+            AGZ_WSYNC();
+            if (valid && lead) { if (created) tab[rank1 - 1u] = make_float2(nq, R.pm); else tab[rank1 - 1u].x = nq; }   // the edge just updated
+            AGZ_WSYNC();
+            float qa[KPL];                                            // q by action: an action without a child reads the zero pair
 #pragma unroll
             for (int j = 0; j < KPL; ++j) {
-                const int rk = (int)((R.rk[j / 4] >> (8 * (j & 3))) & 0xffu);
-                tabp[rk - 1] = R.p[j]; tabq[rk - 1] = R.q[j];
+                const int rk = (int)((rkw.w[j / 4] >> (8 * (j & 3))) & 0xffu);
+                qa[j] = tab[rk - 1].x;
             }
-            AGZ_WSYNC();
-            if (created && lead) { tabp[nch - 1] = R.pm; tabq[nch - 1] = nq; }
-            AGZ_WSYNC();
             // ---- :116-138   // PHASE items: lambda, alpha0
             const float nf = 1.0f + (float)nvis, Af = (float)npos;
             const float lnum = T.cpuct * sqrt_count(nf), lden = Af + nf;
@@ -507,7 +561,7 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
             for (int j = 0; j < KPL; ++j) {
                 const float lp = lambda * R.p[j];
                 const float gap = lp > 1e-4f ? lp : 1e-4f;
-                const float c = R.q[j] + gap;
+                const float c = qa[j] + gap;
                 am = __builtin_fmaxf(c, am);                          // (no NaN can occur: one v_max_f32)
             }
             float alpha = grp_max<G>(am);
@@ -521,7 +575,7 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
                 const bool v0 = sub <= (int)nch;
                 float top0 = 0.0f, qv0 = 0.0f;
                 if (sub == 0) top0 = prior_rem;
-                else if (v0) { top0 = lambda * tabp[sub - 1]; qv0 = tabq[sub - 1]; }
+                else if (v0) { const float2 e = tab[sub - 1]; top0 = lambda * e.y; qv0 = e.x; }
                 for (int it = 0; it < 100; ++it) {
                     float t, uu;
                     {
@@ -535,7 +589,8 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
                         const int c = j0 + sub;
                         const bool vc = c <= (int)nch;
                         const int ci = vc ? c - 1 : 0;
-                        const float top = lambda * tabp[ci], bot = alpha - tabq[ci];
+                        const float2 e = tab[ci];
+                        const float top = lambda * e.y, bot = alpha - e.x;
                         if (FDr) fd_div_pair(top, bot, -top, bot * bot, t, uu); else div_pair(top, bot, -top, bot * bot, t, uu);
                         t = vc ? t : 0.0f; uu = vc ? uu : 0.0f;
                         a += t; b += uu;
@@ -554,11 +609,11 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
             if (FDr) {
 #pragma unroll
                 for (int j = 0; j < KPL; j += 2)
-                    fd_div_pair(lambda * R.p[j], alpha - R.q[j], lambda * R.p[j + 1], alpha - R.q[j + 1], pol[j], pol[j + 1]);
+                    fd_div_pair(lambda * R.p[j], alpha - qa[j], lambda * R.p[j + 1], alpha - qa[j + 1], pol[j], pol[j + 1]);
             } else {
 #pragma unroll
                 for (int j = 0; j < KPL; j += 2)
-                    div_pair(lambda * R.p[j], alpha - R.q[j], lambda * R.p[j + 1], alpha - R.q[j + 1], pol[j], pol[j + 1]);
+                    div_pair(lambda * R.p[j], alpha - qa[j], lambda * R.p[j + 1], alpha - qa[j + 1], pol[j], pol[j + 1]);
             }
             ChildWords<KPL> cdk;
 #pragma unroll
@@ -578,7 +633,7 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
             float dummy;
             const float st = grp_ordered_start<KPL, false>(pol, sub, dummy, nlanes);
             const float u = dpt < 32 ? utab[gi * 32 + dpt] : uniform_search(T.seed, T.game_id[valid ? slot_base + gi : sl], T.step, SF.rollout - 1u, (uint32_t)dpt);
-            const uint32_t nx = sample_next(pol, st, u, cdk, created ? move : -1, (uint32_t)ileaf);
+            const uint32_t nx = sample_next(pol, st, u, cdk, rkw, move, (uint32_t)ileaf);
             if (valid && lead) waux[ind] = make_uint4(__float_as_uint(prem_raw), nx, auxz, 0u);
             STAMPW(8);
         }
@@ -617,12 +672,12 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
                         const uint64_t app = __ballot(lead);           // (only lanes of groups that go on are here)
                         if (lead) {
                             const uint32_t pos = wcount + (uint32_t)__popcll(app & ((1ull << lane) - 1ull));
-                            const uint32_t e = (uint32_t)node | ((uint32_t)move << 8) | ((uint32_t)(depth - 1) << 16) | ((uint32_t)g << 24);
+                            const uint32_t e = (uint32_t)node | (((nx >> 17) & 0x7fu) << 8) | ((uint32_t)(depth - 1) << 16) | ((uint32_t)g << 24);   // (an old edge goes by its rank)
                             if (LEAN && pos < wl_cap_lds) wl_lds[pos] = e; else wl_g[pos] = e;
                         }
                         node = child; nx = nxc;
                     } else {                                           // existing child that was never expanded: a terminal position
-                        spnew = (uint32_t)node | ((uint32_t)move << 8) | ((uint32_t)depth << 16) | SP_VALID;
+                        spnew = (uint32_t)node | (((nx >> 17) & 0x7fu) << 8) | ((uint32_t)depth << 16) | SP_VALID;
                         node = child;
                         descending = false;
                     }
