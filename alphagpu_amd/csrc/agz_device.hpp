@@ -128,7 +128,6 @@ struct TreePar {
     Pos* states;
     uint32_t* meta;
     uint32_t *ncount, *leaf, *game_id, *cnt_p, *cnt_new;
-    uint4* aux4;             // [L][V] {prior_rem before lambda, next word (action | child << 8 | valid), npos | nvis << 8 | nch << 16, -}
     uint32_t *wl, *wl_n, *sp;   // work lists [blocks][wl_cap], their lengths [blocks], last path node per slot [L]
     uint32_t wl_cap;
     int32_t fastdiv;         // operands of the tree's divisions are inside agz_fastdiv.hpp's range (bf16 mode, cpuct in [2^-10, 2^10])

@@ -127,7 +127,7 @@ struct agz_engine {
     small_fn k_small = nullptr; int small_maxl = 5120;   // 16-game workgroups of the whole-search kernel up to small_maxl games (AGZ_SMALL_MAXL): 2.60 vs 2.45 ms per ply at 6144 games, 2.90 vs 2.72 at 8192 with 32-game workgroups and sparse waves
     int reg3_max_waves = 0;      // largest grid the 3-waves-per-SIMD build of the stand-alone tree kernel is used for
     rollout_fn k_eager = nullptr, k_eager3 = nullptr;   // the tree kernel (agz_tree_eager.hpp), register budgets for 4 / 3 waves per SIMD
-    uint4* aux4 = nullptr; uint32_t *wl = nullptr, *wl_n = nullptr, *sp = nullptr; uint32_t wl_cap = 0;
+    uint32_t *wl = nullptr, *wl_n = nullptr, *sp = nullptr; uint32_t wl_cap = 0;
     size_t reg_lds = 0; int reg_kpl = 0;   // LDS of one tree wave; actions per lane (8 lanes per tree)
     uint32_t step_rollout = 0;   // stepwise API: rollout index of the last select
 
@@ -228,7 +228,7 @@ void agz_destroy(agz_engine* h) {
     hipFree(h->actf0); hipFree(h->actf1); hipFree(h->newpos); hipFree(h->alive); hipFree(h->newslot); hipFree(h->d_count);
     hipFree(h->s_boards); hipFree(h->s_policy); hipFree(h->s_move); hipFree(h->g_nplies); hipFree(h->g_result);
     hipFree(h->g_final); hipFree(h->d_stats); hipFree(h->d_acc); hipFree(h->scratch_f);
-    hipFree(h->aux4); hipFree(h->wl); hipFree(h->wl_n); hipFree(h->sp);
+    hipFree(h->wl); hipFree(h->wl_n); hipFree(h->sp);
     hipFree(h->d_order);
     hipFree(h->stage_dev); if (h->stage_host) hipHostFree(h->stage_host);
     free_net(h->net[0]); free_net(h->net[1]);
@@ -351,7 +351,6 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     {
         h->wl_cap = (uint32_t)(8 * h->V);
         wl_blocks = (size_t)h->Lmax + 64;                  // one block per tree wave; a forced AGZ_SMALL_GPW = 1 makes every game a wave
-        A_(dmalloc(&h->aux4, Lm * V));
         A_(dmalloc(&h->wl, wl_blocks * h->wl_cap)); A_(dmalloc(&h->wl_n, wl_blocks)); A_(dmalloc(&h->sp, Lm));
     }
     if (cfg->nn_mode == AGZ_NN_BF16) { uint16_t* p = nullptr; A_(dmalloc(&p, Lm * h->INP)); h->planes = p; }
@@ -379,12 +378,12 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
 
     TreePar& T = h->tp;
     memset(&T, 0, sizeof T);
-    T.G = P; T.V = h->V; T.rec_bytes = rec_bytes; T.off_q = A2 * 6; T.off_vis = A2 * 6 + 8 * (uint32_t)eager_vl(h->V); T.A2 = A2;   // (off_q: the edge list {q, prior} by rank)
+    T.G = P; T.V = h->V; T.rec_bytes = rec_bytes; T.off_q = 16 + A2 * 6; T.off_vis = 16 + A2 * 6 + 8 * (uint32_t)eager_vl(h->V); T.A2 = A2;   // (off_q: the edge list {q, prior} by rank)
     T.recs = h->recs; T.states = h->states; T.meta = h->meta; T.ncount = h->ncount; T.leaf = h->leaf; T.game_id = h->game_id;
     T.cnt_p = h->cnt_p; T.cnt_new = h->cnt_new; T.planes = h->planes; T.INP = h->INP; T.planes_f32 = cfg->nn_mode == AGZ_NN_EXACT;
     T.logits = h->logits; T.LGS = h->LGS; T.prior_eval = h->prior_eval; T.v_eval = h->v_eval; T.policy_final = h->policy_final;
     T.seed = cfg->seed; T.exact = cfg->nn_mode == AGZ_NN_EXACT;
-    T.aux4 = h->aux4; T.wl = h->wl; T.wl_n = h->wl_n; T.sp = h->sp; T.wl_cap = h->wl_cap;
+    T.wl = h->wl; T.wl_n = h->wl_n; T.sp = h->sp; T.wl_cap = h->wl_cap;
     FA_(hipMemsetAsync(h->wl_n, 0, wl_blocks * 4, h->stream)); hipMemsetAsync(h->sp, 0, Lm * 4, h->stream);
 #ifdef AGZ_STAMPS
     { unsigned long long* d = nullptr; hipMalloc((void**)&d, (size_t)65536 * 16 * 8); hipMemset(d, 0, (size_t)65536 * 16 * 8); T.dbg = d; }
@@ -983,7 +982,7 @@ static int stats_getter(agz_engine* h, float* out, int want_q) {
     HIPCHK(h, hipSetDevice(h->cfg.device));
     if (h->L == 0) return AGZ_OK;
     hipLaunchKernelGGL(k_root_stats, dim3((unsigned)h->L), dim3(128), 0, h->stream, (const uint8_t*)h->recs, (const uint32_t*)h->meta, h->V,
-                       h->tp.rec_bytes, h->tp.A2 * 4, h->tp.off_q, h->tp.off_vis, h->G.A, h->L, want_q ? (float*)nullptr : h->scratch_f,
+                       h->tp.rec_bytes, 16 + h->tp.A2 * 4, h->tp.off_q, h->tp.off_vis, h->G.A, h->L, want_q ? (float*)nullptr : h->scratch_f,
                        want_q ? h->scratch_f : (float*)nullptr);
     HIPCHK(h, hipGetLastError());
     return fetch(h, out, h->scratch_f, (size_t)h->L * h->G.A * 4);

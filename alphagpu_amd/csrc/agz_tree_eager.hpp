@@ -17,11 +17,12 @@
 //   * the descent follows those words: one 4-byte load per level, no arithmetic.
 // Same arithmetic, same order of every fp32 operation as the reference restated by the oracle; only the time at which a row is
 // computed changes.  Layout (A2 = 8 KPL >= A):
-//   rec[L][V]  [prior f32 x A2][rank u8 x A2][cid u8 x A2] by action: creation rank + 1 and node id of the child under each action
+//   rec[L][V]  [aux 16 bytes, below][prior f32 x A2][rank u8 x A2][cid u8 x A2] by action: creation rank + 1 and node id of the child under each action
 //              (0 = none); [edge {q, prior} f32x2 x VL][visits u8 x VL] by creation rank (VL = V rounded up to 16): the running
 //              mean and the visit count of the edge to the child — only as many entries as the node has children are ever
 //              read, and an expansion writes the per-action rows only (a fresh node has no edge)
-//   aux[L][V]  {prior_rem before lambda (:120-124), next word (action | child << 8 | valid << 16 | rank + 1 of the child << 17),
+//   aux        (the head of the record: the descent's look at a node brings in the cache line its item reads first)
+//              {prior_rem before lambda (:120-124), next word (action | child << 8 | valid << 16 | rank + 1 of the child << 17),
 //              npos | nvis << 8 | nch << 16, -}
 //   wl[block][8 V] work list of the wave (in LDS inside the whole-search kernel): one word per expanded node passed below which
 //   the descent went on; sp[slot]: the last expanded node of the path (the parent of the leaf) — these 8 items are processed
@@ -76,9 +77,9 @@ __device__ __forceinline__ uint32_t legal_block(const GamePar& P, const WPos<NC>
     return m & ((1u << nval) - 1u);
 }
 
-// bytes of a node record [prior f32 x A2][rank u8 x A2][cid u8 x A2][edge f32x2 x VL][visits u8 x VL] (A2 a multiple of 32)
+// bytes of a node record [aux uint4][prior f32 x A2][rank u8 x A2][cid u8 x A2][edge f32x2 x VL][visits u8 x VL] (A2 a multiple of 32)
 __host__ __device__ constexpr int eager_vl(int V) { return (V + 15) & ~15; }
-__host__ __device__ constexpr int eager_rec_bytes(int A2, int V) { return 6 * A2 + 9 * eager_vl(V); }
+__host__ __device__ constexpr int eager_rec_bytes(int A2, int V) { return 16 + 6 * A2 + 9 * eager_vl(V); }
 
 struct EagerLds { int tab, tstride, val, utab, total; };
 __host__ __device__ inline EagerLds eager_lds_layout(int V) {
@@ -139,7 +140,7 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
     // the row geometry follows from KPL alone (the engine lays the records out with the same formulas): compile-time offsets,
     // so that every load / store of a row is one base address + an immediate
     constexpr int A2 = G * KPL;
-    constexpr int OFF_RK = 4 * A2, OFF_CID = 5 * A2, OFF_EL = 6 * A2;   // per-action rows, then the edge list by rank ...
+    constexpr int OFF_P = 16, OFF_RK = 16 + 4 * A2, OFF_CID = 16 + 5 * A2, OFF_EL = 16 + 6 * A2;   // aux, per-action rows, then the edge list by rank ...
     const int A = P.A, V = T.V;
     const uint32_t OFF_VIS = (uint32_t)(OFF_EL + 8 * eager_vl(V)), ROWS = (uint32_t)eager_rec_bytes(A2, V);   // ... and the visit bytes by rank
     const EagerLds LO = eager_lds_layout(V);
@@ -171,7 +172,7 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
     // (a wave of the ragged last workgroup may own no game at all: its idle loads then go to the launch's first game)
     const int mem_base = slot_base < T.L ? slot_base : T.slot0;
     uint8_t* const wrecs = T.recs + (size_t)mem_base * (size_t)V * ROWS;
-    uint4* const waux = T.aux4 + (size_t)mem_base * (size_t)V;
+    auto auxp = [&](const uint32_t nd_) -> uint4* { return reinterpret_cast<uint4*>(wrecs + __umul24(nd_, ROWS)); };   // a node's aux words
     uint32_t* const wmeta = T.meta + (size_t)mem_base * (size_t)V;
     Pos* const wstates = T.states + (size_t)mem_base * (size_t)V;
     const int gl = live ? g : 0;                                                  // this group's game inside the wave (0 when it has none)
@@ -249,11 +250,11 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
         const uint32_t nd = (uint32_t)((R.valid ? R.gi : gl) * V) + node;
         const uint8_t* const rec = wrecs + __umul24(nd, ROWS);
         {
-            const uint4 ax = waux[nd];
+            const uint4 ax = *reinterpret_cast<const uint4*>(rec);
             R.ax_x = ax.x; R.ax_z = ax.z;                             // (raw: nothing here may wait for a load — the item body masks them)
 #pragma unroll
             for (int j = 0; j < KPL; j += 4) {
-                const float4 a = *reinterpret_cast<const float4*>(rec + (uint32_t)(k0 + j) * 4u);
+                const float4 a = *reinterpret_cast<const float4*>(rec + OFF_P + (uint32_t)(k0 + j) * 4u);
                 R.p[j] = a.x; R.p[j + 1] = a.y; R.p[j + 2] = a.z; R.p[j + 3] = a.w;
                 R.rk[j / 4] = *reinterpret_cast<const uint32_t*>(rec + OFF_RK + (uint32_t)(k0 + j));
                 R.cd[j / 4] = *reinterpret_cast<const uint32_t*>(rec + OFF_CID + (uint32_t)(k0 + j));
@@ -262,7 +263,7 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
             const uint32_t er = (crt || mr == 0u) ? 0u : mr - 1u;
             const float2 em = *reinterpret_cast<const float2*>(rec + OFF_EL + er * 8u);
             const uint32_t vm = rec[OFF_VIS + er];
-            R.pm = reinterpret_cast<const float*>(rec)[crt ? mr : 0u];
+            R.pm = reinterpret_cast<const float*>(rec + OFF_P)[crt ? mr : 0u];
             R.qm = em.x; R.vism = vm;                                 // (raw: a new edge ignores them)
             // the node's edges for the Newton sums and the per-action q: entry sub of every item; a root (node 0: the node that collects
             // children) also entries 8 + sub, 16 + sub, 24 + sub — what lies beyond is fetched when the item is processed
@@ -291,10 +292,9 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
         uint32_t v = 0u;
         if (valid) {
             const uint32_t nd = (uint32_t)(gi * V) + (ent & 0xffu);
-            // the per-action rows and the head of the edge list (6 A2 + 128 bytes), then the line of the visit bytes
+            // aux + the per-action rows and the head of the edge list (16 + 6 A2 + 128 bytes), then the line of the visit bytes
             const uint32_t toff = (uint32_t)sub * 128u < (uint32_t)OFF_EL + 128u ? (uint32_t)sub * 128u : OFF_VIS;
             v = *reinterpret_cast<const uint32_t*>(wrecs + __umul24(nd, ROWS) + toff);
-            if (sub == 0) v ^= reinterpret_cast<const uint32_t*>(waux + nd)[0];
         }
         return v;
     };
@@ -420,14 +420,14 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
             uint8_t* rec = wrecs + __umul24(gnode0 + (uint32_t)lf, ROWS);
 #pragma unroll
             for (int j = 0; j < KPL; j += 4) {                        // (the per-action rows only: a fresh node has no edge)
-                *reinterpret_cast<float4*>(rec + (size_t)(k0 + j) * 4) = make_float4(x[j], x[j + 1], x[j + 2], x[j + 3]);
+                *reinterpret_cast<float4*>(rec + OFF_P + (size_t)(k0 + j) * 4) = make_float4(x[j], x[j + 1], x[j + 2], x[j + 3]);
                 *reinterpret_cast<uint32_t*>(rec + OFF_RK + (size_t)(k0 + j)) = 0u;
                 *reinterpret_cast<uint32_t*>(rec + OFF_CID + (size_t)(k0 + j)) = 0u;
             }
             ml |= M_EXPANDED;                                         // :256
             if (lead) {
                 gmeta[lf] = ml;
-                waux[gnode0 + (uint32_t)lf] = make_uint4(__float_as_uint(total), nx, (uint32_t)npos | (wide ? AUX_SLOW : 0u), 0u);
+                *reinterpret_cast<uint4*>(rec) = make_uint4(__float_as_uint(total), nx, (uint32_t)npos | (wide ? AUX_SLOW : 0u), 0u);
             }
         } else if (__builtin_expect(live && lf == 0, 0)) {
 #pragma unroll
@@ -513,7 +513,7 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
             const uint32_t auxz = npos | (nvis << 8) | (nch << 16) | (ax_z & AUX_SLOW);
             const bool FDr = FD && !__ballot(ax_z & AUX_SLOW);      // (wave-uniform)
             if (!recompute) {
-                if (valid && lead) waux[ind] = make_uint4(__float_as_uint(prem_raw), 0u, auxz, 0u);
+                if (valid && lead) *reinterpret_cast<uint4*>(rec) = make_uint4(__float_as_uint(prem_raw), 0u, auxz, 0u);
                 if constexpr (PF) { if (r + 1 < rounds) item_fetch(R, r + 1, nwl); }
                 continue;
             }
@@ -634,7 +634,7 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
             const float st = grp_ordered_start<KPL, false>(pol, sub, dummy, nlanes);
             const float u = dpt < 32 ? utab[gi * 32 + dpt] : uniform_search(T.seed, T.game_id[valid ? slot_base + gi : sl], T.step, SF.rollout - 1u, (uint32_t)dpt);
             const uint32_t nx = sample_next(pol, st, u, cdk, rkw, move, (uint32_t)ileaf);
-            if (valid && lead) waux[ind] = make_uint4(__float_as_uint(prem_raw), nx, auxz, 0u);
+            if (valid && lead) *reinterpret_cast<uint4*>(rec) = make_uint4(__float_as_uint(prem_raw), nx, auxz, 0u);
             STAMPW(8);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");        // rows written by one lane-group are read by the descent of another
@@ -650,7 +650,7 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
         if constexpr (LEAN) __builtin_amdgcn_s_setprio(2);
         // every expanded node carries the action its next visit samples and the child under it: the descent follows the words
         int node = 0, depth = 0;
-        uint32_t nx = (live && C.root_exp) ? waux[gnode0].y : 0u;
+        uint32_t nx = (live && C.root_exp) ? auxp(gnode0)->y : 0u;
         bool descending = (nx & NX_VALID) != 0;
         int create_from = -1, create_move = 0;
         uint32_t spnew = 0u;
@@ -666,7 +666,7 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
                     spnew = (uint32_t)node | ((uint32_t)move << 8) | ((uint32_t)depth << 16) | SP_VALID | SP_CREATED;
                     descending = false;
                 } else {
-                    const uint32_t nxc = waux[gnode0 + (uint32_t)child].y;     // (cleared when the child was created, set by its expansion)
+                    const uint32_t nxc = auxp(gnode0 + (uint32_t)child)->y;     // (cleared when the child was created, set by its expansion)
                     STAMPW(11);
                     if (nxc & NX_VALID) {                              // expanded child: the descent goes on (:192)
                         const uint64_t app = __ballot(lead);           // (only lanes of groups that go on are here)
@@ -705,7 +705,7 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
                 ++C.add_new;
                 wstates[gnode0 + child] = pack(lst);
                 gmeta[child] = mc;
-                reinterpret_cast<uint32_t*>(waux + (gnode0 + child))[1] = 0u;      // not expanded: no next word yet
+                reinterpret_cast<uint32_t*>(auxp(gnode0 + child))[1] = 0u;      // not expanded: no next word yet
             }
             mn = mc; node = (int)child;
         } else if (live) mn = gmeta[node];
