@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak (same guide)
+SIMDS, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs; one VALU instruction of a 64-wide wavefront occupies a SIMD for 4 cycles
 
 CONFIGS = {                    # BASELINE.json configs[k-1]
     1: dict(game="gobang", n=3, nvict=3, games=256, rollouts=16, filters=128, towers=6),
@@ -235,11 +236,19 @@ def main():
         alg = algorithmic_bytes(game, sum_p, sum_new, r_cnt, S)
         gl, gname = game_label(args)
         traffic = None          # HBM bytes per launch from the committed PMC passes, scaled by this run's algorithmic bytes
+        valu_obj = None         # VALU-issue roofline of the same kernel: SQ_INSTS_VALU (PMC pass) x 4 cycles / (SIMDs x clock x time)
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             key = f"{gl}_{V}_{args.filters}x{args.towers}"
             if key in pm:
                 traffic = pm[key]["traffic_over_algorithmic"] * alg / max(launches, 1)
+                if "valu_insts_per_rollout" in pm[key] and busy_ms > 0:
+                    insts = pm[key]["valu_insts_per_rollout"] * r_cnt      # wave-instructions of the instrumented searches
+                    valu_obj = {"bound": "valu", "achieved": insts / (busy_ms * 1e-3) / 1e9, "peak": SIMDS * CLOCK_HZ / 4 / 1e9,
+                                "unit": "G wave-instructions/s", "frac": insts * 4 / (SIMDS * CLOCK_HZ * busy_ms * 1e-3),
+                                "note": "SQ_INSTS_VALU per (game, rollout) of the first-ply PMC pass (profiles/pmc_traffic.json) x this run's "
+                                        "rollouts; 4 cycles per wave-instruction on 1024 SIMDs at 2.4 GHz (the counters show ~2.0 GHz under "
+                                        "this load: the real issue utilisation is ~1.2 x higher)"}
         except Exception:
             traffic = None
         hbm_achieved = alg / (busy_ms * 1e-3) / 1e9 if busy_ms > 0 else 0.0   # aggregate over the launches in flight together
@@ -280,6 +289,8 @@ def main():
                        "parallelism": f"game-shard x{world}, RCCL all-gather of samples at generation end" if world > 1 else "single GPU"},
             "roofline": nn_obj if nn_dominant else tree_obj,
             "roofline_other": tree_obj if nn_dominant else nn_obj,
+            "roofline_valu": valu_obj,
+            "value_with_host_delivery": (host or {}).get("rollouts_per_s_with_delivery_into_PoolSample"),
             "rank0": {"search_only_rollouts_per_s": rollouts / search_s if search_s > 0 else None,
                       "search_kernel_ms": tree_ms, "network_kernel_ms": nn_ms, "search_ms": search_s * 1e3,
                       "instrumented_rollouts": r_cnt, "plies": plies, "samples": nsamples, "wall_s": dt,
