@@ -56,7 +56,9 @@ __host__ __device__ inline int nw_hidden_groups(int INP, int H, int T) {
 // larger LT when the batch is big enough for the L2 weight stream to become the bound).
 // DEPTH = groups (layers) of weight fragments in flight per wave: 4 hides the whole L2 latency behind one workgroup's own
 // work, 2 halves the registers so that twice as many workgroups share a CU (throughput mode for big batches).
-template <int H, int LT, int DEPTH, bool PRE_BARRIER = false, bool IO = false>
+// ZC: a group that opens a layer accumulates from the constant 0 instead of cleared registers (16 moves less per layer; the
+// duplicated first k-step costs registers: not in the 128-register build of the whole-search kernel, where it spills)
+template <int H, int LT, int DEPTH, bool PRE_BARRIER = false, bool IO = false, bool ZC = false>
 __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const smem, const int bidx, uint8_t* const io = nullptr,
                                               const int io_bw = 0, const int io_lgs = 0);
 
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(64 * NW_WAVES) void k_mlp_wave(const Fused3Par P) {
 // owns tile rows 8 w .. 8 w + 7 has left their planes in block w of `io` (io_bw bytes per block, rows of PROWB bytes, zero padded),
 // and the head leaves logits (and the value in column A) in the same block, rows of io_lgs floats; the global arrays are not
 // written (agz_get_logits reads what the stepwise API's network launch left).
-template <int H, int LT, int DEPTH, bool PRE_BARRIER, bool IO>
+template <int H, int LT, int DEPTH, bool PRE_BARRIER, bool IO, bool ZC>
 __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const smem, const int bidx, uint8_t* const io, const int io_bw,
                                               const int io_lgs) {
     constexpr int NTH = H / 16, KTH = H / 32, TPW = NTH / NW_WAVES;
@@ -142,7 +144,21 @@ __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const
         const uint8_t* const brow_ = g_ < G0 ? prow0 + (size_t)g_ * KTH * 64                             \
                                              : act0 + (size_t)cur * ML * ROWB + (size_t)lrow * ROWB;    \
         const int bstride_ = g_ < G0 ? pstride : 16 * ROWB;       /* next 16-leaf tile */               \
-        _Pragma("unroll") for (int k = 0; k < KTH; ++k)                                                 \
+        /* a group that opens a layer accumulates from the constant 0 (no clearing of 16 registers per layer) */ \
+        if (ZC && (g_ == 0 || g_ >= G0)) {                                                              \
+            _Pragma("unroll") for (int lt = 0; lt < LT; ++lt) {                                         \
+                const bf16x8 b_ = *reinterpret_cast<const bf16x8*>(brow_ + (size_t)lt * bstride_ + q4 * 16); \
+                _Pragma("unroll") for (int t = 0; t < TPW; ++t)                                         \
+                    acc[lt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[d][0][t], b_, (f32x4){0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0); \
+            }                                                                                           \
+        } else {                                                                                        \
+            _Pragma("unroll") for (int lt = 0; lt < LT; ++lt) {                                         \
+                const bf16x8 b_ = *reinterpret_cast<const bf16x8*>(brow_ + (size_t)lt * bstride_ + q4 * 16); \
+                _Pragma("unroll") for (int t = 0; t < TPW; ++t)                                         \
+                    acc[lt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[d][0][t], b_, acc[lt][t], 0, 0, 0); \
+            }                                                                                           \
+        }                                                                                               \
+        _Pragma("unroll") for (int k = 1; k < KTH; ++k)                                                 \
             _Pragma("unroll") for (int lt = 0; lt < LT; ++lt) {                                         \
                 const bf16x8 b_ = *reinterpret_cast<const bf16x8*>(brow_ + (size_t)lt * bstride_ + k * 64 + q4 * 16); \
                 _Pragma("unroll") for (int t = 0; t < TPW; ++t)                                         \
@@ -165,7 +181,7 @@ __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const
                         /* (no second relu: b >= 0 and relu(W b) >= 0, so the sum is its own relu, bit for bit) */ \
                     }                                                                                   \
                     *reinterpret_cast<uint2*>(new_ + n * 2) = make_uint2(pk_bf16(x0, x1), pk_bf16(x2, x3)); \
-                    acc[lt][t] = zero4;                                                                 \
+                    if constexpr (!ZC) acc[lt][t] = zero4;                                              \
                 }                                                                                       \
             }                                                                                           \
             cur ^= 1;                                                                                   \

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(64 * NW_WAVES, WV) void k_search_small(const SmallP
             // and child creation in the tree step: dependent loads) go first, so that the waves get back to the arithmetic of the
             // work items sooner (measured -1.6 % per generation)
             __builtin_amdgcn_s_setprio(3);
-            mlp_wave_body<H, TW / 2, 2, true, true>(S.F, nn_lds, bx, lds_small + S.io_off, S.io_bw, S.io_lgs);
+            mlp_wave_body<H, TW / 2, 2, true, true, (WV < 4)>(S.F, nn_lds, bx, lds_small + S.io_off, S.io_bw, S.io_lgs);
             __syncthreads();                                      // logits and values are visible to the tree waves
             __builtin_amdgcn_s_setprio(0);
         }
