@@ -672,12 +672,12 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
                         const uint64_t app = __ballot(lead);           // (only lanes of groups that go on are here)
                         if (lead) {
                             const uint32_t pos = wcount + (uint32_t)__popcll(app & ((1ull << lane) - 1ull));
-                            const uint32_t e = (uint32_t)node | (((nx >> 17) & 0x7fu) << 8) | ((uint32_t)(depth - 1) << 16) | ((uint32_t)g << 24);   // (an old edge goes by its rank)
+                            const uint32_t e = (uint32_t)node | (((nx >> 17) & 0xffu) << 8) | ((uint32_t)(depth - 1) << 16) | ((uint32_t)g << 24);   // (an old edge goes by its rank)
                             if (LEAN && pos < wl_cap_lds) wl_lds[pos] = e; else wl_g[pos] = e;
                         }
                         node = child; nx = nxc;
                     } else {                                           // existing child that was never expanded: a terminal position
-                        spnew = (uint32_t)node | (((nx >> 17) & 0x7fu) << 8) | ((uint32_t)depth << 16) | SP_VALID;
+                        spnew = (uint32_t)node | (((nx >> 17) & 0xffu) << 8) | ((uint32_t)depth << 16) | SP_VALID;
                         node = child;
                         descending = false;
                     }

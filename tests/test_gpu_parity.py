@@ -92,7 +92,8 @@ def test_exact_search_matches_golden(path):
 @pytest.mark.parametrize("name,L,V,H,T", [
     ("tictactoe", 64, 16, 128, 6), ("gobang9", 48, 64, 128, 6), ("connect4", 64, 64, 128, 6),
     ("hex9", 24, 128, 64, 2), ("reversi8", 32, 64, 64, 3), ("reversi6", 32, 48, 32, 2),
-    ("gobang13", 12, 32, 32, 1), ("hex11", 8, 24, 32, 1)])
+    ("gobang13", 12, 32, 32, 1), ("hex11", 8, 24, 32, 1),
+    ("gobang9", 6, 200, 32, 1), ("connect4", 6, 256, 32, 1)])        # trees of more than 128 nodes (rank / child ids above 127)
 def test_exact_search_matches_oracle(name, L, V, H, T):
     g, og = spec(name)
     net, onet = nets(g, og, H, T)
