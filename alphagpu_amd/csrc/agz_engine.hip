@@ -793,8 +793,9 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
             // window behind it carries planes (tree -> network) and logits (network -> tree), one block of 8 rows per tree wave
             const int prowb = g0 * kth * 64 + 16;
             S.io_prowb = prowb; S.io_lgs = n.AOP; S.io_bw = (8 * std::max(prowb, 4 * n.AOP) + 15) & ~15;
-            S.io_off = (int)((std::max((size_t)tw * h->reg_lds, (size_t)8 * tw * 2 * (n.H * 2 + 16)) + 15) & ~(size_t)15);
-            const size_t shared = (size_t)S.io_off + (size_t)tw * S.io_bw;
+            S.io_off = (int)((std::max((size_t)4 * h->reg_lds, (size_t)8 * tw * 2 * (n.H * 2 + 16)) + 15) & ~(size_t)15);   // (16-game workgroups: the two helper waves have tables of their own)
+            const size_t shared = (size_t)S.io_off + (size_t)tw * S.io_bw + (size_t)tw * 144;   // ... + the carry a tree wave publishes for its helper
+            S.xch_off = S.io_off + tw * S.io_bw;
             // + the tree waves' work lists (kept across the network phase): what the CU's LDS leaves when every workgroup of the launch
             // must be resident (4 per CU at 32768 games); entries beyond the region, rare, go to the global list
             const int wgs_per_cu = tw == 2 ? 2 : 2 + occ;

@@ -22,6 +22,7 @@ struct SmallPar {
     int wl_off, wl_bytes;     // the tree waves' work lists live past the window the two phases share: offset, bytes per wave
     int io_off, io_bw;        // hand-over window (planes to the network, logits back): offset, bytes per tree wave (8 rows)
     int io_prowb, io_lgs;     // ... bytes of a row of planes, floats of a row of logits
+    int xch_off;              // 16-game workgroups: per tree wave the carry it publishes for its helper wave (33 words, 144 bytes)
 };
 
 // TW = tree waves per workgroup (2 or 4): the workgroup owns 8*TW games and runs the network with TW/2 leaf tiles.
@@ -38,14 +39,40 @@ __global__ __launch_bounds__(64 * NW_WAVES, WV) void k_search_small(const SmallP
     uint32_t* const wl_lds = reinterpret_cast<uint32_t*>(lds_small + S.wl_off + (size_t)(wave % TW) * S.wl_bytes);
     EagerCarry C = {1u, 0u, 0u, 0u, 0u, 0u, 0u};                      // what a game carries from rollout to rollout: in registers
     uint32_t wcount = 0;
+    // 16-game workgroups (TW = 2: the small batches of a generation's tail, where a rollout's dependent chain is what a ply
+    // costs): waves 2 and 3 would idle through the tree phase, so they take the BACKUP WORK ITEMS of the tree waves 0 and 1 while
+    // those expand the leaf — the two halves of a rollout's first phase are independent (agz_tree_eager.hpp ROLE_*); a workgroup
+    // barrier joins them before the descent.
+    constexpr bool SPLIT = TW == 2;
+    uint8_t* const own_lds = lds_small + (size_t)(SPLIT ? wave : wave % TW) * S.tree_lds;   // (a helper wave has tables of its own)
+    uint32_t* const xch = reinterpret_cast<uint32_t*>(lds_small + S.xch_off + (size_t)(wave % TW) * 144);
     for (int k = 0; k <= S.V; ++k) {
-        const StepFlags SF = {(uint32_t)k, k == 0, k > 0, k < S.V, k == S.V - 1, k == S.V};
         // the workgroup index is made opaque once per rollout: otherwise every per-game address of both bodies is hoisted out
         // of this loop and kept alive across them (hundreds of registers, spills)
         int bx = (int)blockIdx.x;
         asm volatile("" : "+s"(bx));
-        if (wave < TW) rollout_eager_body<FAM, NC, KPL, true, (WV < 4 ? 2 : 1), true>(S.T, SF, tree_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
-                                                                               lds_small + S.io_off + (size_t)wave * S.io_bw, S.io_prowb, S.io_lgs);
+        uint8_t* const io_blk = lds_small + S.io_off + (size_t)(wave % TW) * S.io_bw;
+        if constexpr (SPLIT) {
+            if (k > 0) {
+                const StepFlags SE = {(uint32_t)k, 0, 1, 0, k == S.V - 1, k == S.V};
+                if (wave < TW) rollout_eager_body<FAM, NC, KPL, true, 2, true, ROLE_EXPAND>(S.T, SE, own_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
+                                                                                         io_blk, S.io_prowb, S.io_lgs, xch);
+                else rollout_eager_body<FAM, NC, KPL, true, 2, true, ROLE_ITEMS>(S.T, SE, own_lds, bx * TW + wave % TW, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
+                                                                               io_blk, S.io_prowb, S.io_lgs, xch);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __syncthreads();                                  // the leaf is expanded, the path's rows and next words are rebuilt
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
+            if (k < S.V && wave < TW) {
+                const StepFlags SS = {(uint32_t)k, k == 0, 0, 1, k == S.V - 1, 0};
+                rollout_eager_body<FAM, NC, KPL, true, 2, true, ROLE_EXPAND>(S.T, SS, own_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
+                                                                            io_blk, S.io_prowb, S.io_lgs, xch);
+            }
+        } else {
+            const StepFlags SF = {(uint32_t)k, k == 0, k > 0, k < S.V, k == S.V - 1, k == S.V};
+            if (wave < TW) rollout_eager_body<FAM, NC, KPL, true, (WV < 4 ? 2 : 1), true>(S.T, SF, tree_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
+                                                                                   io_blk, S.io_prowb, S.io_lgs);
+        }
 #ifdef AGZ_STAMPS
         const unsigned long long t_nn0 = __builtin_amdgcn_s_memtime();
 #endif

@@ -120,10 +120,17 @@ template <int KPL> struct ItemRows {
 // io_blk (LIO builds): this wave's block of the LDS hand-over window of k_search_small — the network body left the logits
 // of game g in row g (io_lgs floats, the value in column A) and takes the leaf's planes from row g (io_prowb bytes, zero padded to
 // whole k-rows): one round trip through L2 less in each direction on the rollout's chain.  The global arrays are not written then.
-template <int FAM, int NC, int KPL, bool LEAN, int PFM, bool LIO = false>
+// ROLE (whole-search kernel with idle network-only waves: the 16-game workgroups): the expansion of a rollout's leaf and the
+// backup work items of its path are independent of each other (the first needs the logits, the second the value), so two waves
+// run them side by side — ROLE_EXPAND: the game's tree wave expands (and, in a second call after a workgroup barrier, descends);
+// ROLE_ITEMS: a helper wave processes the work items of that tree wave's games from the carry the tree wave published in `xch`
+// (per game {leaf, special item, leaf meta word}, then the length of the work list).  ROLE_ALL: one wave does everything.
+enum { ROLE_ALL = 0, ROLE_EXPAND = 1, ROLE_ITEMS = 2 };
+template <int FAM, int NC, int KPL, bool LEAN, int PFM, bool LIO = false, int ROLE = ROLE_ALL>
 __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepFlags SF, uint8_t* const lds, const int bidx,
                                                    EagerCarry& C, uint32_t* const wl_lds, const uint32_t wl_cap_lds, uint32_t& wcount,
-                                                   uint8_t* const io_blk = nullptr, const int io_prowb = 0, const int io_lgs = 0) {
+                                                   uint8_t* const io_blk = nullptr, const int io_prowb = 0, const int io_lgs = 0,
+                                                   uint32_t* const xch = nullptr) {
     using GM = Game<FAM, NC>;
     constexpr bool REV = FAM == F_REV;
     constexpr int G = 8, NG = 8;
@@ -303,6 +310,10 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
     // expand (mcts_gpu.jl:250-302) of the previous rollout's leaf, then backUp (:306-328) + the recomputation of every row
     // the backup makes stale (:114-169)
     // =============================================================================================
+    if constexpr (ROLE == ROLE_ITEMS) {                              // the tree wave's carry (published by its select call)
+        C.leafn = xch[4 * gl]; C.spw = xch[4 * gl + 1]; C.leaf_meta = xch[4 * gl + 2];
+        wcount = ufirst(xch[32]);
+    }
     if (SF.do_expand) {   // PHASE expand: load logits
         const uint32_t nwl = wcount;
         const uint32_t free0 = (uint32_t)(8 - GPW);                  // list entries that round 0 already takes (sparse waves)
@@ -316,7 +327,7 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
             *reinterpret_cast<float4*>(utab + g * 32 + 4 * sub) = make_float4(uq[0], uq[1], uq[2], uq[3]);
         }
         uint32_t sink = 0u;
-        if constexpr (PFM == 1) sink = item_touch(0, nwl);           // the first item's record starts travelling towards L2 now
+        if constexpr (PFM == 1 && ROLE != ROLE_EXPAND) sink = item_touch(0, nwl);   // the first item's record starts travelling towards L2 now
         // ---------------------------------------------------------------------------- expand (lane-group g = game g)
         const int lf = (int)C.leafn;
         uint32_t ml = live ? (LEAN ? C.leaf_meta : gmeta[lf]) : (uint32_t)M_TERM;   // (one memory round trip less on the rollout's chain)
@@ -326,7 +337,10 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
         const uint32_t spw = C.spw;
         float x[KPL]; int npos = 0;
         bool wide = false, fdx = false;                               // (fdx is wave-uniform)
-        if (doexp) {
+        if constexpr (ROLE == ROLE_ITEMS) {                           // (the helper only needs the value of the leaf)
+            if (doexp) vleaf = (LEAN && LIO) ? (reinterpret_cast<const float*>(io_blk) + (size_t)g * io_lgs)[A] : T.v_eval[slot];
+        }
+        if (ROLE != ROLE_ITEMS && doexp) {
             constexpr bool lio = LEAN && LIO;
             const float* src = inject ? T.prior_eval + (size_t)slot * A
                                       : (lio ? reinterpret_cast<const float*>(io_blk) + (size_t)g * io_lgs : T.logits + (size_t)slot * T.LGS);
@@ -405,8 +419,8 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
             }
             npos = grp_sum<G>(npos);                                  // "A" of :125-131 never changes after the expansion
         }
-        if constexpr (PF) item_fetch(R, 0, nwl);                      // the first round's rows travel while the leaf's rows are written
-        if (doexp) {
+        if constexpr (PF && ROLE != ROLE_EXPAND) item_fetch(R, 0, nwl);   // the first round's rows travel while the leaf's rows are written
+        if (ROLE != ROLE_ITEMS && doexp) {
             // policy = prior (:297-299): the first revisit samples from these running sums; their total is prior_rem (:120-124, no   // PHASE expand: running sums + write rows
             // child yet)
             float total;
@@ -429,7 +443,7 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
                 gmeta[lf] = ml;
                 *reinterpret_cast<uint4*>(rec) = make_uint4(__float_as_uint(total), nx, (uint32_t)npos | (wide ? AUX_SLOW : 0u), 0u);
             }
-        } else if (__builtin_expect(live && lf == 0, 0)) {
+        } else if (__builtin_expect(ROLE != ROLE_ITEMS && live && lf == 0, 0)) {
 #pragma unroll
             for (int j = 0; j < KPL; ++j) if (j < nval) T.policy_final[(size_t)slot * A + k0 + j] = 0.0f;   // terminal root
         }
@@ -437,7 +451,7 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
         // ---- what the backup adds at the ancestors (:312-324): value_1 = 1 - v at even levels (the parent is level 0), value_2 =   // PHASE values of the backup
         // 1 - value_1 at odd ones — the alternation value <- 1 - value is 2-periodic from its first step (1 - x is exact for x in
         // [0.5, 1], and one of value_1, value_2 lies there); a terminal leaf starts from (1 + player*r)/2 in Float64 (:314)
-        if (lead) {
+        if (ROLE != ROLE_EXPAND && lead) {
             const int tv2 = (int)((ml >> M_TV_SHIFT) & 3u);
             const float v0 = term ? 0.5f * (float)tv2 : vleaf;
             const float v1 = 1.0f - v0, v2 = 1.0f - v1;
@@ -449,7 +463,7 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
         // ---------------------------------------------------------------------------- work items
         const bool recompute = !(T.final_ || SF.fin);                 // after the last rollout of a search nobody descends again   // PHASE items: loop control
 #pragma unroll 1
-        for (int r = 0; r < rounds; ++r) {
+        for (int r = 0; r < (ROLE == ROLE_EXPAND ? 0 : rounds); ++r) {
             if constexpr (!PF) item_fetch(R, r, nwl);
             if constexpr (PFM == 1) {
                 asm volatile("" :: "v"(sink));                        // (keeps the touch loads alive; they completed long ago)
@@ -767,8 +781,14 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
     }
 
     STAMPW(13);
+    if constexpr (ROLE == ROLE_EXPAND) {                             // what the helper wave needs for the backup of this rollout
+        if (SF.do_select) {
+            if (lead) { xch[4 * g] = C.leafn; xch[4 * g + 1] = C.spw; xch[4 * g + 2] = C.leaf_meta; }
+            if (lane == 0) xch[32] = wcount;
+        }
+    }
     // ---- bookkeeping: the stand-alone kernel hands the carry over through global memory; the whole-search kernel only at its end   // PHASE bookkeeping
-    if (!LEAN || !SF.do_select) {
+    if (ROLE != ROLE_ITEMS && (!LEAN || SF.fin)) {
         if (live && lead) {
             T.ncount[slot] = C.ncount;
             T.leaf[slot] = C.leafn;
