@@ -124,7 +124,7 @@ struct agz_engine {
     int small4_maxl = 1 << 30;   // ... used for batches in (small_maxl, small4_maxl] that fit the chip at once (AGZ_SMALL4_MAXL)
     int cus = 256;
     int small_gpw = 0;           // games per tree wave of the 16-game variant: 0 = by batch size (AGZ_SMALL_GPW = 1, 2, 4, 8)
-    small_fn k_small = nullptr; int small_maxl = 5120;   // 16-game workgroups of the whole-search kernel up to small_maxl games (AGZ_SMALL_MAXL): 2.60 vs 2.45 ms per ply at 6144 games, 2.90 vs 2.72 at 8192 with 32-game workgroups and sparse waves
+    small_fn k_small = nullptr; int small_maxl = 8192;   // 16-game workgroups of the whole-search kernel (helper waves take the backup items) up to small_maxl games (AGZ_SMALL_MAXL): 1.88 vs 2.04 ms per ply at 6144 games, 2.01 vs 2.18 at 7168, 2.14 vs 2.17 at 8192 against 32-game workgroups with sparse waves
     int reg3_max_waves = 0;      // largest grid the 3-waves-per-SIMD build of the stand-alone tree kernel is used for
     rollout_fn k_eager = nullptr, k_eager3 = nullptr;   // the tree kernel (agz_tree_eager.hpp), register budgets for 4 / 3 waves per SIMD
     uint32_t *wl = nullptr, *wl_n = nullptr, *sp = nullptr; uint32_t wl_cap = 0;
@@ -836,7 +836,8 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
             const int wgs = (h->L + 4 * S.T.gpw - 1) / (4 * S.T.gpw);
             const int occ = wgs <= h->cus ? 0 : 1;                 // 1 or 2 workgroups per CU
             S.V = V; S.tree_lds = (int)h->reg_lds;
-            const size_t shared = (std::max((size_t)4 * h->reg_lds, (size_t)32 * big_rowb) + 15) & ~(size_t)15;
+            S.xch_off = (int)((std::max((size_t)8 * h->reg_lds, (size_t)32 * big_rowb) + 15) & ~(size_t)15);   // (tree waves and helper waves have tables of their own)
+            const size_t shared = (size_t)S.xch_off + 4 * 144;
             const size_t room = (size_t)(160 * 1024) / (size_t)(occ + 1) > shared ? (size_t)(160 * 1024) / (size_t)(occ + 1) - shared : 0;
             S.wl_off = (int)shared; S.wl_bytes = (int)std::min({(size_t)(8 * h->V * 4), (room / 4) & ~(size_t)15, (size_t)h->wl_lds_max});
             const size_t lds = shared + (size_t)4 * S.wl_bytes;

@@ -20,6 +20,7 @@ struct BigSearchPar {
     int V;                    // rollouts
     int tree_lds;             // bytes of LDS of one tree wave
     int wl_off, wl_bytes;     // the tree waves' work lists live past the window the two phases share: offset, bytes per wave
+    int xch_off;              // per tree wave: the carry it publishes for its helper wave (agz_tree_eager.hpp ROLE_*), 144 bytes
 };
 
 // WG = workgroups per CU the register budget is cut for (1: 256 registers, 2: 128)
@@ -28,18 +29,41 @@ __global__ __launch_bounds__(NB_THREADS, 2 * WG) void k_search_big(const BigSear
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_bigs[];
     constexpr int TW = 4;                                         // tree waves: 32 games = the 2 leaf tiles of mlp_big_body<H, 2>
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    uint8_t* const tree_lds = lds_bigs + (size_t)(wave % TW) * S.tree_lds;
+    uint8_t* const own_lds = lds_bigs + (size_t)wave * S.tree_lds;   // (tree waves 0-3 and their helper waves 4-7 have tables of their own)
     uint32_t* const wl_lds = reinterpret_cast<uint32_t*>(lds_bigs + S.wl_off + (size_t)(wave % TW) * S.wl_bytes);
+    uint32_t* const xch = reinterpret_cast<uint32_t*>(lds_bigs + S.xch_off + (size_t)(wave % TW) * 144);
     EagerCarry C = {1u, 0u, 0u, 0u, 0u, 0u, 0u};
     uint32_t wcount = 0;
     // wave priorities: the tree waves (which also take part in the network phase) run above the four network-only waves from their
     // first descent on (rollout_eager_body raises the priority there and nothing lowers it here): 9.36 vs 9.72 ms per ply at 16384 games
+    // The network-only waves 4-7 take the BACKUP WORK ITEMS of the tree waves 0-3 while those expand the leaf (the two halves of a
+    // rollout's first phase are independent: agz_tree_eager.hpp ROLE_*); a workgroup barrier joins them before the descent.
+    // (one workgroup per CU only: with two the helpers compete with the other workgroup's waves, 8.43 vs 8.23 ms per ply at 16384 games)
+    constexpr int PF_ = WG < 2 ? 2 : 1;
+    constexpr bool SPLIT = WG < 2;
     for (int k = 0; k <= S.V; ++k) {
-        const StepFlags SF = {(uint32_t)k, k == 0, k > 0, k < S.V, k == S.V - 1, k == S.V};
         int bx = (int)blockIdx.x;
         asm volatile("" : "+s"(bx));                              // (see k_search_small)
-        if (wave < TW) rollout_eager_body<FAM, NC, KPL, true, (WG < 2 ? 2 : 1)>(S.T, SF, tree_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount);
+        if constexpr (!SPLIT) {
+            const StepFlags SF = {(uint32_t)k, k == 0, k > 0, k < S.V, k == S.V - 1, k == S.V};
+            if (wave < TW) rollout_eager_body<FAM, NC, KPL, true, PF_>(S.T, SF, own_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount);
+        }
+        if (SPLIT && k > 0) {
+            const StepFlags SE = {(uint32_t)k, 0, 1, 0, k == S.V - 1, k == S.V};
+            if (wave < TW) rollout_eager_body<FAM, NC, KPL, true, PF_, false, ROLE_EXPAND>(S.T, SE, own_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
+                                                                                        nullptr, 0, 0, xch);
+            else rollout_eager_body<FAM, NC, KPL, true, PF_, false, ROLE_ITEMS>(S.T, SE, own_lds, bx * TW + wave % TW, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
+                                                                              nullptr, 0, 0, xch);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();                                      // the leaf is expanded, the path's rows and next words are rebuilt
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
         if (k < S.V) {
+            if (SPLIT && wave < TW) {
+                const StepFlags SS = {(uint32_t)k, k == 0, 0, 1, k == S.V - 1, 0};
+                rollout_eager_body<FAM, NC, KPL, true, PF_, false, ROLE_EXPAND>(S.T, SS, own_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
+                                                                             nullptr, 0, 0, xch);
+            }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __syncthreads();                                      // the planes of the 32 leaves are written
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");

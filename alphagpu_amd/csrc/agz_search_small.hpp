@@ -5,7 +5,7 @@
 // critical path of every game.  Here a 4-wave workgroup owns its games for the whole search: TW of its waves run the eager-policy
 // tree step (rollout_eager_body, up to 8 games each), a workgroup barrier hands the leaves to all four waves for the network
 // forward (mlp_wave_body; planes and logits change hands through LDS), a second barrier hands logits and values back.
-// TW = 2 (16 games per workgroup) up to 5120 games, TW = 4 (32 games) above; up to 64 games per CU the waves are sparse (the
+// TW = 2 (16 games per workgroup; its two network-only waves take the backup work items) up to 8192 games, TW = 4 (32 games) above; up to 64 games per CU the waves are sparse (the
 // fewest games per wave that keep every workgroup resident; lane-groups without a game take work items of the wave's games).
 // The two bodies are the very functions the stand-alone kernels run — same arithmetic, same bits (tested).
 #pragma once

@@ -157,7 +157,7 @@ int  agz_set_profiling(agz_engine *h, int mode);       /* HIP events per launch:
 /*
  * Environment switches read by agz_create (all optional; results never depend on them, the tests use them to reach every
  * kernel build at small sizes):
- *   AGZ_SMALL_MAXL=n       128-wide trunk: 16 games per workgroup of the one-launch search up to n games (default 5120), 32 above;
+ *   AGZ_SMALL_MAXL=n       128-wide trunk: 16 games per workgroup of the one-launch search up to n games (default 8192), 32 above;
  *                          0 together with AGZ_SMALL4_MAXL=0 disables the one-launch form (two kernels per rollout)
  *   AGZ_SMALL4_MAXL=n      largest batch of the 32-games-per-workgroup one-launch search
  *   AGZ_SMALL4_OCC=0|1|2   force the 2 / 3 / 4 workgroups-per-CU register budget of that kernel
