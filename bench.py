@@ -236,6 +236,7 @@ def main():
         alg = algorithmic_bytes(game, sum_p, sum_new, r_cnt, S)
         gl, gname = game_label(args)
         traffic = None          # HBM bytes per launch from the committed PMC passes, scaled by this run's algorithmic bytes
+        pm, key = {}, ""
         valu_obj = None         # VALU-issue roofline of the same kernel: SQ_INSTS_VALU (PMC pass) x 4 cycles / (SIMDs x clock x time)
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
@@ -271,8 +272,14 @@ def main():
                     "note": ("one launch = one ply of the generation (all games alive, V rollouts)" if whole else
                              "one launch = one rollout of all games alive; busy time = union of the launch intervals of the sub-batch chains")
                             + "; algorithmic bytes are the tree path's (SURVEY 8d)"}
+        nn_traffic = None       # HBM bytes per stand-alone network launch (PMC passes of the config's first ply x this run's leaves per launch)
+        try:
+            if not whole and nn_leaves > 0 and "nn_hbm_bytes_per_leaf" in pm.get(key, {}):
+                nn_traffic = pm[key]["nn_hbm_bytes_per_leaf"] * nn_leaves / max(launches * V / (V + 1.0), 1.0)
+        except Exception:
+            nn_traffic = None
         nn_obj = {"kernel": form_nn, "bound": "mfma", "achieved": mfma_achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                  "frac": mfma_achieved / MFMA_PEAK_TFLOPS, "traffic": None,
+                  "frac": mfma_achieved / MFMA_PEAK_TFLOPS, "traffic": nn_traffic,
                   "flops_per_leaf": nn_flops_per_leaf(game, args.filters, args.towers), "leaves": (r_cnt if (whole or nn_leaves == 0) else nn_leaves),
                   "time_ms": nn_t_ms, "note": nn_note}
         # the dominant kernel of the configuration: the network when its launches take longer than the tree kernel's

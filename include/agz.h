@@ -99,8 +99,9 @@ int  agz_rollout_select(agz_engine *h, uint32_t rollout, int last);             
 int  agz_rollout_eval(agz_engine *h);                                             /* :414-417 actor + softmax! */
 int  agz_get_eval(agz_engine *h, float *prior /*[L][A]*/, float *v /*[L]*/);      /* softmaxed priors as used */
 int  agz_inject_eval(agz_engine *h, const float *prior, const float *v);          /* replaces the actor output */
-int  agz_get_logits(agz_engine *h, float *logits /*[L][A]*/, float *v /*[L]*/);   /* raw actor output of the last network launch
-                                                                                     (DenseNet.jl:294-304, before softmax!) */
+int  agz_get_logits(agz_engine *h, float *logits /*[L][A]*/, float *v /*[L]*/);   /* raw actor output of the last STAND-ALONE network launch
+                                                                                     (agz_rollout_eval; DenseNet.jl:294-304, before softmax!);
+                                                                                     the one-launch searches keep logits in LDS */
 int  agz_rollout_expand_backup(agz_engine *h);                                    /* :424-431 expand + backUp */
 int  agz_search_end(agz_engine *h);                                               /* :441-444 decoder_roots, copy_pol */
 

@@ -32,5 +32,31 @@ d = {key: {
     "traffic_over_algorithmic": (2 * fetch + write) * 1024 / alg, "traffic_over_algorithmic_uncorrected": (fetch + write) * 1024 / alg,
     "tcc_hit_rate": (hit / (hit + miss)) if hit and miss else None,
     "valu_insts_per_launch": valu, "valu_insts_per_rollout": valu / rollouts if valu else None}}
+# BASELINE configs 2..5 (scratch/pmc_configs.sh): tree traffic over algorithmic bytes, HBM bytes per leaf of the wide-trunk network
+cs = os.path.join(src, "cfg_summary.txt")
+if os.path.exists(cs):
+    shutil.copy(cs, os.path.join(P, f"{pre}_pmc_configs_first_ply.txt"))
+    ctxt = open(cs).read()
+    keys = {2: "connect4_64_128x6", 3: "gobang9x9_nvict5_64_512x8", 4: "hex9x9_128_512x8", 5: "reversi8_64_512x8"}
+    blocks = re.split(r"# cfg (\d) (FETCH_SIZE|WRITE_SIZE)\n", ctxt)[1:]
+    data = {}
+    for i in range(0, len(blocks), 3):
+        cfg, ctr, body = int(blocks[i]), blocks[i + 1], blocks[i + 2]
+        e = data.setdefault(cfg, {})
+        for m in re.finditer(r"sum void agz::(\w+) (\d+) launches (\d+)", body):
+            e[(m.group(1), ctr)] = int(m.group(2))
+        m = re.search(r'"algorithmic_bytes_per_search_launch": ([0-9.e+]+), "nn_leaves": (\d+)', body)
+        e["alg"], e["leaves"] = float(m.group(1)), int(m.group(2))
+    for cfg, e in data.items():
+        tree = [k for k in ("k_search_small", "k_rollout_eager") if (k, "FETCH_SIZE") in e][0]
+        f, w = e[(tree, "FETCH_SIZE")] / 2, e[(tree, "WRITE_SIZE")] / 2          # two searches per pass
+        o = {"what": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of one first-ply search at 32768 games (scratch/pmc_configs.sh, CFG=%d; the wide-trunk configs as one chain of V x {k_rollout_eager, k_mlp_big<512,8>}); sums over the launches of the search; see %s_pmc_configs_first_ply.txt" % (cfg, pre),
+             "tree_kernel": tree, "fetch_size_kb_per_search_raw": f, "write_size_kb_per_search": w, "algorithmic_bytes_per_search": e["alg"],
+             "traffic_over_algorithmic": (2 * f + w) * 1024 / e["alg"], "traffic_over_algorithmic_uncorrected": (f + w) * 1024 / e["alg"]}
+        if ("k_mlp_big", "FETCH_SIZE") in e:
+            nf, nw = e[("k_mlp_big", "FETCH_SIZE")], e[("k_mlp_big", "WRITE_SIZE")]
+            o["nn_hbm_bytes_per_leaf"] = (2 * nf + nw) * 1024 / (2 * e["leaves"])
+            o["nn_hbm_bytes_per_leaf_uncorrected"] = (nf + nw) * 1024 / (2 * e["leaves"])
+        d[keys[cfg]] = o
 json.dump(d, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(d[key], indent=1))
