@@ -25,8 +25,14 @@ struct BigSearchPar {
 
 // WG = workgroups per CU the register budget is cut for (1: 256 registers, 2: 128)
 template <int FAM, int NC, int KPL, int H, int WG>
-__global__ __launch_bounds__(NB_THREADS, 2 * WG) void k_search_big(const BigSearchPar S) {
+__global__ __launch_bounds__(NB_THREADS, 2 * WG) void k_search_big(const BigSearchPar) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_bigs[];
+    // the parameters are read from the kernel-argument segment per phase (see tree_par(), agz_tree_eager.hpp)
+    static_assert(offsetof(BigSearchPar, T) == 0, "rollout_eager_body reads its TreePar from the start of the argument segment");
+    typedef const BigSearchPar __attribute__((address_space(4)))* KArg;
+    const KArg karg = (KArg)__builtin_amdgcn_kernarg_segment_ptr();
+    const auto par = [&]() -> const BigSearchPar& { KArg p = karg; asm volatile("" : "+s"(p)); return *(const BigSearchPar*)p; };
+    const BigSearchPar& S = par();
     constexpr int TW = 4;                                         // tree waves: 32 games = the 2 leaf tiles of mlp_big_body<H, 2>
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     uint8_t* const own_lds = lds_bigs + (size_t)wave * S.tree_lds;   // (tree waves 0-3 and their helper waves 4-7 have tables of their own)
@@ -41,18 +47,20 @@ __global__ __launch_bounds__(NB_THREADS, 2 * WG) void k_search_big(const BigSear
     // (one workgroup per CU only: with two the helpers compete with the other workgroup's waves, 8.43 vs 8.23 ms per ply at 16384 games)
     constexpr int PF_ = WG < 2 ? 2 : 1;
     constexpr bool SPLIT = WG < 2;
-    for (int k = 0; k <= S.V; ++k) {
+    const int V_ = S.V;
+    for (int k = 0; k <= V_; ++k) {
         int bx = (int)blockIdx.x;
         asm volatile("" : "+s"(bx));                              // (see k_search_small)
+        const BigSearchPar& S = par();
         if constexpr (!SPLIT) {
             const StepFlags SF = {(uint32_t)k, k == 0, k > 0, k < S.V, k == S.V - 1, k == S.V};
-            if (wave < TW) rollout_eager_body<FAM, NC, KPL, true, PF_>(S.T, SF, own_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount);
+            if (wave < TW) rollout_eager_body<FAM, NC, KPL, true, PF_>(SF, own_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount);
         }
         if (SPLIT && k > 0) {
             const StepFlags SE = {(uint32_t)k, 0, 1, 0, k == S.V - 1, k == S.V};
-            if (wave < TW) rollout_eager_body<FAM, NC, KPL, true, PF_, false, ROLE_EXPAND>(S.T, SE, own_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
+            if (wave < TW) rollout_eager_body<FAM, NC, KPL, true, PF_, false, ROLE_EXPAND>(SE, own_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
                                                                                         nullptr, 0, 0, xch);
-            else rollout_eager_body<FAM, NC, KPL, true, PF_, false, ROLE_ITEMS>(S.T, SE, own_lds, bx * TW + wave % TW, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
+            else rollout_eager_body<FAM, NC, KPL, true, PF_, false, ROLE_ITEMS>(SE, own_lds, bx * TW + wave % TW, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
                                                                               nullptr, 0, 0, xch);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __syncthreads();                                      // the leaf is expanded, the path's rows and next words are rebuilt
@@ -61,12 +69,13 @@ __global__ __launch_bounds__(NB_THREADS, 2 * WG) void k_search_big(const BigSear
         if (k < S.V) {
             if (SPLIT && wave < TW) {
                 const StepFlags SS = {(uint32_t)k, k == 0, 0, 1, k == S.V - 1, 0};
-                rollout_eager_body<FAM, NC, KPL, true, PF_, false, ROLE_EXPAND>(S.T, SS, own_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
+                rollout_eager_body<FAM, NC, KPL, true, PF_, false, ROLE_EXPAND>(SS, own_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
                                                                              nullptr, 0, 0, xch);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __syncthreads();                                      // the planes of the 32 leaves are written
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const BigSearchPar& S = par();
             const int gpw = S.T.gpw, L = S.T.L;
             mlp_big_body<H, 2>(S.B, lds_bigs, [&](int row) { return (row & 7) < gpw ? (bx * TW + (row >> 3)) * gpw + (row & 7) : L; });
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

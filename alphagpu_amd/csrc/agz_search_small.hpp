@@ -29,8 +29,17 @@ struct SmallPar {
 // WV = waves per SIMD the register budget is cut for (2: 172 VGPRs, no spills; 3, 4: more workgroups per CU so that 24576 /
 // 32768 games are resident at once with 32 games per workgroup).
 template <int FAM, int NC, int KPL, int H, int TW, int WV>
-__global__ __launch_bounds__(64 * NW_WAVES, WV) void k_search_small(const SmallPar S) {
+__global__ __launch_bounds__(64 * NW_WAVES, WV) void k_search_small(const SmallPar) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_small[];
+    // The parameters are READ FROM THE KERNEL-ARGUMENT SEGMENT where they are needed (scalar loads), through a pointer made opaque
+    // once per phase: held in scalar registers from the entry on they (some 90 words) push the lane masks and addresses of the
+    // tree step out into spill lanes, and every v_readlane / v_writelane of a spill is a 4-cycle vector instruction of a kernel
+    // that is bound by vector issue.
+    static_assert(offsetof(SmallPar, T) == 0, "rollout_eager_body reads its TreePar from the start of the argument segment");
+    typedef const SmallPar __attribute__((address_space(4)))* KArg;
+    const KArg karg = (KArg)__builtin_amdgcn_kernarg_segment_ptr();
+    const auto par = [&]() -> const SmallPar& { KArg p = karg; asm volatile("" : "+s"(p)); return *(const SmallPar*)p; };
+    const SmallPar& S = par();
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);   // (scalar: the tree step's addresses are scalar base + offset)
     static_assert(TW == 2 || TW == 4, "tree waves per workgroup");
     uint8_t* const tree_lds = lds_small + (size_t)(wave % TW) * S.tree_lds;
@@ -46,18 +55,20 @@ __global__ __launch_bounds__(64 * NW_WAVES, WV) void k_search_small(const SmallP
     constexpr bool SPLIT = TW == 2;
     uint8_t* const own_lds = lds_small + (size_t)(SPLIT ? wave : wave % TW) * S.tree_lds;   // (a helper wave has tables of its own)
     uint32_t* const xch = reinterpret_cast<uint32_t*>(lds_small + S.xch_off + (size_t)(wave % TW) * 144);
-    for (int k = 0; k <= S.V; ++k) {
+    const int V_ = S.V;
+    for (int k = 0; k <= V_; ++k) {
         // the workgroup index is made opaque once per rollout: otherwise every per-game address of both bodies is hoisted out
         // of this loop and kept alive across them (hundreds of registers, spills)
         int bx = (int)blockIdx.x;
         asm volatile("" : "+s"(bx));
+        const SmallPar& S = par();
         uint8_t* const io_blk = lds_small + S.io_off + (size_t)(wave % TW) * S.io_bw;
         if constexpr (SPLIT) {
             if (k > 0) {
                 const StepFlags SE = {(uint32_t)k, 0, 1, 0, k == S.V - 1, k == S.V};
-                if (wave < TW) rollout_eager_body<FAM, NC, KPL, true, 2, true, ROLE_EXPAND>(S.T, SE, own_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
+                if (wave < TW) rollout_eager_body<FAM, NC, KPL, true, 2, true, ROLE_EXPAND>(SE, own_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
                                                                                          io_blk, S.io_prowb, S.io_lgs, xch);
-                else rollout_eager_body<FAM, NC, KPL, true, 2, true, ROLE_ITEMS>(S.T, SE, own_lds, bx * TW + wave % TW, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
+                else rollout_eager_body<FAM, NC, KPL, true, 2, true, ROLE_ITEMS>(SE, own_lds, bx * TW + wave % TW, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
                                                                                io_blk, S.io_prowb, S.io_lgs, xch);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __syncthreads();                                  // the leaf is expanded, the path's rows and next words are rebuilt
@@ -65,12 +76,12 @@ __global__ __launch_bounds__(64 * NW_WAVES, WV) void k_search_small(const SmallP
             }
             if (k < S.V && wave < TW) {
                 const StepFlags SS = {(uint32_t)k, k == 0, 0, 1, k == S.V - 1, 0};
-                rollout_eager_body<FAM, NC, KPL, true, 2, true, ROLE_EXPAND>(S.T, SS, own_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
+                rollout_eager_body<FAM, NC, KPL, true, 2, true, ROLE_EXPAND>(SS, own_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
                                                                             io_blk, S.io_prowb, S.io_lgs, xch);
             }
         } else {
             const StepFlags SF = {(uint32_t)k, k == 0, k > 0, k < S.V, k == S.V - 1, k == S.V};
-            if (wave < TW) rollout_eager_body<FAM, NC, KPL, true, (WV < 4 ? 2 : 1), true>(S.T, SF, tree_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
+            if (wave < TW) rollout_eager_body<FAM, NC, KPL, true, (WV < 4 ? 2 : 1), true>(SF, tree_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
                                                                                    io_blk, S.io_prowb, S.io_lgs);
         }
 #ifdef AGZ_STAMPS
@@ -82,6 +93,7 @@ __global__ __launch_bounds__(64 * NW_WAVES, WV) void k_search_small(const SmallP
             // and child creation in the tree step: dependent loads) go first, so that the waves get back to the arithmetic of the
             // work items sooner (measured -1.6 % per generation)
             __builtin_amdgcn_s_setprio(3);
+            const SmallPar& S = par();
             mlp_wave_body<H, TW / 2, 2, true, true, (WV < 4)>(S.F, nn_lds, bx, lds_small + S.io_off, S.io_bw, S.io_lgs);
             __syncthreads();                                      // logits and values are visible to the tree waves
             __builtin_amdgcn_s_setprio(0);

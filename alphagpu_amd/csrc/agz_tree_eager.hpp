@@ -126,8 +126,21 @@ template <int KPL> struct ItemRows {
 // ROLE_ITEMS: a helper wave processes the work items of that tree wave's games from the carry the tree wave published in `xch`
 // (per game {leaf, special item, leaf meta word}, then the length of the work list).  ROLE_ALL: one wave does everything.
 enum { ROLE_ALL = 0, ROLE_EXPAND = 1, ROLE_ITEMS = 2 };
+
+// The tree parameters are READ FROM THE KERNEL-ARGUMENT SEGMENT at the head of every phase (scalar loads through a pointer made
+// opaque there) instead of living in scalar registers from the kernel's entry on: some 60 words of parameters next to the lane
+// masks and wave-uniform addresses of the tree step are more than the 102 scalar registers of a wave, and every spilled one costs
+// v_writelane / v_readlane — 4-cycle VECTOR instructions (13 % of the vector instructions of the 9x9 kernel before this).
+// Every kernel that runs rollout_eager_body has its TreePar at the START of its argument segment (static_assert at each).
+typedef const TreePar __attribute__((address_space(4)))* TreeKArg;
+__device__ __forceinline__ const TreePar& tree_par() {
+    TreeKArg p = (TreeKArg)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *(const TreePar*)p;
+}
+
 template <int FAM, int NC, int KPL, bool LEAN, int PFM, bool LIO = false, int ROLE = ROLE_ALL>
-__device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepFlags SF, uint8_t* const lds, const int bidx,
+__device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* const lds, const int bidx,
                                                    EagerCarry& C, uint32_t* const wl_lds, const uint32_t wl_cap_lds, uint32_t& wcount,
                                                    uint8_t* const io_blk = nullptr, const int io_prowb = 0, const int io_lgs = 0,
                                                    uint32_t* const xch = nullptr) {
@@ -135,6 +148,7 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
     constexpr bool REV = FAM == F_REV;
     constexpr int G = 8, NG = 8;
     static_assert(KPL % 4 == 0, "block of actions per lane must be a multiple of 4");
+    const TreePar& T = tree_par();
     const GamePar& P = T.G;
     int lane_ = lane_id();
     asm volatile("" : "+v"(lane_));                              // opaque per call (see rollout_reg_body)   // PHASE setup
@@ -315,6 +329,8 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
         wcount = ufirst(xch[32]);
     }
     if (SF.do_expand) {   // PHASE expand: load logits
+        const TreePar& T = tree_par();
+        const GamePar& P = T.G;
         const uint32_t nwl = wcount;
         const uint32_t free0 = (uint32_t)(8 - GPW);                  // list entries that round 0 already takes (sparse waves)
         const int rounds = 1 + (nwl > free0 ? (int)((nwl - free0 + 7u) >> 3) : 0);
@@ -461,7 +477,8 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
 
         STAMPW(2);
         // ---------------------------------------------------------------------------- work items
-        const bool recompute = !(T.final_ || SF.fin);                 // after the last rollout of a search nobody descends again   // PHASE items: loop control
+        const TreePar& TI = tree_par();                               // (the item loop's own view of the parameters)
+        const bool recompute = !(TI.final_ || SF.fin);                 // after the last rollout of a search nobody descends again   // PHASE items: loop control
 #pragma unroll 1
         for (int r = 0; r < (ROLE == ROLE_EXPAND ? 0 : rounds); ++r) {
             if constexpr (!PF) item_fetch(R, r, nwl);
@@ -567,7 +584,7 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
             }
             // ---- :116-138   // PHASE items: lambda, alpha0
             const float nf = 1.0f + (float)nvis, Af = (float)npos;
-            const float lnum = T.cpuct * sqrt_count(nf), lden = Af + nf;
+            const float lnum = TI.cpuct * sqrt_count(nf), lden = Af + nf;
             const float lambda = FDr ? fd_div(lnum, lden, fd_rcp(lden)) : lnum / lden;   // :132
             const float prior_rem = prem_raw * lambda;               // :134
             float am = 0.0f;
@@ -639,14 +656,14 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
             if (__builtin_expect(__ballot(valid && node == 0 && SF.last) != 0, 0)) {     // copy_pol (:330-339): the row the last descent samples from
                 if (valid && node == 0) {
 #pragma unroll
-                    for (int j = 0; j < KPL; ++j) if (j < nval) T.policy_final[(size_t)(slot_base + gi) * A + k0 + j] = pol[j];
+                    for (int j = 0; j < KPL; ++j) if (j < nval) TI.policy_final[(size_t)(slot_base + gi) * A + k0 + j] = pol[j];
                 }
             }
             // the child bytes are needed past the prefetch of the next item: kept aside   // PHASE items: running sums + sampling
             STAMPW(7);
             float dummy;
             const float st = grp_ordered_start<KPL, false>(pol, sub, dummy, nlanes);
-            const float u = dpt < 32 ? utab[gi * 32 + dpt] : uniform_search(T.seed, T.game_id[valid ? slot_base + gi : sl], T.step, SF.rollout - 1u, (uint32_t)dpt);
+            const float u = dpt < 32 ? utab[gi * 32 + dpt] : uniform_search(TI.seed, TI.game_id[valid ? slot_base + gi : sl], TI.step, SF.rollout - 1u, (uint32_t)dpt);
             const uint32_t nx = sample_next(pol, st, u, cdk, rkw, move, (uint32_t)ileaf);
             if (valid && lead) *reinterpret_cast<uint4*>(rec) = make_uint4(__float_as_uint(prem_raw), nx, auxz, 0u);
             STAMPW(8);
@@ -661,6 +678,8 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
     // kdescendTree! (mcts_gpu.jl:100-199) over the stored running sums + decoder (:202-223)
     // =============================================================================================
     if (SF.do_select) {   // PHASE descent: rounds
+        const TreePar& T = tree_par();
+        const GamePar& P = T.G;
         if constexpr (LEAN) __builtin_amdgcn_s_setprio(2);
         // every expanded node carries the action its next visit samples and the child under it: the descent follows the words
         int node = 0, depth = 0;
@@ -789,6 +808,7 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
     }
     // ---- bookkeeping: the stand-alone kernel hands the carry over through global memory; the whole-search kernel only at its end   // PHASE bookkeeping
     if (ROLE != ROLE_ITEMS && (!LEAN || SF.fin)) {
+        const TreePar& T = tree_par();
         if (live && lead) {
             T.ncount[slot] = C.ncount;
             T.leaf[slot] = C.leafn;
@@ -806,11 +826,12 @@ __device__ __forceinline__ void rollout_eager_body(const TreePar& T, const StepF
 }
 
 template <int FAM, int NC, int KPL, int WV = 4>
-__global__ __launch_bounds__(64, WV) void k_rollout_eager(const TreePar T) {
+__global__ __launch_bounds__(64, WV) void k_rollout_eager(const TreePar) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_eager[];
+    const TreePar& T = tree_par();
     const StepFlags SF = {T.rollout, T.do_reset, T.do_expand, T.do_select, T.last, T.final_};
     EagerCarry C; uint32_t wcount = 0;
-    rollout_eager_body<FAM, NC, KPL, false, (WV < 4 ? 2 : 1)>(T, SF, lds_eager, (int)blockIdx.x, C, nullptr, 0u, wcount);
+    rollout_eager_body<FAM, NC, KPL, false, (WV < 4 ? 2 : 1)>(SF, lds_eager, (int)blockIdx.x, C, nullptr, 0u, wcount);
 }
 
 }  // namespace agz
