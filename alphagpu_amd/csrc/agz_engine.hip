@@ -412,12 +412,13 @@ int agz_get_info(const agz_engine* h, agz_game_info* out) {
 }
 void* agz_stream(agz_engine* h) { return h ? (void*)h->stream : nullptr; }
 #ifdef AGZ_STAMPS
+// out[0..15]: the tree step's phases (blocks below 32768), out[16..31]: the network body's (blocks from 32768 on)
 extern "C" int agz_debug_stamps(agz_engine* h, unsigned long long* out, int reset) {
     hipStreamSynchronize(h->stream);
     std::vector<unsigned long long> all((size_t)65536 * 16);
     hipMemcpy(all.data(), h->tp.dbg, all.size() * 8, hipMemcpyDeviceToHost);
-    for (int i = 0; i < 16; ++i) out[i] = 0;
-    for (size_t b = 0; b < 65536; ++b) for (int i = 0; i < 16; ++i) out[i] += all[b * 16 + i];
+    for (int i = 0; i < 32; ++i) out[i] = 0;
+    for (size_t b = 0; b < 65536; ++b) for (int i = 0; i < 16; ++i) out[(b >= 32768 ? 16 : 0) + i] += all[b * 16 + i];
     if (reset) hipMemset(h->tp.dbg, 0, all.size() * 8);
     return 0;
 }

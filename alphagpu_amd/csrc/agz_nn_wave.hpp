@@ -60,7 +60,7 @@ __host__ __device__ inline int nw_hidden_groups(int INP, int H, int T) {
 // duplicated first k-step costs registers: not in the 128-register build of the whole-search kernel, where it spills)
 template <int H, int LT, int DEPTH, bool PRE_BARRIER = false, bool IO = false, bool ZC = false>
 __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const smem, const int bidx, uint8_t* const io = nullptr,
-                                              const int io_bw = 0, const int io_lgs = 0);
+                                              const int io_bw = 0, const int io_lgs = 0, unsigned long long* const nn_dbg = nullptr);
 
 template <int H, int LT, int DEPTH>
 __global__ __launch_bounds__(64 * NW_WAVES) void k_mlp_wave(const Fused3Par P) {
@@ -77,7 +77,13 @@ __global__ __launch_bounds__(64 * NW_WAVES) void k_mlp_wave(const Fused3Par P) {
 // written (agz_get_logits reads what the stepwise API's network launch left).
 template <int H, int LT, int DEPTH, bool PRE_BARRIER, bool IO, bool ZC>
 __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const smem, const int bidx, uint8_t* const io, const int io_bw,
-                                              const int io_lgs) {
+                                              const int io_lgs, unsigned long long* const nn_dbg) {
+#ifdef AGZ_STAMPS
+    unsigned long long st_[6] = {0, 0, 0, 0, 0, 0}, st_t = __builtin_amdgcn_s_memtime();
+#define NN_STAMP(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_[i] += n_ - st_t; st_t = n_; } while (0)
+#else
+#define NN_STAMP(i) do {} while (0)
+#endif
     constexpr int NTH = H / 16, KTH = H / 32, TPW = NTH / NW_WAVES;
     constexpr int ROWB = H * 2 + 16;
     static_assert(TPW >= 1, "at least one neuron tile per wave");
@@ -112,7 +118,9 @@ __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const
     } while (0)
     NW_LOADGROUP(0); NW_LOADGROUP(1);
     if constexpr (DEPTH == 4) { NW_LOADGROUP(2); NW_LOADGROUP(3); }
+    NN_STAMP(0);
     if constexpr (PRE_BARRIER) __syncthreads();
+    NN_STAMP(1);
 
     if constexpr (!IO) {   // the ML rows of input planes -> LDS (coalesced 16-B loads), zero beyond INP
         const int segs = G0 * KTH * 4, isegs = P.INP / 8;
@@ -164,6 +172,7 @@ __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const
                 _Pragma("unroll") for (int t = 0; t < TPW; ++t)                                         \
                     acc[lt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[d][k][t], b_, acc[lt][t], 0, 0, 0); \
             }                                                                                           \
+        NN_STAMP(2);                                                                                    \
         NW_LOADGROUP(d);                                          /* group g + DEPTH */                 \
         if (g_ >= G0 - 1) {                                                                             \
             const bool res_ = g_ >= G0;                                                                 \
@@ -185,7 +194,9 @@ __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const
                 }                                                                                       \
             }                                                                                           \
             cur ^= 1;                                                                                   \
+            NN_STAMP(3);                                                                                \
             __syncthreads();                                                                            \
+            NN_STAMP(4);                                                                                \
         }                                                                                               \
     } while (0)
 #pragma unroll 1
@@ -246,6 +257,13 @@ __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const
         if (NT > NTH) { NW_HEAD(1, NTH) }                           // (wave-uniform, rare)
 #undef NW_HEAD
     }
+    NN_STAMP(5);
+#ifdef AGZ_STAMPS
+    // [0] weight requests, [1] first barrier (wait for the tree waves), [2] B reads + MFMA issue (waits for the weights),
+    // [3] epilogue (waits for the MFMAs), [4] layer barriers, [5] head
+    if (nn_dbg && lane == 0) for (int i = 0; i < 6; ++i) nn_dbg[i] += st_[i];
+#endif
+#undef NN_STAMP
 }
 
 }  // namespace agz
