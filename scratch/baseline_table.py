@@ -1,11 +1,11 @@
-# BASELINE.md section 3 rows from the committed bench lines (profiles/r02_bench_*.json)
+# BASELINE.md section 3 rows from the committed bench lines (profiles/r03_bench_*.json)
 import json, sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def load(n):
     return json.loads(open(os.path.join(ROOT, "profiles", n)).read().strip().splitlines()[-1])
-rows = [("Gobang 9×9/5, 32768×64, 128×6 (**headline**)", "r02_bench_headline.json"), ("Connect4, 32768×64, 128×6", "r02_bench_config2.json"),
-        ("Gobang 9×9/5, 32768×64, 512×8", "r02_bench_config3.json"), ("Hex 9×9, 32768×128, 512×8", "r02_bench_config4.json"),
-        ("Reversi 8×8, 32768×64, 512×8", "r02_bench_config5.json")]
+rows = [("Gobang 9×9/5, 32768×64, 128×6 (**headline**)", "r03_bench_headline.json"), ("Connect4, 32768×64, 128×6", "r03_bench_config2.json"),
+        ("Gobang 9×9/5, 32768×64, 512×8", "r03_bench_config3.json"), ("Hex 9×9, 32768×128, 512×8", "r03_bench_config4.json"),
+        ("Reversi 8×8, 32768×64, 512×8", "r03_bench_config5.json")]
 print("| Config | GPUs | rollouts/s (generation = `value`) | rollouts/s (search kernels only) | rollouts/s (+ samples delivered to host) | HBM frac (tree) | MFMA frac (net) | CPU baseline rollouts/s (threads) | parity |")
 print("|---|---|---|---|---|---|---|---|---|")
 for name, f in rows:
