@@ -482,10 +482,6 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
 #pragma unroll 1
         for (int r = 0; r < (ROLE == ROLE_EXPAND ? 0 : rounds); ++r) {
             if constexpr (!PF) item_fetch(R, r, nwl);
-            if constexpr (PFM == 1) {
-                asm volatile("" :: "v"(sink));                        // (keeps the touch loads alive; they completed long ago)
-                if (r + 1 < rounds) sink = item_touch(r + 1, nwl);
-            }
             const bool valid = R.valid, special = r == 0 && g < GPW;
             const int gi = R.gi;   // PHASE items: fetch item
             const int node = (int)(R.ent & 0xffu), mr = (int)((R.ent >> 8) & 0xffu), dpt_e = (int)((R.ent >> 16) & 0xffu);
@@ -635,6 +631,13 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
                 }
             }
             STAMPW(6);
+            // the 128-register build touches the next item's record HERE, not at the head of the round: a full round ahead, the lines
+            // touched by the 512 waves of an XCD (5.2 MB per round) do not survive in its 4 MB L2 until they are read; half a round
+            // (~6 us) still covers an HBM miss (first ply at 32768 games 4.22 -> 4.15 ms)
+            if constexpr (PFM == 1) {
+                asm volatile("" :: "v"(sink));                        // (keeps the touch loads alive; they completed long ago)
+                if (r + 1 < rounds) sink = item_touch(r + 1, nwl);
+            }
             // ---- the policy row (:165-169) and its running sums (:172-181)   // PHASE items: policy row
             float pol[KPL];
             if (FDr) {
