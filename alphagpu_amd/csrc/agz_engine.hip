@@ -760,10 +760,10 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
         DevNet& n = h->net[which];
         if (h->k_small && h->cfg.nn_mode == AGZ_NN_BF16 && n.H == 128 && n.w16w && h->L > 0 &&
             h->V <= 128 && (h->V & 3) == 0 && 8 * h->reg_kpl <= h->LGS &&   // the lean build of the tree step (rollout_eager_body<..., LEAN>)
-            // (rows of 16+ actions per lane — 13x13 boards, Hex 11x11 — spill in the 3- and 4-workgroups-per-CU builds: two kernels per
-            //  rollout are faster there, 13.1 vs 16.6 ms per ply at 24576 games of Gobang 13x13; up to 64 games per CU the one-launch
-            //  form wins, 6.6 vs 10.2 ms at 16384)
-            h->L <= std::min(std::max(h->small_maxl, h->small4_maxl), (h->reg_kpl >= 16 ? 64 : 128) * h->cus) && !h->no_fused_nn) {
+            // (rows of 24 actions per lane — 13x13 boards — still spill ~60 vector registers in the 3- and 4-workgroups-per-CU builds, and
+            //  the one-launch form wins all the same since the scalar spills went: 11.4 vs 24.0 ms per ply at 32768 games of Gobang
+            //  13x13, 9.2 vs 20.5 at 24576; 16 actions per lane (11x11 boards) do not spill: 5.6 vs 16.5 ms at 32768 games of Gobang 11x11)
+            h->L <= std::min(std::max(h->small_maxl, h->small4_maxl), 128 * h->cus) && !h->no_fused_nn) {
             // 16 games per workgroup up to small_maxl; beyond, 32 games per workgroup with the loosest register budget that still
             // keeps every workgroup resident (2 / 3 / 4 workgroups per CU = 64 / 96 / 128 games per CU)
             const int tw = h->L <= h->small_maxl ? 2 : 4;

@@ -9,6 +9,7 @@ import oracle_lib as O
 GAMES = {
     "tictactoe": ("gobang", 3, 3),
     "gobang9": ("gobang", 9, 5),
+    "gobang11": ("gobang", 11, 5),
     "gobang13": ("gobang", 13, 5),
     "connect4": ("connect4", 0, 0),
     "hex5": ("hex", 5, 0),

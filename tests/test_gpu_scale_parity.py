@@ -88,6 +88,15 @@ def test_full_size_first_ply_slice_matches_oracle(label, name, H, T, V, n_each, 
         run_slice_case(name, H, T, V, L, n_each, form, nn)
 
 
+# boards with 16 / 24 actions per lane (11x11, 13x13: the reference's README promises boards up to 13x13) in the one-launch search at
+# the batch sizes that need the denser register budgets (3 and 4 workgroups per CU; the 24-action builds spill vector registers there)
+@pytest.mark.parametrize("name,L,V,n_each,form", [
+    ("gobang13", 32768, 32, 8, "k_search_small<KPL=24,H=128,TW=4,WV=4>"), ("gobang13", 20000, 32, 8, "k_search_small<KPL=24,H=128,TW=4,WV=3>"),
+    ("gobang11", 32768, 32, 8, "k_search_small<KPL=16,H=128,TW=4,WV=4>"), ("hex11", 24000, 32, 8, "k_search_small<KPL=16,H=128,TW=4,WV=3>")])
+def test_wide_rows_full_size_slice_matches_oracle(name, L, V, n_each, form):
+    run_slice_case(name, 128, 2, V, L, n_each, form, "inside k_search_small", step=2)
+
+
 @pytest.mark.parametrize("name,L,V,n_each", [("gobang9", 16384, 64, 12), ("reversi8", 8192, 64, 12), ("gobang9", 136, 64, 16)])
 def test_wide_trunk_one_launch_search_slice_matches_oracle(name, L, V, n_each):
     """k_search_big (512x8, whole mcts_single per launch) at its largest batches and at V = 64 on a small one."""
