@@ -52,6 +52,8 @@ __global__ __launch_bounds__(64 * NW_WAVES, WV) void k_search_small(const SmallP
     // costs): waves 2 and 3 would idle through the tree phase, so they take the BACKUP WORK ITEMS of the tree waves 0 and 1 while
     // those expand the leaf — the two halves of a rollout's first phase are independent (agz_tree_eager.hpp ROLE_*); a workgroup
     // barrier joins them before the descent.
+    // (item prefetch: into registers wherever they are free — up to 3 waves per SIMD, and rows of 4 actions per lane in the 128-register
+    //  build: Connect4 85.8 -> 85.0 ms per generation; rows of 8 gain nothing or spill)
     constexpr bool SPLIT = TW == 2;
     uint8_t* const own_lds = lds_small + (size_t)(SPLIT ? wave : wave % TW) * S.tree_lds;   // (a helper wave has tables of its own)
     uint32_t* const xch = reinterpret_cast<uint32_t*>(lds_small + S.xch_off + (size_t)(wave % TW) * 144);
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(64 * NW_WAVES, WV) void k_search_small(const SmallP
             }
         } else {
             const StepFlags SF = {(uint32_t)k, k == 0, k > 0, k < S.V, k == S.V - 1, k == S.V};
-            if (wave < TW) rollout_eager_body<FAM, NC, KPL, true, (WV < 4 ? 2 : 1), true>(SF, tree_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
+            if (wave < TW) rollout_eager_body<FAM, NC, KPL, true, ((WV < 4 || KPL <= 4) ? 2 : 1), true>(SF, tree_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
                                                                                    io_blk, S.io_prowb, S.io_lgs);
         }
 #ifdef AGZ_STAMPS
