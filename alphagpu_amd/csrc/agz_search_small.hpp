@@ -53,7 +53,8 @@ __global__ __launch_bounds__(64 * NW_WAVES, WV) void k_search_small(const SmallP
     // those expand the leaf — the two halves of a rollout's first phase are independent (agz_tree_eager.hpp ROLE_*); a workgroup
     // barrier joins them before the descent.
     // (item prefetch: into registers wherever they are free — up to 3 waves per SIMD, and rows of 4 actions per lane in the 128-register
-    //  build: Connect4 85.8 -> 85.0 ms per generation; rows of 8 gain nothing or spill)
+    //  build: Connect4 85.8 -> 85.0 ms per generation; rows of 8 gain nothing or spill; rows of 24 actions spill 60 registers with it
+    //  at 3 waves per SIMD and 4 without: Gobang 13x13 at 24576 games 9.2 -> 7.7 ms per ply)
     constexpr bool SPLIT = TW == 2;
     uint8_t* const own_lds = lds_small + (size_t)(SPLIT ? wave : wave % TW) * S.tree_lds;   // (a helper wave has tables of its own)
     uint32_t* const xch = reinterpret_cast<uint32_t*>(lds_small + S.xch_off + (size_t)(wave % TW) * 144);
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(64 * NW_WAVES, WV) void k_search_small(const SmallP
             }
         } else {
             const StepFlags SF = {(uint32_t)k, k == 0, k > 0, k < S.V, k == S.V - 1, k == S.V};
-            if (wave < TW) rollout_eager_body<FAM, NC, KPL, true, ((WV < 4 || KPL <= 4) ? 2 : 1), true>(SF, tree_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
+            if (wave < TW) rollout_eager_body<FAM, NC, KPL, true, ((WV < 3 || (WV == 3 && KPL <= 16) || KPL <= 4) ? 2 : 1), true>(SF, tree_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
                                                                                    io_blk, S.io_prowb, S.io_lgs);
         }
 #ifdef AGZ_STAMPS
