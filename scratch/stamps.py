@@ -5,7 +5,7 @@ aglib.LIB_PATH = os.path.join(os.getcwd(), 'scratch', 'libagz_dbg.so')
 import alphagpu_amd as ag
 from alphagpu_amd import mcts_gpu as M
 V, L = 64, int(os.environ.get("LL", "32768"))
-g = ag.GameSpec('gobang', 9, 5); net = ag.SNetwork2.random(g, 128, 6)
+g = ag.GameSpec(os.environ.get('GK', 'gobang'), int(os.environ.get('GN', '9')), int(os.environ.get('GV', '5'))); net = ag.SNetwork2.random(g, 128, 6)
 e = M.Engine(g, L, V, seed=1, nn_mode=M.NN_BF16); e.set_network(net)
 e.set_roots(None, L=L); e.search(V, cpuct=1.5, training=True, step=0); e.synchronize()
 out = (C.c_ulonglong * 32)()

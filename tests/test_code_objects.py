@@ -1,0 +1,57 @@
+"""The built library's code objects (CPU test: reads metadata, launches nothing): the kernels of the benchmarked configurations keep
+their register budgets — no vector-register spills, few scalar ones — so that a change that silently pushes the item loop into scratch
+memory fails here and not in a later round's profile.  Uses the LLVM tools of the ROCm image (skipped where they are missing)."""
+import glob
+import os
+import re
+import subprocess
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LLVM = "/opt/rocm/lib/llvm/bin/"
+OBJS = sorted(glob.glob(os.path.join(ROOT, "alphagpu_amd", "csrc", "build", "*.o")))
+
+
+def kernel_metadata():
+    rows = {}
+    for obj in OBJS:
+        with tempfile.TemporaryDirectory() as d:
+            co = os.path.join(d, "co")
+            fat = os.path.join(d, "fat")                          # the device code is a bundle in the object's .hip_fatbin section
+            r = subprocess.run([LLVM + "llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", obj], capture_output=True)
+            if r.returncode != 0:
+                continue
+            r = subprocess.run([LLVM + "clang-offload-bundler", "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                                f"--input={fat}", f"--output={co}"], capture_output=True)
+            if r.returncode != 0 or not os.path.exists(co) or os.path.getsize(co) == 0:
+                continue
+            txt = subprocess.run([LLVM + "llvm-readelf", "--notes", co], capture_output=True, text=True).stdout
+        for blk in re.split(r"\n\s+- \.agpr_count", txt)[1:]:
+            def g(k):
+                m = re.search(rf"\.{k}:\s+(\S+)", blk)
+                return m.group(1) if m else None
+            name = subprocess.run(["c++filt", g("name")], capture_output=True, text=True).stdout.strip()
+            rows[re.sub(r"\(.*", "", name).replace("void agz::", "")] = {k: int(g(k)) for k in ("vgpr_count", "vgpr_spill_count", "sgpr_spill_count", "private_segment_fixed_size")}
+    return rows
+
+
+@pytest.mark.skipif(not (OBJS and all(os.path.exists(LLVM + t) for t in ("clang-offload-bundler", "llvm-readelf", "llvm-objcopy"))),
+                    reason="needs the built objects (python -c 'import __graft_entry__ as g; g.build()') and the ROCm LLVM tools")
+def test_benchmarked_kernels_do_not_spill_vector_registers():
+    md = kernel_metadata()
+    assert len(md) > 100, len(md)
+    # the kernels of BASELINE.json's configurations: Gobang 9x9 / Hex 9x9 (12 actions per lane), Connect4 (4), Reversi 8x8 (12) and 6x6 (8), at every
+    # register budget of the one-launch search, the wide-trunk search and the stand-alone tree step
+    for fam_nc_kpl in ("0, 2, 12", "2, 2, 12", "1, 1, 4", "3, 1, 12", "3, 1, 8"):
+        for tail, budget in (("128, 2, 2", 256), ("128, 4, 2", 256), ("128, 4, 3", 168), ("128, 4, 4", 128)):
+            k = md[f"k_search_small<{fam_nc_kpl}, {tail}>"]
+            assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0 and k["vgpr_count"] <= budget, (fam_nc_kpl, tail, k)
+            assert k["sgpr_spill_count"] <= 40, (fam_nc_kpl, tail, k)     # (was 120-150 while the parameters lived in scalar registers)
+        for wg in (1, 2):
+            k = md[f"k_search_big<{fam_nc_kpl}, 512, {wg}>"]
+            assert k["vgpr_spill_count"] == 0 and k["vgpr_count"] <= 256 // wg, (fam_nc_kpl, wg, k)
+        for wv in (3, 4):
+            k = md[f"k_rollout_eager<{fam_nc_kpl}, {wv}>"]
+            assert k["vgpr_spill_count"] == 0 and k["sgpr_spill_count"] <= 40, (fam_nc_kpl, wv, k)
