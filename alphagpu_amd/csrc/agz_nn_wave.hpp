@@ -58,7 +58,7 @@ __host__ __device__ inline int nw_hidden_groups(int INP, int H, int T) {
 // work, 2 halves the registers so that twice as many workgroups share a CU (throughput mode for big batches).
 // ZC: a group that opens a layer accumulates from the constant 0 instead of cleared registers (16 moves less per layer; the
 // duplicated first k-step costs registers: not in the 128-register build of the whole-search kernel, where it spills)
-template <int H, int LT, int DEPTH, bool PRE_BARRIER = false, bool IO = false, bool ZC = false>
+template <int H, int LT, int DEPTH, bool PRE_BARRIER = false, bool IO = false, bool ZC = false, bool BP = false>
 __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const smem, const int bidx, uint8_t* const io = nullptr,
                                               const int io_bw = 0, const int io_lgs = 0, unsigned long long* const nn_dbg = nullptr);
 
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(64 * NW_WAVES) void k_mlp_wave(const Fused3Par P) {
 // owns tile rows 8 w .. 8 w + 7 has left their planes in block w of `io` (io_bw bytes per block, rows of PROWB bytes, zero padded),
 // and the head leaves logits (and the value in column A) in the same block, rows of io_lgs floats; the global arrays are not
 // written (agz_get_logits reads what the stepwise API's network launch left).
-template <int H, int LT, int DEPTH, bool PRE_BARRIER, bool IO, bool ZC>
+template <int H, int LT, int DEPTH, bool PRE_BARRIER, bool IO, bool ZC, bool BP>
 __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const smem, const int bidx, uint8_t* const io, const int io_bw,
                                               const int io_lgs, unsigned long long* const nn_dbg) {
 #ifdef AGZ_STAMPS
@@ -152,39 +152,62 @@ __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const
         const uint8_t* const brow_ = g_ < G0 ? prow0 + (size_t)g_ * KTH * 64                             \
                                              : act0 + (size_t)cur * ML * ROWB + (size_t)lrow * ROWB;    \
         const int bstride_ = g_ < G0 ? pstride : 16 * ROWB;       /* next 16-leaf tile */               \
-        /* a group that opens a layer accumulates from the constant 0 (no clearing of 16 registers per layer) */ \
-        if (ZC && (g_ == 0 || g_ >= G0)) {                                                              \
-            _Pragma("unroll") for (int lt = 0; lt < LT; ++lt) {                                         \
-                const bf16x8 b_ = *reinterpret_cast<const bf16x8*>(brow_ + (size_t)lt * bstride_ + q4 * 16); \
-                _Pragma("unroll") for (int t = 0; t < TPW; ++t)                                         \
-                    acc[lt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[d][0][t], b_, (f32x4){0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0); \
+        /* Builds with register room (BP: up to 2 waves per SIMD) issue ALL operand reads of the group, and the residual's old */ \
+        /* activations, before the first MFMA: left to the compiler each ds_read_b128 sits right in front of its two MFMAs behind an */ \
+        /* lgkmcnt(0) - eight exposed LDS latencies per layer, and four more in the epilogue (read old, wait, write new, four times). */ \
+        /* The denser builds have no room for it (168 registers: 6 - 26 spilled, 3.39 -> 3.50 ms per ply at 24576 games; 128: 36 - 77) */ \
+        /* and hide the latencies behind their other waves anyway; the sparse ones gain 1 - 2 % per ply. */ \
+        const bool res_ = g_ >= G0;                                                                     \
+        bf16x8 bq_[BP ? KTH : 1][LT];                                                                   \
+        uint2 old_[LT][TPW];                                                                            \
+        if constexpr (BP) {                                                                             \
+            _Pragma("unroll") for (int k = 0; k < KTH; ++k)                                             \
+                _Pragma("unroll") for (int lt = 0; lt < LT; ++lt)                                       \
+                    bq_[k][lt] = *reinterpret_cast<const bf16x8*>(brow_ + (size_t)lt * bstride_ + k * 64 + q4 * 16); \
+            if (res_) {                                                                                 \
+                _Pragma("unroll") for (int lt = 0; lt < LT; ++lt)                                       \
+                    _Pragma("unroll") for (int t = 0; t < TPW; ++t)                                     \
+                        old_[lt][t] = *reinterpret_cast<const uint2*>(act0 + (size_t)cur * ML * ROWB + (size_t)(lt * 16 + lrow) * ROWB \
+                                                                      + (16 * (wave * TPW + t) + 4 * q4) * 2); \
+            }                                                                                           \
+            __builtin_amdgcn_sched_barrier(0);                                                          \
+            _Pragma("unroll") for (int k = 0; k < KTH; ++k) {                                           \
+                /* a group that opens a layer accumulates from the constant 0 (no clearing of 16 registers per layer) */ \
+                if (ZC && k == 0 && (g_ == 0 || g_ >= G0)) {                                            \
+                    _Pragma("unroll") for (int lt = 0; lt < LT; ++lt)                                   \
+                        _Pragma("unroll") for (int t = 0; t < TPW; ++t)                                 \
+                            acc[lt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[d][0][t], bq_[0][lt], (f32x4){0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0); \
+                } else {                                                                                \
+                    _Pragma("unroll") for (int lt = 0; lt < LT; ++lt)                                   \
+                        _Pragma("unroll") for (int t = 0; t < TPW; ++t)                                 \
+                            acc[lt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[d][k][t], bq_[k][lt], acc[lt][t], 0, 0, 0); \
+                }                                                                                       \
             }                                                                                           \
         } else {                                                                                        \
-            _Pragma("unroll") for (int lt = 0; lt < LT; ++lt) {                                         \
-                const bf16x8 b_ = *reinterpret_cast<const bf16x8*>(brow_ + (size_t)lt * bstride_ + q4 * 16); \
-                _Pragma("unroll") for (int t = 0; t < TPW; ++t)                                         \
-                    acc[lt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[d][0][t], b_, acc[lt][t], 0, 0, 0); \
-            }                                                                                           \
+            _Pragma("unroll") for (int k = 0; k < KTH; ++k)                                             \
+                _Pragma("unroll") for (int lt = 0; lt < LT; ++lt) {                                     \
+                    const bf16x8 b_ = *reinterpret_cast<const bf16x8*>(brow_ + (size_t)lt * bstride_ + k * 64 + q4 * 16); \
+                    if (ZC && k == 0 && (g_ == 0 || g_ >= G0)) {                                        \
+                        _Pragma("unroll") for (int t = 0; t < TPW; ++t)                                 \
+                            acc[lt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[d][0][t], b_, (f32x4){0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0); \
+                    } else {                                                                            \
+                        _Pragma("unroll") for (int t = 0; t < TPW; ++t)                                 \
+                            acc[lt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[d][k][t], b_, acc[lt][t], 0, 0, 0); \
+                    }                                                                                   \
+                }                                                                                       \
         }                                                                                               \
-        _Pragma("unroll") for (int k = 1; k < KTH; ++k)                                                 \
-            _Pragma("unroll") for (int lt = 0; lt < LT; ++lt) {                                         \
-                const bf16x8 b_ = *reinterpret_cast<const bf16x8*>(brow_ + (size_t)lt * bstride_ + k * 64 + q4 * 16); \
-                _Pragma("unroll") for (int t = 0; t < TPW; ++t)                                         \
-                    acc[lt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[d][k][t], b_, acc[lt][t], 0, 0, 0); \
-            }                                                                                           \
         NN_STAMP(2);                                                                                    \
         NW_LOADGROUP(d);                                          /* group g + DEPTH */                 \
         if (g_ >= G0 - 1) {                                                                             \
-            const bool res_ = g_ >= G0;                                                                 \
             _Pragma("unroll") for (int lt = 0; lt < LT; ++lt) {                                         \
-                const uint8_t* const old_ = act0 + (size_t)cur * ML * ROWB + (size_t)(lt * 16 + lrow) * ROWB; \
                 uint8_t* const new_ = act0 + (size_t)(cur ^ 1) * ML * ROWB + (size_t)(lt * 16 + lrow) * ROWB; \
                 _Pragma("unroll") for (int t = 0; t < TPW; ++t) {                                       \
                     const int n = 16 * (wave * TPW + t) + 4 * q4;  /* acc[lt][t][r] = out[neuron n + r][leaf 16 lt + lrow] */ \
                     float x0 = relu_bits(acc[lt][t][0]), x1 = relu_bits(acc[lt][t][1]);                 \
                     float x2 = relu_bits(acc[lt][t][2]), x3 = relu_bits(acc[lt][t][3]);                 \
                     if (res_) {                                    /* b = relu(b + relu(W b)) */        \
-                        const uint2 o = *reinterpret_cast<const uint2*>(old_ + n * 2);                  \
+                        const uint2 o = BP ? old_[lt][t]                                                \
+                                           : *reinterpret_cast<const uint2*>(act0 + (size_t)cur * ML * ROWB + (size_t)(lt * 16 + lrow) * ROWB + n * 2); \
                         x0 += __uint_as_float(o.x << 16); x1 += __uint_as_float(o.x & 0xffff0000u);     \
                         x2 += __uint_as_float(o.y << 16); x3 += __uint_as_float(o.y & 0xffff0000u);     \
                         /* (no second relu: b >= 0 and relu(W b) >= 0, so the sum is its own relu, bit for bit) */ \

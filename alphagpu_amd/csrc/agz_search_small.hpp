@@ -98,10 +98,10 @@ __global__ __launch_bounds__(64 * NW_WAVES, WV) void k_search_small(const SmallP
             __builtin_amdgcn_s_setprio(3);
             const SmallPar& S = par();
 #ifdef AGZ_STAMPS
-            mlp_wave_body<H, TW / 2, 2, true, true, (WV < 4)>(S.F, nn_lds, bx, lds_small + S.io_off, S.io_bw, S.io_lgs,
+            mlp_wave_body<H, TW / 2, 2, true, true, (WV < 4), (WV < 3)>(S.F, nn_lds, bx, lds_small + S.io_off, S.io_bw, S.io_lgs,
                                                               S.T.dbg ? S.T.dbg + (size_t)(32768 + bx * NW_WAVES + wave) * 16 : nullptr);
 #else
-            mlp_wave_body<H, TW / 2, 2, true, true, (WV < 4)>(S.F, nn_lds, bx, lds_small + S.io_off, S.io_bw, S.io_lgs);
+            mlp_wave_body<H, TW / 2, 2, true, true, (WV < 4), (WV < 3)>(S.F, nn_lds, bx, lds_small + S.io_off, S.io_bw, S.io_lgs);
 #endif
             __syncthreads();                                      // logits and values are visible to the tree waves
             __builtin_amdgcn_s_setprio(0);
