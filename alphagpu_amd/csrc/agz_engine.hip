@@ -58,6 +58,9 @@ namespace agz {
 #define X(F, C, K) AGZ_SMALL_VARIANTS(F, C, K, extern) AGZ_BIG_VARIANTS(F, C, K, extern)
 AGZ_SMALL_SHAPES(X)          // defined in agz_small_inst.hip
 #undef X
+#define X(F, C, K, R) AGZ_SMALL_CMP_VARIANTS(F, C, K, R, extern)
+AGZ_SMALL_CMP_SHAPES(X)
+#undef X
 }
 typedef void (*advance_fn)(const PlyPar);
 typedef void (*softmax_fn)(const float*, int, float*, int, int, int);
@@ -118,6 +121,13 @@ struct agz_engine {
     int wl_lds_max = 1 << 30;    // cap (bytes per tree wave) of the LDS part of the work lists (AGZ_WL_LDS_BYTES; tests: the global overflow path)
     int big_mt = 0;              // != 0: force the leaf tiles per workgroup of the stand-alone wide-trunk network (AGZ_BIG_MT = 2, 4, 8)
     int big_maxl = 16384;        // ... used for batches up to this many games (AGZ_BIG_MAXL): 6.2 vs 8.0 ms per ply at 8192 games, 4.5 vs 7.3 at 1024, 9.9 vs 10.2 at 16384
+    // the same kernels with node rows indexed by the root's legal rank (agz_tree_eager.hpp KPR_; Gobang / Hex 9x9: 8 instead of 12 entries
+    // per lane), used by the ply loop once the roots cannot have more legal actions than the rows hold (legal_bound, set per ply)
+    // (two levels: 8 entries per lane while a root may have up to 64 legal actions, 4 up to 32)
+    small_fn k_small_c[2] = {nullptr, nullptr}, k_small4_c[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    int legal_bound = 1 << 30, tree_kpr = 0;
+    bool no_compact = false;            // AGZ_NO_COMPACT (A/B, tests)
+    advance_fn k_spread = nullptr;      // policy_final rows from rank order back to action order after such a search
     small_fn k_small4[3] = {nullptr, nullptr, nullptr};   // the same with 32 games per workgroup, register budgets for 2 / 3 / 4 workgroups per SIMD set
     std::string form_tree, form_nn;   // kernels of the last search (agz_get_search_form)
     int small4_occ = -1;         // >= 0: force the register budget k_small4[occ] (AGZ_SMALL4_OCC = 0, 1, 2)
@@ -147,7 +157,7 @@ struct agz_engine {
 
 static bool bind_kernels(agz_engine* h) {
     const GamePar& P = h->G;
-#define X(F, R, C) if (P.fam == F && P.NR == R && P.NC == C) h->k_adv = k_advance<F, R, C>;
+#define X(F, R, C) if (P.fam == F && P.NR == R && P.NC == C) { h->k_adv = k_advance<F, R, C>; h->k_spread = k_spread_policy<F, R, C>; }
     AGZ_COMBOS(X)
 #undef X
     // smallest block length KPL with 8*KPL >= A among the instantiated shapes
@@ -156,6 +166,10 @@ static bool bind_kernels(agz_engine* h) {
         h->k_small = k_search_small<F, C, K, 128, 2, 2>; h->k_small4[0] = k_search_small<F, C, K, 128, 4, 2>; h->k_small4[1] = k_search_small<F, C, K, 128, 4, 3>; \
         h->k_small4[2] = k_search_small<F, C, K, 128, 4, 4>; h->k_big[0] = k_search_big<F, C, K, 512, 1>; h->k_big[1] = k_search_big<F, C, K, 512, 2>; h->reg_kpl = K; }
     AGZ_SMALL_SHAPES(Z)
+#undef Z
+#define Z(F, C, K, R) if (P.fam == F && P.NC == C && kpl == K) { const int lv = R == 8 ? 0 : 1; h->k_small_c[lv] = k_search_small<F, C, K, 128, 2, 2, R>; \
+        h->k_small4_c[lv][0] = k_search_small<F, C, K, 128, 4, 2, R>; h->k_small4_c[lv][1] = k_search_small<F, C, K, 128, 4, 3, R>; h->k_small4_c[lv][2] = k_search_small<F, C, K, 128, 4, 4, R>; }
+    AGZ_SMALL_CMP_SHAPES(Z)
 #undef Z
     if (P.NR == 1) h->k_soft = k_softmax<1>; else if (P.NR == 2) h->k_soft = k_softmax<2>; else h->k_soft = k_softmax<3>;
     return h->k_adv != nullptr && h->k_eager != nullptr;
@@ -266,6 +280,7 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
         h->chains = e ? atoi(e) : 0;
         h->no_fastdiv = getenv("AGZ_NO_FASTDIV") != nullptr;        // every switch is read here, once: no getenv on a launch path
         h->no_fused_nn = getenv("AGZ_NO_FUSED_NN") != nullptr;
+        h->no_compact = getenv("AGZ_NO_COMPACT") != nullptr;
         e = getenv("AGZ_NN_WAVE_DEPTH");
         if (e && (atoi(e) == 2 || atoi(e) == 4)) h->nn_wave_depth = atoi(e);
         e = getenv("AGZ_NN_WAVE_LT");
@@ -335,6 +350,10 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
         if (e3 && atoi(e3) >= 0 && atoi(e3) <= 2) h->small4_occ = atoi(e3);
         if (h->k_small) FA_(hipFuncSetAttribute((const void*)h->k_small, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         for (int i = 0; i < 3; ++i) if (h->k_small4[i]) FA_(hipFuncSetAttribute((const void*)h->k_small4[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        for (int lv = 0; lv < 2; ++lv) {
+            if (h->k_small_c[lv]) FA_(hipFuncSetAttribute((const void*)h->k_small_c[lv], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            for (int i = 0; i < 3; ++i) if (h->k_small4_c[lv][i]) FA_(hipFuncSetAttribute((const void*)h->k_small4_c[lv][i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        }
     }
     const size_t Lm = (size_t)h->Lmax, V = (size_t)h->V;
     h->INP = round_up(2 * P.VS, 32);
@@ -743,6 +762,7 @@ static int check_search_args(agz_engine* h, int V) {
 }
 
 int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training, uint32_t step) {
+    if (h) h->tree_kpr = 0;
     if (!h) return AGZ_ERR_ARG;
     int rc = check_search_args(h, V); if (rc) return rc;
     if (which < 0 || which > 1 || !h->net[which].loaded) { h->fail("no network loaded in slot %d", which); return AGZ_ERR_STATE; }
@@ -769,7 +789,16 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
             const int tw = h->L <= h->small_maxl ? 2 : 4;
             int occ = h->L <= 64 * h->cus ? 0 : (h->L <= 96 * h->cus ? 1 : 2);
             if (h->small4_occ >= 0) occ = h->small4_occ;      // AGZ_SMALL4_OCC (tests: every register budget at small sizes)
-            const small_fn kfn = tw == 2 ? h->k_small : h->k_small4[occ];
+            // rows by the root's legal rank once no root can have more legal actions than they hold (the ply loop knows: A - ply); the
+            // expansion compacts through the group's edge table, 2 V >= 8 KPR floats
+            int lv = -1;                                          // 0: 8 entries per lane (<= 64 legal actions), 1: 4 (<= 32)
+            if (!h->no_compact) {
+                if (h->k_small_c[1] && h->legal_bound <= 32 && 2 * h->V >= 32) lv = 1;
+                else if (h->k_small_c[0] && h->legal_bound <= 64 && 2 * h->V >= 64) lv = 0;
+            }
+            const bool cmp = lv >= 0;
+            const small_fn kfn = cmp ? (tw == 2 ? h->k_small_c[lv] : h->k_small4_c[lv][occ]) : (tw == 2 ? h->k_small : h->k_small4[occ]);
+            h->tree_kpr = cmp ? (lv == 0 ? 8 : 4) : 0;
             SmallPar S;
             S.T = h->tp;
             S.T.L = h->L; S.T.slot0 = 0; S.T.step = h->step; S.T.cpuct = h->cpuct; S.T.training = h->training;
@@ -806,8 +835,13 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
             std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
             if ((h->profiling & 1) && h->prof_this) { ev = next_events(h, h->ev_tree, h->ev_tree_used); hipEventRecord(ev->first, h->stream); }
             hipLaunchKernelGGL(kfn, dim3((unsigned)((h->L + S.T.gpw * tw - 1) / (S.T.gpw * tw))), dim3(64 * NW_WAVES), lds, h->stream, S);
-            { char b[160]; snprintf(b, sizeof b, "k_search_small<KPL=%d,H=128,TW=%d,WV=%d> (whole mcts_single per launch, %d games per workgroup, %d per tree wave)",
-                                    h->reg_kpl, tw, tw == 2 ? 2 : 2 + occ, S.T.gpw * tw, S.T.gpw); h->form_tree = b; h->form_nn = "inside k_search_small (mlp_wave_body<128>)"; }
+            if (cmp) {   // policy_final back to action order (one wave per game, in place)
+                PlyPar Q; memset(&Q, 0, sizeof Q);
+                Q.G = h->G; Q.L = h->L; Q.V = h->V; Q.states = h->states; Q.policy_final = h->policy_final;
+                hipLaunchKernelGGL(h->k_spread, dim3((unsigned)((h->L + 3) / 4)), dim3(256), 0, h->stream, Q);
+            }
+            { char b[200]; snprintf(b, sizeof b, "k_search_small<KPL=%d,H=128,TW=%d,WV=%d%s> (whole mcts_single per launch, %d games per workgroup, %d per tree wave)",
+                                    h->reg_kpl, tw, tw == 2 ? 2 : 2 + occ, cmp ? (lv == 0 ? ",rows by legal rank KPR=8" : ",rows by legal rank KPR=4") : "", S.T.gpw * tw, S.T.gpw); h->form_tree = b; h->form_nn = "inside k_search_small (mlp_wave_body<128>)"; }
             if (ev) hipEventRecord(ev->second, h->stream);
             HIPCHK(h, hipGetLastError());
             h->cnt_live = true;
@@ -895,7 +929,7 @@ int agz_search(agz_engine* h, int V, float cpuct, int training, uint32_t step) {
 // ---- stepwise (teacher-forced parity) ---------------------------------------------------------------
 int agz_search_begin(agz_engine* h, float cpuct, int training, uint32_t step) {
     if (!h) return AGZ_ERR_ARG;
-    h->cpuct = cpuct; h->training = training; h->step = step; h->need_reset = true; h->injected = false; h->step_last = false;
+    h->cpuct = cpuct; h->training = training; h->step = step; h->need_reset = true; h->injected = false; h->step_last = false; h->tree_kpr = 0;
     return AGZ_OK;
 }
 int agz_rollout_select(agz_engine* h, uint32_t rollout, int last) {
@@ -984,6 +1018,7 @@ static int stats_getter(agz_engine* h, float* out, int want_q) {
     if (!h || !out) return AGZ_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     if (h->L == 0) return AGZ_OK;
+    if (h->tree_kpr) { h->fail("root statistics are not available after a ply-loop search with rows by legal rank (AGZ_NO_COMPACT=1 keeps rows by action)"); return AGZ_ERR_STATE; }
     hipLaunchKernelGGL(k_root_stats, dim3((unsigned)h->L), dim3(128), 0, h->stream, (const uint8_t*)h->recs, (const uint32_t*)h->meta, h->V,
                        h->tp.rec_bytes, 16 + h->tp.A2 * 4, h->tp.off_q, h->tp.off_vis, h->G.A, h->L, want_q ? (float*)nullptr : h->scratch_f,
                        want_q ? h->scratch_f : (float*)nullptr);
@@ -1086,7 +1121,10 @@ static int run_games(agz_engine* h, int ngames, int V, float cpuct, int tau_plie
     while (h->L > 0) {                                                          // :494
         const int which = duel ? ((ply & 1) == 0 ? duel_first : 1 - duel_first) : 0;   // :592-596
         if (hipEventRecord(e0, h->stream) != hipSuccess) { h->fail("hipEventRecord failed"); rc = AGZ_ERR_HIP; break; }
-        rc = agz_search_actor(h, which, V, cpuct, training, (uint32_t)ply); if (rc) break;      // :503
+        h->legal_bound = (h->G.fam == F_LINE || h->G.fam == F_HEX) ? h->G.A - ply : 1 << 30;   // every game started from Position(): ply stones on the board
+        rc = agz_search_actor(h, which, V, cpuct, training, (uint32_t)ply);      // :503
+        h->legal_bound = 1 << 30;
+        if (rc) break;
         if (hipEventRecord(e1, h->stream) != hipSuccess) { h->fail("hipEventRecord failed"); rc = AGZ_ERR_HIP; break; }
         rollouts += (int64_t)h->L * V;
         const bool fold = h->profiling && h->prof_this;                         // descent counters of this search -> d_acc (queued before the

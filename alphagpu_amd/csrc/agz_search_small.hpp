@@ -28,7 +28,8 @@ struct SmallPar {
 // TW = tree waves per workgroup (2 or 4): the workgroup owns 8*TW games and runs the network with TW/2 leaf tiles.
 // WV = waves per SIMD the register budget is cut for (2: 172 VGPRs, no spills; 3, 4: more workgroups per CU so that 24576 /
 // 32768 games are resident at once with 32 games per workgroup).
-template <int FAM, int NC, int KPL, int H, int TW, int WV>
+// KPR: entries per lane of the node rows when they are indexed by the root's legal rank (agz_tree_eager.hpp KPR_), 0 = by action
+template <int FAM, int NC, int KPL, int H, int TW, int WV, int KPR = 0>
 __global__ __launch_bounds__(64 * NW_WAVES, WV) void k_search_small(const SmallPar) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_small[];
     // The parameters are READ FROM THE KERNEL-ARGUMENT SEGMENT where they are needed (scalar loads), through a pointer made opaque
@@ -69,9 +70,9 @@ __global__ __launch_bounds__(64 * NW_WAVES, WV) void k_search_small(const SmallP
         if constexpr (SPLIT) {
             if (k > 0) {
                 const StepFlags SE = {(uint32_t)k, 0, 1, 0, k == S.V - 1, k == S.V};
-                if (wave < TW) rollout_eager_body<FAM, NC, KPL, true, 2, true, ROLE_EXPAND>(SE, own_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
+                if (wave < TW) rollout_eager_body<FAM, NC, KPL, true, 2, true, ROLE_EXPAND, KPR>(SE, own_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
                                                                                          io_blk, S.io_prowb, S.io_lgs, xch);
-                else rollout_eager_body<FAM, NC, KPL, true, 2, true, ROLE_ITEMS>(SE, own_lds, bx * TW + wave % TW, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
+                else rollout_eager_body<FAM, NC, KPL, true, 2, true, ROLE_ITEMS, KPR>(SE, own_lds, bx * TW + wave % TW, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
                                                                                io_blk, S.io_prowb, S.io_lgs, xch);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __syncthreads();                                  // the leaf is expanded, the path's rows and next words are rebuilt
@@ -79,12 +80,12 @@ __global__ __launch_bounds__(64 * NW_WAVES, WV) void k_search_small(const SmallP
             }
             if (k < S.V && wave < TW) {
                 const StepFlags SS = {(uint32_t)k, k == 0, 0, 1, k == S.V - 1, 0};
-                rollout_eager_body<FAM, NC, KPL, true, 2, true, ROLE_EXPAND>(SS, own_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
+                rollout_eager_body<FAM, NC, KPL, true, 2, true, ROLE_EXPAND, KPR>(SS, own_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
                                                                             io_blk, S.io_prowb, S.io_lgs, xch);
             }
         } else {
             const StepFlags SF = {(uint32_t)k, k == 0, k > 0, k < S.V, k == S.V - 1, k == S.V};
-            if (wave < TW) rollout_eager_body<FAM, NC, KPL, true, ((WV < 3 || (WV == 3 && KPL <= 16) || KPL <= 4) ? 2 : 1), true>(SF, tree_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
+            if (wave < TW) rollout_eager_body<FAM, NC, KPL, true, ((WV < 3 || (WV == 3 && KPL <= 16) || KPL <= 4) ? 2 : 1), true, ROLE_ALL, KPR>(SF, tree_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
                                                                                    io_blk, S.io_prowb, S.io_lgs);
         }
 #ifdef AGZ_STAMPS
@@ -124,5 +125,12 @@ __global__ __launch_bounds__(64 * NW_WAVES, WV) void k_search_small(const SmallP
     KW template __global__ void k_search_small<F, C, K, 128, 4, 2>(const SmallPar); \
     KW template __global__ void k_search_small<F, C, K, 128, 4, 3>(const SmallPar); \
     KW template __global__ void k_search_small<F, C, K, 128, 4, 4>(const SmallPar);
+// rows by the root's legal rank (12 -> 8 entries per lane: 9x9 boards from ply 17 on, -> 4 from ply 49 on); part 4 of agz_small_inst.hip
+#define AGZ_SMALL_CMP_SHAPES(X) X(F_LINE, 2, 12, 8) X(F_HEX, 2, 12, 8) X(F_LINE, 2, 12, 4) X(F_HEX, 2, 12, 4)
+#define AGZ_SMALL_CMP_VARIANTS(F, C, K, R, KW)                               \
+    KW template __global__ void k_search_small<F, C, K, 128, 2, 2, R>(const SmallPar); \
+    KW template __global__ void k_search_small<F, C, K, 128, 4, 2, R>(const SmallPar); \
+    KW template __global__ void k_search_small<F, C, K, 128, 4, 3, R>(const SmallPar); \
+    KW template __global__ void k_search_small<F, C, K, 128, 4, 4, R>(const SmallPar);
 
 }  // namespace agz

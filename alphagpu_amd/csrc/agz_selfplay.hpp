@@ -115,6 +115,32 @@ __global__ __launch_bounds__(256) void k_advance(const PlyPar T) {
     }
 }
 
+// policy_final rows that a search with node rows by the root's legal RANK (agz_tree_eager.hpp KPR_) left in rank order -> action order, in
+// place: entry k of the result is the rank(k)-th entry of the row if action k is legal at the root, else 0.  One wavefront per slot;
+// every load of a row comes before its first store.
+template <int FAM, int NR, int NC>
+__global__ __launch_bounds__(256) void k_spread_policy(const PlyPar T) {
+    using G = Game<FAM, NC>;
+    const GamePar& P = T.G;
+    const int lane = lane_id();
+    const int slot = ufirst((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    if (slot >= T.L) return;
+    const int A = P.A;
+    const WPos<NC> root = load_pos<NC>(T.states + (size_t)slot * T.V);
+    float* const row = const_cast<float*>(T.policy_final) + (size_t)slot * A;
+    float out[NR]; int base = 0;
+    for (int r = 0; r < NR; ++r) {
+        const int k = 64 * r + lane;
+        const bool legal = k < A && G::canPlay(P, root, k);
+        const uint64_t m = __ballot(legal);
+        const int rank = base + (int)__popcll(m & ((1ull << lane) - 1ull));
+        out[r] = legal ? row[rank] : 0.0f;
+        base += (int)__popcll(m);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    for (int r = 0; r < NR; ++r) { const int k = 64 * r + lane; if (k < A) row[k] = out[r]; }
+}
+
 // sums of the per-slot descent counters of the last search, added to two device accumulators (roofline bookkeeping without a
 // device-to-host copy per ply)
 __global__ __launch_bounds__(256) void k_fold_counters(const uint32_t* cnt_p, const uint32_t* cnt_new, int L, unsigned long long* acc) {

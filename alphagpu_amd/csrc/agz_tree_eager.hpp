@@ -139,7 +139,14 @@ __device__ __forceinline__ const TreePar& tree_par() {
     return *(const TreePar*)p;
 }
 
-template <int FAM, int NC, int KPL, bool LEAN, int PFM, bool LIO = false, int ROLE = ROLE_ALL>
+// KPR_ (legal-compacted rows, Gobang / Hex in the whole-search kernels): a stone is never removed, so every node of a search has its legal
+// actions among the ROOT's legal actions; with KPR_ set the node rows are indexed by the root's legal RANK (the r-th legal action
+// of the root, in action order) and hold KPR_ < KPL entries per lane — from ply 17 of a 9x9 game 64 ranks cover every tree.  The
+// ordered sums of the reference run over the actions in action order and an illegal action contributes an exact zero, so the
+// sums over the ranks are the same bits; the softmax denominator still runs over all A logits (action space, KPL per lane) and the
+// expansion compacts the masked numerators into rank order through LDS.  policy_final is written in rank order too (the engine
+// spreads it back over the actions after the search: k_spread_policy).
+template <int FAM, int NC, int KPL, bool LEAN, int PFM, bool LIO = false, int ROLE = ROLE_ALL, int KPR_ = 0>
 __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* const lds, const int bidx,
                                                    EagerCarry& C, uint32_t* const wl_lds, const uint32_t wl_cap_lds, uint32_t& wcount,
                                                    uint8_t* const io_blk = nullptr, const int io_prowb = 0, const int io_lgs = 0,
@@ -148,6 +155,9 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
     constexpr bool REV = FAM == F_REV;
     constexpr int G = 8, NG = 8;
     static_assert(KPL % 4 == 0, "block of actions per lane must be a multiple of 4");
+    constexpr int KPR = KPR_ ? KPR_ : KPL;                        // entries per lane of the node ROWS
+    constexpr bool CMP = KPR != KPL;                              // rows by the root's legal rank
+    static_assert(!CMP || (LEAN && KPR % 4 == 0 && KPR < KPL && (FAM == F_LINE || FAM == F_HEX)), "legal-compacted rows: lean builds of the stone-placing games");
     const TreePar& T = tree_par();
     const GamePar& P = T.G;
     int lane_ = lane_id();
@@ -160,7 +170,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
     const bool lead = sub == 0;
     // the row geometry follows from KPL alone (the engine lays the records out with the same formulas): compile-time offsets,
     // so that every load / store of a row is one base address + an immediate
-    constexpr int A2 = G * KPL;
+    constexpr int A2 = G * KPR;
     constexpr int OFF_P = 16, OFF_RK = 16 + 4 * A2, OFF_CID = 16 + 5 * A2, OFF_EL = 16 + 6 * A2;   // aux, per-action rows, then the edge list by rank ...
     const int A = P.A, V = T.V;
     const uint32_t OFF_VIS = (uint32_t)(OFF_EL + 8 * eager_vl(V)), ROWS = (uint32_t)eager_rec_bytes(A2, V);   // ... and the visit bytes by rank
@@ -172,6 +182,11 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
     const int k0 = sub * KPL;
     const int nlanes = (A + KPL - 1) / KPL;                            // lanes of a group whose block holds real actions (wave-uniform)
     const int nval = A - k0 < 0 ? 0 : (A - k0 > KPL ? KPL : A - k0);   // real actions in this lane's block (padding sits at the end of the last blocks)
+    // the same three for the lane's block of a node ROW (compacted rows: every rank slot takes part — slots past the root's legal
+    // count hold zeros like illegal actions do)
+    const int r0 = sub * KPR;
+    const int nlr = CMP ? G : nlanes;
+    const int nvr = CMP ? KPR : nval;
     const bool inject = !LEAN && T.inject, capture = !LEAN && T.capture;
     const bool exact = !LEAN && T.exact, planes_f32 = !LEAN && T.planes_f32;
     // FD: quotients by agz_fastdiv.hpp (same bits as '/', half the instructions) wherever the operands are inside its range by
@@ -221,27 +236,29 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
     // the block, the visit's uniform u and the child bytes of the block: the number of running sums below u — the row of sums is
     // nondecreasing — or, when the whole row sums below u, the last positive action.  Returns the next word.
     // next word: action | child << 8 | NX_VALID | creation rank + 1 of the child << 17 (0: no child yet)
-    auto sample_next = [&](const float (&pol)[KPL], const float st, const float u, const ChildWords<KPL> cdw, const ChildWords<KPL> rkw,
+    auto sample_next = [&](const float (&pol)[KPR], const float st, const float u, const ChildWords<KPR> cdw, const ChildWords<KPR> rkw,
                            const int fix_move, const uint32_t fix_child) -> uint32_t {
         float c = st; int cnt = 0;
 #pragma unroll
-        for (int j = 0; j < KPL; ++j) { c += pol[j]; cnt += c < u ? 1 : 0; }
-        cnt = cnt < nval ? cnt : nval;                                         // (padded actions never count)
+        for (int j = 0; j < KPR; ++j) { c += pol[j]; cnt += c < u ? 1 : 0; }
+        cnt = cnt < nvr ? cnt : nvr;                                           // (padded actions never count)
         int bestmove = grp_sum<G>(cnt);
-        if (__builtin_expect(__ballot(bestmove >= A) != 0, 0)) {               // the row sums below u: the last positive action wins (:175-181)
+        // (compacted rows: the slots past the root's legal count repeat the row's total, so a row that sums below u counts all G KPR)
+        const int AE = CMP ? G * KPR : A;
+        if (__builtin_expect(__ballot(bestmove >= AE) != 0, 0)) {              // the row sums below u: the last positive action wins (:175-181)
             int lastpos = -1;
 #pragma unroll
-            for (int j = 0; j < KPL; ++j) lastpos = pol[j] > 0.0f ? k0 + j : lastpos;
+            for (int j = 0; j < KPR; ++j) lastpos = pol[j] > 0.0f ? r0 + j : lastpos;
             lastpos = grp_max_i<G>(lastpos);
-            bestmove = bestmove >= A ? lastpos : bestmove;
+            bestmove = bestmove >= AE ? lastpos : bestmove;
         }
         if (bestmove < 0) return 0u;                                           // (the reference would index [-1]: the visit ends here)
-        const uint32_t idx = (uint32_t)(bestmove - k0);
+        const uint32_t idx = (uint32_t)(bestmove - r0);
         uint32_t wsel = cdw.w[0], rsel = rkw.w[0];
 #pragma unroll
-        for (int j = 1; j < KPL / 4; ++j) { wsel = (idx >> 2) == (uint32_t)j ? cdw.w[j] : wsel; rsel = (idx >> 2) == (uint32_t)j ? rkw.w[j] : rsel; }
+        for (int j = 1; j < KPR / 4; ++j) { wsel = (idx >> 2) == (uint32_t)j ? cdw.w[j] : wsel; rsel = (idx >> 2) == (uint32_t)j ? rkw.w[j] : rsel; }
         // (child id in bits 0..7, rank in bits 8..15 of one sum: both are 0 in every lane but the one that owns the action)
-        const uint32_t both = idx < (uint32_t)KPL ? __builtin_amdgcn_ubfe(wsel, (idx & 3u) * 8u, 8u) | (__builtin_amdgcn_ubfe(rsel, (idx & 3u) * 8u, 8u) << 8) : 0u;
+        const uint32_t both = idx < (uint32_t)KPR ? __builtin_amdgcn_ubfe(wsel, (idx & 3u) * 8u, 8u) | (__builtin_amdgcn_ubfe(rsel, (idx & 3u) * 8u, 8u) << 8) : 0u;
         const uint32_t cr = (uint32_t)grp_sum<G>((int)both);
         uint32_t child = cr & 0xffu;
         const uint32_t rank = cr >> 8;                                         // (the rank bytes of this item's own new edge are already in rkw)
@@ -250,7 +267,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
     };
 
     // one work item's rows -> registers (zeros for a lane-group without an item).  entry: node | move << 8 | depth << 16 | game << 24
-    auto item_fetch = [&](ItemRows<KPL>& R, const int r, const uint32_t nwl) {
+    auto item_fetch = [&](ItemRows<KPR>& R, const int r, const uint32_t nwl) {
         R.ent = 0u; R.gi = g; R.valid = false;
         // round 0: the lane-groups that own a game take its special item, the others (sparse waves: g >= GPW) already take list entries
         if (r == 0 && g < GPW) { R.ent = C.spw; R.valid = live && (C.spw & SP_VALID); }
@@ -274,11 +291,11 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
             const uint4 ax = *reinterpret_cast<const uint4*>(rec);
             R.ax_x = ax.x; R.ax_z = ax.z;                             // (raw: nothing here may wait for a load — the item body masks them)
 #pragma unroll
-            for (int j = 0; j < KPL; j += 4) {
-                const float4 a = *reinterpret_cast<const float4*>(rec + OFF_P + (uint32_t)(k0 + j) * 4u);
+            for (int j = 0; j < KPR; j += 4) {
+                const float4 a = *reinterpret_cast<const float4*>(rec + OFF_P + (uint32_t)(r0 + j) * 4u);
                 R.p[j] = a.x; R.p[j + 1] = a.y; R.p[j + 2] = a.z; R.p[j + 3] = a.w;
-                R.rk[j / 4] = *reinterpret_cast<const uint32_t*>(rec + OFF_RK + (uint32_t)(k0 + j));
-                R.cd[j / 4] = *reinterpret_cast<const uint32_t*>(rec + OFF_CID + (uint32_t)(k0 + j));
+                R.rk[j / 4] = *reinterpret_cast<const uint32_t*>(rec + OFF_RK + (uint32_t)(r0 + j));
+                R.cd[j / 4] = *reinterpret_cast<const uint32_t*>(rec + OFF_CID + (uint32_t)(r0 + j));
             }
             // the edge taken: an existing one is entry mr - 1 of the list; a new one has q = 0, no visit, and the prior of its action
             const uint32_t er = (crt || mr == 0u) ? 0u : mr - 1u;
@@ -334,7 +351,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
         const uint32_t nwl = wcount;
         const uint32_t free0 = (uint32_t)(8 - GPW);                  // list entries that round 0 already takes (sparse waves)
         const int rounds = 1 + (nwl > free0 ? (int)((nwl - free0 + 7u) >> 3) : 0);
-        ItemRows<KPL> R;
+        ItemRows<KPR> R;
         const uint32_t gid = live ? T.game_id[slot] : 0u;
         {   // the uniforms of the rows this call makes: U(seed; game, step, rollout whose leaf is expanded / backed up, depth);
             // lane sub draws depths 4 sub .. 4 sub + 3 (deeper nodes, rare: drawn where they are needed)
@@ -351,7 +368,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
         const bool doexp = live && !term;
         float vleaf = 0.0f;
         const uint32_t spw = C.spw;
-        float x[KPL]; int npos = 0;
+        float x[KPL], xr[KPR], sden = 1.0f; int npos = 0;   // x: the lane's block of logits / softmax numerators by ACTION; xr: its block of the node row
         bool wide = false, fdx = false;                               // (fdx is wave-uniform)
         if constexpr (ROLE == ROLE_ITEMS) {                           // (the helper only needs the value of the leaf)
             if (doexp) vleaf = (LEAN && LIO) ? (reinterpret_cast<const float*>(io_blk) + (size_t)g * io_lgs)[A] : T.v_eval[slot];
@@ -385,52 +402,93 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
                 float s;
                 (void)grp_ordered_start<KPL, true>(x, sub, s, nlanes);
                 fdx = FD && !__ballot(wide);
-                if (fdx) {
-                    const float rs = fd_rcp(s);
+                sden = s;
+                if constexpr (!CMP) {
+                    if (fdx) {
+                        const float rs = fd_rcp(s);
 #pragma unroll
-                    for (int j = 0; j < KPL; j += 2) fd_div2(x[j], s, rs, x[j + 1], s, rs, x[j], x[j + 1]);
-                } else {
+                        for (int j = 0; j < KPL; j += 2) fd_div2(x[j], s, rs, x[j + 1], s, rs, x[j], x[j + 1]);
+                    } else {
 #pragma unroll
-                    for (int j = 0; j < KPL; j += 2) div_pair(x[j], s, x[j + 1], s, x[j], x[j + 1]);
-                }
-                if (capture) {
+                        for (int j = 0; j < KPL; j += 2) div_pair(x[j], s, x[j + 1], s, x[j], x[j + 1]);
+                    }
+                    if (capture) {
 #pragma unroll
-                    for (int j = 0; j < KPL; ++j) if (j < nval) T.prior_eval[(size_t)slot * A + k0 + j] = x[j];
+                        for (int j = 0; j < KPL; ++j) if (j < nval) T.prior_eval[(size_t)slot * A + k0 + j] = x[j];
+                    }
                 }
             }
-            bool lg[KPL];                                             // legal mask; masked priors (:260-268 / :284-290)   // PHASE expand: legal mask + normalize sum
+            bool lg[KPR];                                             // legal mask; masked priors (:260-268 / :284-290)   // PHASE expand: legal mask + normalize sum
             const uint32_t lmask = legal_block<FAM, NC, KPL>(P, st, k0, nval);
-#pragma unroll
-            for (int j = 0; j < KPL; ++j) {
-                lg[j] = (lmask >> j) & 1u;
-                x[j] = lg[j] ? x[j] : 0.0f;
-            }
             const int nl = grp_sum<G>(__builtin_popcount(lmask));
+            if constexpr (CMP) {
+                // the masked softmax NUMERATORS of the lane's actions go to the slots of their ranks among the root's legal actions
+                // (an action of the root's legal set that is taken at this node leaves the illegal mark -0 in its slot, and so do the
+                // slots past the root's legal count), then every lane takes its KPR slots and divides what is legal by the denominator:
+                // the same quotients as x / s of the action form, for fewer actions
+                const WPos<NC> rst = grp_load_pos<NC, REV>(wstates + gnode0);
+                const uint32_t rmask = legal_block<FAM, NC, KPL>(P, rst, k0, nval);
+                int rank = grp_excl_prefix8(__builtin_popcount(rmask), sub);
+                float* const cs = reinterpret_cast<float*>(tab);      // (the group's edge table is idle during the expansion: 2 V >= G KPR floats)
+                const float nz = __uint_as_float(0x80000000u);
+#pragma unroll
+                for (int j = 0; j < KPR; j += 4) *reinterpret_cast<float4*>(cs + r0 + j) = make_float4(nz, nz, nz, nz);
+                AGZ_WSYNC();
+#pragma unroll
+                for (int j = 0; j < KPL; ++j) {
+                    if ((rmask >> j) & 1u) { cs[rank] = ((lmask >> j) & 1u) ? x[j] : nz; ++rank; }
+                }
+                AGZ_WSYNC();
+#pragma unroll
+                for (int j = 0; j < KPR; j += 4) {
+                    const float4 a = *reinterpret_cast<const float4*>(cs + r0 + j);
+                    xr[j] = a.x; xr[j + 1] = a.y; xr[j + 2] = a.z; xr[j + 3] = a.w;
+                }
+                AGZ_WSYNC();
+#pragma unroll
+                for (int j = 0; j < KPR; ++j) { lg[j] = !(__float_as_uint(xr[j]) >> 31); xr[j] = lg[j] ? xr[j] : 0.0f; }
+                if (!inject) {
+                    if (fdx) {
+                        const float rs = fd_rcp(sden);
+#pragma unroll
+                        for (int j = 0; j < KPR; j += 2) fd_div2(xr[j], sden, rs, xr[j + 1], sden, rs, xr[j], xr[j + 1]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < KPR; j += 2) div_pair(xr[j], sden, xr[j + 1], sden, xr[j], xr[j + 1]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < KPR; ++j) {
+                    lg[j] = (lmask >> j) & 1u;
+                    xr[j] = lg[j] ? x[j < KPL ? j : 0] : 0.0f;
+                }
+            }
             float normalize;
-            (void)grp_ordered_start<KPL, true>(x, sub, normalize, nlanes);
+            (void)grp_ordered_start<KPR, true>(xr, sub, normalize, nlr);
             const bool rootmix = lf == 0 && T.training;               // :270-275 vs :277-279, :292-294   // PHASE expand: mix / divide
             const float Af = (float)nl;
-            float qn_[KPL];
+            float qn_[KPR];
             if (fdx && !__ballot(doexp && !(normalize >= 7.8886090522101181e-31f))) {        // 2^-100
                 const float rn = fd_rcp(normalize);
 #pragma unroll
-                for (int j = 0; j < KPL; j += 2)
-                    fd_div2(rootmix ? 0.75f * x[j] : x[j], normalize, rn, rootmix ? 0.75f * x[j + 1] : x[j + 1], normalize, rn, qn_[j], qn_[j + 1]);
+                for (int j = 0; j < KPR; j += 2)
+                    fd_div2(rootmix ? 0.75f * xr[j] : xr[j], normalize, rn, rootmix ? 0.75f * xr[j + 1] : xr[j + 1], normalize, rn, qn_[j], qn_[j + 1]);
             } else {
 #pragma unroll
-                for (int j = 0; j < KPL; j += 2)
-                    div_pair(rootmix ? 0.75f * x[j] : x[j], normalize, rootmix ? 0.75f * x[j + 1] : x[j + 1], normalize, qn_[j], qn_[j + 1]);
+                for (int j = 0; j < KPR; j += 2)
+                    div_pair(rootmix ? 0.75f * xr[j] : xr[j], normalize, rootmix ? 0.75f * xr[j + 1] : xr[j + 1], normalize, qn_[j], qn_[j + 1]);
             }
 #pragma unroll
-            for (int j = 0; j < KPL; ++j) {
+            for (int j = 0; j < KPR; ++j) {
                 float pr = rootmix ? (lg[j] ? qn_[j] + 0.25f / Af : 0.0f) : qn_[j];
-                if (j >= nval) pr = 0.0f;
-                x[j] = pr;
+                if (j >= nvr) pr = 0.0f;
+                xr[j] = pr;
                 npos += pr > 0.0f ? 1 : 0;
             }
             if (__builtin_expect(lf == 0, 0)) {                       // root expansion: policy == prior is what copy_pol sees for V <= 2
 #pragma unroll
-                for (int j = 0; j < KPL; ++j) if (j < nval) T.policy_final[(size_t)slot * A + k0 + j] = x[j];
+                for (int j = 0; j < KPR; ++j) if (j < nvr) T.policy_final[(size_t)slot * A + r0 + j] = xr[j];
                 C.root_exp = 1u;
             }
             npos = grp_sum<G>(npos);                                  // "A" of :125-131 never changes after the expansion
@@ -440,19 +498,19 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
             // policy = prior (:297-299): the first revisit samples from these running sums; their total is prior_rem (:120-124, no   // PHASE expand: running sums + write rows
             // child yet)
             float total;
-            const float st0 = grp_ordered_start<KPL, true>(x, sub, total, nlanes);
+            const float st0 = grp_ordered_start<KPR, true>(xr, sub, total, nlr);
             const int Dl = (int)((spw >> 16) & 0xffu);                // depth of the leaf = expanded nodes above it
             const float ul = Dl < 32 ? utab[g * 32 + Dl] : uniform_search(T.seed, gid, T.step, SF.rollout - 1u, (uint32_t)Dl);
-            ChildWords<KPL> nocd;
+            ChildWords<KPR> nocd;
 #pragma unroll
-            for (int j = 0; j < KPL / 4; ++j) nocd.w[j] = 0u;
-            const uint32_t nx = sample_next(x, st0, ul, nocd, nocd, -1, 0u);
+            for (int j = 0; j < KPR / 4; ++j) nocd.w[j] = 0u;
+            const uint32_t nx = sample_next(xr, st0, ul, nocd, nocd, -1, 0u);
             uint8_t* rec = wrecs + __umul24(gnode0 + (uint32_t)lf, ROWS);
 #pragma unroll
-            for (int j = 0; j < KPL; j += 4) {                        // (the per-action rows only: a fresh node has no edge)
-                *reinterpret_cast<float4*>(rec + OFF_P + (size_t)(k0 + j) * 4) = make_float4(x[j], x[j + 1], x[j + 2], x[j + 3]);
-                *reinterpret_cast<uint32_t*>(rec + OFF_RK + (size_t)(k0 + j)) = 0u;
-                *reinterpret_cast<uint32_t*>(rec + OFF_CID + (size_t)(k0 + j)) = 0u;
+            for (int j = 0; j < KPR; j += 4) {                        // (the per-action rows only: a fresh node has no edge)
+                *reinterpret_cast<float4*>(rec + OFF_P + (size_t)(r0 + j) * 4) = make_float4(xr[j], xr[j + 1], xr[j + 2], xr[j + 3]);
+                *reinterpret_cast<uint32_t*>(rec + OFF_RK + (size_t)(r0 + j)) = 0u;
+                *reinterpret_cast<uint32_t*>(rec + OFF_CID + (size_t)(r0 + j)) = 0u;
             }
             ml |= M_EXPANDED;                                         // :256
             if (lead) {
@@ -511,22 +569,22 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
             const uint32_t npos = ax_z & 0xffu, nvis = ((ax_z >> 8) & 0xffu) + 1u, nch_old = (ax_z >> 16) & 0xffu;
             const uint32_t nch = nch_old + (created ? 1u : 0u);
             const uint32_t rank1 = created ? nch : (uint32_t)mr;      // creation rank + 1 of the edge taken (:183-191 for a new one)
-            ChildWords<KPL> rkw;                                      // rank bytes of the block, the new edge registered
-            {   const uint32_t idx = (uint32_t)(move - k0);
+            ChildWords<KPR> rkw;                                      // rank bytes of the block, the new edge registered
+            {   const uint32_t idx = (uint32_t)(move - r0);
 #pragma unroll
-                for (int j = 0; j < KPL / 4; ++j) rkw.w[j] = (created && (idx >> 2) == (uint32_t)j) ? (R.rk[j] | (nch << ((idx & 3u) * 8u))) : R.rk[j];
+                for (int j = 0; j < KPR / 4; ++j) rkw.w[j] = (created && (idx >> 2) == (uint32_t)j) ? (R.rk[j] | (nch << ((idx & 3u) * 8u))) : R.rk[j];
             }
             float prem_raw = valid ? __uint_as_float(R.ax_x) : 0.0f;   // sum of the priors of childless actions, before lambda
             if (__builtin_expect(__ballot(valid && created) != 0, 0)) {
                 // the node loses one childless action: re-sum prior_rem in source order (:120-124), once per rollout
-                float m[KPL];
+                float m[KPR];
 #pragma unroll
-                for (int j = 0; j < KPL; ++j) {
+                for (int j = 0; j < KPR; ++j) {
                     const uint32_t rk = (rkw.w[j / 4] >> (8 * (j & 3))) & 0xffu;
                     m[j] = (created && rk == 0) ? R.p[j] : 0.0f;
                 }
                 float tot;
-                (void)grp_ordered_start<KPL, true>(m, sub, tot, nlanes);
+                (void)grp_ordered_start<KPR, true>(m, sub, tot, nlr);
                 prem_raw = created ? tot : prem_raw;
             }
             if (valid && lead) {
@@ -572,9 +630,9 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
             AGZ_WSYNC();
             if (valid && lead) { if (created) tab[rank1 - 1u] = make_float2(nq, R.pm); else tab[rank1 - 1u].x = nq; }   // the edge just updated
             AGZ_WSYNC();
-            float qa[KPL];                                            // q by action: an action without a child reads the zero pair
+            float qa[KPR];                                            // q by action: an action without a child reads the zero pair
 #pragma unroll
-            for (int j = 0; j < KPL; ++j) {
+            for (int j = 0; j < KPR; ++j) {
                 const int rk = (int)((rkw.w[j / 4] >> (8 * (j & 3))) & 0xffu);
                 qa[j] = tab[rk - 1].x;
             }
@@ -585,7 +643,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
             const float prior_rem = prem_raw * lambda;               // :134
             float am = 0.0f;
 #pragma unroll
-            for (int j = 0; j < KPL; ++j) {
+            for (int j = 0; j < KPR; ++j) {
                 const float lp = lambda * R.p[j];
                 const float gap = lp > 1e-4f ? lp : 1e-4f;
                 const float c = qa[j] + gap;
@@ -639,19 +697,19 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
                 if (r + 1 < rounds) sink = item_touch(r + 1, nwl);
             }
             // ---- the policy row (:165-169) and its running sums (:172-181)   // PHASE items: policy row
-            float pol[KPL];
+            float pol[KPR];
             if (FDr) {
 #pragma unroll
-                for (int j = 0; j < KPL; j += 2)
+                for (int j = 0; j < KPR; j += 2)
                     fd_div_pair(lambda * R.p[j], alpha - qa[j], lambda * R.p[j + 1], alpha - qa[j + 1], pol[j], pol[j + 1]);
             } else {
 #pragma unroll
-                for (int j = 0; j < KPL; j += 2)
+                for (int j = 0; j < KPR; j += 2)
                     div_pair(lambda * R.p[j], alpha - qa[j], lambda * R.p[j + 1], alpha - qa[j + 1], pol[j], pol[j + 1]);
             }
-            ChildWords<KPL> cdk;
+            ChildWords<KPR> cdk;
 #pragma unroll
-            for (int j = 0; j < KPL / 4; ++j) cdk.w[j] = R.cd[j];
+            for (int j = 0; j < KPR / 4; ++j) cdk.w[j] = R.cd[j];
             // the rows of this item are dead: the next item's start travelling now (its table entries are written after the
             // AGZ_WSYNC below)
             AGZ_WSYNC();
@@ -659,13 +717,13 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
             if (__builtin_expect(__ballot(valid && node == 0 && SF.last) != 0, 0)) {     // copy_pol (:330-339): the row the last descent samples from
                 if (valid && node == 0) {
 #pragma unroll
-                    for (int j = 0; j < KPL; ++j) if (j < nval) TI.policy_final[(size_t)(slot_base + gi) * A + k0 + j] = pol[j];
+                    for (int j = 0; j < KPR; ++j) if (j < nvr) TI.policy_final[(size_t)(slot_base + gi) * A + r0 + j] = pol[j];
                 }
             }
             // the child bytes are needed past the prefetch of the next item: kept aside   // PHASE items: running sums + sampling
             STAMPW(7);
             float dummy;
-            const float st = grp_ordered_start<KPL, false>(pol, sub, dummy, nlanes);
+            const float st = grp_ordered_start<KPR, false>(pol, sub, dummy, nlr);
             const float u = dpt < 32 ? utab[gi * 32 + dpt] : uniform_search(TI.seed, TI.game_id[valid ? slot_base + gi : sl], TI.step, SF.rollout - 1u, (uint32_t)dpt);
             const uint32_t nx = sample_next(pol, st, u, cdk, rkw, move, (uint32_t)ileaf);
             if (valid && lead) *reinterpret_cast<uint4*>(rec) = make_uint4(__float_as_uint(prem_raw), nx, auxz, 0u);
@@ -732,7 +790,20 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
         if (live && create_from >= 0) {                                    // :183-191 node creation (at most one per rollout)
             const uint32_t child = C.ncount; C.ncount += 1;
             const WPos<NC> ps = grp_load_pos<NC, REV>(wstates + (gnode0 + (uint32_t)create_from));
-            lst = GM::play(P, ps, create_move);
+            int amove = create_move;
+            if constexpr (CMP) {
+                // rows by rank: the move is the create_move-th legal action of the ROOT — the lane whose block holds that rank finds the
+                // action (the rel-th set bit of its part of the root's legal mask), the group sums the one non-zero answer
+                const WPos<NC> rst = grp_load_pos<NC, REV>(wstates + gnode0);
+                const uint32_t rmask = legal_block<FAM, NC, KPL>(P, rst, k0, nval);
+                const int cnt = __builtin_popcount(rmask);
+                const int rel = create_move - grp_excl_prefix8(cnt, sub);
+                uint32_t m = rmask;
+#pragma unroll
+                for (int i = 0; i < KPL - 1; ++i) m = i < rel ? m & (m - 1u) : m;
+                amove = grp_sum<G>((rel >= 0 && rel < cnt) ? k0 + (int)__builtin_ctz(m) : 0);
+            }
+            lst = GM::play(P, ps, amove);
             have_state = true;
             int rr; const bool f = GM::isOver(P, lst, rr);
             uint32_t mc = (uint32_t)create_from | ((uint32_t)create_move << 8) | M_EXISTS | M_EVAL;

@@ -98,6 +98,15 @@ __device__ __forceinline__ void grp_pull_sums(float& a, const float t, float& b,
 template <int D> __device__ __forceinline__ float lane_shl(float x) {      // value of lane + D (same 16-lane row), own value past the row's end
     return __int_as_float(dpp_mov<0x100 + D, 0xF>(__float_as_int(x), __float_as_int(x)));
 }
+// exclusive prefix sum over the 8 lanes of a group: lane sub gets the sum of the lanes 0 .. sub - 1 (three row_shr steps; a lane
+// whose source lies in the neighbouring group of the DPP row, or outside the row, adds nothing)
+__device__ __forceinline__ int grp_excl_prefix8(const int v, const int sub) {
+    int a = v;
+    int t = dpp_mov<0x111, 0xF>(0, a); a += sub >= 1 ? t : 0;
+    t = dpp_mov<0x112, 0xF>(0, a); a += sub >= 2 ? t : 0;
+    t = dpp_mov<0x114, 0xF>(0, a); a += sub >= 4 ? t : 0;
+    return a - v;
+}
 __device__ __forceinline__ float lane_shr1(float x) { return __int_as_float(dpp_mov<DPP_SHR1, 0xF>(__float_as_int(x), __float_as_int(x))); }
 
 // Source-order running sums over the group's 8*KPL values (lane sub holds block sub): returns the sum of everything BEFORE the

@@ -146,6 +146,34 @@ def test_bf16_search_matches_oracle_bitwise(name, L, V, H, T):
         assert e.counters()[:2] == (p, n)
 
 
+@pytest.mark.parametrize("name,n,V,H,T", [("gobang9", 40, 32, 128, 1), ("hex9", 20, 32, 128, 1), ("gobang9", 300, 36, 128, 2)])
+def test_bf16_generation_with_rows_by_legal_rank_matches_oracle_bitwise(name, n, V, H, T):
+    """From ply 17 of a 9x9 game of Gobang / Hex the ply loop searches with node rows indexed by the ROOT's legal rank (8 instead of
+    12 entries per lane: agz_tree_eager.hpp KPR_, `policy_final` spread back over the actions by k_spread_policy): the generation is
+    the oracle's, sample for sample, and the same with the rows kept by action (AGZ_NO_COMPACT=1).  The third case has enough games
+    for 32-game workgroups in the first plies."""
+    g, og = spec(name)
+    net, onet = nets(g, og, H, T)
+    ref = O.selfplay(og, onet.bf16(), n, V, 1.5, 25, 91, 700)
+    assert ref["rc"] == 0
+    for no_compact in (False, True):
+        if no_compact:
+            os.environ["AGZ_NO_COMPACT"] = "1"
+        try:
+            with M.Engine(g, n, V, seed=91, game_id_base=700, nn_mode=M.NN_BF16) as e:
+                e.set_network(net)
+                st = e.selfplay(n, V, cpuct=1.5, tau_plies=25)
+                s = e.samples()
+                form = e.search_form()[0]
+        finally:
+            os.environ.pop("AGZ_NO_COMPACT", None)
+        assert ("rows by legal rank" in form) == (not no_compact), form      # (the last plies of a generation have few legal actions)
+        assert st["valid"]
+        assert (st["wins"], st["draws"], st["losses"], st["total_plies"]) == (ref["wins"], ref["draws"], ref["losses"], ref["total_plies"])
+        for key in ("game_id", "ply", "move", "player", "state", "fstate", "policy", "value"):
+            assert_same_bits(s[key], ref[key], key)
+
+
 @pytest.mark.parametrize("name,n,V,H,T", [("tictactoe", 256, 16, 128, 6), ("connect4", 48, 16, 128, 2), ("gobang9", 16, 8, 128, 1), ("reversi6", 24, 12, 64, 1)])
 def test_bf16_selfplay_generation_matches_oracle_bitwise(name, n, V, H, T):
     """A whole self-play generation in the benchmarked bf16 mode (device ply loop, whole-search kernel) == the oracle's generation
