@@ -58,7 +58,7 @@ namespace agz {
 #define X(F, C, K) AGZ_SMALL_VARIANTS(F, C, K, extern) AGZ_BIG_VARIANTS(F, C, K, extern)
 AGZ_SMALL_SHAPES(X)          // defined in agz_small_inst.hip
 #undef X
-#define X(F, C, K, R) AGZ_SMALL_CMP_VARIANTS(F, C, K, R, extern)
+#define X(F, C, K, R) AGZ_SMALL_CMP_VARIANTS(F, C, K, R, extern) AGZ_BIG_CMP_VARIANTS(F, C, K, R, extern)
 AGZ_SMALL_CMP_SHAPES(X)
 #undef X
 }
@@ -125,6 +125,7 @@ struct agz_engine {
     // per lane), used by the ply loop once the roots cannot have more legal actions than the rows hold (legal_bound, set per ply)
     // (two levels: 8 entries per lane while a root may have up to 64 legal actions, 4 up to 32)
     small_fn k_small_c[2] = {nullptr, nullptr}, k_small4_c[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    big_fn k_big_c[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // k_search_big: [level][workgroups per CU - 1]
     int legal_bound = 1 << 30, tree_kpr = 0;
     bool no_compact = false;            // AGZ_NO_COMPACT (A/B, tests)
     advance_fn k_spread = nullptr;      // policy_final rows from rank order back to action order after such a search
@@ -168,7 +169,8 @@ static bool bind_kernels(agz_engine* h) {
     AGZ_SMALL_SHAPES(Z)
 #undef Z
 #define Z(F, C, K, R) if (P.fam == F && P.NC == C && kpl == K) { const int lv = R == 8 ? 0 : 1; h->k_small_c[lv] = k_search_small<F, C, K, 128, 2, 2, R>; \
-        h->k_small4_c[lv][0] = k_search_small<F, C, K, 128, 4, 2, R>; h->k_small4_c[lv][1] = k_search_small<F, C, K, 128, 4, 3, R>; h->k_small4_c[lv][2] = k_search_small<F, C, K, 128, 4, 4, R>; }
+        h->k_small4_c[lv][0] = k_search_small<F, C, K, 128, 4, 2, R>; h->k_small4_c[lv][1] = k_search_small<F, C, K, 128, 4, 3, R>; h->k_small4_c[lv][2] = k_search_small<F, C, K, 128, 4, 4, R>; \
+        h->k_big_c[lv][0] = k_search_big<F, C, K, 512, 1, R>; h->k_big_c[lv][1] = k_search_big<F, C, K, 512, 2, R>; }
     AGZ_SMALL_CMP_SHAPES(Z)
 #undef Z
     if (P.NR == 1) h->k_soft = k_softmax<1>; else if (P.NR == 2) h->k_soft = k_softmax<2>; else h->k_soft = k_softmax<3>;
@@ -346,6 +348,7 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
         e3 = getenv("AGZ_WL_LDS_BYTES");
         if (e3 && atoi(e3) >= 0) h->wl_lds_max = atoi(e3) & ~15;
         for (int i = 0; i < 2; ++i) if (h->k_big[i]) FA_(hipFuncSetAttribute((const void*)h->k_big[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        for (int lv = 0; lv < 2; ++lv) for (int i = 0; i < 2; ++i) if (h->k_big_c[lv][i]) FA_(hipFuncSetAttribute((const void*)h->k_big_c[lv][i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         e3 = getenv("AGZ_SMALL4_OCC");
         if (e3 && atoi(e3) >= 0 && atoi(e3) <= 2) h->small4_occ = atoi(e3);
         if (h->k_small) FA_(hipFuncSetAttribute((const void*)h->k_small, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -878,9 +881,21 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
             const size_t lds = shared + (size_t)4 * S.wl_bytes;
             std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
             if ((h->profiling & 1) && h->prof_this) { ev = next_events(h, h->ev_tree, h->ev_tree_used); hipEventRecord(ev->first, h->stream); }
-            hipLaunchKernelGGL(h->k_big[occ], dim3((unsigned)wgs), dim3(NB_THREADS), lds, h->stream, S);
-            { char b[160]; snprintf(b, sizeof b, "k_search_big<KPL=%d,H=512,WG=%d> (whole mcts_single per launch, %d games per workgroup, %d per tree wave)",
-                                    h->reg_kpl, occ + 1, 4 * S.T.gpw, S.T.gpw); h->form_tree = b; h->form_nn = "inside k_search_big (mlp_big_body<512,2>)"; }
+            int lv = -1;                                          // rows by the root's legal rank (see k_search_small above)
+            if (!h->no_compact) {
+                if (h->k_big_c[1][occ] && h->legal_bound <= 32 && 2 * h->V >= 32) lv = 1;
+                else if (h->k_big_c[0][occ] && h->legal_bound <= 64 && 2 * h->V >= 64) lv = 0;
+            }
+            h->tree_kpr = lv < 0 ? 0 : (lv == 0 ? 8 : 4);
+            hipLaunchKernelGGL(lv < 0 ? h->k_big[occ] : h->k_big_c[lv][occ], dim3((unsigned)wgs), dim3(NB_THREADS), lds, h->stream, S);
+            if (lv >= 0) {
+                PlyPar Q; memset(&Q, 0, sizeof Q);
+                Q.G = h->G; Q.L = h->L; Q.V = h->V; Q.states = h->states; Q.policy_final = h->policy_final;
+                hipLaunchKernelGGL(h->k_spread, dim3((unsigned)((h->L + 3) / 4)), dim3(256), 0, h->stream, Q);
+            }
+            { char b[200]; snprintf(b, sizeof b, "k_search_big<KPL=%d,H=512,WG=%d%s> (whole mcts_single per launch, %d games per workgroup, %d per tree wave)",
+                                    h->reg_kpl, occ + 1, lv < 0 ? "" : (lv == 0 ? ",rows by legal rank KPR=8" : ",rows by legal rank KPR=4"), 4 * S.T.gpw, S.T.gpw);
+              h->form_tree = b; h->form_nn = "inside k_search_big (mlp_big_body<512,2>)"; }
             if (ev) hipEventRecord(ev->second, h->stream);
             HIPCHK(h, hipGetLastError());
             h->cnt_live = true;

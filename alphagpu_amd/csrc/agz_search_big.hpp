@@ -24,7 +24,8 @@ struct BigSearchPar {
 };
 
 // WG = workgroups per CU the register budget is cut for (1: 256 registers, 2: 128)
-template <int FAM, int NC, int KPL, int H, int WG>
+// KPR: node rows by the root's legal rank (agz_tree_eager.hpp KPR_), 0 = by action
+template <int FAM, int NC, int KPL, int H, int WG, int KPR = 0>
 __global__ __launch_bounds__(NB_THREADS, 2 * WG) void k_search_big(const BigSearchPar) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_bigs[];
     // the parameters are read from the kernel-argument segment per phase (see tree_par(), agz_tree_eager.hpp)
@@ -54,13 +55,13 @@ __global__ __launch_bounds__(NB_THREADS, 2 * WG) void k_search_big(const BigSear
         const BigSearchPar& S = par();
         if constexpr (!SPLIT) {
             const StepFlags SF = {(uint32_t)k, k == 0, k > 0, k < S.V, k == S.V - 1, k == S.V};
-            if (wave < TW) rollout_eager_body<FAM, NC, KPL, true, PF_>(SF, own_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount);
+            if (wave < TW) rollout_eager_body<FAM, NC, KPL, true, PF_, false, ROLE_ALL, KPR>(SF, own_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount);
         }
         if (SPLIT && k > 0) {
             const StepFlags SE = {(uint32_t)k, 0, 1, 0, k == S.V - 1, k == S.V};
-            if (wave < TW) rollout_eager_body<FAM, NC, KPL, true, PF_, false, ROLE_EXPAND>(SE, own_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
+            if (wave < TW) rollout_eager_body<FAM, NC, KPL, true, PF_, false, ROLE_EXPAND, KPR>(SE, own_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
                                                                                         nullptr, 0, 0, xch);
-            else rollout_eager_body<FAM, NC, KPL, true, PF_, false, ROLE_ITEMS>(SE, own_lds, bx * TW + wave % TW, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
+            else rollout_eager_body<FAM, NC, KPL, true, PF_, false, ROLE_ITEMS, KPR>(SE, own_lds, bx * TW + wave % TW, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
                                                                               nullptr, 0, 0, xch);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __syncthreads();                                      // the leaf is expanded, the path's rows and next words are rebuilt
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(NB_THREADS, 2 * WG) void k_search_big(const BigSear
         if (k < S.V) {
             if (SPLIT && wave < TW) {
                 const StepFlags SS = {(uint32_t)k, k == 0, 0, 1, k == S.V - 1, 0};
-                rollout_eager_body<FAM, NC, KPL, true, PF_, false, ROLE_EXPAND>(SS, own_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
+                rollout_eager_body<FAM, NC, KPL, true, PF_, false, ROLE_EXPAND, KPR>(SS, own_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
                                                                              nullptr, 0, 0, xch);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -88,5 +89,8 @@ __global__ __launch_bounds__(NB_THREADS, 2 * WG) void k_search_big(const BigSear
 #define AGZ_BIG_VARIANTS(F, C, K, KW)                                        \
     KW template __global__ void k_search_big<F, C, K, 512, 1>(const BigSearchPar); \
     KW template __global__ void k_search_big<F, C, K, 512, 2>(const BigSearchPar);
+#define AGZ_BIG_CMP_VARIANTS(F, C, K, R, KW)                                 \
+    KW template __global__ void k_search_big<F, C, K, 512, 1, R>(const BigSearchPar); \
+    KW template __global__ void k_search_big<F, C, K, 512, 2, R>(const BigSearchPar);
 
 }  // namespace agz

@@ -21,7 +21,7 @@ AGZ_SMALL_SHAPES_3(X)
 #endif
 #undef X
 #if AGZ_PART == 4
-#define X(F, C, K, R) AGZ_SMALL_CMP_VARIANTS(F, C, K, R, )
+#define X(F, C, K, R) AGZ_SMALL_CMP_VARIANTS(F, C, K, R, ) AGZ_BIG_CMP_VARIANTS(F, C, K, R, )
 AGZ_SMALL_CMP_SHAPES(X)
 #undef X
 #endif
