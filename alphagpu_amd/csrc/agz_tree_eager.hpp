@@ -436,7 +436,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
                 AGZ_WSYNC();
 #pragma unroll
                 for (int j = 0; j < KPL; ++j) {
-                    if ((rmask >> j) & 1u) { cs[rank] = ((lmask >> j) & 1u) ? x[j] : nz; ++rank; }
+                    if ((rmask >> j) & 1u) { if (rank < G * KPR) cs[rank] = ((lmask >> j) & 1u) ? x[j] : nz; ++rank; }   // (the engine guarantees rank < G KPR: A - ply legal actions)
                 }
                 AGZ_WSYNC();
 #pragma unroll
