@@ -123,9 +123,9 @@ struct agz_engine {
     int big_maxl = 16384;        // ... used for batches up to this many games (AGZ_BIG_MAXL): 6.2 vs 8.0 ms per ply at 8192 games, 4.5 vs 7.3 at 1024, 9.9 vs 10.2 at 16384
     // the same kernels with node rows indexed by the root's legal rank (agz_tree_eager.hpp KPR_; Gobang / Hex 9x9: 8 instead of 12 entries
     // per lane), used by the ply loop once the roots cannot have more legal actions than the rows hold (legal_bound, set per ply)
-    // (two levels: 8 entries per lane while a root may have up to 64 legal actions, 4 up to 32)
-    small_fn k_small_c[2] = {nullptr, nullptr}, k_small4_c[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
-    big_fn k_big_c[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // k_search_big: [level][workgroups per CU - 1]
+    // (levels by entries per lane R: usable while no root has more than 8 R legal actions; 9x9 boards 8 / 4, 11x11 12 / 8 / 4, 13x13 16 / 8 / 4)
+    struct CmpLevel { int kpr = 0; small_fn s2 = nullptr, s4[3] = {nullptr, nullptr, nullptr}; big_fn b[2] = {nullptr, nullptr}; };
+    CmpLevel cmp[4]; int ncmp = 0;
     int legal_bound = 1 << 30, tree_kpr = 0;
     bool no_compact = false;            // AGZ_NO_COMPACT (A/B, tests)
     advance_fn k_spread = nullptr;      // policy_final rows from rank order back to action order after such a search
@@ -168,9 +168,9 @@ static bool bind_kernels(agz_engine* h) {
         h->k_small4[2] = k_search_small<F, C, K, 128, 4, 4>; h->k_big[0] = k_search_big<F, C, K, 512, 1>; h->k_big[1] = k_search_big<F, C, K, 512, 2>; h->reg_kpl = K; }
     AGZ_SMALL_SHAPES(Z)
 #undef Z
-#define Z(F, C, K, R) if (P.fam == F && P.NC == C && kpl == K) { const int lv = R == 8 ? 0 : 1; h->k_small_c[lv] = k_search_small<F, C, K, 128, 2, 2, R>; \
-        h->k_small4_c[lv][0] = k_search_small<F, C, K, 128, 4, 2, R>; h->k_small4_c[lv][1] = k_search_small<F, C, K, 128, 4, 3, R>; h->k_small4_c[lv][2] = k_search_small<F, C, K, 128, 4, 4, R>; \
-        h->k_big_c[lv][0] = k_search_big<F, C, K, 512, 1, R>; h->k_big_c[lv][1] = k_search_big<F, C, K, 512, 2, R>; }
+#define Z(F, C, K, R) if (P.fam == F && P.NC == C && kpl == K && h->ncmp < 4) { agz_engine::CmpLevel& c = h->cmp[h->ncmp++]; c.kpr = R; \
+        c.s2 = k_search_small<F, C, K, 128, 2, 2, R>; c.s4[0] = k_search_small<F, C, K, 128, 4, 2, R>; c.s4[1] = k_search_small<F, C, K, 128, 4, 3, R>; \
+        c.s4[2] = k_search_small<F, C, K, 128, 4, 4, R>; c.b[0] = k_search_big<F, C, K, 512, 1, R>; c.b[1] = k_search_big<F, C, K, 512, 2, R>; }
     AGZ_SMALL_CMP_SHAPES(Z)
 #undef Z
     if (P.NR == 1) h->k_soft = k_softmax<1>; else if (P.NR == 2) h->k_soft = k_softmax<2>; else h->k_soft = k_softmax<3>;
@@ -348,14 +348,14 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
         e3 = getenv("AGZ_WL_LDS_BYTES");
         if (e3 && atoi(e3) >= 0) h->wl_lds_max = atoi(e3) & ~15;
         for (int i = 0; i < 2; ++i) if (h->k_big[i]) FA_(hipFuncSetAttribute((const void*)h->k_big[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        for (int lv = 0; lv < 2; ++lv) for (int i = 0; i < 2; ++i) if (h->k_big_c[lv][i]) FA_(hipFuncSetAttribute((const void*)h->k_big_c[lv][i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         e3 = getenv("AGZ_SMALL4_OCC");
         if (e3 && atoi(e3) >= 0 && atoi(e3) <= 2) h->small4_occ = atoi(e3);
         if (h->k_small) FA_(hipFuncSetAttribute((const void*)h->k_small, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         for (int i = 0; i < 3; ++i) if (h->k_small4[i]) FA_(hipFuncSetAttribute((const void*)h->k_small4[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        for (int lv = 0; lv < 2; ++lv) {
-            if (h->k_small_c[lv]) FA_(hipFuncSetAttribute((const void*)h->k_small_c[lv], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            for (int i = 0; i < 3; ++i) if (h->k_small4_c[lv][i]) FA_(hipFuncSetAttribute((const void*)h->k_small4_c[lv][i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        for (int lv = 0; lv < h->ncmp; ++lv) {
+            FA_(hipFuncSetAttribute((const void*)h->cmp[lv].s2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            for (int i = 0; i < 3; ++i) FA_(hipFuncSetAttribute((const void*)h->cmp[lv].s4[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            for (int i = 0; i < 2; ++i) FA_(hipFuncSetAttribute((const void*)h->cmp[lv].b[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         }
     }
     const size_t Lm = (size_t)h->Lmax, V = (size_t)h->V;
@@ -764,6 +764,18 @@ static int check_search_args(agz_engine* h, int V) {
     return AGZ_OK;
 }
 
+// the level of rows by legal rank for the coming search: the fewest entries per lane R with 8 R >= the bound on a root's legal actions
+// (set by the ply loop) whose compaction buffer fits the lane-group's edge table (2 V floats >= 8 R); -1: rows by action
+static int cmp_level(const agz_engine* h) {
+    int best = -1;
+    if (h->no_compact) return best;
+    for (int i = 0; i < h->ncmp; ++i) {
+        const int r = h->cmp[i].kpr;
+        if (h->legal_bound <= 8 * r && 2 * h->V >= 8 * r && (best < 0 || r < h->cmp[best].kpr)) best = i;
+    }
+    return best;
+}
+
 int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training, uint32_t step) {
     if (h) h->tree_kpr = 0;
     if (!h) return AGZ_ERR_ARG;
@@ -794,14 +806,10 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
             if (h->small4_occ >= 0) occ = h->small4_occ;      // AGZ_SMALL4_OCC (tests: every register budget at small sizes)
             // rows by the root's legal rank once no root can have more legal actions than they hold (the ply loop knows: A - ply); the
             // expansion compacts through the group's edge table, 2 V >= 8 KPR floats
-            int lv = -1;                                          // 0: 8 entries per lane (<= 64 legal actions), 1: 4 (<= 32)
-            if (!h->no_compact) {
-                if (h->k_small_c[1] && h->legal_bound <= 32 && 2 * h->V >= 32) lv = 1;
-                else if (h->k_small_c[0] && h->legal_bound <= 64 && 2 * h->V >= 64) lv = 0;
-            }
+            const int lv = cmp_level(h);                          // the narrowest rows that hold every root's legal actions, or -1
             const bool cmp = lv >= 0;
-            const small_fn kfn = cmp ? (tw == 2 ? h->k_small_c[lv] : h->k_small4_c[lv][occ]) : (tw == 2 ? h->k_small : h->k_small4[occ]);
-            h->tree_kpr = cmp ? (lv == 0 ? 8 : 4) : 0;
+            const small_fn kfn = cmp ? (tw == 2 ? h->cmp[lv].s2 : h->cmp[lv].s4[occ]) : (tw == 2 ? h->k_small : h->k_small4[occ]);
+            h->tree_kpr = cmp ? h->cmp[lv].kpr : 0;
             SmallPar S;
             S.T = h->tp;
             S.T.L = h->L; S.T.slot0 = 0; S.T.step = h->step; S.T.cpuct = h->cpuct; S.T.training = h->training;
@@ -843,8 +851,9 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
                 Q.G = h->G; Q.L = h->L; Q.V = h->V; Q.states = h->states; Q.policy_final = h->policy_final;
                 hipLaunchKernelGGL(h->k_spread, dim3((unsigned)((h->L + 3) / 4)), dim3(256), 0, h->stream, Q);
             }
-            { char b[200]; snprintf(b, sizeof b, "k_search_small<KPL=%d,H=128,TW=%d,WV=%d%s> (whole mcts_single per launch, %d games per workgroup, %d per tree wave)",
-                                    h->reg_kpl, tw, tw == 2 ? 2 : 2 + occ, cmp ? (lv == 0 ? ",rows by legal rank KPR=8" : ",rows by legal rank KPR=4") : "", S.T.gpw * tw, S.T.gpw); h->form_tree = b; h->form_nn = "inside k_search_small (mlp_wave_body<128>)"; }
+            { char kb[48] = ""; if (cmp) snprintf(kb, sizeof kb, ",rows by legal rank KPR=%d", h->tree_kpr);
+              char b[200]; snprintf(b, sizeof b, "k_search_small<KPL=%d,H=128,TW=%d,WV=%d%s> (whole mcts_single per launch, %d games per workgroup, %d per tree wave)",
+                                    h->reg_kpl, tw, tw == 2 ? 2 : 2 + occ, kb, S.T.gpw * tw, S.T.gpw); h->form_tree = b; h->form_nn = "inside k_search_small (mlp_wave_body<128>)"; }
             if (ev) hipEventRecord(ev->second, h->stream);
             HIPCHK(h, hipGetLastError());
             h->cnt_live = true;
@@ -881,20 +890,17 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
             const size_t lds = shared + (size_t)4 * S.wl_bytes;
             std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
             if ((h->profiling & 1) && h->prof_this) { ev = next_events(h, h->ev_tree, h->ev_tree_used); hipEventRecord(ev->first, h->stream); }
-            int lv = -1;                                          // rows by the root's legal rank (see k_search_small above)
-            if (!h->no_compact) {
-                if (h->k_big_c[1][occ] && h->legal_bound <= 32 && 2 * h->V >= 32) lv = 1;
-                else if (h->k_big_c[0][occ] && h->legal_bound <= 64 && 2 * h->V >= 64) lv = 0;
-            }
-            h->tree_kpr = lv < 0 ? 0 : (lv == 0 ? 8 : 4);
-            hipLaunchKernelGGL(lv < 0 ? h->k_big[occ] : h->k_big_c[lv][occ], dim3((unsigned)wgs), dim3(NB_THREADS), lds, h->stream, S);
+            const int lv = cmp_level(h);                          // rows by the root's legal rank (see k_search_small above)
+            h->tree_kpr = lv < 0 ? 0 : h->cmp[lv].kpr;
+            hipLaunchKernelGGL(lv < 0 ? h->k_big[occ] : h->cmp[lv].b[occ], dim3((unsigned)wgs), dim3(NB_THREADS), lds, h->stream, S);
             if (lv >= 0) {
                 PlyPar Q; memset(&Q, 0, sizeof Q);
                 Q.G = h->G; Q.L = h->L; Q.V = h->V; Q.states = h->states; Q.policy_final = h->policy_final;
                 hipLaunchKernelGGL(h->k_spread, dim3((unsigned)((h->L + 3) / 4)), dim3(256), 0, h->stream, Q);
             }
-            { char b[200]; snprintf(b, sizeof b, "k_search_big<KPL=%d,H=512,WG=%d%s> (whole mcts_single per launch, %d games per workgroup, %d per tree wave)",
-                                    h->reg_kpl, occ + 1, lv < 0 ? "" : (lv == 0 ? ",rows by legal rank KPR=8" : ",rows by legal rank KPR=4"), 4 * S.T.gpw, S.T.gpw);
+            { char kb[48] = ""; if (lv >= 0) snprintf(kb, sizeof kb, ",rows by legal rank KPR=%d", h->tree_kpr);
+              char b[200]; snprintf(b, sizeof b, "k_search_big<KPL=%d,H=512,WG=%d%s> (whole mcts_single per launch, %d games per workgroup, %d per tree wave)",
+                                    h->reg_kpl, occ + 1, kb, 4 * S.T.gpw, S.T.gpw);
               h->form_tree = b; h->form_nn = "inside k_search_big (mlp_big_body<512,2>)"; }
             if (ev) hipEventRecord(ev->second, h->stream);
             HIPCHK(h, hipGetLastError());

@@ -125,8 +125,12 @@ __global__ __launch_bounds__(64 * NW_WAVES, WV) void k_search_small(const SmallP
     KW template __global__ void k_search_small<F, C, K, 128, 4, 2>(const SmallPar); \
     KW template __global__ void k_search_small<F, C, K, 128, 4, 3>(const SmallPar); \
     KW template __global__ void k_search_small<F, C, K, 128, 4, 4>(const SmallPar);
-// rows by the root's legal rank (12 -> 8 entries per lane: 9x9 boards from ply 17 on, -> 4 from ply 49 on); part 4 of agz_small_inst.hip
-#define AGZ_SMALL_CMP_SHAPES(X) X(F_LINE, 2, 12, 8) X(F_HEX, 2, 12, 8) X(F_LINE, 2, 12, 4) X(F_HEX, 2, 12, 4)
+// rows by the root's legal rank (12 -> 8 entries per lane: 9x9 boards from ply 17 on, -> 4 from ply 49 on); parts 4-6 of agz_small_inst.hip
+#define AGZ_SMALL_CMP_SHAPES_4(X) X(F_LINE, 2, 12, 8) X(F_HEX, 2, 12, 8) X(F_LINE, 2, 12, 4) X(F_HEX, 2, 12, 4)
+// 11x11 (16 actions per lane -> 12 / 8 / 4) and 13x13 (24 -> 16 / 8 / 4): parts 5 and 6
+#define AGZ_SMALL_CMP_SHAPES_5(X) X(F_LINE, 2, 16, 12) X(F_LINE, 2, 16, 8) X(F_LINE, 2, 16, 4) X(F_LINE, 3, 24, 16) X(F_LINE, 3, 24, 8) X(F_LINE, 3, 24, 4)
+#define AGZ_SMALL_CMP_SHAPES_6(X) X(F_HEX, 2, 16, 12) X(F_HEX, 2, 16, 8) X(F_HEX, 2, 16, 4) X(F_HEX, 3, 16, 12) X(F_HEX, 3, 16, 8) X(F_HEX, 3, 16, 4)
+#define AGZ_SMALL_CMP_SHAPES(X) AGZ_SMALL_CMP_SHAPES_4(X) AGZ_SMALL_CMP_SHAPES_5(X) AGZ_SMALL_CMP_SHAPES_6(X)
 #define AGZ_SMALL_CMP_VARIANTS(F, C, K, R, KW)                               \
     KW template __global__ void k_search_small<F, C, K, 128, 2, 2, R>(const SmallPar); \
     KW template __global__ void k_search_small<F, C, K, 128, 4, 2, R>(const SmallPar); \

@@ -146,13 +146,15 @@ def test_bf16_search_matches_oracle_bitwise(name, L, V, H, T):
         assert e.counters()[:2] == (p, n)
 
 
-@pytest.mark.parametrize("name,n,V,H,T", [("gobang9", 40, 32, 128, 1), ("hex9", 20, 32, 128, 1), ("gobang9", 300, 36, 128, 2), ("gobang9", 32, 16, 128, 1), ("gobang9", 24, 32, 512, 1), ("hex9", 12, 32, 512, 1)])
+@pytest.mark.parametrize("name,n,V,H,T", [("gobang9", 40, 32, 128, 1), ("hex9", 20, 32, 128, 1), ("gobang9", 300, 36, 128, 2), ("gobang9", 32, 16, 128, 1), ("gobang9", 24, 32, 512, 1), ("hex9", 12, 32, 512, 1),
+                                          ("gobang13", 6, 64, 128, 1), ("gobang11", 8, 48, 128, 1), ("hex11", 6, 48, 128, 1)])
 def test_bf16_generation_with_rows_by_legal_rank_matches_oracle_bitwise(name, n, V, H, T):
     """From ply 17 of a 9x9 game of Gobang / Hex the ply loop searches with node rows indexed by the ROOT's legal rank (8 instead of
     12 entries per lane: agz_tree_eager.hpp KPR_, `policy_final` spread back over the actions by k_spread_policy): the generation is
     the oracle's, sample for sample, and the same with the rows kept by action (AGZ_NO_COMPACT=1).  The third case has enough games
     for 32-game workgroups in the first plies; the fourth has trees of 16 nodes: too small for the compaction buffer of the 8-entry
-    level (it lives in the edge table, 2 V floats), so only the 4-entry level from ply 49 on is used; the last two run the wide-trunk search k_search_big."""
+    level (it lives in the edge table, 2 V floats), so only the 4-entry level from ply 49 on is used; the next two run the wide-trunk search k_search_big; 13x13 / 11x11 boards have levels of 16 / 8 / 4 and 12 / 8 / 4 entries per lane
+    (24 and 16 by action)."""
     g, og = spec(name)
     net, onet = nets(g, og, H, T)
     ref = O.selfplay(og, onet.bf16(), n, V, 1.5, 25, 91, 700)
