@@ -59,27 +59,25 @@ __global__ __launch_bounds__(256) void k_advance(const PlyPar T) {
     int c = -1;
     if (T.ply < T.tau_plies) {
         // sample(lp, Weights(pol[lp])): t = u * sum(w), first index whose running sum >= t (source order)
-        float total = 0.0f; bool st = false; uint64_t nzm[NR];
+        float total = 0.0f; bool st = false; uint64_t nzm[NR]; float run[NR];   // run: the running sum up to and including the lane's action
         for (int r = 0; r < NR; ++r) {
             nzm[r] = __ballot(64 * r + lane < A && pol[r] != 0.0f);
-            (void)chain64(pol[r], nzm[r], total, false, 0.0f, st);
+            run[r] = chain64(pol[r], nzm[r], total, false, 0.0f, st);
         }
         const float u = ufirst(uniform_move(T.seed, gid, (uint32_t)T.ply));
         const float tt = u * total;
         // duel (:606): sample(1:maxActions, Weights(policy)) walks ALL actions, zero weights included — the same index as the
         // nonzero-list walk of self-play (:519-520) whenever tt > 0, and u is never 0 (uniform_move): a zero-weight action is never
         // chosen
-        float carry = 0.0f; bool stopped = false; int last = -1;
+        // (the walk compares the SAME running sums the total came from: one ordered pass over the row, not two)
+        int last = -1;
         for (int r = 0; r < NR; ++r) {
             if (!nzm[r]) continue;
             last = 64 * r + 63 - __builtin_clzll(nzm[r]);
             if (c >= 0) continue;
-            bool s2 = false;
-            float pre = chain64(pol[r], nzm[r], carry, false, 0.0f, s2);
-            uint64_t ge = __ballot(((nzm[r] >> lane) & 1ull) && !(pre < tt));
-            if (ge) { c = 64 * r + __builtin_ctzll(ge); stopped = true; }
+            uint64_t ge = __ballot(((nzm[r] >> lane) & 1ull) && !(run[r] < tt));
+            if (ge) c = 64 * r + __builtin_ctzll(ge);
         }
-        (void)stopped;
         if (c < 0) c = last;
     } else {
         // argmax(pol): first maximum
