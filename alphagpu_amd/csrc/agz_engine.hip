@@ -124,8 +124,11 @@ struct agz_engine {
     // the same kernels with node rows indexed by the root's legal rank (agz_tree_eager.hpp KPR_; Gobang / Hex 9x9: 8 instead of 12 entries
     // per lane), used by the ply loop once the roots cannot have more legal actions than the rows hold (legal_bound, set per ply)
     // (levels by entries per lane R: usable while no root has more than 8 R legal actions; 9x9 boards 8 / 4, 11x11 12 / 8 / 4, 13x13 16 / 8 / 4)
-    struct CmpLevel { int kpr = 0; small_fn s2 = nullptr, s4[3] = {nullptr, nullptr, nullptr}; big_fn b[2] = {nullptr, nullptr}; };
+    struct CmpLevel { int kpr = 0; small_fn s2 = nullptr, s4[3] = {nullptr, nullptr, nullptr}, s8 = nullptr; big_fn b[2] = {nullptr, nullptr}; };
     CmpLevel cmp[4]; int ncmp = 0;
+    // 64-game workgroups of eight waves (every wave a tree wave; the network body gives each one tile of neurons: half the weight
+    // stream per game) for batches beyond 96 games per CU; tw8: -1 never, 1 wherever the batch allows, 0 (default) the shapes it was measured on
+    small_fn k_small8 = nullptr; int tw8 = 0;
     int legal_bound = 1 << 30, tree_kpr = 0;
     bool no_compact = false;            // AGZ_NO_COMPACT (A/B, tests)
     advance_fn k_spread = nullptr;      // policy_final rows from rank order back to action order after such a search
@@ -165,12 +168,12 @@ static bool bind_kernels(agz_engine* h) {
     const int kpl = P.A <= 32 ? 4 : (P.A <= 64 ? 8 : (P.A <= 96 ? 12 : (P.A <= 128 ? 16 : (P.A <= 192 ? 24 : 0))));
 #define Z(F, C, K) if (P.fam == F && P.NC == C && kpl == K) { h->k_eager = k_rollout_eager<F, C, K, 4>; h->k_eager3 = k_rollout_eager<F, C, K, 3>; \
         h->k_small = k_search_small<F, C, K, 128, 2, 2>; h->k_small4[0] = k_search_small<F, C, K, 128, 4, 2>; h->k_small4[1] = k_search_small<F, C, K, 128, 4, 3>; \
-        h->k_small4[2] = k_search_small<F, C, K, 128, 4, 4>; h->k_big[0] = k_search_big<F, C, K, 512, 1>; h->k_big[1] = k_search_big<F, C, K, 512, 2>; h->reg_kpl = K; }
+        h->k_small4[2] = k_search_small<F, C, K, 128, 4, 4>; h->k_small8 = k_search_small<F, C, K, 128, 8, 4>; h->k_big[0] = k_search_big<F, C, K, 512, 1>; h->k_big[1] = k_search_big<F, C, K, 512, 2>; h->reg_kpl = K; }
     AGZ_SMALL_SHAPES(Z)
 #undef Z
 #define Z(F, C, K, R) if (P.fam == F && P.NC == C && kpl == K && h->ncmp < 4) { agz_engine::CmpLevel& c = h->cmp[h->ncmp++]; c.kpr = R; \
         c.s2 = k_search_small<F, C, K, 128, 2, 2, R>; c.s4[0] = k_search_small<F, C, K, 128, 4, 2, R>; c.s4[1] = k_search_small<F, C, K, 128, 4, 3, R>; \
-        c.s4[2] = k_search_small<F, C, K, 128, 4, 4, R>; c.b[0] = k_search_big<F, C, K, 512, 1, R>; c.b[1] = k_search_big<F, C, K, 512, 2, R>; }
+        c.s4[2] = k_search_small<F, C, K, 128, 4, 4, R>; c.s8 = k_search_small<F, C, K, 128, 8, 4, R>; c.b[0] = k_search_big<F, C, K, 512, 1, R>; c.b[1] = k_search_big<F, C, K, 512, 2, R>; }
     AGZ_SMALL_CMP_SHAPES(Z)
 #undef Z
     if (P.NR == 1) h->k_soft = k_softmax<1>; else if (P.NR == 2) h->k_soft = k_softmax<2>; else h->k_soft = k_softmax<3>;
@@ -283,6 +286,7 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
         h->no_fastdiv = getenv("AGZ_NO_FASTDIV") != nullptr;        // every switch is read here, once: no getenv on a launch path
         h->no_fused_nn = getenv("AGZ_NO_FUSED_NN") != nullptr;
         h->no_compact = getenv("AGZ_NO_COMPACT") != nullptr;
+        { const char* e8 = getenv("AGZ_TW8"); h->tw8 = e8 ? (atoi(e8) > 0 ? 1 : -1) : 0; }
         e = getenv("AGZ_NN_WAVE_DEPTH");
         if (e && (atoi(e) == 2 || atoi(e) == 4)) h->nn_wave_depth = atoi(e);
         e = getenv("AGZ_NN_WAVE_LT");
@@ -351,9 +355,11 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
         e3 = getenv("AGZ_SMALL4_OCC");
         if (e3 && atoi(e3) >= 0 && atoi(e3) <= 2) h->small4_occ = atoi(e3);
         if (h->k_small) FA_(hipFuncSetAttribute((const void*)h->k_small, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if (h->k_small8) FA_(hipFuncSetAttribute((const void*)h->k_small8, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         for (int i = 0; i < 3; ++i) if (h->k_small4[i]) FA_(hipFuncSetAttribute((const void*)h->k_small4[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         for (int lv = 0; lv < h->ncmp; ++lv) {
             FA_(hipFuncSetAttribute((const void*)h->cmp[lv].s2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            FA_(hipFuncSetAttribute((const void*)h->cmp[lv].s8, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             for (int i = 0; i < 3; ++i) FA_(hipFuncSetAttribute((const void*)h->cmp[lv].s4[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             for (int i = 0; i < 2; ++i) FA_(hipFuncSetAttribute((const void*)h->cmp[lv].b[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         }
@@ -801,14 +807,19 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
             h->L <= std::min(std::max(h->small_maxl, h->small4_maxl), 128 * h->cus) && !h->no_fused_nn) {
             // 16 games per workgroup up to small_maxl; beyond, 32 games per workgroup with the loosest register budget that still
             // keeps every workgroup resident (2 / 3 / 4 workgroups per CU = 64 / 96 / 128 games per CU)
-            const int tw = h->L <= h->small_maxl ? 2 : 4;
+            int tw = h->L <= h->small_maxl ? 2 : 4;
             int occ = h->L <= 64 * h->cus ? 0 : (h->L <= 96 * h->cus ? 1 : 2);
             if (h->small4_occ >= 0) occ = h->small4_occ;      // AGZ_SMALL4_OCC (tests: every register budget at small sizes)
+            // beyond 96 games per CU: 64-game workgroups of eight waves (measured per ply at 32768 / 28672 games of Gobang 9x9: 4.10 / 3.91
+            // vs 4.18 / 4.00 ms with four 32-game workgroups per CU; at 24576 games 3.80 vs 3.39 ms: not below)
+            const bool t8 = h->k_small8 && tw == 4 && occ == 2 && (h->tw8 > 0 || (h->tw8 == 0 && h->reg_kpl == 12 && h->G.fam != F_REV));   // (Connect4 +1 %, Reversi 8x8 0 .. +2 %, 11x11 / 13x13 -0.5 .. -1.6 %: not by default)
+            if (t8) tw = 8;
             // rows by the root's legal rank once no root can have more legal actions than they hold (the ply loop knows: A - ply); the
             // expansion compacts through the group's edge table, 2 V >= 8 KPR floats
             const int lv = cmp_level(h);                          // the narrowest rows that hold every root's legal actions, or -1
             const bool cmp = lv >= 0;
-            const small_fn kfn = cmp ? (tw == 2 ? h->cmp[lv].s2 : h->cmp[lv].s4[occ]) : (tw == 2 ? h->k_small : h->k_small4[occ]);
+            const small_fn kfn = t8 ? (cmp ? h->cmp[lv].s8 : h->k_small8)
+                                    : (cmp ? (tw == 2 ? h->cmp[lv].s2 : h->cmp[lv].s4[occ]) : (tw == 2 ? h->k_small : h->k_small4[occ]));
             h->tree_kpr = cmp ? h->cmp[lv].kpr : 0;
             SmallPar S;
             S.T = h->tp;
@@ -822,10 +833,10 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
             // 2.9 vs 4.0 ms at 256 games, 3.1 vs 3.9 at 1024, 3.5 vs 3.9 at 2048; no gain from 4 games per wave at 4096)
             // the fewest games per tree wave that keep every workgroup resident (4 tree waves per CU): 1 .. 8
             // (16-game workgroups: 2 tree waves x 2 workgroups per CU; 32-game workgroups at 2 per CU: 8 tree waves per CU)
-            const int res_waves = (tw == 4 ? 4 * (2 + occ) : 4) * h->cus;      // tree waves resident at once
+            const int res_waves = (tw >= 4 ? 4 * (2 + occ) : 4) * h->cus;      // tree waves resident at once
             // sparse waves up to 64 games per CU (measured per ply: 2.40 vs 2.82 ms at 5120 games, 2.90 vs 3.43 at 10240); with 3 and 4
             // workgroups per CU (more than 16384 games) 7 games per wave are not reliably faster than 8 (3.8 vs 4.2 ms at 17408, 6.8 vs 6.2 at 26624)
-            const int gpw = (tw == 4 && occ > 0) ? 8 : std::min(8, std::max(1, (h->L + res_waves - 1) / res_waves));
+            const int gpw = (tw >= 4 && occ > 0) ? 8 : std::min(8, std::max(1, (h->L + res_waves - 1) / res_waves));
             S.T.gpw = h->small_gpw > 0 && (tw == 2 || occ == 0) ? h->small_gpw : gpw;
             S.F.gpw = S.T.gpw < 8 ? S.T.gpw : 0; S.F.tw = tw;
             S.V = V; S.tree_lds = (int)h->reg_lds;
@@ -834,18 +845,18 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
             // window behind it carries planes (tree -> network) and logits (network -> tree), one block of 8 rows per tree wave
             const int prowb = g0 * kth * 64 + 16;
             S.io_prowb = prowb; S.io_lgs = n.AOP; S.io_bw = (8 * std::max(prowb, 4 * n.AOP) + 15) & ~15;
-            S.io_off = (int)((std::max((size_t)4 * h->reg_lds, (size_t)8 * tw * 2 * (n.H * 2 + 16)) + 15) & ~(size_t)15);   // (16-game workgroups: the two helper waves have tables of their own)
+            S.io_off = (int)((std::max((size_t)(tw == 8 ? 8 : 4) * h->reg_lds, (size_t)8 * tw * 2 * (n.H * 2 + 16)) + 15) & ~(size_t)15);   // (16-game workgroups: the two helper waves have tables of their own)
             const size_t shared = (size_t)S.io_off + (size_t)tw * S.io_bw + (size_t)tw * 144;   // ... + the carry a tree wave publishes for its helper
             S.xch_off = S.io_off + tw * S.io_bw;
             // + the tree waves' work lists (kept across the network phase): what the CU's LDS leaves when every workgroup of the launch
             // must be resident (4 per CU at 32768 games); entries beyond the region, rare, go to the global list
-            const int wgs_per_cu = tw == 2 ? 2 : 2 + occ;
+            const int wgs_per_cu = tw == 2 || tw == 8 ? 2 : 2 + occ;
             const size_t room = (size_t)(160 * 1024) / (size_t)wgs_per_cu > shared ? (size_t)(160 * 1024) / (size_t)wgs_per_cu - shared : 0;
             S.wl_off = (int)shared; S.wl_bytes = (int)std::min({(size_t)(8 * h->V * 4), (room / (size_t)tw) & ~(size_t)15, (size_t)h->wl_lds_max});
             const size_t lds = shared + (size_t)tw * S.wl_bytes;
             std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
             if ((h->profiling & 1) && h->prof_this) { ev = next_events(h, h->ev_tree, h->ev_tree_used); hipEventRecord(ev->first, h->stream); }
-            hipLaunchKernelGGL(kfn, dim3((unsigned)((h->L + S.T.gpw * tw - 1) / (S.T.gpw * tw))), dim3(64 * NW_WAVES), lds, h->stream, S);
+            hipLaunchKernelGGL(kfn, dim3((unsigned)((h->L + S.T.gpw * tw - 1) / (S.T.gpw * tw))), dim3(64 * (tw == 8 ? 8 : NW_WAVES)), lds, h->stream, S);
             if (cmp) {   // policy_final back to action order (one wave per game, in place)
                 PlyPar Q; memset(&Q, 0, sizeof Q);
                 Q.G = h->G; Q.L = h->L; Q.V = h->V; Q.states = h->states; Q.policy_final = h->policy_final;

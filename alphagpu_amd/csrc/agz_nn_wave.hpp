@@ -58,7 +58,7 @@ __host__ __device__ inline int nw_hidden_groups(int INP, int H, int T) {
 // work, 2 halves the registers so that twice as many workgroups share a CU (throughput mode for big batches).
 // ZC: a group that opens a layer accumulates from the constant 0 instead of cleared registers (16 moves less per layer; the
 // duplicated first k-step costs registers: not in the 128-register build of the whole-search kernel, where it spills)
-template <int H, int LT, int DEPTH, bool PRE_BARRIER = false, bool IO = false, bool ZC = false, bool BP = false>
+template <int H, int LT, int DEPTH, bool PRE_BARRIER = false, bool IO = false, bool ZC = false, bool BP = false, int NWV = 4>
 __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const smem, const int bidx, uint8_t* const io = nullptr,
                                               const int io_bw = 0, const int io_lgs = 0, unsigned long long* const nn_dbg = nullptr);
 
@@ -75,7 +75,8 @@ __global__ __launch_bounds__(64 * NW_WAVES) void k_mlp_wave(const Fused3Par P) {
 // owns tile rows 8 w .. 8 w + 7 has left their planes in block w of `io` (io_bw bytes per block, rows of PROWB bytes, zero padded),
 // and the head leaves logits (and the value in column A) in the same block, rows of io_lgs floats; the global arrays are not
 // written (agz_get_logits reads what the stepwise API's network launch left).
-template <int H, int LT, int DEPTH, bool PRE_BARRIER, bool IO, bool ZC, bool BP>
+// NWV: waves of the workgroup (4, or 8: 64-game workgroups of k_search_small — every wave then owns one tile of neurons instead of two)
+template <int H, int LT, int DEPTH, bool PRE_BARRIER, bool IO, bool ZC, bool BP, int NWV>
 __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const smem, const int bidx, uint8_t* const io, const int io_bw,
                                               const int io_lgs, unsigned long long* const nn_dbg) {
 #ifdef AGZ_STAMPS
@@ -84,12 +85,12 @@ __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const
 #else
 #define NN_STAMP(i) do {} while (0)
 #endif
-    constexpr int NTH = H / 16, KTH = H / 32, TPW = NTH / NW_WAVES;
+    constexpr int NTH = H / 16, KTH = H / 32, TPW = NTH / NWV;
     constexpr int ROWB = H * 2 + 16;
     static_assert(TPW >= 1, "at least one neuron tile per wave");
     int tid_ = (int)threadIdx.x;
     asm volatile("" : "+v"(tid_));                            // opaque per call (see rollout_reg_body)
-    const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6) & (NW_WAVES - 1);
+    const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6) & (NWV - 1);
     constexpr int ML = 16 * LT;                                   // leaves per workgroup
     const int leaf0 = bidx * ML;
     // leaf (game slot) of tile row `row`, or a value >= P.L for an unused row
@@ -125,8 +126,8 @@ __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const
     if constexpr (!IO) {   // the ML rows of input planes -> LDS (coalesced 16-B loads), zero beyond INP
         const int segs = G0 * KTH * 4, isegs = P.INP / 8;
         const AGZ_GLB uint16_t* gp = (const AGZ_GLB uint16_t*)P.planes;
-        constexpr int TPR = 64 * NW_WAVES / ML;                   // threads per tile row (a power of two): no division by segs
-        const int row = (tid_ & (64 * NW_WAVES - 1)) / TPR, mm = leaf_of(row);
+        constexpr int TPR = 64 * NWV / ML;                   // threads per tile row (a power of two): no division by segs
+        const int row = (tid_ & (64 * NWV - 1)) / TPR, mm = leaf_of(row);
         for (int seg = tid_ & (TPR - 1); seg < segs; seg += TPR) {
             v4u v = {0u, 0u, 0u, 0u};
             if (mm < P.L && seg < isegs) v = *(const AGZ_GLB v4u*)(gp + (size_t)mm * P.INP + seg * 8);

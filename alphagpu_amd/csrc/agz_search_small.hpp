@@ -30,7 +30,7 @@ struct SmallPar {
 // 32768 games are resident at once with 32 games per workgroup).
 // KPR: entries per lane of the node rows when they are indexed by the root's legal rank (agz_tree_eager.hpp KPR_), 0 = by action
 template <int FAM, int NC, int KPL, int H, int TW, int WV, int KPR = 0>
-__global__ __launch_bounds__(64 * NW_WAVES, WV) void k_search_small(const SmallPar) {
+__global__ __launch_bounds__(64 * (TW == 8 ? 8 : NW_WAVES), WV) void k_search_small(const SmallPar) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_small[];
     // The parameters are READ FROM THE KERNEL-ARGUMENT SEGMENT where they are needed (scalar loads), through a pointer made opaque
     // once per phase: held in scalar registers from the entry on they (some 90 words) push the lane masks and addresses of the
@@ -42,7 +42,8 @@ __global__ __launch_bounds__(64 * NW_WAVES, WV) void k_search_small(const SmallP
     const auto par = [&]() -> const SmallPar& { KArg p = karg; asm volatile("" : "+s"(p)); return *(const SmallPar*)p; };
     const SmallPar& S = par();
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);   // (scalar: the tree step's addresses are scalar base + offset)
-    static_assert(TW == 2 || TW == 4, "tree waves per workgroup");
+    static_assert(TW == 2 || TW == 4 || TW == 8, "tree waves per workgroup");
+    constexpr int NWV = TW == 8 ? 8 : NW_WAVES;                   // waves of the workgroup (TW = 8: 64 games, every wave a tree wave)
     uint8_t* const tree_lds = lds_small + (size_t)(wave % TW) * S.tree_lds;
     uint8_t* const nn_lds = lds_small;                            // the two phases never overlap and the tree step keeps nothing
                                                                   // in this window from one rollout to the next: same memory
@@ -99,10 +100,10 @@ __global__ __launch_bounds__(64 * NW_WAVES, WV) void k_search_small(const SmallP
             __builtin_amdgcn_s_setprio(3);
             const SmallPar& S = par();
 #ifdef AGZ_STAMPS
-            mlp_wave_body<H, TW / 2, 2, true, true, (WV < 4), (WV < 3)>(S.F, nn_lds, bx, lds_small + S.io_off, S.io_bw, S.io_lgs,
-                                                              S.T.dbg ? S.T.dbg + (size_t)(32768 + bx * NW_WAVES + wave) * 16 : nullptr);
+            mlp_wave_body<H, TW / 2, 2, true, true, (WV < 4), (WV < 3), NWV>(S.F, nn_lds, bx, lds_small + S.io_off, S.io_bw, S.io_lgs,
+                                                              S.T.dbg ? S.T.dbg + (size_t)(32768 + bx * NWV + wave) * 16 : nullptr);
 #else
-            mlp_wave_body<H, TW / 2, 2, true, true, (WV < 4), (WV < 3)>(S.F, nn_lds, bx, lds_small + S.io_off, S.io_bw, S.io_lgs);
+            mlp_wave_body<H, TW / 2, 2, true, true, (WV < 4), (WV < 3), NWV>(S.F, nn_lds, bx, lds_small + S.io_off, S.io_bw, S.io_lgs);
 #endif
             __syncthreads();                                      // logits and values are visible to the tree waves
             __builtin_amdgcn_s_setprio(0);
@@ -124,7 +125,8 @@ __global__ __launch_bounds__(64 * NW_WAVES, WV) void k_search_small(const SmallP
     KW template __global__ void k_search_small<F, C, K, 128, 2, 2>(const SmallPar); \
     KW template __global__ void k_search_small<F, C, K, 128, 4, 2>(const SmallPar); \
     KW template __global__ void k_search_small<F, C, K, 128, 4, 3>(const SmallPar); \
-    KW template __global__ void k_search_small<F, C, K, 128, 4, 4>(const SmallPar);
+    KW template __global__ void k_search_small<F, C, K, 128, 4, 4>(const SmallPar); \
+    KW template __global__ void k_search_small<F, C, K, 128, 8, 4>(const SmallPar);
 // rows by the root's legal rank (12 -> 8 entries per lane: 9x9 boards from ply 17 on, -> 4 from ply 49 on); parts 4-6 of agz_small_inst.hip
 #define AGZ_SMALL_CMP_SHAPES_4(X) X(F_LINE, 2, 12, 8) X(F_HEX, 2, 12, 8) X(F_LINE, 2, 12, 4) X(F_HEX, 2, 12, 4)
 // 11x11 (16 actions per lane -> 12 / 8 / 4) and 13x13 (24 -> 16 / 8 / 4): parts 5 and 6
@@ -135,6 +137,7 @@ __global__ __launch_bounds__(64 * NW_WAVES, WV) void k_search_small(const SmallP
     KW template __global__ void k_search_small<F, C, K, 128, 2, 2, R>(const SmallPar); \
     KW template __global__ void k_search_small<F, C, K, 128, 4, 2, R>(const SmallPar); \
     KW template __global__ void k_search_small<F, C, K, 128, 4, 3, R>(const SmallPar); \
-    KW template __global__ void k_search_small<F, C, K, 128, 4, 4, R>(const SmallPar);
+    KW template __global__ void k_search_small<F, C, K, 128, 4, 4, R>(const SmallPar); \
+    KW template __global__ void k_search_small<F, C, K, 128, 8, 4, R>(const SmallPar);
 
 }  // namespace agz

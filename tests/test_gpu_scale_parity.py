@@ -73,7 +73,7 @@ def run_slice_case(name, H, T, V, L, n_each, form_prefix, nn_prefix=None, step=0
 
 # BASELINE.json: the metric configuration and configs[1..4], each at its full size and default dispatch
 @pytest.mark.parametrize("label,name,H,T,V,n_each,form,nn", [
-    ("headline", "gobang9", 128, 6, 64, 24, "k_search_small<KPL=12,H=128,TW=4,WV=4>", "inside k_search_small"),
+    ("headline", "gobang9", 128, 6, 64, 24, "k_search_small<KPL=12,H=128,TW=8,WV=4>", "inside k_search_small"),
     ("config2", "connect4", 128, 6, 64, 24, "k_search_small<KPL=4,H=128,TW=4,WV=4>", "inside k_search_small"),
     ("config3", "gobang9", 512, 8, 64, 16, None, None),
     ("config4", "hex9", 512, 8, 128, 8, None, None),
@@ -86,6 +86,19 @@ def test_full_size_first_ply_slice_matches_oracle(label, name, H, T, V, n_each, 
         assert ("k_search_big" in got[0]) or ("k_rollout_eager" in got[0] and "k_mlp_big" in got[1]), got
     else:
         run_slice_case(name, H, T, V, L, n_each, form, nn)
+
+
+# Beyond 96 games per CU the one-launch search runs 64-game workgroups of eight waves on the 9x9 boards of Gobang / Hex (default) and four
+# 32-game workgroups per CU elsewhere; AGZ_TW8 forces either form: both against the oracle at full size, on a shape of each kind
+@pytest.mark.parametrize("name,tw8,form", [("gobang9", "0", "k_search_small<KPL=12,H=128,TW=4,WV=4>"), ("connect4", "1", "k_search_small<KPL=4,H=128,TW=8,WV=4>"),
+                                           ("hex9", None, "k_search_small<KPL=12,H=128,TW=8,WV=4>")])
+def test_workgroup_shapes_of_the_full_batch_match_oracle(name, tw8, form):
+    if tw8 is not None:
+        os.environ["AGZ_TW8"] = tw8
+    try:
+        run_slice_case(name, 128, 2, 32, 32768, 8, form, "inside k_search_small", step=1)
+    finally:
+        os.environ.pop("AGZ_TW8", None)
 
 
 # boards with 16 / 24 actions per lane (11x11, 13x13: the reference's README promises boards up to 13x13) in the one-launch search at
