@@ -45,11 +45,11 @@ def test_benchmarked_kernels_do_not_spill_vector_registers():
     # the kernels of BASELINE.json's configurations: Gobang 9x9 / Hex 9x9 (12 actions per lane), Connect4 (4), Reversi 8x8 (12) and 6x6 (8), at every
     # register budget of the one-launch search, the wide-trunk search and the stand-alone tree step
     for fam_nc_kpl in ("0, 2, 12", "2, 2, 12", "1, 1, 4", "3, 1, 12", "3, 1, 8"):
-        for tail, budget in (("128, 2, 2", 256), ("128, 4, 2", 256), ("128, 4, 3", 168), ("128, 4, 4", 128)):
+        for tail, budget in (("128, 2, 2", 256), ("128, 4, 2", 256), ("128, 4, 3", 168), ("128, 4, 4", 128), ("128, 8, 4", 128)):
             names = [f"k_search_small<{fam_nc_kpl}, {tail}, 0>"]
             if fam_nc_kpl in ("0, 2, 12", "2, 2, 12"):                     # Gobang / Hex 9x9: also the build with rows by legal rank
                 names.append(f"k_search_small<{fam_nc_kpl}, {tail}, 8>")
-                if not (fam_nc_kpl == "2, 2, 12" and tail == "128, 4, 4"):   # (Hex, 4 entries, 128 registers: 4 spilled registers, a tail-ply kernel)
+                if not (fam_nc_kpl == "2, 2, 12" and tail in ("128, 4, 4", "128, 8, 4")):   # (Hex, 4 entries, 128 registers: 4 spilled registers, a tail-ply kernel)
                     names.append(f"k_search_small<{fam_nc_kpl}, {tail}, 4>")
             for name in names:
                 k = md[name]
