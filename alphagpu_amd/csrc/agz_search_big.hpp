@@ -25,7 +25,9 @@ struct BigSearchPar {
 
 // WG = workgroups per CU the register budget is cut for (1: 256 registers, 2: 128)
 // KPR: node rows by the root's legal rank (agz_tree_eager.hpp KPR_), 0 = by action
-template <int FAM, int NC, int KPL, int H, int WG, int KPR = 0>
+// TWB: tree waves (4: 32 games, the other four waves run the network only and, in the one-workgroup build, take the backup items;
+// 8: 64 games, every wave a tree wave, the network body works on four leaf tiles: a layer's weights stream once for 64 games)
+template <int FAM, int NC, int KPL, int H, int WG, int KPR = 0, int TWB = 4>
 __global__ __launch_bounds__(NB_THREADS, 2 * WG) void k_search_big(const BigSearchPar) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_bigs[];
     // the parameters are read from the kernel-argument segment per phase (see tree_par(), agz_tree_eager.hpp)
@@ -34,7 +36,7 @@ __global__ __launch_bounds__(NB_THREADS, 2 * WG) void k_search_big(const BigSear
     const KArg karg = (KArg)__builtin_amdgcn_kernarg_segment_ptr();
     const auto par = [&]() -> const BigSearchPar& { KArg p = karg; asm volatile("" : "+s"(p)); return *(const BigSearchPar*)p; };
     const BigSearchPar& S = par();
-    constexpr int TW = 4;                                         // tree waves: 32 games = the 2 leaf tiles of mlp_big_body<H, 2>
+    constexpr int TW = TWB;                                       // tree waves: 8 TW games = the TW / 2 leaf tiles of mlp_big_body<H, TW / 2>
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     uint8_t* const own_lds = lds_bigs + (size_t)wave * S.tree_lds;   // (tree waves 0-3 and their helper waves 4-7 have tables of their own)
     uint32_t* const wl_lds = reinterpret_cast<uint32_t*>(lds_bigs + S.wl_off + (size_t)(wave % TW) * S.wl_bytes);
@@ -47,7 +49,7 @@ __global__ __launch_bounds__(NB_THREADS, 2 * WG) void k_search_big(const BigSear
     // rollout's first phase are independent: agz_tree_eager.hpp ROLE_*); a workgroup barrier joins them before the descent.
     // (one workgroup per CU only: with two the helpers compete with the other workgroup's waves, 8.43 vs 8.23 ms per ply at 16384 games)
     constexpr int PF_ = WG < 2 ? 2 : 1;
-    constexpr bool SPLIT = WG < 2;
+    constexpr bool SPLIT = WG < 2 && TW == 4;
     const int V_ = S.V;
     for (int k = 0; k <= V_; ++k) {
         int bx = (int)blockIdx.x;
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(NB_THREADS, 2 * WG) void k_search_big(const BigSear
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             const BigSearchPar& S = par();
             const int gpw = S.T.gpw, L = S.T.L;
-            mlp_big_body<H, 2>(S.B, lds_bigs, [&](int row) { return (row & 7) < gpw ? (bx * TW + (row >> 3)) * gpw + (row & 7) : L; });
+            mlp_big_body<H, TW / 2>(S.B, lds_bigs, [&](int row) { return (row & 7) < gpw ? (bx * TW + (row >> 3)) * gpw + (row & 7) : L; });
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __syncthreads();                                      // logits and values are visible to the tree waves
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -88,9 +90,11 @@ __global__ __launch_bounds__(NB_THREADS, 2 * WG) void k_search_big(const BigSear
 
 #define AGZ_BIG_VARIANTS(F, C, K, KW)                                        \
     KW template __global__ void k_search_big<F, C, K, 512, 1>(const BigSearchPar); \
-    KW template __global__ void k_search_big<F, C, K, 512, 2>(const BigSearchPar);
+    KW template __global__ void k_search_big<F, C, K, 512, 2>(const BigSearchPar); \
+    KW template __global__ void k_search_big<F, C, K, 512, 1, 0, 8>(const BigSearchPar);
 #define AGZ_BIG_CMP_VARIANTS(F, C, K, R, KW)                                 \
     KW template __global__ void k_search_big<F, C, K, 512, 1, R>(const BigSearchPar); \
-    KW template __global__ void k_search_big<F, C, K, 512, 2, R>(const BigSearchPar);
+    KW template __global__ void k_search_big<F, C, K, 512, 2, R>(const BigSearchPar); \
+    KW template __global__ void k_search_big<F, C, K, 512, 1, R, 8>(const BigSearchPar);
 
 }  // namespace agz

@@ -110,10 +110,18 @@ def test_wide_rows_full_size_slice_matches_oracle(name, L, V, n_each, form):
     run_slice_case(name, 128, 2, V, L, n_each, form, "inside k_search_small", step=2)
 
 
-@pytest.mark.parametrize("name,L,V,n_each", [("gobang9", 16384, 64, 12), ("reversi8", 8192, 64, 12), ("gobang9", 136, 64, 16)])
-def test_wide_trunk_one_launch_search_slice_matches_oracle(name, L, V, n_each):
-    """k_search_big (512x8, whole mcts_single per launch) at its largest batches and at V = 64 on a small one."""
-    run_slice_case(name, 512, 8, V, L, n_each, "k_search_big", "inside k_search_big", step=3)
+@pytest.mark.parametrize("name,L,V,n_each,big8,form", [
+    ("gobang9", 16384, 64, 12, None, "k_search_big<KPL=12,H=512,WG=1,TW=8>"), ("gobang9", 12000, 32, 8, "0", "k_search_big<KPL=12,H=512,WG=2>"),
+    ("reversi8", 8192, 64, 12, None, "k_search_big<KPL=12,H=512,WG=1>"), ("gobang9", 136, 64, 16, None, "k_search_big")])
+def test_wide_trunk_one_launch_search_slice_matches_oracle(name, L, V, n_each, big8, form):
+    """k_search_big (512x8, whole mcts_single per launch) at its largest batches — one 64-game workgroup per CU above 32 games per CU
+    (default) or two 32-game workgroups (AGZ_BIG8=0) — and at V = 64 on a small one."""
+    if big8 is not None:
+        os.environ["AGZ_BIG8"] = big8
+    try:
+        run_slice_case(name, 512, 8, V, L, n_each, form, "inside k_search_big", step=3)
+    finally:
+        os.environ.pop("AGZ_BIG8", None)
 
 
 @pytest.mark.parametrize("name,L,V,H,T,form", [
