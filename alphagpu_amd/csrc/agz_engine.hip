@@ -124,12 +124,12 @@ struct agz_engine {
     // the same kernels with node rows indexed by the root's legal rank (agz_tree_eager.hpp KPR_; Gobang / Hex 9x9: 8 instead of 12 entries
     // per lane), used by the ply loop once the roots cannot have more legal actions than the rows hold (legal_bound, set per ply)
     // (levels by entries per lane R: usable while no root has more than 8 R legal actions; 9x9 boards 8 / 4, 11x11 12 / 8 / 4, 13x13 16 / 8 / 4)
-    struct CmpLevel { int kpr = 0; small_fn s2 = nullptr, s4[3] = {nullptr, nullptr, nullptr}, s8 = nullptr; big_fn b[2] = {nullptr, nullptr}, b8 = nullptr; };
+    struct CmpLevel { int kpr = 0; small_fn s2 = nullptr, s4[3] = {nullptr, nullptr, nullptr}, s8 = nullptr; big_fn b[2] = {nullptr, nullptr}, b8 = nullptr, b8x = nullptr; };
     CmpLevel cmp[4]; int ncmp = 0;
     // 64-game workgroups of eight waves (every wave a tree wave; the network body gives each one tile of neurons: half the weight
     // stream per game) for batches beyond 96 games per CU; tw8: -1 never, 1 wherever the batch allows, 0 (default) the shapes it was measured on
     small_fn k_small8 = nullptr; int tw8 = 0;
-    big_fn k_big8 = nullptr; int big8 = 0;   // k_search_big with 64-game workgroups (eight tree waves, one workgroup per CU) above 32 games per CU: AGZ_BIG8
+    big_fn k_big8 = nullptr, k_big8x = nullptr; int big8 = 0;   // k_big8x: two such workgroups per CU (128 registers) above 64 games per CU   // k_search_big with 64-game workgroups (eight tree waves, one workgroup per CU) above 32 games per CU: AGZ_BIG8
     int legal_bound = 1 << 30, tree_kpr = 0;
     bool no_compact = false;            // AGZ_NO_COMPACT (A/B, tests)
     advance_fn k_spread = nullptr;      // policy_final rows from rank order back to action order after such a search
@@ -169,12 +169,12 @@ static bool bind_kernels(agz_engine* h) {
     const int kpl = P.A <= 32 ? 4 : (P.A <= 64 ? 8 : (P.A <= 96 ? 12 : (P.A <= 128 ? 16 : (P.A <= 192 ? 24 : 0))));
 #define Z(F, C, K) if (P.fam == F && P.NC == C && kpl == K) { h->k_eager = k_rollout_eager<F, C, K, 4>; h->k_eager3 = k_rollout_eager<F, C, K, 3>; \
         h->k_small = k_search_small<F, C, K, 128, 2, 2>; h->k_small4[0] = k_search_small<F, C, K, 128, 4, 2>; h->k_small4[1] = k_search_small<F, C, K, 128, 4, 3>; \
-        h->k_small4[2] = k_search_small<F, C, K, 128, 4, 4>; h->k_small8 = k_search_small<F, C, K, 128, 8, 4>; h->k_big[0] = k_search_big<F, C, K, 512, 1>; h->k_big[1] = k_search_big<F, C, K, 512, 2>; h->k_big8 = k_search_big<F, C, K, 512, 1, 0, 8>; h->reg_kpl = K; }
+        h->k_small4[2] = k_search_small<F, C, K, 128, 4, 4>; h->k_small8 = k_search_small<F, C, K, 128, 8, 4>; h->k_big[0] = k_search_big<F, C, K, 512, 1>; h->k_big[1] = k_search_big<F, C, K, 512, 2>; h->k_big8 = k_search_big<F, C, K, 512, 1, 0, 8>; h->k_big8x = k_search_big<F, C, K, 512, 2, 0, 8>; h->reg_kpl = K; }
     AGZ_SMALL_SHAPES(Z)
 #undef Z
 #define Z(F, C, K, R) if (P.fam == F && P.NC == C && kpl == K && h->ncmp < 4) { agz_engine::CmpLevel& c = h->cmp[h->ncmp++]; c.kpr = R; \
         c.s2 = k_search_small<F, C, K, 128, 2, 2, R>; c.s4[0] = k_search_small<F, C, K, 128, 4, 2, R>; c.s4[1] = k_search_small<F, C, K, 128, 4, 3, R>; \
-        c.s4[2] = k_search_small<F, C, K, 128, 4, 4, R>; c.s8 = k_search_small<F, C, K, 128, 8, 4, R>; c.b[0] = k_search_big<F, C, K, 512, 1, R>; c.b[1] = k_search_big<F, C, K, 512, 2, R>; c.b8 = k_search_big<F, C, K, 512, 1, R, 8>; }
+        c.s4[2] = k_search_small<F, C, K, 128, 4, 4, R>; c.s8 = k_search_small<F, C, K, 128, 8, 4, R>; c.b[0] = k_search_big<F, C, K, 512, 1, R>; c.b[1] = k_search_big<F, C, K, 512, 2, R>; c.b8 = k_search_big<F, C, K, 512, 1, R, 8>; c.b8x = k_search_big<F, C, K, 512, 2, R, 8>; }
     AGZ_SMALL_CMP_SHAPES(Z)
 #undef Z
     if (P.NR == 1) h->k_soft = k_softmax<1>; else if (P.NR == 2) h->k_soft = k_softmax<2>; else h->k_soft = k_softmax<3>;
@@ -355,6 +355,7 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
         if (e3 && atoi(e3) >= 0) h->wl_lds_max = atoi(e3) & ~15;
         for (int i = 0; i < 2; ++i) if (h->k_big[i]) FA_(hipFuncSetAttribute((const void*)h->k_big[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         if (h->k_big8) FA_(hipFuncSetAttribute((const void*)h->k_big8, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if (h->k_big8x) FA_(hipFuncSetAttribute((const void*)h->k_big8x, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         e3 = getenv("AGZ_SMALL4_OCC");
         if (e3 && atoi(e3) >= 0 && atoi(e3) <= 2) h->small4_occ = atoi(e3);
         if (h->k_small) FA_(hipFuncSetAttribute((const void*)h->k_small, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -366,6 +367,7 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
             for (int i = 0; i < 3; ++i) FA_(hipFuncSetAttribute((const void*)h->cmp[lv].s4[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             for (int i = 0; i < 2; ++i) FA_(hipFuncSetAttribute((const void*)h->cmp[lv].b[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             FA_(hipFuncSetAttribute((const void*)h->cmp[lv].b8, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            FA_(hipFuncSetAttribute((const void*)h->cmp[lv].b8x, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         }
     }
     const size_t Lm = (size_t)h->Lmax, V = (size_t)h->V;
@@ -882,7 +884,7 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
         const int big_rowb = 2 * std::max(n.H, 32 * n.k0r) + 16;
         if (h->k_big[0] && h->cfg.nn_mode == AGZ_NN_BF16 && n.H == 512 && n.wbig && h->L > 0 && 8 * h->reg_kpl <= h->LGS &&
             h->V <= 128 && (h->V & 3) == 0 &&                    // (the shapes the lean build of the tree step is tested at, as for k_search_small)
-            h->L <= std::min(h->big_maxl, 64 * h->cus) && !h->no_fused_nn) {
+            h->L <= (h->big8 >= 0 && h->k_big8x && h->big_maxl >= 64 * h->cus ? 128 * h->cus : std::min(h->big_maxl, 64 * h->cus)) && !h->no_fused_nn) {
             BigSearchPar S;
             S.T = h->tp;
             S.T.L = h->L; S.T.slot0 = 0; S.T.step = h->step; S.T.cpuct = h->cpuct; S.T.training = h->training;
@@ -900,12 +902,15 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
             // above 32 games per CU: one 64-game workgroup per CU (eight tree waves, four leaf tiles per network pass: a layer's weights
             // stream once for 64 games, and 185 instead of 128 registers) rather than two 32-game workgroups
             const bool b8 = occ == 1 && h->k_big8 && h->big8 >= 0 && S.T.gpw == 8;
+            // ... and two of them above 64 games per CU: the 128-register build of the 64-leaf network pass spills ~40 registers and still beats
+            // the two-kernel form (first ply at 32768 games of Gobang 9x9 512x8: 12.3 vs 14.1 ms, 24576: 11.2 vs 12.8)
+            const bool x8 = b8 && h->L > 64 * h->cus;
             const int twb = b8 ? 8 : 4;
             if (b8) wgs = (h->L + 63) / 64;
             S.V = V; S.tree_lds = (int)h->reg_lds;
             S.xch_off = (int)((std::max((size_t)8 * h->reg_lds, (size_t)8 * twb * big_rowb) + 15) & ~(size_t)15);   // (tree waves and helper waves have tables of their own)
             const size_t shared = (size_t)S.xch_off + 4 * 144;
-            const int wgcu = b8 ? 1 : occ + 1;
+            const int wgcu = x8 ? 2 : (b8 ? 1 : occ + 1);
             const size_t room = (size_t)(160 * 1024) / (size_t)wgcu > shared ? (size_t)(160 * 1024) / (size_t)wgcu - shared : 0;
             S.wl_off = (int)shared; S.wl_bytes = (int)std::min({(size_t)(8 * h->V * 4), (room / (size_t)twb) & ~(size_t)15, (size_t)h->wl_lds_max});
             const size_t lds = shared + (size_t)twb * S.wl_bytes;
@@ -913,7 +918,7 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
             if ((h->profiling & 1) && h->prof_this) { ev = next_events(h, h->ev_tree, h->ev_tree_used); hipEventRecord(ev->first, h->stream); }
             const int lv = cmp_level(h);                          // rows by the root's legal rank (see k_search_small above)
             h->tree_kpr = lv < 0 ? 0 : h->cmp[lv].kpr;
-            hipLaunchKernelGGL(b8 ? (lv < 0 ? h->k_big8 : h->cmp[lv].b8) : (lv < 0 ? h->k_big[occ] : h->cmp[lv].b[occ]), dim3((unsigned)wgs), dim3(NB_THREADS), lds, h->stream, S);
+            hipLaunchKernelGGL(x8 ? (lv < 0 ? h->k_big8x : h->cmp[lv].b8x) : b8 ? (lv < 0 ? h->k_big8 : h->cmp[lv].b8) : (lv < 0 ? h->k_big[occ] : h->cmp[lv].b[occ]), dim3((unsigned)wgs), dim3(NB_THREADS), lds, h->stream, S);
             if (lv >= 0) {
                 PlyPar Q; memset(&Q, 0, sizeof Q);
                 Q.G = h->G; Q.L = h->L; Q.V = h->V; Q.states = h->states; Q.policy_final = h->policy_final;
@@ -921,8 +926,8 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
             }
             { char kb[48] = ""; if (lv >= 0) snprintf(kb, sizeof kb, ",rows by legal rank KPR=%d", h->tree_kpr);
               char b[200]; snprintf(b, sizeof b, "k_search_big<KPL=%d,H=512,WG=%d%s%s> (whole mcts_single per launch, %d games per workgroup, %d per tree wave)",
-                                    h->reg_kpl, b8 ? 1 : occ + 1, b8 ? ",TW=8" : "", kb, twb * S.T.gpw, S.T.gpw);
-              h->form_tree = b; h->form_nn = "inside k_search_big (mlp_big_body<512,2>)"; }
+                                    h->reg_kpl, x8 ? 2 : (b8 ? 1 : occ + 1), b8 ? ",TW=8" : "", kb, twb * S.T.gpw, S.T.gpw);
+              h->form_tree = b; h->form_nn = b8 ? "inside k_search_big (mlp_big_body<512,4>)" : "inside k_search_big (mlp_big_body<512,2>)"; }
             if (ev) hipEventRecord(ev->second, h->stream);
             HIPCHK(h, hipGetLastError());
             h->cnt_live = true;

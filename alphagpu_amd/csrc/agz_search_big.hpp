@@ -91,10 +91,12 @@ __global__ __launch_bounds__(NB_THREADS, 2 * WG) void k_search_big(const BigSear
 #define AGZ_BIG_VARIANTS(F, C, K, KW)                                        \
     KW template __global__ void k_search_big<F, C, K, 512, 1>(const BigSearchPar); \
     KW template __global__ void k_search_big<F, C, K, 512, 2>(const BigSearchPar); \
-    KW template __global__ void k_search_big<F, C, K, 512, 1, 0, 8>(const BigSearchPar);
+    KW template __global__ void k_search_big<F, C, K, 512, 1, 0, 8>(const BigSearchPar); \
+    KW template __global__ void k_search_big<F, C, K, 512, 2, 0, 8>(const BigSearchPar);
 #define AGZ_BIG_CMP_VARIANTS(F, C, K, R, KW)                                 \
     KW template __global__ void k_search_big<F, C, K, 512, 1, R>(const BigSearchPar); \
     KW template __global__ void k_search_big<F, C, K, 512, 2, R>(const BigSearchPar); \
-    KW template __global__ void k_search_big<F, C, K, 512, 1, R, 8>(const BigSearchPar);
+    KW template __global__ void k_search_big<F, C, K, 512, 1, R, 8>(const BigSearchPar); \
+    KW template __global__ void k_search_big<F, C, K, 512, 2, R, 8>(const BigSearchPar);
 
 }  // namespace agz

@@ -168,7 +168,8 @@ int  agz_set_profiling(agz_engine *h, int mode);       /* HIP events per launch:
  *   AGZ_REG3_MAX_WAVES=n   two-kernel form: largest grid that uses the 3-waves-per-SIMD build of the tree kernel
  *   AGZ_NN_WAVE_LT, AGZ_NN_WAVE_DEPTH   tile count / prefetch depth of k_mlp_wave
  *   AGZ_NO_FUSED_NN=1      per-layer network kernels (k_layer_bf16) and no one-launch search
- *   AGZ_BIG8=0             k_search_big above 32 games per CU: two 32-game workgroups per CU instead of one 64-game workgroup
+ *   AGZ_BIG8=0             k_search_big above 32 games per CU: two 32-game workgroups per CU instead of one 64-game workgroup, and the
+ *                          two-kernel form above 64 games per CU instead of two 64-game workgroups per CU
  *   AGZ_TW8=1|0            one-launch search beyond 96 games per CU: 64-game workgroups of eight waves for every board shape (1) or
  *                          for none (0); default: the 9x9 shapes they were measured on
  *   AGZ_NO_COMPACT=1       the ply loop keeps node rows by action on Gobang / Hex 9x9 (default: rows by the root's legal rank from ply 17 on,
