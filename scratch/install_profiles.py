@@ -48,9 +48,9 @@ if os.path.exists(cs):
         m = re.search(r'"algorithmic_bytes_per_search_launch": ([0-9.e+]+), "nn_leaves": (\d+)', body)
         e["alg"], e["leaves"] = float(m.group(1)), int(m.group(2))
     for cfg, e in data.items():
-        tree = [k for k in ("k_search_small", "k_rollout_eager") if (k, "FETCH_SIZE") in e][0]
+        tree = [k for k in ("k_search_small", "k_search_big", "k_rollout_eager") if (k, "FETCH_SIZE") in e][0]
         f, w = e[(tree, "FETCH_SIZE")] / 2, e[(tree, "WRITE_SIZE")] / 2          # two searches per pass
-        o = {"what": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of one first-ply search at 32768 games (scratch/pmc_configs.sh, CFG=%d; the wide-trunk configs as one chain of V x {k_rollout_eager, k_mlp_big<512,8>}); sums over the launches of the search; see %s_pmc_configs_first_ply.txt" % (cfg, pre),
+        o = {"what": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of one first-ply search at 32768 games (scratch/pmc_configs.sh, CFG=%d; the whole-search kernel's launch: tree step and network together for the wide trunks); sums over the launches of the search; see %s_pmc_configs_first_ply.txt" % (cfg, pre),
              "tree_kernel": tree, "fetch_size_kb_per_search_raw": f, "write_size_kb_per_search": w, "algorithmic_bytes_per_search": e["alg"],
              "traffic_over_algorithmic": (2 * f + w) * 1024 / e["alg"], "traffic_over_algorithmic_uncorrected": (f + w) * 1024 / e["alg"]}
         if ("k_mlp_big", "FETCH_SIZE") in e:
