@@ -163,7 +163,8 @@ int  agz_set_profiling(agz_engine *h, int mode);       /* HIP events per launch:
  *   AGZ_SMALL4_MAXL=n      largest batch of the 32-games-per-workgroup one-launch search
  *   AGZ_SMALL4_OCC=0|1|2   force the 2 / 3 / 4 workgroups-per-CU register budget of that kernel
  *   AGZ_SMALL_GPW=1..8    games per tree wave of the one-launch forms (sparse waves for small batches)
- *   AGZ_BIG_MAXL=n         512-wide trunk: one-launch search (k_search_big) up to n games (default 16384; 0 disables)
+ *   AGZ_BIG_MAXL=n         512-wide trunk: one-launch search (k_search_big) up to n games (0 disables; from the default 16384 on the limit
+ *                          is 128 games per CU: two 64-game workgroups per CU, see AGZ_BIG8)
  *   AGZ_CHAINS=k           two-kernel form: k sub-batches on parallel streams (default 2-3 from 12000 games)
  *   AGZ_REG3_MAX_WAVES=n   two-kernel form: largest grid that uses the 3-waves-per-SIMD build of the tree kernel
  *   AGZ_NN_WAVE_LT, AGZ_NN_WAVE_DEPTH   tile count / prefetch depth of k_mlp_wave
