@@ -9,7 +9,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     from alphagpu_amd import mcts_gpu as M
     gk, gn, gv, V = os.environ.get("GK", "gobang"), int(os.environ.get("GN", "9")), int(os.environ.get("GV", "5")), int(os.environ.get("VV", "64"))
     L = int(os.environ.get("LL", "32768"))
-    g = ag.GameSpec(gk, gn, gv); net = ag.SNetwork2.random(g, 128, 6)
+    g = ag.GameSpec(gk, gn, gv); net = ag.SNetwork2.random(g, int(os.environ.get('NH', '128')), int(os.environ.get('NT', '6')))
     e = M.Engine(g, L, V, seed=3, nn_mode=M.NN_BF16); e.set_network(net)
     ts = []
     for r in range(3):

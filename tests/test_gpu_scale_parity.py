@@ -101,6 +101,34 @@ def test_workgroup_shapes_of_the_full_batch_match_oracle(name, tw8, form):
         os.environ.pop("AGZ_TW8", None)
 
 
+@pytest.mark.parametrize("name,H,T,V,n", [("gobang9", 512, 1, 32, 24000), ("hex9", 128, 1, 32, 32768)])
+def test_full_size_generation_same_with_rows_by_rank_and_by_action(name, H, T, V, n):
+    """The kernel variants a FULL-SIZE generation walks through with rows by legal rank (64-game workgroups of k_search_big, two per CU,
+    and of k_search_small; every compaction level; sparse waves in the tail) leave the same packed sample records, byte for byte, as the
+    generation with rows by action (whose forms the oracle slices above check): compared by a checksum computed on the device."""
+    import torch
+    g, _ = spec(name)
+    net = ag.SNetwork2.random(g, H, T)
+    sums = []
+    for no_compact in (False, True):
+        if no_compact:
+            os.environ["AGZ_NO_COMPACT"] = "1"
+        try:
+            with M.Engine(g, n, V, seed=5, nn_mode=M.NN_BF16) as e:
+                e.set_network(net)
+                st = e.selfplay(n, V, cpuct=1.5, tau_plies=25)
+                ns = e.num_samples()
+                buf = torch.empty(ns * g.rec_bytes, dtype=torch.uint8, device="cuda:0")
+                assert e.samples_packed_into(buf.data_ptr(), ns) == ns
+                torch.cuda.synchronize()
+                w = (torch.arange(buf.numel(), device="cuda:0", dtype=torch.int64) % 1000003) + 1
+                sums.append((ns, st["wins"], st["draws"], st["losses"], int((buf.to(torch.int64) * w).sum().item()), int(buf.to(torch.int64).sum().item())))
+                del buf, w
+        finally:
+            os.environ.pop("AGZ_NO_COMPACT", None)
+    assert sums[0] == sums[1], sums
+
+
 # boards with 16 / 24 actions per lane (11x11, 13x13: the reference's README promises boards up to 13x13) in the one-launch search at
 # the batch sizes that need the denser register budgets (3 and 4 workgroups per CU; the 24-action builds spill vector registers there)
 @pytest.mark.parametrize("name,L,V,n_each,form", [
