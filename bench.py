@@ -178,7 +178,7 @@ def main():
     eng.set_roots(None, L=G)
     eng.search(V, cpuct=args.cpuct, training=True, step=0)
     form_tree, form_nn = eng.search_form()
-    whole = form_tree.startswith("k_search_small")
+    whole = form_tree.startswith("k_search_small") or form_tree.startswith("k_search_big")   # one launch per ply at every size
     eng.set_profiling(1 if whole else 7)
     eng.kernel_times(reset=True)
     fence()
@@ -284,6 +284,13 @@ def main():
                   "time_ms": nn_t_ms, "note": nn_note}
         # the dominant kernel of the configuration: the network when its launches take longer than the tree kernel's
         nn_dominant = (not whole) and nn_ms > busy_ms
+        if whole and args.filters >= 512:
+            # one launch per search with a 512-wide trunk (k_search_big): the network pass inside it is what the launch waits for (its
+            # matrix work is 30 x the 128-wide trunk's) — the launch is priced against the MFMA peak, whole-launch time as the denominator
+            nn_dominant = True
+            nn_obj["kernel"] = form_tree + " [" + form_nn + "]"
+            nn_obj["traffic"] = traffic
+            nn_obj["avg_launch_ms"] = tree_ms / max(launches, 1); nn_obj["launches"] = launches
         out = {
             "metric": f"self-play rollouts/sec at {G} games x {V} rollouts, {gname}",
             "value": total_rollouts / dt_max, "unit": "rollouts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
