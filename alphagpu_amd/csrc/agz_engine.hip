@@ -1291,8 +1291,17 @@ int agz_get_samples(agz_engine* h, int8_t* state, float* policy, int8_t* player,
     rc = agz_get_samples_packed(h, h->stage_dev, n, &n); if (rc) return rc;
     if (hipMemcpyAsync(h->stage_host, h->stage_dev, (size_t)n * rb, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
         hipStreamSynchronize(h->stream) != hipSuccess) { h->fail("sample D2H failed"); return AGZ_ERR_HIP; }
-    const int A = h->G.A, VS = h->G.VS, FS = h->G.FS;
-    const uint8_t* const host = h->stage_host;
+    return agz_unpack_records(&h->info, h->stage_host, n, state, policy, player, value, fstate, game_id, ply, move);
+}
+// Host-only helper: n packed records (agz_get_samples_packed layout, in host memory) -> PoolSample-layout arrays (any may be NULL).
+// No handle, no device: a host loop that copies the records of generation k to pinned memory on a side stream unpacks them here
+// while generation k + 1 runs on the engine's stream.
+int agz_unpack_records(const agz_game_info* info, const void* records, int64_t n, int8_t* state, float* policy, int8_t* player,
+                       float* value, int8_t* fstate, uint32_t* game_id, int32_t* ply, int32_t* move) {
+    if (!info || (!records && n > 0) || n < 0) return AGZ_ERR_ARG;
+    const int A = info->A, VS = info->VS, FS = info->FS;
+    const size_t rb = (size_t)info->rec_bytes;
+    const uint8_t* const host = (const uint8_t*)records;
     auto unpack = [=](int64_t s0, int64_t s1) {          // records [s0, s1) -> the caller's arrays (PoolSample layout)
         for (int64_t s = s0; s < s1; ++s) {
             const uint8_t* r = host + (size_t)s * rb;

@@ -18,6 +18,7 @@ class GameSpec:
         rc = _lib.load_library().agz_query_game(C.byref(cfg), C.byref(info))
         if rc != 0:
             raise ValueError(f"unsupported game parameters {game} n={n} nvict={nvict}")
+        self.info = info
         self.maxActions, self.VectorizedState = info.A, info.VS
         self.FeatureSize, self.maxLengthGame = info.FS, info.ML
         self.max_plies, self.pos_image_bytes, self.rec_bytes = info.max_plies, info.pos_image_bytes, info.rec_bytes

@@ -5,10 +5,18 @@ replica; nothing is exchanged during the generation.  The ONE exchange step is a
 sample records at generation end (RCCL over xGMI on GPUs: torch.distributed backend "nccl"; "gloo" on CPU
 for tests).  Because every uniform is keyed by the global game id, the gathered samples are identical to a
 single-GPU run over all W*G games.
+
+Two forms of the exchange:
+  * `allgather_records`  — blocking: counts, then the records padded to the largest count (tests, one-off callers);
+  * `RecordExchange`     — pipelined: ONE asynchronous collective per generation that carries the rank's record count in a
+    16-byte header in front of its records, issued WITHOUT any host synchronisation or blocking read (the host never waits
+    for another rank between two generations); the counts are read when the caller waits for the collective.
 """
 import numpy as np
 import torch
 import torch.distributed as dist
+
+HEADER = 16          # bytes in front of a rank's records in a RecordExchange buffer: int64 record count, int64 reserved
 
 
 def shard_base(rank, games_per_rank):
@@ -16,50 +24,114 @@ def shard_base(rank, games_per_rank):
     return int(rank) * int(games_per_rank)
 
 
-class PendingGather:
-    """An all-gather of sample records in flight.  `wait()` returns (gathered [world, max_n*rec_bytes], counts) once the
-    collective has completed for the HOST (the engine writes the source buffer on its own stream, so stream-ordered
-    completion in torch's sense is not enough to reuse it)."""
-
-    def __init__(self, work, out, counts, src):
-        self.work, self.out, self.counts, self.src = work, out, counts, src     # src kept alive until completion
-
-    def wait(self):
-        if self.work is not None:
-            self.work.wait()
-            if self.out.is_cuda:
-                torch.cuda.current_stream(self.out.device).synchronize()
-            self.work = None
-            self.src = None
-        return self.out, self.counts
-
-
-def allgather_records_async(local, n_local, rec_bytes, group=None):
-    """Start the exchange step: counts (tiny, blocking), then the padded records as an asynchronous collective, so that
-    the next generation's kernels overlap the transfer (xGMI is per-link bound: a ring all-gather of 8 x 0.75 GB takes
-    ~0.1 s, a fifth of a generation).  local: uint8 tensor with >= n_local*rec_bytes bytes (device or host); it must not
-    be modified until wait() returns."""
+def allgather_records(local, n_local, rec_bytes, group=None):
+    """Blocking exchange.  local: uint8 tensor holding >= n_local*rec_bytes bytes (device or host).  Returns (parts, counts):
+    parts[r] = uint8 tensor with the counts[r]*rec_bytes bytes of rank r's records.  Two collectives: counts, then the
+    records padded to the largest count."""
     world = dist.get_world_size(group)
     dev = local.device
     cnt = torch.tensor([int(n_local)], dtype=torch.int64, device=dev)
     counts = torch.zeros(world, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(counts, cnt, group=group)
-    max_n = int(counts.max().item())
-    need = max_n * rec_bytes
+    counts = counts.cpu()
+    need = int(counts.max()) * rec_bytes
     if local.numel() < need:
         pad = torch.zeros(need, dtype=torch.uint8, device=dev)
         pad[: local.numel()] = local
         local = pad
-    src = local[:need].contiguous()
     out = torch.empty(world * need, dtype=torch.uint8, device=dev)
-    work = dist.all_gather_into_tensor(out, src, group=group, async_op=True)
-    return PendingGather(work, out.view(world, need), counts, src)
+    dist.all_gather_into_tensor(out, local[:need].contiguous(), group=group)
+    out = out.view(world, need)
+    return [out[r, : int(counts[r]) * rec_bytes] for r in range(world)], counts
 
 
-def allgather_records(local, n_local, rec_bytes, group=None):
-    """local: uint8 tensor holding >= n_local*rec_bytes bytes (device or host).  Returns (gathered uint8 tensor
-    [world, max_n*rec_bytes], counts int64 tensor [world]).  Two collectives: counts, then padded records."""
-    return allgather_records_async(local, n_local, rec_bytes, group).wait()
+class PendingGather:
+    """A RecordExchange collective in flight.  `wait()` returns (parts, counts) once the collective has completed for the
+    HOST (the engine writes the source buffer on its own stream, so stream-ordered completion in torch's sense is not
+    enough to reuse it)."""
+
+    def __init__(self, ex, work, out, src, sent):
+        self.ex, self.work, self.out, self.src, self.sent = ex, work, out, src, sent
+        self.result = None
+
+    def wait(self):
+        if self.result is not None:
+            return self.result
+        ex, rb = self.ex, self.ex.rb
+        self.work.wait()
+        if self.out.is_cuda:
+            torch.cuda.current_stream(self.out.device).synchronize()
+        world = self.out.shape[0]
+        counts = self.out[:, :8].contiguous().view(torch.int64).reshape(world).cpu()
+        max_n = int(counts.max())
+        if max_n > ex.cap:
+            raise RuntimeError(f"a rank produced {max_n} records, more than the exchange capacity {ex.cap}")
+        tail = None
+        if max_n > self.sent:
+            # some rank produced more records than every rank agreed to send in the first collective (the prediction from the
+            # previous generations was too small): every rank sees the same counts, so all of them take this branch together
+            # and gather the rest, blocking.  Rare by construction (slack over the largest count seen so far).
+            tn = (max_n - self.sent) * rb
+            tail = torch.empty(world, tn, dtype=torch.uint8, device=self.out.device)
+            dist.all_gather_into_tensor(tail.view(-1), self.src[HEADER + self.sent * rb: HEADER + max_n * rb].contiguous(), group=ex.group)
+            if tail.is_cuda:
+                torch.cuda.current_stream(tail.device).synchronize()
+            ex.tails += 1
+        parts = []
+        for r in range(world):
+            n = int(counts[r])
+            if n <= self.sent:
+                parts.append(self.out[r, HEADER: HEADER + n * rb])
+            else:
+                parts.append(torch.cat([self.out[r, HEADER: HEADER + self.sent * rb], tail[r, : (n - self.sent) * rb]]))
+        ex._observe(max_n)
+        self.work = self.src = None
+        self.result = (parts, counts)
+        return self.result
+
+
+class RecordExchange:
+    """The exchange step of a generation as one asynchronous all-gather, issued without reading anything back.
+
+    Every rank sends `HEADER + sent * rec_bytes` bytes where `sent` is a record count ALL ranks agree on without talking to
+    each other: the capacity (games x max plies) for the first generation, afterwards the largest count any rank has produced
+    in a generation whose collective has been waited for, plus a slack, rounded up — derived only from gathered counts, which
+    are identical on every rank, and updated inside wait(), which every rank calls in the same order.  A rank that produces
+    more than `sent` records is completed by a second (blocking) collective inside wait().  The record count of the rank
+    travels in the header, so the host reads no count before the collective is issued."""
+
+    def __init__(self, capacity_records, rec_bytes, group=None, slack=1.0 / 32):
+        self.cap, self.rb, self.group, self.slack = int(capacity_records), int(rec_bytes), group, float(slack)
+        self.seen_max = None
+        self.tails = 0               # collectives that needed the second step (diagnostics)
+
+    def buffer_bytes(self):
+        return HEADER + self.cap * self.rb
+
+    def new_buffer(self, device):
+        """A send buffer: the engine writes its packed records at data_ptr() + HEADER (agz_get_samples_packed)."""
+        return torch.zeros(self.buffer_bytes(), dtype=torch.uint8, device=device)
+
+    def agreed_count(self):
+        if self.seen_max is None:
+            return self.cap
+        n = self.seen_max + int(self.seen_max * self.slack) + 64
+        return min(self.cap, (n + 255) & ~255)
+
+    def _observe(self, max_n):
+        self.seen_max = max_n if self.seen_max is None else max(self.seen_max, max_n)
+
+    def start(self, buf, n_local):
+        """buf: a new_buffer() tensor whose records region holds n_local records; it must not be modified until wait()."""
+        world = dist.get_world_size(self.group)
+        if n_local > self.cap:
+            raise ValueError(f"{n_local} records exceed the exchange capacity {self.cap}")
+        buf[:8].view(torch.int64).fill_(int(n_local))          # (a fill with a scalar argument: nothing is read back, no host buffer)
+        sent = self.agreed_count()
+        nbytes = HEADER + sent * self.rb
+        out = torch.empty(world, nbytes, dtype=torch.uint8, device=buf.device)
+        work = dist.all_gather_into_tensor(out.view(-1), buf[:nbytes], group=self.group, async_op=True)
+        return PendingGather(self, work, out, buf, sent)
 
 
 def unpack_records(buf, n, game):

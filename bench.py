@@ -75,6 +75,22 @@ def cpu_baseline(args):
                       f"fp32 {args.filters}x{args.towers} net, OpenMP over games ({r} rollouts in {dt:.1f}s)"}
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` as typed: start the N rank processes as CHILDREN (torch.distributed.run, one rank per GPU) before
+    anything in this process touches the GPU, relay rank 0's JSON line (the children inherit stdout) and exit with their status."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,7 +110,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-delivery", action="store_true", help="skip the extra (untimed) generation that measures sample delivery to the host")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI); gloo only for single-GPU smoke tests of the N>1 path")
+    ap.add_argument("--dump-records", default="", help="rank 0 writes the gathered samples of the LAST timed generation (PoolSample order) to this .npz")
     args = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
     if args.config:
         for k, v in CONFIGS[args.config].items():
             setattr(args, k, v)
@@ -112,11 +131,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch as `python bench.py --gpus N` or under torch.distributed.run with --nproc-per-node N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libagz has no CPU path)")
     ndev = torch.cuda.device_count()
+    if world > ndev and args.backend == "nccl":
+        raise SystemExit(f"{world} ranks over RCCL need {world} GPUs ({ndev} visible); `--backend gloo` runs the N > 1 path with all ranks on one GPU (smoke test)")
     dev = local_rank % max(ndev, 1)             # (several ranks on one GPU only with --backend gloo)
     torch.cuda.set_device(dev)
     import torch.distributed as dist
@@ -134,9 +154,13 @@ def main():
                    nn_mode=M.NN_BF16 if args.mode == "bf16" else M.NN_EXACT)
     eng.set_network(net)
     rb = game.rec_bytes
-    # the exchange of generation k overlaps generation k+1: two sample buffers, at most two collectives in flight
-    sample_bufs = [torch.empty(G * game.max_plies * rb, dtype=torch.uint8, device="cuda") for _ in range(2)] if world > 1 else None
+    # the exchange of generation k overlaps generation k+1: two sample buffers, at most two collectives in flight; a collective is
+    # issued without any read-back (the rank's record count travels in the buffer's header: shard.RecordExchange)
+    ex = shard.RecordExchange(G * game.max_plies, rb) if world > 1 else None
+    sample_bufs = [ex.new_buffer("cuda") for _ in range(2)] if world > 1 else None
+    host_bufs = [ex.new_buffer("cpu").pin_memory() for _ in range(2)] if world > 1 and args.backend != "nccl" else None
     inflight = [None, None]
+    last_gather = [None]
     nstep = [0]
 
     def step():
@@ -149,11 +173,14 @@ def main():
         if world > 1:                       # the one exchange step: all-gather of the generated samples
             if inflight[k] is not None:
                 inflight[k].wait()          # the collective that read sample_bufs[k] two generations ago
-            n = eng.samples_packed_into(sample_bufs[k].data_ptr(), G * game.max_plies)
+            n = eng.samples_packed_into(sample_bufs[k].data_ptr() + shard.HEADER, G * game.max_plies)
             if args.backend == "nccl":
-                inflight[k] = shard.allgather_records_async(sample_bufs[k], n, rb)
+                inflight[k] = ex.start(sample_bufs[k], n)
             else:                               # gloo smoke path: stage through host memory
-                inflight[k] = shard.allgather_records_async(sample_bufs[k][: n * rb].cpu(), n, rb)
+                lo, hi = shard.HEADER, shard.HEADER + n * rb
+                host_bufs[k][lo:hi].copy_(sample_bufs[k][lo:hi])
+                inflight[k] = ex.start(host_bufs[k], n)
+            last_gather[0] = inflight[k]
         return st
 
     def fence():
@@ -200,11 +227,25 @@ def main():
     sum_p, sum_new, r_cnt = eng.counters()
     nn_leaves = eng.nn_leaves()
 
+    if args.dump_records:                   # (tests: the samples of the last timed generation as the host sees them)
+        import numpy as np
+        if world > 1:
+            parts, counts = last_gather[0].wait()
+            if rank == 0:
+                merged = shard.merge_poolsample_order([shard.unpack_records(parts[r].cpu().numpy(), int(counts[r]), game) for r in range(world)])
+                np.savez(args.dump_records, **merged)
+        else:
+            np.savez(args.dump_records, **eng.samples())
+
     # host delivery (SURVEY §8d "end-to-end"): the reference's generation ends with the samples in the host PoolSample
-    # (mcts_gpu.jl:515, mainGobang.jl:54-80).  One extra generation, outside the timed region: generation + packed records D2H
-    # into pinned host memory (+ push into the PoolSample arrays).
+    # (mcts_gpu.jl:515, mainGobang.jl:54-80).  Outside the timed region: (a) one generation + packed records D2H into pinned host
+    # memory + push into the PoolSample arrays, serially; (b) the PIPELINED host loop a trainer would run: the records of
+    # generation k are packed into device buffer k & 1, copied to pinned host memory on a second stream and unpacked into the
+    # PoolSample ring by a host thread (agz_unpack_records) while generation k + 1 runs on the engine's stream.
     host = None
     if world == 1 and not args.no_host_delivery:
+        import threading
+        import queue
         eng.set_profiling(0)
         buf = ag.PoolSample(game, 2_000_000)               # mainGobang.jl:130
         eng.samples_packed_host(); eng.samples_into(None, None, None, None, None)   # (staging buffers of the delivery paths are allocated once per run, not per generation)
@@ -221,7 +262,54 @@ def main():
         host = {"generation_s": h1 - h0, "packed_records_to_pinned_host_s": h2 - h1, "samples_into_PoolSample_s": h3 - h2,
                 "bytes": int(recs.size), "samples": int(recs.shape[0]),
                 "rollouts_per_s_with_host_delivery": st["rollouts"] / (h2 - h0),
-                "rollouts_per_s_with_delivery_into_PoolSample": st["rollouts"] / (h1 - h0 + h3 - h2)}
+                "rollouts_per_s_with_delivery_into_PoolSample_serial": st["rollouts"] / (h1 - h0 + h3 - h2)}
+        # (b) pipelined
+        cap = G * game.max_plies
+        dbuf = [torch.empty(cap * rb, dtype=torch.uint8, device="cuda") for _ in range(2)]
+        hbuf = [torch.empty(cap * rb, dtype=torch.uint8).pin_memory() for _ in range(2)]
+        side = torch.cuda.Stream()
+        free = [threading.Semaphore(1), threading.Semaphore(1)]
+        jobs = queue.Queue()
+        err = []
+
+        def deliver():
+            try:
+                while True:
+                    job = jobs.get()
+                    if job is None:
+                        return
+                    k, n = job
+                    with torch.cuda.stream(side):
+                        hbuf[k][: n * rb].copy_(dbuf[k][: n * rb], non_blocking=True)
+                    side.synchronize()
+                    buf.push_packed(hbuf[k][: n * rb].numpy(), n)
+                    free[k].release()
+            except Exception as e:          # noqa: BLE001 — reported by the main thread
+                err.append(e)
+                free[0].release(); free[1].release()
+
+        th = threading.Thread(target=deliver, daemon=True)
+        th.start()
+        gens = max(2, args.steps)
+        p_rollouts = 0
+        p0 = time.perf_counter()
+        for i in range(gens):
+            k = i & 1
+            free[k].acquire()               # the delivery of generation i - 2 has left buffer k
+            st = step()
+            n = eng.samples_packed_into(dbuf[k].data_ptr(), cap)
+            jobs.put((k, n))
+            p_rollouts += st["rollouts"]
+        jobs.put(None)
+        th.join()
+        p1 = time.perf_counter()
+        if err:
+            raise err[0]
+        host["pipelined_generations"] = gens
+        host["pipelined_wall_s"] = p1 - p0
+        host["rollouts_per_s_with_delivery_into_PoolSample"] = p_rollouts / (p1 - p0)
+        host["poolsample_length_after"] = buf.length_buffer()
+        del dbuf, hbuf
 
     cdev = "cuda" if args.backend == "nccl" else "cpu"
     tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
@@ -235,23 +323,36 @@ def main():
         S = game.pos_image_bytes
         alg = algorithmic_bytes(game, sum_p, sum_new, r_cnt, S)
         gl, gname = game_label(args)
-        traffic = None          # HBM bytes per launch from the committed PMC passes, scaled by this run's algorithmic bytes
-        pm, key = {}, ""
+        # HBM bytes per launch: NOT measured in this run (counters need rocprofv3 passes of their own) — the ratio traffic /
+        # algorithmic bytes of the committed PMC passes (profiles/pmc_traffic.json, one key per configuration) times this run's
+        # algorithmic bytes.  A whole-generation ratio (separate FETCH_SIZE / WRITE_SIZE passes over every launch of a generation,
+        # summed over the kernel variants of its plies) is used where one was measured, the first-ply ratio otherwise; the
+        # object names its source.  A BASELINE configuration without a committed pass is an error, not a silent null.
+        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        key = f"{gl}_{V}_{args.filters}x{args.towers}"
+        traffic, traffic_source = None, "none: no committed PMC pass for this shape (profiles/pmc_traffic.json has no key %s)" % key
         valu_obj = None         # VALU-issue roofline of the same kernel: SQ_INSTS_VALU (PMC pass) x 4 cycles / (SIMDs x clock x time)
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            key = f"{gl}_{V}_{args.filters}x{args.towers}"
-            if key in pm:
-                traffic = pm[key]["traffic_over_algorithmic"] * alg / max(launches, 1)
-                if "valu_insts_per_rollout" in pm[key] and busy_ms > 0:
-                    insts = pm[key]["valu_insts_per_rollout"] * r_cnt      # wave-instructions of the instrumented searches
-                    valu_obj = {"bound": "valu", "achieved": insts / (busy_ms * 1e-3) / 1e9, "peak": SIMDS * CLOCK_HZ / 4 / 1e9,
-                                "unit": "G wave-instructions/s", "frac": insts * 4 / (SIMDS * CLOCK_HZ * busy_ms * 1e-3),
-                                "note": "SQ_INSTS_VALU per (game, rollout) of the first-ply PMC pass (profiles/pmc_traffic.json) x this run's "
-                                        "rollouts; 4 cycles per wave-instruction on 1024 SIMDs at 2.4 GHz (the counters show ~2.0 GHz under "
-                                        "this load: the real issue utilisation is ~1.2 x higher)"}
-        except Exception:
-            traffic = None
+        baseline_shape = any(all(getattr(args, k) == v for k, v in c.items()) for kk, c in CONFIGS.items() if kk != 1) or \
+            (args.game, args.n, args.nvict, G, V, args.filters, args.towers) == ("gobang", 9, 5, 32768, 64, 128, 6)
+        if key not in pm and baseline_shape and args.mode == "bf16":
+            raise SystemExit(f"profiles/pmc_traffic.json has no entry {key}: a BASELINE configuration must carry measured HBM traffic")
+        if key in pm and args.mode == "bf16":
+            e = pm[key]
+            if "generation" in e:
+                ratio = e["generation"]["traffic_over_algorithmic"]
+                traffic_source = f"profiles/pmc_traffic.json[{key}].generation ({e['generation']['source']}): whole-generation ratio"
+            else:
+                ratio = e["traffic_over_algorithmic"]
+                traffic_source = f"profiles/pmc_traffic.json[{key}]: first-ply ratio (32768 games) applied to every ply of the generation"
+            traffic = ratio * alg / max(launches, 1)
+            vi = e.get("generation", {}).get("valu_insts_per_rollout", e.get("valu_insts_per_rollout"))
+            if vi is not None and busy_ms > 0:
+                insts = vi * r_cnt                                      # wave-instructions of the instrumented searches
+                valu_obj = {"bound": "valu", "achieved": insts / (busy_ms * 1e-3) / 1e9, "peak": SIMDS * CLOCK_HZ / 4 / 1e9,
+                            "unit": "G wave-instructions/s", "frac": insts * 4 / (SIMDS * CLOCK_HZ * busy_ms * 1e-3),
+                            "note": "SQ_INSTS_VALU per (game, rollout) of the committed PMC pass (" + traffic_source + ") x this run's "
+                                    "rollouts; 4 cycles per wave-instruction on 1024 SIMDs at 2.4 GHz (the counters show ~2.0 GHz under "
+                                    "this load: the real issue utilisation is ~1.2 x higher)"}
         hbm_achieved = alg / (busy_ms * 1e-3) / 1e9 if busy_ms > 0 else 0.0   # aggregate over the launches in flight together
         if whole or nn_leaves == 0:
             # the network forward runs inside the search kernel: its time is not separable, the fraction is taken against the
@@ -265,7 +366,7 @@ def main():
             nn_t_ms, nn_note = nn_ms, "stand-alone network launches of the instrumented searches (leaves and HIP-event time of those launches only)"
         mfma_achieved = flops / (nn_t_ms * 1e-3) / 1e12 if nn_t_ms > 0 else 0.0
         tree_obj = {"kernel": form_tree, "bound": "hbm", "achieved": hbm_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": hbm_achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "frac": hbm_achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                     "algorithmic_bytes_per_launch": alg / max(launches, 1), "avg_launch_ms": tree_ms / max(launches, 1),
                     "launches": launches, "launch_concurrency": tree_ms / busy_ms if busy_ms > 0 else None,
                     "mean_depth_p": sum_p / max(r_cnt, 1),
@@ -273,11 +374,8 @@ def main():
                              "one launch = one rollout of all games alive; busy time = union of the launch intervals of the sub-batch chains")
                             + "; algorithmic bytes are the tree path's (SURVEY 8d)"}
         nn_traffic = None       # HBM bytes per stand-alone network launch (PMC passes of the config's first ply x this run's leaves per launch)
-        try:
-            if not whole and nn_leaves > 0 and "nn_hbm_bytes_per_leaf" in pm.get(key, {}):
-                nn_traffic = pm[key]["nn_hbm_bytes_per_leaf"] * nn_leaves / max(launches * V / (V + 1.0), 1.0)
-        except Exception:
-            nn_traffic = None
+        if not whole and nn_leaves > 0 and "nn_hbm_bytes_per_leaf" in pm.get(key, {}):
+            nn_traffic = pm[key]["nn_hbm_bytes_per_leaf"] * nn_leaves / max(launches * V / (V + 1.0), 1.0)
         nn_obj = {"kernel": form_nn, "bound": "mfma", "achieved": mfma_achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                   "frac": mfma_achieved / MFMA_PEAK_TFLOPS, "traffic": nn_traffic,
                   "flops_per_leaf": nn_flops_per_leaf(game, args.filters, args.towers), "leaves": (r_cnt if (whole or nn_leaves == 0) else nn_leaves),
@@ -289,7 +387,7 @@ def main():
             # matrix work is 30 x the 128-wide trunk's) — the launch is priced against the MFMA peak, whole-launch time as the denominator
             nn_dominant = True
             nn_obj["kernel"] = form_tree + " [" + form_nn + "]"
-            nn_obj["traffic"] = traffic
+            nn_obj["traffic"] = traffic; nn_obj["traffic_source"] = traffic_source
             nn_obj["avg_launch_ms"] = tree_ms / max(launches, 1); nn_obj["launches"] = launches
         out = {
             "metric": f"self-play rollouts/sec at {G} games x {V} rollouts, {gname}",

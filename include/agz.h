@@ -139,6 +139,11 @@ int  agz_get_samples(agz_engine *h, int8_t *state, float *policy, int8_t *player
  * (see agz_game_info) to dev_out; returns n via *n_out.  Record: {u32 game_id, i32 ply, i32 move, f32 value,
  * i8 player, i8 pad[3], f32 policy[A], i8 state[2VS], i8 fstate[FS], pad to 16 B}. */
 int  agz_get_samples_packed(agz_engine *h, void *dev_out, int64_t capacity_records, int64_t *n_out);
+/* Host-only helper (no handle, no device): n packed records in HOST memory -> the PoolSample-layout arrays of agz_get_samples
+ * (push_buffer / update_buffer, mainGobang.jl:54-80).  Lets a host loop copy the records of generation k to pinned memory on a side
+ * stream and unpack them while generation k+1 runs. */
+int  agz_unpack_records(const agz_game_info *info, const void *records, int64_t n, int8_t *state, float *policy, int8_t *player,
+                        float *value, int8_t *fstate, uint32_t *game_id, int32_t *ply, int32_t *move);
 
 /* stream / timing plumbing */
 void *agz_stream(agz_engine *h);                       /* the engine's hipStream_t */

@@ -249,7 +249,7 @@ def _engine_shard_worker(rank, world, port, backend, q):
         n = e.samples_packed_into(buf.data_ptr(), G * g.max_plies)
         assert n == st["nsamples"]
         local = buf if backend == "nccl" else buf[: n * rb].cpu()
-        out, counts = shard.allgather_records_async(local, n, rb).wait()
+        out, counts = shard.allgather_records(local, n, rb)
         parts = [shard.unpack_records(out[r].cpu().numpy(), int(counts[r]), g) for r in range(world)]
         merged = shard.merge_poolsample_order(parts)
     if rank == 0:
@@ -309,3 +309,47 @@ def test_exchange_over_rccl_with_one_rank():
     for k in ("game_id", "ply", "move", "player", "state", "fstate", "value", "policy"):
         assert parity.same_bits(merged[k], one[k]), k
         assert parity.same_bits(merged[k], ref[k]), k
+
+
+# ---- `python bench.py --gpus N` as the driver types it: the ranks are children of the command ---------------------------
+def _bench_two_ranks(backend, tmp_path):
+    """bench.py --gpus 2 started WITHOUT torch.distributed.run: it launches its two ranks itself, rank 0 prints ONE JSON line with
+    n_gpus 2, and the samples it gathered (pipelined RecordExchange, as in the timed region) are those of ONE engine running all
+    4096 games — record for record."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dump = str(tmp_path / "records.npz")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", backend, "--games", "2048", "--steps", "1",
+           "--warmup", "0", "--no-cpu-baseline", "--dump-records", dump]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 1 and out["scaling"] == "weak"
+    assert out["value"] > 0 and out["roofline"]["frac"] > 0
+    got = dict(np.load(dump))
+    g = ag.GameSpec("gobang", 9, 5)
+    net = ag.SNetwork2.random(g, 128, 6)
+    with M.Engine(g, 4096, 64, seed=1, game_id_base=0, nn_mode=M.NN_BF16) as e:     # bench.py: seed 1 + generation index
+        e.set_network(net)
+        st = e.selfplay(4096, 64, cpuct=1.5, tau_plies=25)
+        assert st["valid"]
+        one = e.samples()
+    assert len(got["ply"]) == len(one["ply"]) == st["nsamples"] and out["rank0"]["samples"] < st["nsamples"]
+    for k in ("game_id", "ply", "move", "player", "state", "fstate", "value", "policy"):
+        assert parity.same_bits(got[k], one[k]), k + " (bench.py --gpus 2 vs one engine)"
+
+
+def test_bench_gpus_2_launches_its_own_ranks_gloo(tmp_path):
+    _bench_two_ranks("gloo", tmp_path)
+
+
+def test_bench_gpus_2_over_rccl(tmp_path):
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one visible GPU: the two-rank RCCL run needs two (the gloo form of the same test runs)")
+    _bench_two_ranks("nccl", tmp_path)

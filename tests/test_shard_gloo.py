@@ -40,8 +40,33 @@ def _worker(rank, world, port, q):
     out, counts = shard.allgather_records(local, s["n"], game.rec_bytes)
     parts = [shard.unpack_records(out[r].numpy(), int(counts[r]), game) for r in range(world)]
     merged = shard.merge_poolsample_order(parts)
+    # the pipelined form (what bench.py runs): one asynchronous collective per generation, the count in the buffer's header, no
+    # read-back when it is issued.  Four "generations", each waited for after the next one was issued (double buffering): the first two
+    # are sent at full capacity, the next two with the count agreed from the gathered counts of the first; the last outgrows that
+    # prediction on rank 1 only and is completed by the second (blocking) step inside wait() -- every one must deliver exactly the records each rank packed.
+    rb = game.rec_bytes
+    ex = shard.RecordExchange(40 * game.max_plies, rb, slack=0.0)
+    sent, pipelined_ok = [], True
+    pend = []
+    for gen, ng in enumerate((6, 6, 6, 6 if rank == 0 else 40)):
+        sg = O.selfplay(og, net, ng, 8, 1.5, 25, 11 + gen, shard.shard_base(rank, 40))
+        buf = ex.new_buffer("cpu")
+        pk = torch.from_numpy(_pack(sg, game))
+        buf[shard.HEADER: shard.HEADER + pk.numel()] = pk
+        pend.append((ex.start(buf, sg["n"]), pk, sg["n"]))
+        sent.append(pend[-1][0].sent)
+        if gen == 0:                       # double buffering: generation k is waited for after generation k + 1 was issued ...
+            continue
+        pg, pk0, n0 = pend[gen - 1]
+        parts_g, counts_g = pg.wait()
+        pipelined_ok &= int(counts_g[rank]) == n0 and bool((parts_g[rank] == pk0).all())
+    pg, pk0, n0 = pend[-1]
+    parts_g, counts_g = pg.wait()
+    pipelined_ok &= int(counts_g[rank]) == n0 and bool((parts_g[rank] == pk0).all()) and int(counts_g.max()) == int(counts_g[1])
     if rank == 0:
-        q.put({k: v for k, v in merged.items()})
+        q.put(dict(merged=dict(merged), sent=sent, tails=ex.tails, ok=pipelined_ok, cap=ex.cap))
+    else:
+        q.put(dict(ok=pipelined_ok))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -56,10 +81,17 @@ def test_two_rank_allgather_equals_unsharded_run():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    merged = q.get(timeout=120)
+    res = [q.get(timeout=120), q.get(timeout=120)]
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
+    assert all(r["ok"] for r in res)
+    r0 = [r for r in res if "merged" in r][0]
+    merged = r0["merged"]
+    # generations 0 and 1 travel at full capacity (nothing has been waited for when they are issued), 2 and 3 with the count
+    # agreed from the gathered counts; only generation 3 needs the second step
+    cap, sent = r0["cap"], r0["sent"]
+    assert sent[0] == cap and sent[1] == cap and sent[2] < cap and sent[3] == sent[2] and r0["tails"] == 1, (sent, cap, r0["tails"])
     og = O.make_game("gobang", 3, 3)
     ref = O.selfplay(og, O.OracleNet(og, 16, 1), 12, 8, 1.5, 25, 11, 0)
     assert len(merged["ply"]) == ref["n"]
