@@ -34,13 +34,15 @@ AGZ_HD float uniform_search(uint64_t seed, uint32_t game, uint32_t step, uint32_
     const uint32_t w = depth & 3u;
     return w == 0 ? u[0] : (w == 1 ? u[1] : (w == 2 ? u[2] : u[3]));
 }
-// uniform in (0,1] standing for rand() inside StatsBase.sample (mcts_gpu.jl:520): (24 random bits + 1/2) 2^-24.  Never 0: the
+// uniform in (0,1) standing for rand() inside StatsBase.sample (mcts_gpu.jl:520): (23 random bits + 1/2) 2^-23 — the odd multiples
+// of 2^-24, every one exactly representable in fp32 (no rounding in the conversion, so host and device agree whatever the
+// compiler's intermediate precision; never 1: rand() is in [0,1)).  Never 0: the
 // reference's Float64 rand() is 0 with probability 2^-53 — never in practice — whereas a 24-bit draw that could be 0 would stop the
 // duel's all-actions walk (:606) at action 1 whatever its weight once in 2^24 draws
 AGZ_HD float uniform_move(uint64_t seed, uint32_t game, uint32_t step) {
     uint32_t o[4];
     philox4x32_10(game, step, 0u, 0x80000000u, (uint32_t)seed, (uint32_t)(seed >> 32), o);
-    return ((float)(o[0] >> 8) + 0.5f) * 5.9604644775390625e-8f;
+    return (float)(2u * (o[0] >> 9) + 1u) * 5.9604644775390625e-8f;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -146,6 +148,9 @@ struct TreePar {
     int32_t training;
     int32_t do_reset, do_expand, do_select, last, exact, inject, capture;
     unsigned long long* dbg;      // diagnostic builds (-DAGZ_STAMPS): per-phase cycle sums; unused otherwise
+    unsigned long long* rank_fault;   // rows by the root's legal rank: counts the expansions whose ROOT had more legal actions than the rows hold
+                                      // (the dispatch picks the row width from a bound on the legal actions; a root that breaks the bound must not
+                                      // lose actions silently: the generation fails)
 };
 
 // ---------------------------------------------------------------------------------------------------

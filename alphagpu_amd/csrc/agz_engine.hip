@@ -418,6 +418,7 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     T.logits = h->logits; T.LGS = h->LGS; T.prior_eval = h->prior_eval; T.v_eval = h->v_eval; T.policy_final = h->policy_final;
     T.seed = cfg->seed; T.exact = cfg->nn_mode == AGZ_NN_EXACT;
     T.wl = h->wl; T.wl_n = h->wl_n; T.sp = h->sp; T.wl_cap = h->wl_cap;
+    T.rank_fault = h->d_stats + 5;
     FA_(hipMemsetAsync(h->wl_n, 0, wl_blocks * 4, h->stream)); hipMemsetAsync(h->sp, 0, Lm * 4, h->stream);
 #ifdef AGZ_STAMPS
     { unsigned long long* d = nullptr; hipMalloc((void**)&d, (size_t)65536 * 16 * 8); hipMemset(d, 0, (size_t)65536 * 16 * 8); T.dbg = d; }
@@ -1192,7 +1193,11 @@ static int run_games(agz_engine* h, int ngames, int V, float cpuct, int tau_plie
             for (uint32_t spin = 0;; ++spin) {
                 const unsigned long long w = __atomic_load_n(f, __ATOMIC_ACQUIRE);
                 if ((uint32_t)(w >> 32) == seq) { *hcount = (uint32_t)w; have = true; break; }
+#if defined(__x86_64__) || defined(__i386__)
                 __builtin_ia32_pause();                                            // (a polite spin: the core is shared with the host's other threads)
+#else
+                std::this_thread::yield();
+#endif
                 if ((spin & 1023u) == 1023u) {
                     const hipError_t q = hipStreamQuery(h->stream);
                     if (q != hipErrorNotReady) { (void)hipGetLastError(); break; }
@@ -1225,6 +1230,7 @@ static int run_games(agz_engine* h, int ngames, int V, float cpuct, int tau_plie
         st->total_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         st->nsamples = h->sp_nsamples;
     }
+    if (hs[5]) { h->fail("%llu expansion(s) found a root with more legal actions than the rows by legal rank hold (legal_bound violated)", hs[5]); return AGZ_ERR_STATE; }
     if (hs[4]) { h->fail("%llu illegal sampled move(s) (\"faute\", mcts_gpu.jl:526-529)", hs[4]); return AGZ_ERR_ILLEGAL_MOVE; }
     return AGZ_OK;
 }

@@ -41,7 +41,9 @@ __device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {
 }
 __device__ __attribute__((noinline)) float sigmoid_ool(float x) { return sigmoid_spec(x); }
 // relu of an MFMA accumulator element (x > 0 ? x : 0 for every non-NaN x, -0 included) as ONE integer instruction: the bits of a
-// non-negative float order like the integer, those of a negative one are a negative integer
+// non-negative float order like the integer, those of a negative one are a negative integer.  (A NaN with a clear sign bit passes
+// through, where the comparison form returns 0: the bit-identity with the per-layer kernels of agz_nn.hpp, which keep the
+// comparison, and the dropped second relu of the residual sum hold for FINITE weights and activations — what a network is.)
 __device__ __forceinline__ float relu_bits(float x) { const int b = __float_as_int(x); return __int_as_float(b > 0 ? b : 0); }
 
 constexpr int NW_WAVES = 4;               // waves per workgroup (= per 16-leaf tile)

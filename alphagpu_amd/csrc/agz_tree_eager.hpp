@@ -438,6 +438,8 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
                 for (int j = 0; j < KPL; ++j) {
                     if ((rmask >> j) & 1u) { if (rank < G * KPR) cs[rank] = ((lmask >> j) & 1u) ? x[j] : nz; ++rank; }   // (the engine guarantees rank < G KPR: A - ply legal actions)
                 }
+                // ... and a root that breaks the guarantee is REPORTED, not served with a truncated row (the ply loop fails the generation)
+                if (__builtin_expect(rank > G * KPR, 0)) atomicAdd(T.rank_fault, 1ull);
                 AGZ_WSYNC();
 #pragma unroll
                 for (int j = 0; j < KPR; j += 4) {

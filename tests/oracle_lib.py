@@ -56,7 +56,13 @@ def lib():
     if _LIB is None:
         path = os.path.join(ORACLE_DIR, "libagz_oracle.so")
         src = os.path.join(ORACLE_DIR, "agz_oracle.c")
-        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+        if os.environ.get("AGZ_ORACLE_SAN"):
+            # the ASan + UBSan build of the oracle (make -C oracle SAN=1; run the CPU suite with
+            # LD_PRELOAD=$(gcc -print-file-name=libasan.so) AGZ_ORACLE_SAN=1, see oracle/Makefile)
+            path = os.path.join(ORACLE_DIR, "libagz_oracle_san.so")
+            if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+                subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "SAN=1"])
+        elif not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
             build()
         L = C.CDLL(path)
         L.agzo_uniform_search.restype = C.c_float

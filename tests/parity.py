@@ -1,13 +1,18 @@
 """Comparison helpers of the GPU parity tests (test infrastructure; uses the oracle).
 
-bf16 mode is compared BIT FOR BIT against the oracle's model of the bf16 MFMA forward.  That model was fitted to instruction
-outputs captured on the hardware and misses one captured element by 1 ulp (oracle/agz_oracle.c agzo_mfma_dot), so a future seed
-may hit an un-modelled rounding case with no product bug behind it.  `assert_bf16_search_matches` therefore falls back, on a bit
-mismatch, to what does not depend on the model: the games that differ are searched again through the stepwise API with the
-GPU's own priors and values teacher-forced into the oracle — the trees must then be bit-identical — and the GPU logits must lie
-within the bf16 bound of the oracle's fp32 forward (DenseNet.jl:294-304).  The offending network outputs are printed so that
-the known-answer fixture (tests/golden/mfma_kat.npz) can be extended.  Anything else fails.
+bf16 mode is compared BIT FOR BIT against the oracle's model of the bf16 MFMA forward, and A MISMATCH FAILS.
+
+That model was fitted to instruction outputs captured on the hardware (oracle/agz_oracle.c agzo_mfma_dot), so a future seed may hit an
+un-modelled rounding case with no product bug behind it.  For that case only — and only when the developer asks for it with
+AGZ_ALLOW_MFMA_MODEL_MISS=1 — `assert_bf16_search_matches` runs a diagnosis instead of failing at once: the games that differ are
+searched again through the stepwise API with the GPU's own priors and values teacher-forced into the oracle (the trees must then be
+bit-identical and the GPU logits within the bf16 bound of the oracle's fp32 forward, DenseNet.jl:294-304), the stepwise run must have
+met a network output the model misses, AND the fused one-launch result that mismatched must equal that stepwise GPU run bit for bit
+(same MFMA instruction, operand and k order in both forms) — which ties the fused kernel itself, not just the stepwise kernels, to the
+teacher-forced oracle run.  The offending network outputs are printed so that the known-answer fixture (tests/golden/mfma_kat.npz) can
+be extended.  Without the switch, and in every other case with it, the test fails.
 """
+import os
 import warnings
 
 import numpy as np
@@ -49,8 +54,8 @@ def differing_games(a, b):
 
 def teacher_forced_check(make_engine, og, onet, roots, ids, V, cpuct, training, seed, step, what=""):
     """Stepwise search on the GPU (agz_rollout_*), the GPU's softmaxed priors and values handed to the oracle rollout by rollout:
-    leaves, planes and the final trees must be bit-identical; logits within the bf16 bound of the fp32 forward.  Returns the list of
-    (rollout, row, column, gpu, model) network outputs that differ from the bf16 MFMA model."""
+    leaves, planes and the final trees must be bit-identical; logits within the bf16 bound of the fp32 forward.  Returns (the list of
+    (rollout, row, column, gpu, model) network outputs that differ from the bf16 MFMA model, the stepwise GPU run's result dict)."""
     L = len(roots)
     t = O.OracleTree(og, L, V)
     t.set_roots(roots, ids)
@@ -84,7 +89,7 @@ def teacher_forced_check(make_engine, og, onet, roots, ids, V, cpuct, training, 
         got, ref = engine_result(e), oracle_result(t)
         for key in ("leaf", "node_count", "visits", "q"):
             assert same_bits(got[key], ref[key]), f"{what}: {key} differs with teacher-forced priors"
-    return misses
+    return misses, got
 
 
 def assert_bf16_search_matches(got, ref, fallback, what=""):
@@ -95,10 +100,15 @@ def assert_bf16_search_matches(got, ref, fallback, what=""):
         assert np.abs(got["q"] - ref["q"]).max() <= 1e-4
         return
     detail = ", ".join(f"{k}: {int((np.asarray(got[k]) != np.asarray(ref[k])).sum())}" for k in KEYS)
-    assert fallback is not None, f"{what}: {len(bad)} games differ from the oracle ({detail})"
-    misses = fallback(bad[:8])
+    allow = os.environ.get("AGZ_ALLOW_MFMA_MODEL_MISS") == "1" and fallback is not None
+    assert allow, (f"{what}: {len(bad)} games differ from the oracle ({detail}); rerun with AGZ_ALLOW_MFMA_MODEL_MISS=1 to find out "
+                   f"whether an un-modelled MFMA rounding case is behind it")
+    rows = bad[:8]
+    misses, stepwise = fallback(rows)
     assert misses, (f"{what}: {len(bad)} games differ from the oracle ({detail}) although every network output of the stepwise "
                     f"re-run equals the bf16 MFMA model")
+    for k in KEYS:                          # the fused form that mismatched == the stepwise GPU form that the oracle followed
+        assert same_bits(np.asarray(got[k])[rows], stepwise[k]), f"{what}: {k} of the one-launch search differs from the stepwise GPU run"
     msg = (f"{what}: {len(bad)} games differ from the oracle's bf16 MFMA MODEL; with the GPU's priors teacher-forced the trees are "
            f"bit-identical and the logits are within the bf16 bound of the fp32 forward -> un-modelled MFMA rounding case, not a "
            f"product bug.  Network outputs to add to tests/golden/mfma_kat.npz (rollout, row, column, gpu, model): {misses[:8]}")

@@ -1,6 +1,7 @@
 """The built library's code objects (CPU test: reads metadata, launches nothing): the kernels of the benchmarked configurations keep
-their register budgets — no vector-register spills, few scalar ones — so that a change that silently pushes the item loop into scratch
-memory fails here and not in a later round's profile.  Uses the LLVM tools of the ROCm image (skipped where they are missing)."""
+their register budgets — no vector-register spills in the 128-wide-trunk searches and the one-workgroup-per-CU wide-trunk searches, a
+bounded number (tree state parked across the network pass, none in its k-loop) in the two-workgroups-per-CU build of the 64-game
+wide-trunk search — so that a change that silently pushes the item loop into scratch memory fails here and not in a later round's profile.  Uses the LLVM tools of the ROCm image (skipped where they are missing)."""
 import glob
 import os
 import re
@@ -20,7 +21,9 @@ def kernel_metadata():
         with tempfile.TemporaryDirectory() as d:
             co = os.path.join(d, "co")
             fat = os.path.join(d, "fat")                          # the device code is a bundle in the object's .hip_fatbin section
-            r = subprocess.run([LLVM + "llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", obj], capture_output=True)
+            # (an explicit output file: without one llvm-objcopy rewrites its INPUT in place — the build's objects would get new
+            #  time stamps and `make` would relink the library after every test run)
+            r = subprocess.run([LLVM + "llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", obj, os.path.join(d, "copy.o")], capture_output=True)
             if r.returncode != 0:
                 continue
             r = subprocess.run([LLVM + "clang-offload-bundler", "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
@@ -57,9 +60,14 @@ def test_benchmarked_kernels_do_not_spill_vector_registers():
                 assert k["sgpr_spill_count"] <= 40, (name, k)            # (was 120-150 while the parameters lived in scalar registers)
         for wg in (1, 2):
             for kpr in ((0, 8, 4) if fam_nc_kpl in ("0, 2, 12", "2, 2, 12") else (0,)):
-                for twb in ((4, 8) if wg == 1 else (4,)):                # (64-game workgroups: one per CU only)
+                for twb in (4, 8):
                     k = md[f"k_search_big<{fam_nc_kpl}, 512, {wg}, {kpr}, {twb}>"]
-                    assert k["vgpr_spill_count"] == 0 and k["vgpr_count"] <= 256 // wg, (fam_nc_kpl, wg, kpr, twb, k)
+                    if wg == 2 and twb == 8:
+                        # two 64-game workgroups per CU (the default of configs 3-5 above 64 games per CU): the 128-register build of the
+                        # 64-leaf network pass parks long-lived tree state in scratch — a ceiling, so that it cannot grow unnoticed
+                        assert k["vgpr_spill_count"] <= 56 and k["private_segment_fixed_size"] <= 256 and k["vgpr_count"] <= 128, (fam_nc_kpl, wg, kpr, twb, k)
+                    else:
+                        assert k["vgpr_spill_count"] == 0 and k["vgpr_count"] <= 256 // wg, (fam_nc_kpl, wg, kpr, twb, k)
         for wv in (3, 4):
             k = md[f"k_rollout_eager<{fam_nc_kpl}, {wv}>"]
             assert k["vgpr_spill_count"] == 0 and k["sgpr_spill_count"] <= 40, (fam_nc_kpl, wv, k)
