@@ -1332,4 +1332,52 @@ int agz_unpack_records(const agz_game_info* info, const void* records, int64_t n
     return AGZ_OK;
 }
 
+// Known-answer test hook for the game plugins as the DEVICE runs them (Game<FAM,NC>::canPlay / play / isOver of agz_games.hpp, the
+// code every tree and ply kernel is instantiated from): breadth-first perft from Position() on the GPU.  nodes = positions after
+// exactly `depth` plies (finished games are not extended); terminal[0..2] = finished games met at any ply <= depth with result
+// +1 / 0 / -1 — the usual perft definition (the test suite's CPU checker uses the same one), so published counts (Othello 4, 12, 56, 244, 1396, 8200, ...; TicTacToe's
+// 255168 games; Connect4 7^d ...) pin the device code directly.
+int agz_perft(const agz_config* cfg, int depth, int64_t* nodes, int64_t terminal[3]) {
+    if (!cfg || !nodes || depth < 0 || depth > 64) return AGZ_ERR_ARG;
+    GamePar P;
+    if (make_game_par(cfg->game, cfg->n, cfg->nvict, P) != 0) return AGZ_ERR_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0 || cfg->device < 0 || cfg->device >= ndev) { g_create_error = "agz_perft: no such HIP device (libagz has no CPU path)"; return AGZ_ERR_HIP; }
+    if (hipSetDevice(cfg->device) != hipSuccess) return AGZ_ERR_HIP;
+    typedef void (*perft_fn)(const GamePar, const Pos*, unsigned long long, Pos*, unsigned long long, unsigned long long*, int);
+    perft_fn k = nullptr;
+#define X(F, R, C) if (P.fam == F && P.NC == C) k = k_perft_level<F, C>;
+    AGZ_COMBOS(X)
+#undef X
+    if (!k) return AGZ_ERR_UNSUPPORTED;
+    const unsigned long long cap = 1ull << 22;                             // positions per stored level (320 MB per buffer)
+    Pos *buf[2] = {nullptr, nullptr}; unsigned long long* cnt = nullptr;
+    int rc = AGZ_OK;
+    if (hipMalloc((void**)&buf[0], cap * sizeof(Pos)) != hipSuccess || hipMalloc((void**)&buf[1], cap * sizeof(Pos)) != hipSuccess ||
+        hipMalloc((void**)&cnt, 6 * sizeof(unsigned long long)) != hipSuccess) rc = AGZ_ERR_NOMEM;
+    unsigned long long hc[6] = {0, 0, 0, 0, 0, 0};
+    if (rc == AGZ_OK) {
+        Pos root; memset(&root, 0, sizeof root);
+        for (int i = 0; i < 3; ++i) { root.p[i] = P.start_p[i]; root.o[i] = P.start_o[i]; root.lg[i] = P.start_lg[i]; }
+        root.player = (int8_t)P.start_player; root.aux = (int8_t)P.start_aux;
+        hipMemcpy(buf[0], &root, sizeof root, hipMemcpyHostToDevice);
+        hipMemset(cnt, 0, 6 * sizeof(unsigned long long));
+        unsigned long long n = 1;
+        for (int d = 0; d <= depth && n > 0; ++d) {
+            const int remaining = depth - d;
+            hipLaunchKernelGGL(k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, P, (const Pos*)buf[d & 1], n, buf[(d + 1) & 1], cap, cnt, remaining);
+            if (hipMemcpy(hc, cnt, sizeof hc, hipMemcpyDeviceToHost) != hipSuccess) { rc = AGZ_ERR_HIP; break; }
+            if (hc[5]) { g_create_error = "agz_perft: a level exceeds the position buffer"; rc = AGZ_ERR_NOMEM; break; }
+            n = hc[4];
+            unsigned long long z = 0; hipMemcpy(cnt + 4, &z, 8, hipMemcpyHostToDevice);
+            if (remaining <= 1) break;
+        }
+    }
+    hipFree(buf[0]); hipFree(buf[1]); hipFree(cnt);
+    if (rc != AGZ_OK) return rc;
+    *nodes = (int64_t)hc[0];
+    if (terminal) { terminal[0] = (int64_t)hc[1]; terminal[1] = (int64_t)hc[2]; terminal[2] = (int64_t)hc[3]; }
+    return AGZ_OK;
+}
+
 }  // extern "C"

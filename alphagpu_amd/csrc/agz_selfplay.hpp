@@ -280,4 +280,40 @@ __global__ void k_pack_samples(const PackPar T) {
     for (int j = 20 + 4 * T.A + 2 * T.VS + T.FS + threadIdx.x; j < T.rec_bytes; j += blockDim.x) rec[j] = 0;
 }
 
+// ---- known-answer test of the game plugins ON THE DEVICE (agz_perft): one level of a breadth-first perft ------------------------
+// thread i takes position i of the level: a finished game counts in term[] (result +1 / 0 / -1 in absolute colours) and is not
+// extended (Game::isOver); at the last level every position counts as a node; otherwise every legal action (Game::canPlay) is played
+// (Game::play) — into the next level, or, one ply above the last level (count_only), straight into the counters.
+// cnt: [0] nodes at the final depth, [1..3] finished games by result, [4] positions written to `out`, [5] positions dropped (out full)
+template <int FAM, int NC>
+__global__ __launch_bounds__(256) void k_perft_level(const GamePar P, const Pos* in, const unsigned long long n_in, Pos* out,
+                                                     const unsigned long long cap_out, unsigned long long* cnt, const int remaining) {
+    using G = Game<FAM, NC>;
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_in) return;
+    const WPos<NC> s = unpack<NC>(in[i]);
+    int r;
+    if (G::isOver(P, s, r)) {
+        atomicAdd(&cnt[r == 1 ? 1 : (r == 0 ? 2 : 3)], 1ull);            // (isOver reports the winner in absolute colours)
+        if (remaining == 0) atomicAdd(&cnt[0], 1ull);
+        return;
+    }
+    if (remaining == 0) { atomicAdd(&cnt[0], 1ull); return; }
+    unsigned long long nodes = 0, t[3] = {0, 0, 0};
+    for (int a = 0; a < P.A; ++a) {
+        if (!G::canPlay(P, s, a)) continue;
+        const WPos<NC> c = G::play(P, s, a);
+        if (remaining == 1) {                                             // the last level is counted, not stored
+            int rc;
+            if (G::isOver(P, c, rc)) ++t[rc == 1 ? 0 : (rc == 0 ? 1 : 2)];
+            ++nodes;
+        } else {
+            const unsigned long long k = atomicAdd(&cnt[4], 1ull);
+            if (k < cap_out) out[k] = pack(c); else atomicAdd(&cnt[5], 1ull);
+        }
+    }
+    if (nodes) atomicAdd(&cnt[0], nodes);
+    for (int j = 0; j < 3; ++j) if (t[j]) atomicAdd(&cnt[1 + j], t[j]);
+}
+
 }  // namespace agz

@@ -27,3 +27,16 @@ class GameSpec:
     VS = property(lambda s: s.VectorizedState)
     FS = property(lambda s: s.FeatureSize)
     ML = property(lambda s: s.maxLengthGame)
+
+
+def perft(game, depth, device=0):
+    """Perft of the game plugin as the DEVICE runs it (agz_perft): (positions after exactly `depth` plies, [games finished with
+    result +1, 0, -1 at any ply <= depth]).  Known-answer test hook; needs a GPU."""
+    cfg = _lib.Config(game=game.kind, n=game.n, nvict=game.nvict, max_games=1, max_visits=1, device=int(device))
+    nodes, term = C.c_int64(0), (C.c_int64 * 3)()
+    L = _lib.load_library()
+    rc = L.agz_perft(C.byref(cfg), int(depth), C.byref(nodes), C.byref(term))
+    if rc != 0:
+        msg = L.agz_last_error(None)
+        raise _lib.AgzError(rc, msg.decode() if msg else "agz_perft failed")
+    return nodes.value, [term[0], term[1], term[2]]

@@ -82,6 +82,7 @@ def load_library():
     L.agz_get_samples.argtypes = [vp] + [vp] * 8
     L.agz_get_samples_packed.argtypes = [vp, vp, C.c_int64, C.POINTER(C.c_int64)]
     L.agz_unpack_records.argtypes = [C.POINTER(GameInfo), vp, C.c_int64] + [vp] * 8
+    L.agz_perft.argtypes = [C.POINTER(Config), C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64 * 3)]
     L.agz_stream.argtypes = [vp]
     L.agz_stream.restype = vp
     L.agz_synchronize.argtypes = [vp]

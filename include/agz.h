@@ -145,6 +145,12 @@ int  agz_get_samples_packed(agz_engine *h, void *dev_out, int64_t capacity_recor
 int  agz_unpack_records(const agz_game_info *info, const void *records, int64_t n, int8_t *state, float *policy, int8_t *player,
                         float *value, int8_t *fstate, uint32_t *game_id, int32_t *ply, int32_t *move);
 
+/* Known-answer test hook: breadth-first perft from Position() computed ON THE DEVICE with the game plugin code the kernels are
+ * instantiated from (canPlay / play / isOver: Gobang.jl:25-70, 4IARow.jl:25-81, Hex.jl:37-67, Reversi8x8.jl:84-121).  *nodes = positions
+ * after exactly `depth` plies (finished games are not extended); terminal[0..2] (may be NULL) = finished games met at any ply <= depth
+ * with result +1 / 0 / -1.  Uses cfg->game, n, nvict, device. */
+int  agz_perft(const agz_config *cfg, int depth, int64_t *nodes, int64_t terminal[3]);
+
 /* stream / timing plumbing */
 void *agz_stream(agz_engine *h);                       /* the engine's hipStream_t */
 int  agz_synchronize(agz_engine *h);

@@ -747,3 +747,37 @@ def test_profiling_counters_and_busy_time_are_consistent():
             for k in env:
                 os.environ.pop(k, None)
     assert res[0] == res[1] and res[0][2] == 600 * 16
+
+
+# ---- the game plugins as the DEVICE runs them, against published counts ------------------------------------------------------
+# (tests/test_oracle_games.py pins the ORACLE with the same numbers; here Game<FAM,NC>::canPlay / play / isOver of agz_games.hpp —
+#  the code every tree and ply kernel is instantiated from — run on the GPU: agz_perft)
+def test_device_perft_othello():
+    from alphagpu_amd.game import perft
+    g = ag.GameSpec("reversi8")
+    assert [perft(g, d)[0] for d in range(1, 9)] == [4, 12, 56, 244, 1396, 8200, 55092, 390216]
+
+
+def test_device_perft_tictactoe_full_game_tree():
+    from alphagpu_amd.game import perft
+    nodes, term = perft(ag.GameSpec("gobang", 3, 3), 9)
+    assert term == [131184, 46080, 77904] and sum(term) == 255168       # X wins / draws / O wins: every complete game
+    assert nodes == 127872                                               # games that last all 9 plies: 81792 wins on the last cell + 46080 draws
+
+
+def test_device_perft_connect4():
+    from alphagpu_amd.game import perft
+    g = ag.GameSpec("connect4")
+    assert [perft(g, d)[0] for d in range(1, 9)] == [7, 49, 343, 2401, 16807, 117649, 823536, 5673234]
+
+
+@pytest.mark.parametrize("name", ["gobang9", "hex9", "gobang13", "hex11", "reversi6"])
+def test_device_perft_equals_the_oracle(name):
+    """boards of two and three 64-bit chunks, Hex's padded board, Reversi 6x6: the device counts == the oracle's (which the naive
+    array models and the published tables pin)"""
+    from alphagpu_amd.game import perft
+    kind, n, k = common.GAMES[name]
+    g, og = ag.GameSpec(kind, n, k), O.make_game(kind, n, k)
+    for d in ((1, 2, 3) if g.A > 40 else (1, 2, 3, 4, 5, 6)):
+        nodes, term = O.perft(og, O.pos_init(og), d)
+        assert perft(g, d) == (int(nodes), [int(x) for x in term]), (name, d)

@@ -353,3 +353,36 @@ def test_bench_gpus_2_over_rccl(tmp_path):
     if torch.cuda.device_count() < 2:
         pytest.skip("one visible GPU: the two-rank RCCL run needs two (the gloo form of the same test runs)")
     _bench_two_ranks("nccl", tmp_path)
+
+
+# ---- whole generations at FULL size against the oracle -----------------------------------------------------------------
+# One agz_selfplay of 32768 games runs every kernel variant of the ply loop (rows by action, rows by legal rank 8 and 4, every
+# workgroup shape from 64-game workgroups down to sparse 16-game ones, the order-preserving compaction at every level).  Results
+# are keyed by game id, so the samples of a contiguous slice of game ids — chosen across a 64-game workgroup boundary in the
+# middle of the batch — must equal, record for record and through ALL plies, the oracle playing just those 16 games.
+FULL_GEN_CASES = [
+    # name,      H,   T, V
+    ("gobang9", 128, 6, 64),        # the headline configuration
+    ("connect4", 128, 6, 64),       # BASELINE config 2
+    ("gobang9", 512, 1, 64),        # k_search_big (config 3's trunk width; one tower keeps the oracle's bit-level MFMA model cheap)
+    ("reversi8", 512, 1, 64),       # config 5's game and trunk width: pass moves, 152-byte positions
+    ("hex9", 128, 6, 128),          # config 4's game and rollout count
+]
+
+
+@pytest.mark.parametrize("name,H,T,V", FULL_GEN_CASES)
+def test_full_size_generation_slice_equals_the_oracle_through_all_plies(name, H, T, V):
+    L, base, n, seed = 32768, 16380, 16, 3
+    g, og = spec(name)
+    net, onet = ag.SNetwork2.random(g, H, T), O.OracleNet(og, H, T)
+    with M.Engine(g, L, V, seed=seed, nn_mode=M.NN_BF16) as e:
+        e.set_network(net)
+        st = e.selfplay(L, V, cpuct=1.5, tau_plies=25)
+        assert st["valid"] and st["faults"] == 0
+        s = e.samples()
+    assert len(s["ply"]) == st["nsamples"] and st["wins"] + st["draws"] + st["losses"] == L
+    keep = (s["game_id"] >= base) & (s["game_id"] < base + n)
+    ref = O.selfplay(og, onet.bf16(), n, V, 1.5, 25, seed, base)
+    assert ref["rc"] == 0 and int(keep.sum()) == ref["n"], (int(keep.sum()), ref["n"])
+    for k in ("game_id", "ply", "move", "player", "state", "fstate", "value", "policy"):
+        assert parity.same_bits(s[k][keep], ref[k]), f"{name} {H}x{T}: {k} of games {base}..{base + n - 1} differs from the oracle"
