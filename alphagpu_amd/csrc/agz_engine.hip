@@ -61,6 +61,9 @@ AGZ_SMALL_SHAPES(X)          // defined in agz_small_inst.hip
 #define X(F, C, K, R) AGZ_SMALL_CMP_VARIANTS(F, C, K, R, extern) AGZ_BIG_CMP_VARIANTS(F, C, K, R, extern)
 AGZ_SMALL_CMP_SHAPES(X)
 #undef X
+#define X(F, C, K, R, GG) AGZ_SMALL_NARROW_VARIANTS(F, C, K, R, GG, extern)
+AGZ_SMALL_NARROW_SHAPES(X)
+#undef X
 }
 typedef void (*advance_fn)(const PlyPar);
 typedef void (*softmax_fn)(const float*, int, float*, int, int, int);
@@ -126,6 +129,15 @@ struct agz_engine {
     // (levels by entries per lane R: usable while no root has more than 8 R legal actions; 9x9 boards 8 / 4, 11x11 12 / 8 / 4, 13x13 16 / 8 / 4)
     struct CmpLevel { int kpr = 0; small_fn s2 = nullptr, s4[3] = {nullptr, nullptr, nullptr}, s8 = nullptr; big_fn b[2] = {nullptr, nullptr}, b8 = nullptr, b8x = nullptr; };
     CmpLevel cmp[4]; int ncmp = 0;
+    // the one-launch search with NARROW lane-groups (agz_tree_eager.hpp G_: 4 or 2 lanes per tree, 16 / 32 trees per wave; workgroups of
+    // four tree waves): g lanes per tree, kpl actions per lane, kpr rows per lane by legal rank (0: rows by action); k[0] / k[1]: register
+    // budgets for two / one wave per SIMD.  narrow_mode (AGZ_NARROW): -1 never, 0 by batch size (from narrow_minl games on), 4 / 2: only
+    // that group width (A/B).
+    struct Narrow { int g = 0, kpl = 0, kpr = 0; small_fn k[2] = {nullptr, nullptr}; };
+    Narrow nar[8]; int nnar = 0, narrow_mode = 0, narrow_minl = 1 << 30, narrow_occ = -1;   // narrow_occ (AGZ_NARROW_OCC, tests): force the 2 (0) / 1 (1) waves-per-SIMD build
+    // record geometry of the LAST search (the narrow builds of games with few actions lay their records out for their own row width):
+    // what the root read-back kernels use
+    uint32_t rd_rec_bytes = 0, rd_off_rk = 0, rd_off_el = 0, rd_off_vis = 0;
     // 64-game workgroups of eight waves (every wave a tree wave; the network body gives each one tile of neurons: half the weight
     // stream per game) for batches beyond 96 games per CU; tw8: -1 never, 1 wherever the batch allows, 0 (default) the shapes it was measured on
     small_fn k_small8 = nullptr; int tw8 = 0;
@@ -176,6 +188,11 @@ static bool bind_kernels(agz_engine* h) {
         c.s2 = k_search_small<F, C, K, 128, 2, 2, R>; c.s4[0] = k_search_small<F, C, K, 128, 4, 2, R>; c.s4[1] = k_search_small<F, C, K, 128, 4, 3, R>; \
         c.s4[2] = k_search_small<F, C, K, 128, 4, 4, R>; c.s8 = k_search_small<F, C, K, 128, 8, 4, R>; c.b[0] = k_search_big<F, C, K, 512, 1, R>; c.b[1] = k_search_big<F, C, K, 512, 2, R>; c.b8 = k_search_big<F, C, K, 512, 1, R, 8>; c.b8x = k_search_big<F, C, K, 512, 2, R, 8>; }
     AGZ_SMALL_CMP_SHAPES(Z)
+#undef Z
+    // narrow lane-groups: the shape must hold the game's actions and its records must fit the allocation (rows no wider than the 8-lane rows)
+#define Z(F, C, K, R, GG) if (P.fam == F && P.NC == C && GG * K >= P.A && GG * K <= 8 * kpl && h->nnar < 8) { agz_engine::Narrow& c = h->nar[h->nnar++]; \
+        c.g = GG; c.kpl = K; c.kpr = R; c.k[0] = k_search_small<F, C, K, 128, 4, 2, R, GG>; c.k[1] = k_search_small<F, C, K, 128, 4, 1, R, GG>; }
+    AGZ_SMALL_NARROW_SHAPES(Z)
 #undef Z
     if (P.NR == 1) h->k_soft = k_softmax<1>; else if (P.NR == 2) h->k_soft = k_softmax<2>; else h->k_soft = k_softmax<3>;
     return h->k_adv != nullptr && h->k_eager != nullptr;
@@ -356,6 +373,13 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
         for (int i = 0; i < 2; ++i) if (h->k_big[i]) FA_(hipFuncSetAttribute((const void*)h->k_big[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         if (h->k_big8) FA_(hipFuncSetAttribute((const void*)h->k_big8, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         if (h->k_big8x) FA_(hipFuncSetAttribute((const void*)h->k_big8x, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        e3 = getenv("AGZ_NARROW");
+        if (e3) h->narrow_mode = atoi(e3);
+        e3 = getenv("AGZ_NARROW_MINL");
+        if (e3) h->narrow_minl = atoi(e3);
+        e3 = getenv("AGZ_NARROW_OCC");
+        if (e3 && (atoi(e3) == 0 || atoi(e3) == 1)) h->narrow_occ = atoi(e3);
+        for (int i = 0; i < h->nnar; ++i) for (int j = 0; j < 2; ++j) FA_(hipFuncSetAttribute((const void*)h->nar[i].k[j], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         e3 = getenv("AGZ_SMALL4_OCC");
         if (e3 && atoi(e3) >= 0 && atoi(e3) <= 2) h->small4_occ = atoi(e3);
         if (h->k_small) FA_(hipFuncSetAttribute((const void*)h->k_small, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -412,13 +436,14 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
 
     TreePar& T = h->tp;
     memset(&T, 0, sizeof T);
-    T.G = P; T.V = h->V; T.rec_bytes = rec_bytes; T.off_q = 16 + A2 * 6; T.off_vis = 16 + A2 * 6 + 8 * (uint32_t)eager_vl(h->V); T.A2 = A2;   // (off_q: the edge list {q, prior} by rank)
+    T.G = P; T.V = h->V; T.rec_bytes = rec_bytes; T.off_q = 16 + A2 * 6; T.off_vis = 16 + A2 * 6 + 8 * (uint32_t)eager_vl(h->V, (int)A2); T.A2 = A2;   // (off_q: the edge list {q, prior} by rank)
     T.recs = h->recs; T.states = h->states; T.meta = h->meta; T.ncount = h->ncount; T.leaf = h->leaf; T.game_id = h->game_id;
     T.cnt_p = h->cnt_p; T.cnt_new = h->cnt_new; T.planes = h->planes; T.INP = h->INP; T.planes_f32 = cfg->nn_mode == AGZ_NN_EXACT;
     T.logits = h->logits; T.LGS = h->LGS; T.prior_eval = h->prior_eval; T.v_eval = h->v_eval; T.policy_final = h->policy_final;
     T.seed = cfg->seed; T.exact = cfg->nn_mode == AGZ_NN_EXACT;
     T.wl = h->wl; T.wl_n = h->wl_n; T.sp = h->sp; T.wl_cap = h->wl_cap;
     T.rank_fault = h->d_stats + 5;
+    h->rd_rec_bytes = rec_bytes; h->rd_off_rk = 16 + A2 * 4; h->rd_off_el = T.off_q; h->rd_off_vis = T.off_vis;
     FA_(hipMemsetAsync(h->wl_n, 0, wl_blocks * 4, h->stream)); hipMemsetAsync(h->sp, 0, Lm * 4, h->stream);
 #ifdef AGZ_STAMPS
     { unsigned long long* d = nullptr; hipMalloc((void**)&d, (size_t)65536 * 16 * 8); hipMemset(d, 0, (size_t)65536 * 16 * 8); T.dbg = d; }
@@ -720,7 +745,7 @@ static int launch_network(agz_engine* h, int which, int s0 = 0, int s1 = -1, hip
     } else if (h->cfg.nn_mode == AGZ_NN_BF16 && (n.H == 64 || n.H == 128) && n.w16w && !h->no_fused_nn) {   // one wave per 16 leaves, weights streamed from L2: lowest latency
         Fused3Par F;
         F.planes = (const uint16_t*)planes; F.INP = n.INP; F.w16 = n.w16w; F.bias_head = n.bias_head;
-        F.logits = logits; F.LGS = h->LGS; F.vout = v_eval; F.L = L; F.T = n.T; F.A = h->G.A; F.AOP = n.AOP; F.gpw = 0; F.tw = 0;
+        F.logits = logits; F.LGS = h->LGS; F.vout = v_eval; F.L = L; F.T = n.T; F.A = h->G.A; F.AOP = n.AOP; F.gpw = 0; F.tw = 0; F.rb = 8;
         const int kth = n.H / 32, g0 = (n.INP / 32 + kth - 1) / kth;
         int lt = h->nn_wave_lt > 0 ? h->nn_wave_lt : (L <= 16384 ? 1 : 2);   // measured (128x6): 11 / 14 / 20 us at 2048 / 8192 / 16384 leaves with 1 tile, 27 us at 32768 with 2
         const size_t lds = (size_t)16 * lt * (2 * (n.H * 2 + 16) + (g0 * kth * 64 + 16));
@@ -796,6 +821,7 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
     if (which < 0 || which > 1 || !h->net[which].loaded) { h->fail("no network loaded in slot %d", which); return AGZ_ERR_STATE; }
     HIPCHK(h, hipSetDevice(h->cfg.device));
     h->cpuct = cpuct; h->training = training; h->step = step;
+    h->rd_rec_bytes = h->tp.rec_bytes; h->rd_off_rk = 16 + h->tp.A2 * 4; h->rd_off_el = h->tp.off_q; h->rd_off_vis = h->tp.off_vis;
     // profiling bit 2: instrument (events, per-slot counters) only every 4th search: HIP events around ~10^4 launches per
     // generation cost ~10 % of the time they are meant to measure
     h->prof_this = !(h->profiling & 4) || (h->search_seq++ & 3u) == 0;
@@ -803,6 +829,70 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
     // tile) and each runs its own select -> network -> expand/backup chain on its own stream: while one chain's tree
     // kernel waits on memory latency the other chains' network and tree kernels fill the machine.  Results do not depend
     // on the cut (every per-game quantity is keyed by game id).
+    {   // narrow lane-groups (4 or 2 lanes per tree): big batches of the 128-wide trunk, every game resident at once
+        DevNet& n = h->net[which];
+        const agz_engine::Narrow* nk = nullptr;
+        if (h->narrow_mode >= 0 && h->cfg.nn_mode == AGZ_NN_BF16 && n.H == 128 && n.w16w && h->L >= h->narrow_minl && h->V <= 128 && (h->V & 3) == 0 && !h->no_fused_nn)
+            for (int i = 0; i < h->nnar; ++i) {
+                const agz_engine::Narrow& c = h->nar[i];
+                if (h->narrow_mode > 0 && c.g != h->narrow_mode) continue;
+                if (c.g * c.kpl > h->LGS) continue;                                   // (the lean tree step reads whole blocks of logits)
+                if (c.kpr && (h->no_compact || h->legal_bound > c.g * c.kpr || 2 * h->V < c.g * c.kpr)) continue;
+                const int wgs = (h->L + 4 * (64 / c.g) - 1) / (4 * (64 / c.g));
+                if (wgs > 2 * h->cus) continue;                                       // every workgroup resident (two per CU at most)
+                // the narrowest group first (h->nar lists wider groups first only by accident: pick by g, then the narrowest rows)
+                if (!nk || c.g < nk->g || (c.g == nk->g && (c.kpr ? c.kpr : c.kpl) < (nk->kpr ? nk->kpr : nk->kpl))) nk = &c;
+            }
+        if (nk) {
+            const int G = nk->g, NG = 64 / G, tw = 4, gpwg = tw * NG;
+            const int wgs = (h->L + gpwg - 1) / gpwg;
+            const int one = h->narrow_occ >= 0 && wgs <= h->cus ? h->narrow_occ : (wgs <= h->cus ? 1 : 0);   // one workgroup per CU: the 512-register build
+            const uint32_t A2 = (uint32_t)(G * (nk->kpr ? nk->kpr : nk->kpl));
+            h->tree_kpr = nk->kpr;
+            SmallPar S;
+            S.T = h->tp;
+            S.T.L = h->L; S.T.slot0 = 0; S.T.step = h->step; S.T.cpuct = h->cpuct; S.T.training = h->training;
+            S.T.fastdiv = fastdiv_range(h);
+            S.T.inject = 0; S.T.capture = 0; S.T.rollout = 0; S.T.do_reset = 1; S.T.do_expand = 0; S.T.do_select = 1; S.T.last = 0;
+            S.T.gpw = NG;
+            S.F.planes = (const uint16_t*)h->planes; S.F.INP = n.INP; S.F.w16 = n.w16w; S.F.bias_head = n.bias_head;
+            S.F.logits = h->logits; S.F.LGS = h->LGS; S.F.vout = h->v_eval; S.F.L = h->L; S.F.T = n.T; S.F.A = h->G.A; S.F.AOP = n.AOP;
+            S.F.gpw = 0; S.F.tw = tw; S.F.rb = NG;
+            S.V = V; S.tree_lds = eager_lds_layout(h->V, NG).total;
+            const int kth = n.H / 32, g0 = (n.INP / 32 + kth - 1) / kth;
+            const int prowb = g0 * kth * 64 + 16;
+            const int rs = (std::max(prowb, 4 * n.AOP) + 15) & ~15;
+            S.io_prowb = rs; S.io_lgs = rs / 4; S.io_bw = NG * rs;
+            S.io_off = (int)((std::max((size_t)tw * (size_t)S.tree_lds, (size_t)gpwg * 2 * (n.H * 2 + 16)) + 15) & ~(size_t)15);
+            S.xch_off = S.io_off + tw * S.io_bw;
+            const size_t shared = (size_t)S.xch_off + (size_t)tw * (16 * NG + 16);
+            const size_t cu_lds = (size_t)(160 * 1024) / (size_t)(one ? 1 : 2);
+            const size_t room = cu_lds > shared ? cu_lds - shared : 0;
+            S.wl_off = (int)shared; S.wl_bytes = (int)std::min({(size_t)(NG * h->V * 4), (room / (size_t)tw) & ~(size_t)15, (size_t)h->wl_lds_max});
+            const size_t lds = shared + (size_t)tw * S.wl_bytes;
+            if (lds <= cu_lds) {
+                std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
+                if ((h->profiling & 1) && h->prof_this) { ev = next_events(h, h->ev_tree, h->ev_tree_used); hipEventRecord(ev->first, h->stream); }
+                hipLaunchKernelGGL(nk->k[one], dim3((unsigned)wgs), dim3(64 * NW_WAVES), lds, h->stream, S);
+                if (nk->kpr) {   // policy_final back to action order (one wave per game, in place)
+                    PlyPar Q; memset(&Q, 0, sizeof Q);
+                    Q.G = h->G; Q.L = h->L; Q.V = h->V; Q.states = h->states; Q.policy_final = h->policy_final;
+                    hipLaunchKernelGGL(h->k_spread, dim3((unsigned)((h->L + 3) / 4)), dim3(256), 0, h->stream, Q);
+                }
+                if (ev) hipEventRecord(ev->second, h->stream);
+                HIPCHK(h, hipGetLastError());
+                h->rd_rec_bytes = (uint32_t)eager_rec_bytes((int)A2, h->V); h->rd_off_rk = 16 + A2 * 4; h->rd_off_el = 16 + A2 * 6;
+                h->rd_off_vis = 16 + A2 * 6 + 8 * (uint32_t)eager_vl(h->V, (int)A2);
+                { char kb[48] = ""; if (nk->kpr) snprintf(kb, sizeof kb, ",rows by legal rank KPR=%d", nk->kpr);
+                  char b[220]; snprintf(b, sizeof b, "k_search_small<KPL=%d,H=128,TW=4,WV=%d%s,G=%d> (whole mcts_single per launch, %d lanes per tree, %d games per tree wave, %d per workgroup)",
+                                        nk->kpl, one ? 1 : 2, kb, G, G, NG, gpwg); h->form_tree = b; h->form_nn = "inside k_search_small (mlp_wave_body<128>)"; }
+                h->cnt_live = true;
+                h->need_reset = true; h->injected = false;
+                if (h->prof_this) h->total_rollouts += (uint64_t)h->L * (uint64_t)V;
+                return AGZ_OK;
+            }
+        }
+    }
     {   // every game resident at once (<= 128 per CU): the whole search in one launch (agz_search_small.hpp); profiling bit 0
         // then times that launch (it counts as one "tree launch" of agz_get_kernel_times)
         DevNet& n = h->net[which];
@@ -851,7 +941,9 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
             // the tree waves' tables and the network's two activation strips share one window (the phases never overlap); the hand-over
             // window behind it carries planes (tree -> network) and logits (network -> tree), one block of 8 rows per tree wave
             const int prowb = g0 * kth * 64 + 16;
-            S.io_prowb = prowb; S.io_lgs = n.AOP; S.io_bw = (8 * std::max(prowb, 4 * n.AOP) + 15) & ~15;
+            const int rs = (std::max(prowb, 4 * n.AOP) + 15) & ~15;   // one row per game: the leaf's planes on the way to the network, its logits on the way back
+            S.io_prowb = rs; S.io_lgs = rs / 4; S.io_bw = 8 * rs; S.F.rb = 8;
+            h->rd_rec_bytes = h->tp.rec_bytes; h->rd_off_rk = 16 + h->tp.A2 * 4; h->rd_off_el = h->tp.off_q; h->rd_off_vis = h->tp.off_vis;
             S.io_off = (int)((std::max((size_t)(tw == 8 ? 8 : 4) * h->reg_lds, (size_t)8 * tw * 2 * (n.H * 2 + 16)) + 15) & ~(size_t)15);   // (16-game workgroups: the two helper waves have tables of their own)
             const size_t shared = (size_t)S.io_off + (size_t)tw * S.io_bw + (size_t)tw * 144;   // ... + the carry a tree wave publishes for its helper
             S.xch_off = S.io_off + tw * S.io_bw;
@@ -978,6 +1070,7 @@ int agz_search(agz_engine* h, int V, float cpuct, int training, uint32_t step) {
 int agz_search_begin(agz_engine* h, float cpuct, int training, uint32_t step) {
     if (!h) return AGZ_ERR_ARG;
     h->cpuct = cpuct; h->training = training; h->step = step; h->need_reset = true; h->injected = false; h->step_last = false; h->tree_kpr = 0;
+    h->rd_rec_bytes = h->tp.rec_bytes; h->rd_off_rk = 16 + h->tp.A2 * 4; h->rd_off_el = h->tp.off_q; h->rd_off_vis = h->tp.off_vis;
     return AGZ_OK;
 }
 int agz_rollout_select(agz_engine* h, uint32_t rollout, int last) {
@@ -1068,7 +1161,7 @@ static int stats_getter(agz_engine* h, float* out, int want_q) {
     if (h->L == 0) return AGZ_OK;
     if (h->tree_kpr) { h->fail("root statistics are not available after a ply-loop search with rows by legal rank (AGZ_NO_COMPACT=1 keeps rows by action)"); return AGZ_ERR_STATE; }
     hipLaunchKernelGGL(k_root_stats, dim3((unsigned)h->L), dim3(128), 0, h->stream, (const uint8_t*)h->recs, (const uint32_t*)h->meta, h->V,
-                       h->tp.rec_bytes, 16 + h->tp.A2 * 4, h->tp.off_q, h->tp.off_vis, h->G.A, h->L, want_q ? (float*)nullptr : h->scratch_f,
+                       h->rd_rec_bytes, h->rd_off_rk, h->rd_off_el, h->rd_off_vis, h->G.A, h->L, want_q ? (float*)nullptr : h->scratch_f,
                        want_q ? h->scratch_f : (float*)nullptr);
     HIPCHK(h, hipGetLastError());
     return fetch(h, out, h->scratch_f, (size_t)h->L * h->G.A * 4);

@@ -31,7 +31,8 @@ struct Fused3Par {
     float* logits; int LGS; float* vout;
     int L, T, A, AOP;
     int gpw, tw;                          // k_search_small with sparse waves: row r of a workgroup's tile is game slot
-                                          // (bidx*tw + r/8)*gpw + r%8 if r%8 < gpw (gpw = 0: rows are consecutive leaves)
+                                          // (bidx*tw + r/rb)*gpw + r%rb if r%rb < gpw (gpw = 0: rows are consecutive leaves)
+    int rb;                               // ... rb = games of a full tree wave = rows of its block of the hand-over window (8, 16 or 32)
 };
 
 __device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {
@@ -73,10 +74,11 @@ __global__ __launch_bounds__(64 * NW_WAVES) void k_mlp_wave(const Fused3Par P) {
 // The 4-wave workgroup's forward for the leaves [bidx*16*LT, +16*LT) (also called from k_search_small); contains
 // workgroup barriers: every wave of the workgroup must call it.  PRE_BARRIER: the input planes are being written by other
 // waves of this workgroup; the barrier that publishes them is taken AFTER the first weight fragments have been requested.
-// IO (whole-search kernel): planes and logits are handed over through LDS instead of a round trip through L2 — the tree wave that
-// owns tile rows 8 w .. 8 w + 7 has left their planes in block w of `io` (io_bw bytes per block, rows of PROWB bytes, zero padded),
-// and the head leaves logits (and the value in column A) in the same block, rows of io_lgs floats; the global arrays are not
-// written (agz_get_logits reads what the stepwise API's network launch left).
+// IO (whole-search kernel): planes and logits are handed over through LDS instead of a round trip through L2 — tile row r of the
+// workgroup (game r % rb of tree wave r / rb) is row r of `io`: rows of io_lgs floats (= the row stride, >= the padded plane row),
+// io_bw = rb rows per tree wave; the tree wave has left the leaf's planes there (zero padded to whole k-rows) and the head leaves
+// the logits (and the value in column A) in the same row; the global arrays are not written (agz_get_logits reads what the
+// stepwise API's network launch left).
 // NWV: waves of the workgroup (4, or 8: 64-game workgroups of k_search_small — every wave then owns one tile of neurons instead of two)
 template <int H, int LT, int DEPTH, bool PRE_BARRIER, bool IO, bool ZC, bool BP, int NWV>
 __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const smem, const int bidx, uint8_t* const io, const int io_bw,
@@ -98,7 +100,8 @@ __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const
     // leaf (game slot) of tile row `row`, or a value >= P.L for an unused row
     auto leaf_of = [&](int row) -> int {
         if (P.gpw == 0) return leaf0 + row;
-        return (row & 7) < P.gpw ? (bidx * P.tw + (row >> 3)) * P.gpw + (row & 7) : P.L;
+        const int rb = P.rb;
+        return (row & (rb - 1)) < P.gpw ? (bidx * P.tw + row / rb) * P.gpw + (row & (rb - 1)) : P.L;
     };
     const int G0 = (P.INP / 32 + KTH - 1) / KTH;                 // groups of layer 0
     const int NGH = nw_hidden_groups(P.INP, H, P.T);             // groups before the head
@@ -138,8 +141,9 @@ __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const
         __syncthreads();
     }
     // tile row lrow of tile 0 of the input planes; the next 16-leaf tile is pstride bytes further
-    const uint8_t* const prow0 = IO ? io + (size_t)(lrow >> 3) * io_bw + (size_t)(lrow & 7) * PROWB : pl + (size_t)lrow * PROWB;
-    const int pstride = IO ? 2 * io_bw : 16 * PROWB;
+    const int io_rs = io_lgs * 4;                                 // (IO) bytes of a row of the hand-over window
+    const uint8_t* const prow0 = IO ? io + (size_t)lrow * io_rs : pl + (size_t)lrow * PROWB;
+    const int pstride = IO ? 16 * io_rs : 16 * PROWB;
 
     f32x4 acc[LT][TPW];
     const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -240,11 +244,9 @@ __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const
         const int NT = P.AOP / 16;
         int mrow[LT][4];                                            // game slot of tile row 16 lt + 4 q4 + r (once, not per tile)
 #pragma unroll
-        for (int lt = 0; lt < LT; ++lt) {                          // rows 16 lt + 4 q4 + r: tree wave 2 lt + q4/2, game 4 (q4 & 1) + r of it
-            const int gq = 4 * (q4 & 1);
-            const int base = P.gpw == 0 ? leaf0 + 16 * lt + 4 * q4 : (bidx * P.tw + 2 * lt + (q4 >> 1)) * P.gpw + gq;
+        for (int lt = 0; lt < LT; ++lt) {                          // rows 16 lt + 4 q4 + r
 #pragma unroll
-            for (int r = 0; r < 4; ++r) mrow[lt][r] = (P.gpw == 0 || gq + r < P.gpw) ? base + r : P.L;
+            for (int r = 0; r < 4; ++r) mrow[lt][r] = leaf_of(16 * lt + 4 * q4 + r);
         }
 #define NW_HEAD(buf, tile0)                                                                             \
         if ((tile0) + wave * TPW < NT) {                                                                \
@@ -260,8 +262,8 @@ __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const
                     const int n = 16 * tile + (lane & 15);                                              \
                     const float bias = P.bias_head[n];                                                  \
                     _Pragma("unroll") for (int lt = 0; lt < LT; ++lt) {                                 \
-                        /* (IO) rows 16 lt + 4 q4 + r sit in block 2 lt + q4 / 2, rows 4 (q4 & 1) + r of it */ \
-                        float* const lrow_ = IO ? reinterpret_cast<float*>(io + (size_t)(2 * lt + (q4 >> 1)) * io_bw) + (size_t)(4 * (q4 & 1)) * io_lgs + n : nullptr; \
+                        /* (IO) row 16 lt + 4 q4 + r of the hand-over window */                        \
+                        float* const lrow_ = IO ? reinterpret_cast<float*>(io) + (size_t)(16 * lt + 4 * q4) * io_lgs + n : nullptr; \
                         if (n < P.A) {                                                                  \
                             _Pragma("unroll") for (int r = 0; r < 4; ++r) {                             \
                                 const int m = mrow[lt][r]; const float o = acc[lt][t][r] + bias;        \

@@ -20,16 +20,20 @@ struct SmallPar {
     int V;                    // rollouts
     int tree_lds;             // bytes of LDS of one tree wave
     int wl_off, wl_bytes;     // the tree waves' work lists live past the window the two phases share: offset, bytes per wave
-    int io_off, io_bw;        // hand-over window (planes to the network, logits back): offset, bytes per tree wave (8 rows)
-    int io_prowb, io_lgs;     // ... bytes of a row of planes, floats of a row of logits
-    int xch_off;              // 16-game workgroups: per tree wave the carry it publishes for its helper wave (33 words, 144 bytes)
+    int io_off, io_bw;        // hand-over window (planes to the network, logits back): offset, bytes per tree wave (one row per game of a full wave)
+    int io_prowb, io_lgs;     // ... bytes / floats of a row (the same row carries the leaf's planes to the network and its logits back)
+    int xch_off;              // 16-game workgroups: per tree wave the carry it publishes for its helper wave (4 NG + 1 words in 16 NG + 16 bytes)
 };
 
 // TW = tree waves per workgroup (2 or 4): the workgroup owns 8*TW games and runs the network with TW/2 leaf tiles.
 // WV = waves per SIMD the register budget is cut for (2: 172 VGPRs, no spills; 3, 4: more workgroups per CU so that 24576 /
 // 32768 games are resident at once with 32 games per workgroup).
 // KPR: entries per lane of the node rows when they are indexed by the root's legal rank (agz_tree_eager.hpp KPR_), 0 = by action
-template <int FAM, int NC, int KPL, int H, int TW, int WV, int KPR = 0>
+// G: lanes per game tree (agz_tree_eager.hpp G_): a tree wave walks NG = 64 / G trees, the workgroup owns TW * NG games and the network
+// body runs TW * NG / 16 leaf tiles.  G = 4 (16 trees per wave, 24 actions per lane on a 9x9 board): two 64-game workgroups of four
+// waves per CU hold 32768 games with TWO waves per SIMD and 256 registers each — half the wave-instructions of the item loop's
+// per-round fixed work per game.  G = 2: Connect4's 7 actions in 2 x 4 slots, 32 trees per wave.
+template <int FAM, int NC, int KPL, int H, int TW, int WV, int KPR = 0, int G = 8>
 __global__ __launch_bounds__(64 * (TW == 8 ? 8 : NW_WAVES), WV) void k_search_small(const SmallPar) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_small[];
     // The parameters are READ FROM THE KERNEL-ARGUMENT SEGMENT where they are needed (scalar loads), through a pointer made opaque
@@ -57,9 +61,10 @@ __global__ __launch_bounds__(64 * (TW == 8 ? 8 : NW_WAVES), WV) void k_search_sm
     // (item prefetch: into registers wherever they are free — up to 3 waves per SIMD, and rows of 4 actions per lane in the 128-register
     //  build: Connect4 85.8 -> 85.0 ms per generation; rows of 8 gain nothing or spill; rows of 24 actions spill 60 registers with it
     //  at 3 waves per SIMD and 4 without: Gobang 13x13 at 24576 games 9.2 -> 7.7 ms per ply)
-    constexpr bool SPLIT = TW == 2;
+    constexpr int NG = 64 / G;
+    constexpr bool SPLIT = TW == 2 && G == 8;
     uint8_t* const own_lds = lds_small + (size_t)(SPLIT ? wave : wave % TW) * S.tree_lds;   // (a helper wave has tables of its own)
-    uint32_t* const xch = reinterpret_cast<uint32_t*>(lds_small + S.xch_off + (size_t)(wave % TW) * 144);
+    uint32_t* const xch = reinterpret_cast<uint32_t*>(lds_small + S.xch_off + (size_t)(wave % TW) * (16 * NG + 16));
     const int V_ = S.V;
     for (int k = 0; k <= V_; ++k) {
         // the workgroup index is made opaque once per rollout: otherwise every per-game address of both bodies is hoisted out
@@ -86,7 +91,7 @@ __global__ __launch_bounds__(64 * (TW == 8 ? 8 : NW_WAVES), WV) void k_search_sm
             }
         } else {
             const StepFlags SF = {(uint32_t)k, k == 0, k > 0, k < S.V, k == S.V - 1, k == S.V};
-            if (wave < TW) rollout_eager_body<FAM, NC, KPL, true, ((WV < 3 || (WV == 3 && KPL <= 16) || KPL <= 4) ? 2 : 1), true, ROLE_ALL, KPR>(SF, tree_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
+            if (wave < TW) rollout_eager_body<FAM, NC, KPL, true, ((G < 8 || WV < 3 || (WV == 3 && KPL <= 16) || KPL <= 4) ? 2 : 1), true, ROLE_ALL, KPR, G>(SF, tree_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
                                                                                    io_blk, S.io_prowb, S.io_lgs);
         }
 #ifdef AGZ_STAMPS
@@ -100,10 +105,10 @@ __global__ __launch_bounds__(64 * (TW == 8 ? 8 : NW_WAVES), WV) void k_search_sm
             __builtin_amdgcn_s_setprio(3);
             const SmallPar& S = par();
 #ifdef AGZ_STAMPS
-            mlp_wave_body<H, TW / 2, 2, true, true, (WV < 4), (WV < 3), NWV>(S.F, nn_lds, bx, lds_small + S.io_off, S.io_bw, S.io_lgs,
+            mlp_wave_body<H, TW * NG / 16, 2, true, true, (WV < 4), (WV < 3), NWV>(S.F, nn_lds, bx, lds_small + S.io_off, S.io_bw, S.io_lgs,
                                                               S.T.dbg ? S.T.dbg + (size_t)(32768 + bx * NWV + wave) * 16 : nullptr);
 #else
-            mlp_wave_body<H, TW / 2, 2, true, true, (WV < 4), (WV < 3), NWV>(S.F, nn_lds, bx, lds_small + S.io_off, S.io_bw, S.io_lgs);
+            mlp_wave_body<H, TW * NG / 16, 2, true, true, (WV < 4), (WV < 3), NWV>(S.F, nn_lds, bx, lds_small + S.io_off, S.io_bw, S.io_lgs);
 #endif
             __syncthreads();                                      // logits and values are visible to the tree waves
             __builtin_amdgcn_s_setprio(0);
@@ -139,5 +144,12 @@ __global__ __launch_bounds__(64 * (TW == 8 ? 8 : NW_WAVES), WV) void k_search_sm
     KW template __global__ void k_search_small<F, C, K, 128, 4, 3, R>(const SmallPar); \
     KW template __global__ void k_search_small<F, C, K, 128, 4, 4, R>(const SmallPar); \
     KW template __global__ void k_search_small<F, C, K, 128, 8, 4, R>(const SmallPar);
+
+// narrow lane-groups (G = 4: 16 trees per wave, G = 2: 32): (family, chunks, actions per lane, rows per lane by legal rank or 0, lanes per tree);
+// part 7 of agz_small_inst.hip.  Workgroups of four tree waves; register budgets for 2 and 1 waves per SIMD.
+#define AGZ_SMALL_NARROW_SHAPES(X) X(F_LINE, 2, 24, 0, 4) X(F_LINE, 2, 24, 16, 4) X(F_LINE, 2, 24, 8, 4) X(F_C4, 1, 4, 0, 4) X(F_C4, 1, 4, 0, 2)
+#define AGZ_SMALL_NARROW_VARIANTS(F, C, K, R, GG, KW)                        \
+    KW template __global__ void k_search_small<F, C, K, 128, 4, 2, R, GG>(const SmallPar); \
+    KW template __global__ void k_search_small<F, C, K, 128, 4, 1, R, GG>(const SmallPar);
 
 }  // namespace agz

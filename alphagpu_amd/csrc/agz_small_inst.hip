@@ -1,5 +1,5 @@
 // agz_small_inst.hip — explicit instantiations of k_search_small (agz_search_small.hpp), compiled as seven translation
-// units (-DAGZ_PART=0..6; parts 4-6: the variants with rows by legal rank) so that the ~60 kernels build in parallel; agz_engine.hip declares them `extern template`.
+// units (-DAGZ_PART=0..7; parts 4-6: the variants with rows by legal rank, part 7: lane-groups of 4 and 2) so that the ~60 kernels build in parallel; agz_engine.hip declares them `extern template`.
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include "../../include/agz.h"
@@ -20,7 +20,11 @@ AGZ_SMALL_SHAPES_2(X)
 AGZ_SMALL_SHAPES_3(X)
 #endif
 #undef X
-#if AGZ_PART >= 4
+#if AGZ_PART == 7
+#define X(F, C, K, R, GG) AGZ_SMALL_NARROW_VARIANTS(F, C, K, R, GG, )
+AGZ_SMALL_NARROW_SHAPES(X)
+#undef X
+#elif AGZ_PART >= 4
 #define X(F, C, K, R) AGZ_SMALL_CMP_VARIANTS(F, C, K, R, ) AGZ_BIG_CMP_VARIANTS(F, C, K, R, )
 #if AGZ_PART == 4
 AGZ_SMALL_CMP_SHAPES_4(X)

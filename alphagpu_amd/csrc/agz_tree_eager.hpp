@@ -77,21 +77,23 @@ __device__ __forceinline__ uint32_t legal_block(const GamePar& P, const WPos<NC>
     return m & ((1u << nval) - 1u);
 }
 
-// bytes of a node record [aux uint4][prior f32 x A2][rank u8 x A2][cid u8 x A2][edge f32x2 x VL][visits u8 x VL] (A2 a multiple of 32)
-__host__ __device__ constexpr int eager_vl(int V) { return (V + 15) & ~15; }
-__host__ __device__ constexpr int eager_rec_bytes(int A2, int V) { return 16 + 6 * A2 + 9 * eager_vl(V); }
+// bytes of a node record [aux uint4][prior f32 x A2][rank u8 x A2][cid u8 x A2][edge f32x2 x VL][visits u8 x VL] (A2 a multiple of 8;
+// a node has at most one child per action and per rollout: VL = min(V, A2) rounded up; the record a multiple of 16 bytes)
+__host__ __device__ constexpr int eager_vl(int V, int A2) { return ((V + 15) & ~15) < ((A2 + 7) & ~7) ? ((V + 15) & ~15) : ((A2 + 7) & ~7); }
+__host__ __device__ constexpr int eager_rec_bytes(int A2, int V) { return (16 + 6 * A2 + 9 * eager_vl(V, A2) + 15) & ~15; }
 
 struct EagerLds { int tab, tstride, val, utab, total; };
-__host__ __device__ inline EagerLds eager_lds_layout(int V) {
+// NG = games (lane-groups) per wave = 64 / lanes per group
+__host__ __device__ inline EagerLds eager_lds_layout(int V, int NG = 8) {
     EagerLds o;
     auto up16 = [](int x) { return (x + 15) & ~15; };
     // per lane-group: the edges {q, prior} of the item's node in creation order, a zero pair in front of them (what an action
     // without a child reads)
     o.tab = 16;
     o.tstride = 16 + up16(V * 8);
-    o.val = 8 * o.tstride;                                       // per game: {value_1, value_2, flags, -}
-    o.utab = o.val + 8 * 16;                                     // per game: 32 uniforms (depths 0..31)
-    o.total = o.utab + 8 * 128;
+    o.val = NG * o.tstride;                                      // per game: {value_1, value_2, flags, -}
+    o.utab = o.val + NG * 16;                                    // per game: 32 uniforms (depths 0..31)
+    o.total = o.utab + NG * 128;
     return o;
 }
 
@@ -105,7 +107,7 @@ template <int KPL> struct ItemRows {
     float p[KPL]; uint32_t rk[KPL / 4], cd[KPL / 4];              // priors; rank + 1 / child id bytes of the lane's KPL actions
     uint32_t ax_x, ax_z;                                          // aux: prior_rem bits, npos | nvis << 8 | nch << 16
     float pm, qm; uint32_t vism;                                  // the edge taken: prior of its action (a new edge), q, visits
-    float2 e0, e1, e2, e3;                                        // edges sub, 8 + sub .. of the node's list (e1.. only for a root: the node with many children)
+    float2 e0, e1, e2, e3;                                        // edges sub, G + sub .. of the node's list (e1.. only for a root: the node with many children)
     uint32_t ent; int gi; bool valid;
 };
 
@@ -146,15 +148,21 @@ __device__ __forceinline__ const TreePar& tree_par() {
 // sums over the ranks are the same bits; the softmax denominator still runs over all A logits (action space, KPL per lane) and the
 // expansion compacts the masked numerators into rank order through LDS.  policy_final is written in rank order too (the engine
 // spreads it back over the actions after the search: k_spread_policy).
-template <int FAM, int NC, int KPL, bool LEAN, int PFM, bool LIO = false, int ROLE = ROLE_ALL, int KPR_ = 0>
+// G_ = lanes per game tree (8, or 4 / 2 in the whole-search kernels): a wave walks NG = 64 / G_ trees, lane sub of a group owns the KPL
+// actions sub KPL .. of every row.  Fewer lanes per tree = more trees per wave: the per-round fixed work of the item loop (Newton, the
+// turns of the ordered sums, reductions, sampling, the backup) is shared by twice / four times the items, and a game with few actions
+// (Connect4: 7) does not leave six of eight lanes without an action.
+template <int FAM, int NC, int KPL, bool LEAN, int PFM, bool LIO = false, int ROLE = ROLE_ALL, int KPR_ = 0, int G_ = 8>
 __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* const lds, const int bidx,
                                                    EagerCarry& C, uint32_t* const wl_lds, const uint32_t wl_cap_lds, uint32_t& wcount,
                                                    uint8_t* const io_blk = nullptr, const int io_prowb = 0, const int io_lgs = 0,
                                                    uint32_t* const xch = nullptr) {
     using GM = Game<FAM, NC>;
     constexpr bool REV = FAM == F_REV;
-    constexpr int G = 8, NG = 8;
-    static_assert(KPL % 4 == 0, "block of actions per lane must be a multiple of 4");
+    constexpr int G = G_, NG = 64 / G_;
+    static_assert(G == 8 || G == 4 || G == 2, "lanes per game tree");
+    static_assert(G == 8 || (LEAN && PFM == 2), "narrow lane-groups: whole-search kernels with register prefetch");
+    static_assert(KPL % 4 == 0 && KPL <= 24, "block of actions per lane: a multiple of 4, one 32-bit legal mask");
     constexpr int KPR = KPR_ ? KPR_ : KPL;                        // entries per lane of the node ROWS
     constexpr bool CMP = KPR != KPL;                              // rows by the root's legal rank
     static_assert(!CMP || (LEAN && KPR % 4 == 0 && KPR < KPL && (FAM == F_LINE || FAM == F_HEX)), "legal-compacted rows: lean builds of the stone-placing games");
@@ -173,8 +181,8 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
     constexpr int A2 = G * KPR;
     constexpr int OFF_P = 16, OFF_RK = 16 + 4 * A2, OFF_CID = 16 + 5 * A2, OFF_EL = 16 + 6 * A2;   // aux, per-action rows, then the edge list by rank ...
     const int A = P.A, V = T.V;
-    const uint32_t OFF_VIS = (uint32_t)(OFF_EL + 8 * eager_vl(V)), ROWS = (uint32_t)eager_rec_bytes(A2, V);   // ... and the visit bytes by rank
-    const EagerLds LO = eager_lds_layout(V);
+    const uint32_t OFF_VIS = (uint32_t)(OFF_EL + 8 * eager_vl(V, A2)), ROWS = (uint32_t)eager_rec_bytes(A2, V);   // ... and the visit bytes by rank
+    const EagerLds LO = eager_lds_layout(V, NG);
     float2* const tab = reinterpret_cast<float2*>(lds + (size_t)g * LO.tstride + LO.tab);   // tab[-1] = {0, 0}
     float4* const valtab = reinterpret_cast<float4*>(lds + LO.val);
     float* const utab = reinterpret_cast<float*>(lds + LO.utab);
@@ -201,7 +209,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
     // The backup's own quotient (vis q + 1 - v) / (vis + 1) keeps '/': a value head output may be arbitrarily small.
     const bool FD = T.fastdiv && !inject && !exact;
     const int wl_block = T.slot0 / NG + __builtin_amdgcn_readfirstlane(bidx);
-    uint32_t* const wl_g = T.wl + (size_t)wl_block * (size_t)T.wl_cap;            // this wave's work list (global form)
+    uint32_t* const wl_g = T.wl + (size_t)wl_block * (size_t)T.wl_cap * (size_t)(NG / 8);   // this wave's work list (global form; wl_cap entries per 8 games)
     // the wave's 8 games lie next to each other in every per-node array: ONE wave-uniform base per array (scalar registers) and
     // 32-bit offsets (game-in-wave, node) from it — every load / store of the item loop is base + 32-bit offset + immediate,
     // without 64-bit vector address arithmetic
@@ -272,10 +280,10 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
         // round 0: the lane-groups that own a game take its special item, the others (sparse waves: g >= GPW) already take list entries
         if (r == 0 && g < GPW) { R.ent = C.spw; R.valid = live && (C.spw & SP_VALID); }
         else {
-            const uint32_t idx = r == 0 ? (uint32_t)(g - GPW) : (uint32_t)(8 - GPW) + 8u * (uint32_t)(r - 1) + (uint32_t)g;
+            const uint32_t idx = r == 0 ? (uint32_t)(g - GPW) : (uint32_t)(NG - GPW) + (uint32_t)NG * (uint32_t)(r - 1) + (uint32_t)g;
             if (idx < nwl) {
                 if (LEAN && idx < wl_cap_lds) R.ent = wl_lds[idx]; else R.ent = wl_g[idx];
-                R.valid = true; R.gi = (int)(R.ent >> 24) & 7;
+                R.valid = true; R.gi = (int)(R.ent >> 24) & (NG - 1);
             }
         }
         // entry: node | mr << 8 | ...: mr = the ACTION of a new edge (special item with SP_CREATED), else the creation rank + 1 of
@@ -304,13 +312,14 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
             R.pm = reinterpret_cast<const float*>(rec + OFF_P)[crt ? mr : 0u];
             R.qm = em.x; R.vism = vm;                                 // (raw: a new edge ignores them)
             // the node's edges for the Newton sums and the per-action q: entry sub of every item; a root (node 0: the node that collects
-            // children) also entries 8 + sub, 16 + sub, 24 + sub — what lies beyond is fetched when the item is processed
+            // children) also entries G + sub, 2 G + sub, 3 G + sub — what lies beyond is fetched when the item is processed
             R.e0 = *reinterpret_cast<const float2*>(rec + OFF_EL + (uint32_t)sub * 8u);
             R.e1 = R.e2 = R.e3 = make_float2(0.0f, 0.0f);
             if (node == 0u) {
-                R.e1 = *reinterpret_cast<const float2*>(rec + OFF_EL + (uint32_t)(8 + sub) * 8u);
-                if (V > 16) R.e2 = *reinterpret_cast<const float2*>(rec + OFF_EL + (uint32_t)(16 + sub) * 8u);
-                if (V > 24) R.e3 = *reinterpret_cast<const float2*>(rec + OFF_EL + (uint32_t)(24 + sub) * 8u);
+                const int VLc = eager_vl(V, A2);                      // (entries of the list: reads stay inside the record)
+                if (VLc > G) R.e1 = *reinterpret_cast<const float2*>(rec + OFF_EL + (uint32_t)(G + sub) * 8u);
+                if (VLc > 2 * G) R.e2 = *reinterpret_cast<const float2*>(rec + OFF_EL + (uint32_t)(2 * G + sub) * 8u);
+                if (VLc > 3 * G) R.e3 = *reinterpret_cast<const float2*>(rec + OFF_EL + (uint32_t)(3 * G + sub) * 8u);
             }
         }
     };
@@ -321,10 +330,10 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
         uint32_t ent = 0u; int gi = g; bool valid = false;
         if (r == 0 && g < GPW) { ent = C.spw; valid = live && (C.spw & SP_VALID); }
         else {
-            const uint32_t idx = r == 0 ? (uint32_t)(g - GPW) : (uint32_t)(8 - GPW) + 8u * (uint32_t)(r - 1) + (uint32_t)g;
+            const uint32_t idx = r == 0 ? (uint32_t)(g - GPW) : (uint32_t)(NG - GPW) + (uint32_t)NG * (uint32_t)(r - 1) + (uint32_t)g;
             if (idx < nwl) {
                 if (LEAN && idx < wl_cap_lds) ent = wl_lds[idx]; else ent = wl_g[idx];
-                valid = true; gi = (int)(ent >> 24) & 7;
+                valid = true; gi = (int)(ent >> 24) & (NG - 1);
             }
         }
         uint32_t v = 0u;
@@ -343,21 +352,24 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
     // =============================================================================================
     if constexpr (ROLE == ROLE_ITEMS) {                              // the tree wave's carry (published by its select call)
         C.leafn = xch[4 * gl]; C.spw = xch[4 * gl + 1]; C.leaf_meta = xch[4 * gl + 2];
-        wcount = ufirst(xch[32]);
+        wcount = ufirst(xch[4 * NG]);
     }
     if (SF.do_expand) {   // PHASE expand: load logits
         const TreePar& T = tree_par();
         const GamePar& P = T.G;
         const uint32_t nwl = wcount;
-        const uint32_t free0 = (uint32_t)(8 - GPW);                  // list entries that round 0 already takes (sparse waves)
-        const int rounds = 1 + (nwl > free0 ? (int)((nwl - free0 + 7u) >> 3) : 0);
+        const uint32_t free0 = (uint32_t)(NG - GPW);                 // list entries that round 0 already takes (sparse waves)
+        const int rounds = 1 + (nwl > free0 ? (int)((nwl - free0 + (uint32_t)(NG - 1)) / (uint32_t)NG) : 0);
         ItemRows<KPR> R;
         const uint32_t gid = live ? T.game_id[slot] : 0u;
         {   // the uniforms of the rows this call makes: U(seed; game, step, rollout whose leaf is expanded / backed up, depth);
-            // lane sub draws depths 4 sub .. 4 sub + 3 (deeper nodes, rare: drawn where they are needed)
-            float uq[4];
-            uniform_search4(T.seed, gid, T.step, SF.rollout - 1u, (uint32_t)sub, uq);
-            *reinterpret_cast<float4*>(utab + g * 32 + 4 * sub) = make_float4(uq[0], uq[1], uq[2], uq[3]);
+            // lane sub draws depths 4 sub .. 4 sub + 3 (and 4 (sub + G) .. in a narrow group; deeper nodes, rare: drawn where they are needed)
+#pragma unroll
+            for (int b = 0; b < 8 / G; ++b) {
+                float uq[4];
+                uniform_search4(T.seed, gid, T.step, SF.rollout - 1u, (uint32_t)(sub + b * G), uq);
+                *reinterpret_cast<float4*>(utab + g * 32 + 4 * (sub + b * G)) = make_float4(uq[0], uq[1], uq[2], uq[3]);
+            }
         }
         uint32_t sink = 0u;
         if constexpr (PFM == 1 && ROLE != ROLE_EXPAND) sink = item_touch(0, nwl);   // the first item's record starts travelling towards L2 now
@@ -400,7 +412,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
 #pragma unroll
                 for (int j = 0; j < KPL; ++j) x[j] = (j < nval) ? (exact ? exp_spec(x[j] - mx) : exp2_spec(x[j] - mx)) : 0.0f;
                 float s;
-                (void)grp_ordered_start<KPL, true>(x, sub, s, nlanes);
+                (void)grp_ordered_start<KPL, true, G>(x, sub, s, nlanes);
                 fdx = FD && !__ballot(wide);
                 sden = s;
                 if constexpr (!CMP) {
@@ -428,7 +440,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
                 // the same quotients as x / s of the action form, for fewer actions
                 const WPos<NC> rst = grp_load_pos<NC, REV>(wstates + gnode0);
                 const uint32_t rmask = legal_block<FAM, NC, KPL>(P, rst, k0, nval);
-                int rank = grp_excl_prefix8(__builtin_popcount(rmask), sub);
+                int rank = grp_excl_prefix8<G>(__builtin_popcount(rmask), sub);
                 float* const cs = reinterpret_cast<float*>(tab);      // (the group's edge table is idle during the expansion: 2 V >= G KPR floats)
                 const float nz = __uint_as_float(0x80000000u);
 #pragma unroll
@@ -467,7 +479,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
                 }
             }
             float normalize;
-            (void)grp_ordered_start<KPR, true>(xr, sub, normalize, nlr);
+            (void)grp_ordered_start<KPR, true, G>(xr, sub, normalize, nlr);
             const bool rootmix = lf == 0 && T.training;               // :270-275 vs :277-279, :292-294   // PHASE expand: mix / divide
             const float Af = (float)nl;
             float qn_[KPR];
@@ -500,7 +512,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
             // policy = prior (:297-299): the first revisit samples from these running sums; their total is prior_rem (:120-124, no   // PHASE expand: running sums + write rows
             // child yet)
             float total;
-            const float st0 = grp_ordered_start<KPR, true>(xr, sub, total, nlr);
+            const float st0 = grp_ordered_start<KPR, true, G>(xr, sub, total, nlr);
             const int Dl = (int)((spw >> 16) & 0xffu);                // depth of the leaf = expanded nodes above it
             const float ul = Dl < 32 ? utab[g * 32 + Dl] : uniform_search(T.seed, gid, T.step, SF.rollout - 1u, (uint32_t)Dl);
             ChildWords<KPR> nocd;
@@ -586,7 +598,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
                     m[j] = (created && rk == 0) ? R.p[j] : 0.0f;
                 }
                 float tot;
-                (void)grp_ordered_start<KPR, true>(m, sub, tot, nlr);
+                (void)grp_ordered_start<KPR, true, G>(m, sub, tot, nlr);
                 prem_raw = created ? tot : prem_raw;
             }
             if (valid && lead) {
@@ -610,20 +622,20 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
             {
                 const uint32_t no = valid ? nch_old : 0u;              // (a group without an item has no edge)
                 tab[sub] = (uint32_t)sub < no ? R.e0 : make_float2(0.0f, 0.0f);
-                if (__builtin_expect(__ballot(no > 8u) != 0, 0)) {
-                    // a root's entries 8 .. 31 arrived with the item; any other node with more than 8 children, and a root's
-                    // entries from 32 on, are read here (rare)
+                if (__builtin_expect(__ballot(no > (uint32_t)G) != 0, 0)) {
+                    // a root's entries G .. 4 G - 1 arrived with the item; any other node with more than G children, and a root's
+                    // entries from 4 G on, are read here (rare)
                     const bool pre = node == 0;
                     float2 e[3] = {R.e1, R.e2, R.e3};
 #pragma unroll
                     for (int b = 1; b < 4; ++b) {
-                        const uint32_t i = (uint32_t)(8 * b + sub);
-                        if (__ballot(no > (uint32_t)(8 * b)) == 0) break;
+                        const uint32_t i = (uint32_t)(G * b + sub);
+                        if (__ballot(no > (uint32_t)(G * b)) == 0) break;
                         float2 ev = e[b - 1];
                         if (!pre && i < no) ev = *reinterpret_cast<const float2*>(rec + OFF_EL + i * 8u);
                         if (i < no) tab[i] = ev;
                     }
-                    for (uint32_t b8 = 32u; __ballot(no > b8) != 0; b8 += 8u) {
+                    for (uint32_t b8 = (uint32_t)(4 * G); __ballot(no > b8) != 0; b8 += (uint32_t)G) {
                         const uint32_t i = b8 + (uint32_t)sub;
                         if (i < no) tab[i] = *reinterpret_cast<const float2*>(rec + OFF_EL + i * 8u);
                     }
@@ -656,7 +668,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
             // ---- Newton (:141-162): element 0 is the prior_rem term, elements 1..nch the children in creation order   // PHASE items: Newton
             {
                 float err = __builtin_inff();
-                // block 0 (the prior_rem term and the first 7 children) stays in registers for every iteration; further blocks of 8
+                // block 0 (the prior_rem term and the first G - 1 children) stays in registers for every iteration; further blocks of G
                 // children are read from the group's table as long as ANY group of the wave still has children left (a wave-uniform
                 // loop: groups with fewer children add zeros)
                 const bool v0 = sub <= (int)nch;
@@ -671,7 +683,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
                         t = v0 ? t : 0.0f; uu = v0 ? uu : 0.0f;
                     }
                     float a = t, b = uu;
-                    grp_pull_sums(a, t, b, uu);
+                    grp_pull_sums<G>(a, t, b, uu);
                     for (int j0 = G; __ballot(j0 <= (int)nch) != 0; j0 += G) {
                         const int c = j0 + sub;
                         const bool vc = c <= (int)nch;
@@ -681,7 +693,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
                         if (FDr) fd_div_pair(top, bot, -top, bot * bot, t, uu); else div_pair(top, bot, -top, bot * bot, t, uu);
                         t = vc ? t : 0.0f; uu = vc ? uu : 0.0f;
                         a += t; b += uu;
-                        grp_pull_sums(a, t, b, uu);
+                        grp_pull_sums<G>(a, t, b, uu);
                     }
                     const float S = grp_bcast<G>(a), gg = grp_bcast<G>(b);
                     const float newerr = S - 1.0f;
@@ -725,7 +737,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
             // the child bytes are needed past the prefetch of the next item: kept aside   // PHASE items: running sums + sampling
             STAMPW(7);
             float dummy;
-            const float st = grp_ordered_start<KPR, false>(pol, sub, dummy, nlr);
+            const float st = grp_ordered_start<KPR, false, G>(pol, sub, dummy, nlr);
             const float u = dpt < 32 ? utab[gi * 32 + dpt] : uniform_search(TI.seed, TI.game_id[valid ? slot_base + gi : sl], TI.step, SF.rollout - 1u, (uint32_t)dpt);
             const uint32_t nx = sample_next(pol, st, u, cdk, rkw, move, (uint32_t)ileaf);
             if (valid && lead) *reinterpret_cast<uint4*>(rec) = make_uint4(__float_as_uint(prem_raw), nx, auxz, 0u);
@@ -799,7 +811,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
                 const WPos<NC> rst = grp_load_pos<NC, REV>(wstates + gnode0);
                 const uint32_t rmask = legal_block<FAM, NC, KPL>(P, rst, k0, nval);
                 const int cnt = __builtin_popcount(rmask);
-                const int rel = create_move - grp_excl_prefix8(cnt, sub);
+                const int rel = create_move - grp_excl_prefix8<G>(cnt, sub);
                 uint32_t m = rmask;
 #pragma unroll
                 for (int i = 0; i < KPL - 1; ++i) m = i < rel ? m & (m - 1u) : m;
@@ -845,10 +857,11 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
                 }
                 constexpr bool lio = LEAN && LIO;                    // (the hand-over rows are NC * 128 columns wide: every k is written)
 #pragma unroll
-                for (int k = 0; k < NW; ++k) {
-                    const int j0 = 64 * k + 8 * sub;
+                for (int kk = 0; kk < NW * (8 / G); ++kk) {          // (a lane encodes 8 cells at a time; 8 / G bytes of every word in a narrow group)
+                    const int k = kk / (8 / G), sb = sub + G * (kk % (8 / G));
+                    const int j0 = 64 * k + 8 * sb;
                     if (j0 < T.INP || lio) {
-                        const uint32_t f = (uint32_t)(W[k] >> (8 * sub)) & 0xffu;
+                        const uint32_t f = (uint32_t)(W[k] >> (8 * sb)) & 0xffu;
                         uint4 o;
                         o.x = ((f & 1u) ? 0x3F80u : 0u) | ((f & 2u) ? 0x3F800000u : 0u); o.y = ((f & 4u) ? 0x3F80u : 0u) | ((f & 8u) ? 0x3F800000u : 0u);
                         o.z = ((f & 16u) ? 0x3F80u : 0u) | ((f & 32u) ? 0x3F800000u : 0u); o.w = ((f & 64u) ? 0x3F80u : 0u) | ((f & 128u) ? 0x3F800000u : 0u);
@@ -879,7 +892,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
     if constexpr (ROLE == ROLE_EXPAND) {                             // what the helper wave needs for the backup of this rollout
         if (SF.do_select) {
             if (lead) { xch[4 * g] = C.leafn; xch[4 * g + 1] = C.spw; xch[4 * g + 2] = C.leaf_meta; }
-            if (lane == 0) xch[32] = wcount;
+            if (lane == 0) xch[4 * NG] = wcount;
         }
     }
     // ---- bookkeeping: the stand-alone kernel hands the carry over through global memory; the whole-search kernel only at its end   // PHASE bookkeeping

@@ -66,57 +66,62 @@ template <int G> __device__ __forceinline__ float grp_bcast_last(float xf) {   /
 // wait states: the s_nop 1 in front of every step.  (v_max_f32 and `y > x ? y : x` agree on every non-NaN pair.)
 #define AGZ_DPP_STEP(op, ctrl, x) asm("s_nop 1\n\t" op " %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf" : "+v"(x))
 template <int G> __device__ __forceinline__ int grp_sum(int x) {
-    static_assert(G == 8, "lane-groups of 8");
+    static_assert(G == 2 || G == 4 || G == 8, "lane-groups of 2, 4 or 8");
     AGZ_DPP_STEP("v_add_u32_dpp", "quad_perm:[1,0,3,2]", x);
-    AGZ_DPP_STEP("v_add_u32_dpp", "quad_perm:[2,3,0,1]", x);
-    AGZ_DPP_STEP("v_add_u32_dpp", "row_half_mirror", x);
+    if constexpr (G >= 4) AGZ_DPP_STEP("v_add_u32_dpp", "quad_perm:[2,3,0,1]", x);
+    if constexpr (G >= 8) AGZ_DPP_STEP("v_add_u32_dpp", "row_half_mirror", x);
     return x;
 }
 template <int G> __device__ __forceinline__ int grp_max_i(int x) {
-    static_assert(G == 8, "lane-groups of 8");
+    static_assert(G == 2 || G == 4 || G == 8, "lane-groups of 2, 4 or 8");
     AGZ_DPP_STEP("v_max_i32_dpp", "quad_perm:[1,0,3,2]", x);
-    AGZ_DPP_STEP("v_max_i32_dpp", "quad_perm:[2,3,0,1]", x);
-    AGZ_DPP_STEP("v_max_i32_dpp", "row_half_mirror", x);
+    if constexpr (G >= 4) AGZ_DPP_STEP("v_max_i32_dpp", "quad_perm:[2,3,0,1]", x);
+    if constexpr (G >= 8) AGZ_DPP_STEP("v_max_i32_dpp", "row_half_mirror", x);
     return x;
 }
 template <int G> __device__ __forceinline__ float grp_max(float x) {
-    static_assert(G == 8, "lane-groups of 8");
+    static_assert(G == 2 || G == 4 || G == 8, "lane-groups of 2, 4 or 8");
     AGZ_DPP_STEP("v_max_f32_dpp", "quad_perm:[1,0,3,2]", x);
-    AGZ_DPP_STEP("v_max_f32_dpp", "quad_perm:[2,3,0,1]", x);
-    AGZ_DPP_STEP("v_max_f32_dpp", "row_half_mirror", x);
+    if constexpr (G >= 4) AGZ_DPP_STEP("v_max_f32_dpp", "quad_perm:[2,3,0,1]", x);
+    if constexpr (G >= 8) AGZ_DPP_STEP("v_max_f32_dpp", "row_half_mirror", x);
     return x;
 }
-// a += t[lane + d], b += u[lane + d] for d = 1 .. 7, in that order (the source-order sum of 8 consecutive lanes' values ends up
+// a += t[lane + d], b += u[lane + d] for d = 1 .. G - 1, in that order (the source-order sum of G consecutive lanes' values ends up
 // in the first of them; lanes whose source lies past the 16-lane row add 0 — only a group's first lane is read afterwards)
-__device__ __forceinline__ void grp_pull_sums(float& a, const float t, float& b, const float u) {
+template <int G = 8> __device__ __forceinline__ void grp_pull_sums(float& a, const float t, float& b, const float u) {
 #define AGZ_PULL2(d) "v_add_f32_dpp %0, %2, %0 row_shl:" #d " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
                      "v_add_f32_dpp %1, %3, %1 row_shl:" #d " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-    asm("s_nop 1\n\t" AGZ_PULL2(1) AGZ_PULL2(2) AGZ_PULL2(3) AGZ_PULL2(4) AGZ_PULL2(5) AGZ_PULL2(6) AGZ_PULL2(7)
-        : "+&v"(a), "+&v"(b) : "v"(t), "v"(u));   // (early clobber: a starts as a copy of t and must not share its register)
+    // (early clobber: a starts as a copy of t and must not share its register)
+    if constexpr (G == 8)
+        asm("s_nop 1\n\t" AGZ_PULL2(1) AGZ_PULL2(2) AGZ_PULL2(3) AGZ_PULL2(4) AGZ_PULL2(5) AGZ_PULL2(6) AGZ_PULL2(7) : "+&v"(a), "+&v"(b) : "v"(t), "v"(u));
+    else if constexpr (G == 4)
+        asm("s_nop 1\n\t" AGZ_PULL2(1) AGZ_PULL2(2) AGZ_PULL2(3) : "+&v"(a), "+&v"(b) : "v"(t), "v"(u));
+    else
+        asm("s_nop 1\n\t" AGZ_PULL2(1) : "+&v"(a), "+&v"(b) : "v"(t), "v"(u));
 #undef AGZ_PULL2
 }
 template <int D> __device__ __forceinline__ float lane_shl(float x) {      // value of lane + D (same 16-lane row), own value past the row's end
     return __int_as_float(dpp_mov<0x100 + D, 0xF>(__float_as_int(x), __float_as_int(x)));
 }
-// exclusive prefix sum over the 8 lanes of a group: lane sub gets the sum of the lanes 0 .. sub - 1 (three row_shr steps; a lane
+// exclusive prefix sum over the G lanes of a group: lane sub gets the sum of the lanes 0 .. sub - 1 (log2 G row_shr steps; a lane
 // whose source lies in the neighbouring group of the DPP row, or outside the row, adds nothing)
-__device__ __forceinline__ int grp_excl_prefix8(const int v, const int sub) {
+template <int G = 8> __device__ __forceinline__ int grp_excl_prefix8(const int v, const int sub) {
     int a = v;
     int t = dpp_mov<0x111, 0xF>(0, a); a += sub >= 1 ? t : 0;
-    t = dpp_mov<0x112, 0xF>(0, a); a += sub >= 2 ? t : 0;
-    t = dpp_mov<0x114, 0xF>(0, a); a += sub >= 4 ? t : 0;
+    if constexpr (G >= 4) { t = dpp_mov<0x112, 0xF>(0, a); a += sub >= 2 ? t : 0; }
+    if constexpr (G >= 8) { t = dpp_mov<0x114, 0xF>(0, a); a += sub >= 4 ? t : 0; }
     return a - v;
 }
 __device__ __forceinline__ float lane_shr1(float x) { return __int_as_float(dpp_mov<DPP_SHR1, 0xF>(__float_as_int(x), __float_as_int(x))); }
 
-// Source-order running sums over the group's 8*KPL values (lane sub holds block sub): returns the sum of everything BEFORE the
+// Source-order running sums over the group's G*KPL values (lane sub holds block sub): returns the sum of everything BEFORE the
 // lane's own block — the lanes take turns, lane t adds its KPL values to what lane t-1 ended with (one DPP row_shr:1 per turn),
 // bit-identical to the source-order loop.  nl = lanes whose block holds real actions (ceil(A / KPL), wave-uniform): the blocks
 // of the lanes behind them are all +0 padding, which a sum passes through unchanged, so their turns are not taken — the total is
 // handed down the remaining lanes by one move per lane.  The start of lane nl - 1 needs no turn of its own; its end (the total)
 // does.  (Connect4: 2 turns instead of 8, Gobang 9x9: 7 / 6 instead of 8 / 7.)
-template <int KPL, bool WANT_TOTAL>
-__device__ __forceinline__ float grp_ordered_start(const float (&x)[KPL], int sub, float& total, int nl = 8) {
+template <int KPL, bool WANT_TOTAL, int G = 8>
+__device__ __forceinline__ float grp_ordered_start(const float (&x)[KPL], int sub, float& total, int nl = G) {
     float a = 0.0f, st = 0.0f;
     const int turns = WANT_TOTAL ? nl : nl - 1;
 #pragma unroll 1
@@ -130,8 +135,8 @@ __device__ __forceinline__ float grp_ordered_start(const float (&x)[KPL], int su
     }
     if (WANT_TOTAL) {
 #pragma unroll 1
-        for (int t = nl; t < 8; ++t) { const float carry = lane_shr1(a); a = sub == t ? carry : a; }   // padding lanes pass the total on
-        total = grp_bcast_last<8>(a);
+        for (int t = nl; t < G; ++t) { const float carry = lane_shr1(a); a = sub == t ? carry : a; }   // padding lanes pass the total on
+        total = grp_bcast_last<G>(a);
     } else { const float carry = lane_shr1(a); if (sub == nl - 1) st = carry; }
     return st;
 }

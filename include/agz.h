@@ -184,6 +184,10 @@ int  agz_set_profiling(agz_engine *h, int mode);       /* HIP events per launch:
  *                          two-kernel form above 64 games per CU instead of two 64-game workgroups per CU
  *   AGZ_TW8=1|0            one-launch search beyond 96 games per CU: 64-game workgroups of eight waves for every board shape (1) or
  *                          for none (0); default: the 9x9 shapes they were measured on
+ *   AGZ_NARROW=-1|0|4|2    one-launch search with narrow lane-groups (4 or 2 lanes per game tree: 16 / 32 trees per wave, workgroups of four tree
+ *                          waves): never (-1), by batch size (0, default), or only that group width
+ *   AGZ_NARROW_MINL=n      ... for batches of at least n games (tests: 0)
+ *   AGZ_NARROW_OCC=0|1     ... force its two- / one-wave-per-SIMD register budget (tests)
  *   AGZ_NO_COMPACT=1       the ply loop keeps node rows by action on Gobang / Hex 9x9 (default: rows by the root's legal rank from ply 17 on,
  *                          same results; root statistics cannot be read back after such a search)
  *   AGZ_NO_FASTDIV=1       IEEE '/' everywhere in the tree kernel (agz_fastdiv.hpp off)

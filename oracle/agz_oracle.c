@@ -357,7 +357,7 @@ float agzo_uniform_search(uint64_t seed, uint32_t game_id, uint32_t step, uint32
 float agzo_uniform_move(uint64_t seed, uint32_t game_id, uint32_t step) {
     uint32_t ctr[4] = { game_id, step, 0u, 0x80000000u }, key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) }, o[4];
     agzo_philox4x32_10(ctr, key, o);
-    return ((float)(o[0] >> 8) + 0.5f) * 5.9604644775390625e-8f;
+    return (float)(2u * (o[0] >> 9) + 1u) * 5.9604644775390625e-8f;
 }
 /* Flux 0.12 Dense default init: glorot_uniform weights, zero bias (DenseNet.jl:195-197) */
 static void glorot(uint64_t seed, uint32_t tensor, int out, int in, float *W) {

@@ -18,6 +18,7 @@ import alphagpu_amd as ag
 from alphagpu_amd import mcts_gpu as M
 import common
 import oracle_lib as O
+import parity
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -781,3 +782,61 @@ def test_device_perft_equals_the_oracle(name):
     for d in ((1, 2, 3) if g.A > 40 else (1, 2, 3, 4, 5, 6)):
         nodes, term = O.perft(og, O.pos_init(og), d)
         assert perft(g, d) == (int(nodes), [int(x) for x in term]), (name, d)
+
+
+# ---- narrow lane-groups: 4 or 2 lanes per tree (16 / 32 trees per wave) ---------------------------------------------------------
+@pytest.mark.parametrize("name,L,V,groups", [("gobang9", 300, 24, ("4",)), ("gobang9", 1000, 64, ("4",)), ("connect4", 333, 36, ("4", "2")),
+                                             ("connect4", 2100, 64, ("4", "2"))])
+def test_whole_search_kernel_with_narrow_lane_groups_agrees_bitwise(name, L, V, groups, monkeypatch):
+    """k_search_small<..., G = 4 | 2>: the same tree step with 4 or 2 lanes per tree (24 actions per lane on a 9x9 board; Connect4's 7
+    actions in 4 x 4 or 2 x 4 slots, its records laid out for that row width) — same bits as the two-kernel form with 8 lanes per tree, in
+    both register budgets, ragged last wave and workgroup, work lists that overflow into global memory."""
+    g, _ = spec(name)
+    net = ag.SNetwork2.random(g, 128, 2)
+
+    def run():
+        with M.Engine(g, L, V, seed=11, nn_mode=M.NN_BF16) as e:
+            e.set_network(net)
+            e.set_roots(None, L=L)
+            e.search(V, cpuct=1.5, training=True, step=2)
+            return e.root_visits().copy(), e.policy().copy(), e.root_q().copy(), e.leaf().copy(), e.node_count().copy(), e.search_form()[0]
+
+    monkeypatch.setenv("AGZ_NARROW", "-1")
+    monkeypatch.setenv("AGZ_SMALL_MAXL", "0")
+    monkeypatch.setenv("AGZ_SMALL4_MAXL", "0")
+    ref = run()                                     # two kernels per rollout, 8 lanes per tree
+    assert ref[5].startswith("k_rollout_eager")
+    monkeypatch.delenv("AGZ_SMALL_MAXL")
+    monkeypatch.delenv("AGZ_SMALL4_MAXL")
+    monkeypatch.setenv("AGZ_NARROW_MINL", "0")
+    for grp in groups:
+        for env in ({"AGZ_NARROW_OCC": "0"}, {"AGZ_NARROW_OCC": "1"}, {"AGZ_NARROW_OCC": "0", "AGZ_WL_LDS_BYTES": "16"}):
+            monkeypatch.delenv("AGZ_WL_LDS_BYTES", raising=False)
+            monkeypatch.setenv("AGZ_NARROW", grp)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            got = run()
+            assert f",G={grp}>" in got[5], got[5]
+            for a, b, what in zip(got[:5], ref[:5], ("visits", "policy", "q", "leaf", "node_count")):
+                assert_same_bits(a, b, f"{what} G={grp} {env}")
+
+
+@pytest.mark.parametrize("name,n,V,grp", [("gobang9", 40, 16, "4"), ("connect4", 70, 16, "4"), ("connect4", 70, 16, "2")])
+def test_generation_with_narrow_lane_groups_equals_the_oracle(name, n, V, grp, monkeypatch):
+    """a whole self-play generation through the narrow builds at every ply (Gobang 9x9: rows by action, then by legal rank 16 and 8 per lane):
+    sample for sample the oracle's generation"""
+    g, og = spec(name)
+    net, onet = ag.SNetwork2.random(g, 128, 2), O.OracleNet(og, 128, 2)
+    monkeypatch.setenv("AGZ_NARROW", grp)
+    monkeypatch.setenv("AGZ_NARROW_MINL", "0")
+    forms = set()
+    with M.Engine(g, n, V, seed=6, nn_mode=M.NN_BF16) as e:
+        e.set_network(net)
+        st = e.selfplay(n, V, cpuct=1.5, tau_plies=25)
+        forms.add(e.search_form()[0])
+        s = e.samples()
+    assert st["valid"] and all(f",G={grp}>" in f for f in forms), forms
+    ref = O.selfplay(og, onet.bf16(), n, V, 1.5, 25, 6, 0)
+    assert ref["n"] == len(s["ply"])
+    for k in ("game_id", "ply", "move", "player", "state", "fstate", "value", "policy"):
+        assert parity.same_bits(s[k], ref[k]), f"{name} G={grp}: {k}"
