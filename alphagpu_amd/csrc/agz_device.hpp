@@ -144,6 +144,9 @@ struct TreePar {
     float* policy_final;     // [L][A]
     uint64_t seed;
     uint32_t step, rollout;
+    const uint32_t* slot_ply;     // [L] the ply ("step" of the uniforms' key) of every slot's game: one value for all slots in a plain search and in
+                                  // a lock-step generation, per game once finished games' slots are refilled with new games (agz_selfplay with
+                                  // more games than slots)
     float cpuct;
     int32_t training;
     int32_t do_reset, do_expand, do_select, last, exact, inject, capture;

@@ -88,6 +88,8 @@ struct agz_engine {
     // tree memory
     uint8_t* recs = nullptr; Pos* states = nullptr; uint32_t* meta = nullptr;
     uint32_t *ncount = nullptr, *leaf = nullptr, *game_id = nullptr, *game_id2 = nullptr, *cnt_p = nullptr, *cnt_new = nullptr;
+    uint32_t *slot_ply = nullptr, *slot_ply2 = nullptr;   // the ply of every slot's game (TreePar::slot_ply): filled with `step` by a plain search, kept per game by the ply loop
+    bool in_ply_loop = false;
     // network i/o
     void* planes = nullptr; float* logits = nullptr; float *prior_eval = nullptr, *v_eval = nullptr, *policy_final = nullptr;
     uint16_t *act0 = nullptr, *act1 = nullptr; float *actf0 = nullptr, *actf1 = nullptr;
@@ -260,7 +262,7 @@ void agz_destroy(agz_engine* h) {
     hipSetDevice(h->cfg.device);
     if (h->stream) hipStreamSynchronize(h->stream);
     hipFree(h->recs); hipFree(h->states); hipFree(h->meta); hipFree(h->ncount); hipFree(h->leaf); hipFree(h->game_id);
-    hipFree(h->game_id2); hipFree(h->cnt_p); hipFree(h->cnt_new); hipFree(h->planes); hipFree(h->logits);
+    hipFree(h->game_id2); hipFree(h->slot_ply); hipFree(h->slot_ply2); hipFree(h->cnt_p); hipFree(h->cnt_new); hipFree(h->planes); hipFree(h->logits);
     hipFree(h->prior_eval); hipFree(h->v_eval); hipFree(h->policy_final); hipFree(h->act0); hipFree(h->act1);
     hipFree(h->actf0); hipFree(h->actf1); hipFree(h->newpos); hipFree(h->alive); hipFree(h->newslot); hipFree(h->d_count);
     hipFree(h->s_boards); hipFree(h->s_policy); hipFree(h->s_move); hipFree(h->g_nplies); hipFree(h->g_result);
@@ -321,8 +323,8 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     if (!bind_kernels(h)) { h->fail("no kernel instantiation for this game shape"); return bail(AGZ_ERR_UNSUPPORTED); }
     if (hipEventCreate(&h->ev_ply0) != hipSuccess || hipEventCreate(&h->ev_ply1) != hipSuccess ||
         hipHostMalloc((void**)&h->hcount, 4, 0) != hipSuccess) { h->fail("cannot create the ply-loop events / pinned counter"); return bail(AGZ_ERR_HIP); }
-    if (!getenv("AGZ_NO_HOST_FLAG") && hipHostMalloc((void**)&h->hflag, 8, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
-        *h->hflag = 0;
+    if (!getenv("AGZ_NO_HOST_FLAG") && hipHostMalloc((void**)&h->hflag, 16, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+        h->hflag[0] = 0; h->hflag[1] = 0;
         if (hipHostGetDevicePointer((void**)&h->hflag_dev, h->hflag, 0) != hipSuccess) { hipHostFree(h->hflag); h->hflag = nullptr; h->hflag_dev = nullptr; }
     }
     hipError_t fa = hipSuccess;                                     // first failure of the attribute / memset calls below
@@ -404,6 +406,8 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     A_(dmalloc(&h->states, Lm * V));
     A_(dmalloc(&h->meta, Lm * V));
     A_(dmalloc(&h->ncount, Lm)); A_(dmalloc(&h->leaf, Lm)); A_(dmalloc(&h->game_id, Lm)); A_(dmalloc(&h->game_id2, Lm));
+    A_(dmalloc(&h->slot_ply, Lm)); A_(dmalloc(&h->slot_ply2, Lm));
+    if (h->slot_ply) FA_(hipMemsetAsync(h->slot_ply, 0, Lm * 4, h->stream));
     A_(dmalloc(&h->cnt_p, Lm)); A_(dmalloc(&h->cnt_new, Lm));
     size_t wl_blocks = 0;
     {
@@ -443,6 +447,7 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     T.seed = cfg->seed; T.exact = cfg->nn_mode == AGZ_NN_EXACT;
     T.wl = h->wl; T.wl_n = h->wl_n; T.sp = h->sp; T.wl_cap = h->wl_cap;
     T.rank_fault = h->d_stats + 5;
+    T.slot_ply = h->slot_ply;
     h->rd_rec_bytes = rec_bytes; h->rd_off_rk = 16 + A2 * 4; h->rd_off_el = T.off_q; h->rd_off_vis = T.off_vis;
     FA_(hipMemsetAsync(h->wl_n, 0, wl_blocks * 4, h->stream)); hipMemsetAsync(h->sp, 0, Lm * 4, h->stream);
 #ifdef AGZ_STAMPS
@@ -821,6 +826,7 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
     if (which < 0 || which > 1 || !h->net[which].loaded) { h->fail("no network loaded in slot %d", which); return AGZ_ERR_STATE; }
     HIPCHK(h, hipSetDevice(h->cfg.device));
     h->cpuct = cpuct; h->training = training; h->step = step;
+    if (!h->in_ply_loop && h->L > 0) HIPCHK(h, hipMemsetD32Async((hipDeviceptr_t)h->slot_ply, (int)step, (size_t)h->L, h->stream));   // every slot's game is at ply `step`
     h->rd_rec_bytes = h->tp.rec_bytes; h->rd_off_rk = 16 + h->tp.A2 * 4; h->rd_off_el = h->tp.off_q; h->rd_off_vis = h->tp.off_vis;
     // profiling bit 2: instrument (events, per-slot counters) only every 4th search: HIP events around ~10^4 launches per
     // generation cost ~10 % of the time they are meant to measure
@@ -846,7 +852,7 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
         if (nk) {
             const int G = nk->g, NG = 64 / G, tw = 4, gpwg = tw * NG;
             const int wgs = (h->L + gpwg - 1) / gpwg;
-            const int one = h->narrow_occ >= 0 && wgs <= h->cus ? h->narrow_occ : (wgs <= h->cus ? 1 : 0);   // one workgroup per CU: the 512-register build
+            int one = h->narrow_occ >= 0 && wgs <= h->cus ? h->narrow_occ : (wgs <= h->cus ? 1 : 0);   // one workgroup per CU: the 512-register build
             const uint32_t A2 = (uint32_t)(G * (nk->kpr ? nk->kpr : nk->kpl));
             h->tree_kpr = nk->kpr;
             SmallPar S;
@@ -866,6 +872,7 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
             S.io_off = (int)((std::max((size_t)tw * (size_t)S.tree_lds, (size_t)gpwg * 2 * (n.H * 2 + 16)) + 15) & ~(size_t)15);
             S.xch_off = S.io_off + tw * S.io_bw;
             const size_t shared = (size_t)S.xch_off + (size_t)tw * (16 * NG + 16);
+            if (!one && wgs <= h->cus && shared > (size_t)(80 * 1024)) one = 1;     // (32 trees per wave: the tables of a workgroup take more than half a CU's LDS)
             const size_t cu_lds = (size_t)(160 * 1024) / (size_t)(one ? 1 : 2);
             const size_t room = cu_lds > shared ? cu_lds - shared : 0;
             S.wl_off = (int)shared; S.wl_bytes = (int)std::min({(size_t)(NG * h->V * 4), (room / (size_t)tw) & ~(size_t)15, (size_t)h->wl_lds_max});
@@ -1070,6 +1077,7 @@ int agz_search(agz_engine* h, int V, float cpuct, int training, uint32_t step) {
 int agz_search_begin(agz_engine* h, float cpuct, int training, uint32_t step) {
     if (!h) return AGZ_ERR_ARG;
     h->cpuct = cpuct; h->training = training; h->step = step; h->need_reset = true; h->injected = false; h->step_last = false; h->tree_kpr = 0;
+    if (h->L > 0) { HIPCHK(h, hipSetDevice(h->cfg.device)); HIPCHK(h, hipMemsetD32Async((hipDeviceptr_t)h->slot_ply, (int)step, (size_t)h->L, h->stream)); }
     h->rd_rec_bytes = h->tp.rec_bytes; h->rd_off_rk = 16 + h->tp.A2 * 4; h->rd_off_el = h->tp.off_q; h->rd_off_vis = h->tp.off_vis;
     return AGZ_OK;
 }
@@ -1241,7 +1249,8 @@ static void fill_plypar(agz_engine* h, PlyPar& T, int ply, int tau_plies, bool a
     memset(&T, 0, sizeof T);
     T.all_actions = all_actions ? 1 : 0;
     T.G = h->G; T.L = h->L; T.V = h->V; T.ply = ply; T.tau_plies = tau_plies; T.seed = h->cfg.seed; T.game_id_base = h->cfg.game_id_base;
-    T.states = h->states; T.game_id = h->game_id; T.policy_final = h->policy_final; T.newpos = h->newpos; T.alive = h->alive;
+    T.states = h->states; T.game_id = h->game_id; T.slot_ply = h->slot_ply; T.policy_final = h->policy_final; T.newpos = h->newpos; T.alive = h->alive;
+    T.next_game = h->d_stats + 6;
     T.sample_games = h->sample_games; T.max_plies = h->G.max_plies;
     T.s_boards = h->s_boards; T.s_policy = h->s_policy; T.s_move = h->s_move; T.g_nplies = h->g_nplies; T.g_result = h->g_result;
     T.g_final = h->g_final; T.stats = h->d_stats;
@@ -1250,19 +1259,35 @@ static void fill_plypar(agz_engine* h, PlyPar& T, int ply, int tau_plies, bool a
 static int run_games(agz_engine* h, int ngames, int V, float cpuct, int tau_plies, int training, int duel_first, bool duel,
                      agz_selfplay_stats* st) {
     int rc = check_search_args(h, V); if (rc) return rc;
-    if (ngames < 1 || ngames > h->Lmax) { h->fail("ngames=%d outside [1,%d]", ngames, h->Lmax); return AGZ_ERR_ARG; }
+    // more games than slots (self-play only): the first Lmax games start together, and a slot whose game has ended takes the next game
+    // that has not started yet (k_advance) until all ngames have been started — the batch stays full, every search of the generation
+    // runs at the size the chip is filled by, and each game's samples are the ones a lock-step run over ngames slots gives (results are
+    // keyed by game id and the game's own ply)
+    const int slots = ngames < h->Lmax ? ngames : h->Lmax;
+    if (ngames < 1 || (duel && ngames > h->Lmax)) { h->fail("ngames=%d outside [1,%d]", ngames, h->Lmax); return AGZ_ERR_ARG; }
+    if (ngames > slots && ngames > h->sample_games) { h->fail("ngames=%d exceeds the sample capacity of the engine (%d games: agz_config.sample_capacity_games)", ngames, h->sample_games); return AGZ_ERR_ARG; }
     auto t0 = std::chrono::steady_clock::now();
-    rc = agz_set_roots(h, nullptr, 0, nullptr, ngames); if (rc) return rc;       // Position() for every game (:479)
+    rc = agz_set_roots(h, nullptr, 0, nullptr, slots); if (rc) return rc;       // Position() for every game (:479)
     HIPCHK(h, hipMemsetAsync(h->d_stats, 0, 8 * sizeof(unsigned long long), h->stream));
     HIPCHK(h, hipMemsetAsync(h->g_nplies, 0, (size_t)h->sample_games * 4, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->slot_ply, 0, (size_t)slots * 4, h->stream));
+    {   const unsigned long long started0 = (unsigned long long)slots;
+        HIPCHK(h, hipMemcpyAsync(h->d_stats + 6, &started0, 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream)); }
     h->sp_games = ngames; h->sp_nsamples = 0; h->sp_maxplies = 0;
     const hipEvent_t e0 = h->ev_ply0, e1 = h->ev_ply1;
     double search_ms = 0; int64_t rollouts = 0; int ply = 0;
     uint32_t* const hcount = h->hcount;
+    const bool refill = ngames > slots;
+    // the youngest game alive bounds every root's stone count from below: all games have started (and the youngest was at ply 0 in round
+    // first_all) -> every root of round r holds at least r - first_all stones
+    int first_all = refill ? -1 : 0;                                            // round in which the last started game is at ply 0 (-1: games still start)
+    unsigned long long started = (unsigned long long)slots;
+    h->in_ply_loop = true;
     while (h->L > 0) {                                                          // :494
         const int which = duel ? ((ply & 1) == 0 ? duel_first : 1 - duel_first) : 0;   // :592-596
         if (hipEventRecord(e0, h->stream) != hipSuccess) { h->fail("hipEventRecord failed"); rc = AGZ_ERR_HIP; break; }
-        h->legal_bound = (h->G.fam == F_LINE || h->G.fam == F_HEX) ? h->G.A - ply : 1 << 30;   // every game started from Position(): ply stones on the board
+        h->legal_bound = ((h->G.fam == F_LINE || h->G.fam == F_HEX) && first_all >= 0) ? h->G.A - (ply - first_all) : 1 << 30;   // every game started from Position(): a game at ply p has p stones on the board
         rc = agz_search_actor(h, which, V, cpuct, training, (uint32_t)ply);      // :503
         h->legal_bound = 1 << 30;
         if (rc) break;
@@ -1273,11 +1298,13 @@ static int run_games(agz_engine* h, int ngames, int V, float cpuct, int tau_plie
             hipLaunchKernelGGL(k_fold_counters, dim3((unsigned)std::min(64, (h->L + 255) / 256)), dim3(256), 0, h->stream, (const uint32_t*)h->cnt_p,
                                (const uint32_t*)h->cnt_new, h->L, h->d_acc);
         PlyPar T; fill_plypar(h, T, ply, tau_plies, duel);
+        T.refill_total = refill ? (uint32_t)ngames : 0u;
         hipLaunchKernelGGL(h->k_adv, dim3((unsigned)((h->L + 3) / 4)), dim3(256), 0, h->stream, T);          // :513-549
         const uint32_t seq = ++h->ply_seq ? h->ply_seq : ++h->ply_seq;        // (never 0)
-        hipLaunchKernelGGL(k_scan_alive, dim3(1), dim3(1024), 0, h->stream, (const uint32_t*)h->alive, h->newslot, h->L, h->d_count, h->hflag_dev, seq);
+        hipLaunchKernelGGL(k_scan_alive, dim3(1), dim3(1024), 0, h->stream, (const uint32_t*)h->alive, h->newslot, h->L, h->d_count, h->hflag_dev, seq,
+                           (const unsigned long long*)(h->d_stats + 6));
         hipLaunchKernelGGL(k_compact, dim3((unsigned)((h->L + 255) / 256)), dim3(256), 0, h->stream, T, (const uint32_t*)h->newslot,
-                           (const uint32_t*)h->game_id, h->game_id2);           // :550-561
+                           (const uint32_t*)h->game_id, h->game_id2, h->slot_ply2);           // :550-561
         bool have = false;
         if (h->hflag_dev) {
             // the number of games left, as soon as the scan kernel has it: polled from host-visible memory while the compaction still runs
@@ -1285,7 +1312,7 @@ static int run_games(agz_engine* h, int ngames, int V, float cpuct, int tau_plie
             volatile unsigned long long* const f = h->hflag;
             for (uint32_t spin = 0;; ++spin) {
                 const unsigned long long w = __atomic_load_n(f, __ATOMIC_ACQUIRE);
-                if ((uint32_t)(w >> 32) == seq) { *hcount = (uint32_t)w; have = true; break; }
+                if ((uint32_t)(w >> 32) == seq) { *hcount = (uint32_t)w; started = __atomic_load_n(f + 1, __ATOMIC_RELAXED); have = true; break; }
 #if defined(__x86_64__) || defined(__i386__)
                 __builtin_ia32_pause();                                            // (a polite spin: the core is shared with the host's other threads)
 #else
@@ -1298,15 +1325,22 @@ static int run_games(agz_engine* h, int ngames, int V, float cpuct, int tau_plie
             }
             if (have && hipEventSynchronize(e1) != hipSuccess) have = false;   // (the search's end event is long past)
         }
-        if (!have && (hipMemcpyAsync(hcount, h->d_count, 4, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
-                      hipStreamSynchronize(h->stream) != hipSuccess)) { h->fail("ply loop failed: %s", hipGetErrorString(hipGetLastError())); rc = AGZ_ERR_HIP; break; }
+        if (!have) {
+            if (hipMemcpyAsync(hcount, h->d_count, 4, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+                hipMemcpyAsync(&started, h->d_stats + 6, 8, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+                hipStreamSynchronize(h->stream) != hipSuccess) { h->fail("ply loop failed: %s", hipGetErrorString(hipGetLastError())); rc = AGZ_ERR_HIP; break; }
+        }
         float ms = 0; hipEventElapsedTime(&ms, e0, e1); search_ms += ms;
         if (fold) { h->cnt_live = false; drain_events(h); }
         { uint32_t* s = h->game_id; h->game_id = h->game_id2; h->game_id2 = s; h->tp.game_id = h->game_id; }
+        { uint32_t* s = h->slot_ply; h->slot_ply = h->slot_ply2; h->slot_ply2 = s; h->tp.slot_ply = h->slot_ply; }
         h->L = (int)*hcount;
         ++ply;
-        if (ply > 255) { h->fail("game exceeded 255 plies"); rc = AGZ_ERR_STATE; break; }
+        if (first_all < 0 && started >= (unsigned long long)ngames) first_all = ply;   // the last game was started in this round's k_advance: ply 0 in the next search
+        if (ply > 255 && !refill) { h->fail("game exceeded 255 plies"); rc = AGZ_ERR_STATE; break; }
+        if (ply > 255 * ((ngames + slots - 1) / slots + 1)) { h->fail("ply loop does not end"); rc = AGZ_ERR_STATE; break; }
     }
+    h->in_ply_loop = false;
     if (rc) return rc;
     unsigned long long hs[8];
     HIPCHK(h, hipMemcpy(hs, h->d_stats, sizeof hs, hipMemcpyDeviceToHost));
@@ -1319,7 +1353,7 @@ static int run_games(agz_engine* h, int ngames, int V, float cpuct, int tau_plie
     if (st) {
         memset(st, 0, sizeof *st);
         st->wins = (int64_t)hs[0]; st->draws = (int64_t)hs[1]; st->losses = (int64_t)hs[2]; st->total_plies = (int64_t)hs[3];
-        st->faults = (int32_t)hs[4]; st->rollouts = rollouts; st->plies = ply; st->search_seconds = search_ms * 1e-3;
+        st->faults = (int32_t)hs[4]; st->rollouts = rollouts; st->plies = ply; st->search_seconds = search_ms * 1e-3;   // (plies: rounds of the loop — with refilled slots more than the longest game)
         st->total_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         st->nsamples = h->sp_nsamples;
     }

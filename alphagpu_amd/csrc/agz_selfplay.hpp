@@ -9,11 +9,17 @@ namespace agz {
 
 struct PlyPar {
     GamePar G;
-    int32_t L, V, ply, tau_plies, all_actions;
+    int32_t L, V, ply, tau_plies, all_actions;   // ply: the round of the lock-step loop (diagnostics; every game's own ply is slot_ply[slot])
     uint64_t seed;
     uint32_t game_id_base;
     Pos* states;              // [L][V] roots at node 0
     uint32_t* game_id;        // [L]
+    uint32_t* slot_ply;       // [L] plies played so far by the slot's game (the reference's `round`, mcts_gpu.jl:484,556, per game)
+    // more games than slots (agz_selfplay with ngames > max_games): a slot whose game has ended takes the next game that has not
+    // started yet — game id game_id_base + k for the k-th start, Position(), ply 0 — until refill_total games have been started
+    // (0: no refill).  Results are keyed by game id and ply, never by slot or by the round a game happens to start in.
+    uint32_t refill_total;
+    unsigned long long* next_game;   // games started so far (device counter)
     const float* policy_final;// [L][A]
     // per-slot scratch
     Pos* newpos;              // [L]
@@ -41,13 +47,14 @@ __global__ __launch_bounds__(256) void k_advance(const PlyPar T) {
     const uint32_t gid = ufirst(T.game_id[slot]);
     const int g = (int)(gid - T.game_id_base);
     WPos<NC> root = load_pos<NC>(T.states + (size_t)slot * T.V);
+    const int ply = (int)ufirst(T.slot_ply[slot]);                 // this game's round (:484, :556)
     float pol[NR];
     for (int r = 0; r < NR; ++r) { int k = 64 * r + lane; pol[r] = k < A ? T.policy_final[(size_t)slot * A + k] : 0.0f; }
     const bool in_range = g >= 0 && g < T.sample_games;
-    const bool keep = in_range && T.ply < T.max_plies;
-    const int np_end = T.ply + 1 < T.max_plies ? T.ply + 1 : T.max_plies;
+    const bool keep = in_range && ply < T.max_plies;
+    const int np_end = ply + 1 < T.max_plies ? ply + 1 : T.max_plies;
     if (keep) {                                                     // push_buffer: root planes (as boards) + policy
-        size_t sidx = (size_t)g * T.max_plies + T.ply;
+        size_t sidx = (size_t)g * T.max_plies + ply;
         for (int r = 0; r < NR; ++r) { int k = 64 * r + lane; if (k < A) T.s_policy[sidx * A + k] = pol[r]; }
         if (lane < 6) {
             uint64_t w = 0;
@@ -57,14 +64,14 @@ __global__ __launch_bounds__(256) void k_advance(const PlyPar T) {
     }
     // ---- move choice (:518-524)
     int c = -1;
-    if (T.ply < T.tau_plies) {
+    if (ply < T.tau_plies) {
         // sample(lp, Weights(pol[lp])): t = u * sum(w), first index whose running sum >= t (source order)
         float total = 0.0f; bool st = false; uint64_t nzm[NR]; float run[NR];   // run: the running sum up to and including the lane's action
         for (int r = 0; r < NR; ++r) {
             nzm[r] = __ballot(64 * r + lane < A && pol[r] != 0.0f);
             run[r] = chain64(pol[r], nzm[r], total, false, 0.0f, st);
         }
-        const float u = ufirst(uniform_move(T.seed, gid, (uint32_t)T.ply));
+        const float u = ufirst(uniform_move(T.seed, gid, (uint32_t)ply));
         const float tt = u * total;
         // duel (:606): sample(1:maxActions, Weights(policy)) walks ALL actions, zero weights included — the same index as the
         // nonzero-list walk of self-play (:519-520) whenever tt > 0, and u is never 0 (uniform_move): a zero-weight action is never
@@ -96,20 +103,33 @@ __global__ __launch_bounds__(256) void k_advance(const PlyPar T) {
         fault = !ok;
     }
     if (fault) {
-        if (lane == 0) { atomicAdd(&T.stats[4], 1ull); T.alive[slot] = 0; if (keep) T.s_move[(size_t)g * T.max_plies + T.ply] = (int16_t)c; if (in_range) { T.g_nplies[g] = np_end; T.g_result[g] = 0; T.g_final[g] = pack(root); } }
+        if (lane == 0) { atomicAdd(&T.stats[4], 1ull); T.alive[slot] = 0; if (keep) T.s_move[(size_t)g * T.max_plies + ply] = (int16_t)c; if (in_range) { T.g_nplies[g] = np_end; T.g_result[g] = 0; T.g_final[g] = pack(root); } }
         return;
     }
     WPos<NC> np = G::play(P, root, c);
     int res; const bool f = G::isOver(P, np, res);
     if (lane == 0) {
-        if (keep) T.s_move[(size_t)g * T.max_plies + T.ply] = (int16_t)c;
-        T.newpos[slot] = pack(np);
-        T.alive[slot] = f ? 0u : 1u;
+        if (keep) T.s_move[(size_t)g * T.max_plies + ply] = (int16_t)c;
+        Pos next = pack(np);
+        uint32_t alive = f ? 0u : 1u, nply = (uint32_t)ply + 1u;
         if (f) {
             if (in_range) { T.g_nplies[g] = np_end; T.g_result[g] = (int8_t)res; T.g_final[g] = pack(np); }
             atomicAdd(&T.stats[res == 1 ? 0 : (res == 0 ? 1 : 2)], 1ull);     // :541-547
-            atomicAdd(&T.stats[3], (unsigned long long)T.ply);                 // tot_length += round (:535)
+            atomicAdd(&T.stats[3], (unsigned long long)ply);                   // tot_length += round (:535)
+            if (T.refill_total) {                                              // the slot takes the next game that has not started yet
+                const unsigned long long k = atomicAdd(T.next_game, 1ull);
+                if (k < (unsigned long long)T.refill_total) {
+                    for (int i = 0; i < 3; ++i) { next.p[i] = P.start_p[i]; next.o[i] = P.start_o[i]; next.lg[i] = P.start_lg[i]; }
+                    next.player = (int8_t)P.start_player; next.aux = (int8_t)P.start_aux;
+                    for (int i = 0; i < 6; ++i) next.pad[i] = 0;
+                    T.game_id[slot] = T.game_id_base + (uint32_t)k;
+                    alive = 1u; nply = 0u;
+                }
+            }
         }
+        T.newpos[slot] = next;
+        T.alive[slot] = alive;
+        T.slot_ply[slot] = nply;
     }
 }
 
@@ -153,8 +173,9 @@ __global__ __launch_bounds__(256) void k_fold_counters(const uint32_t* cnt_p, co
 // 16-entry scan of them, one pass for the slots.
 // hostflag (may be null): a 64-bit word in host-visible memory that receives (seq << 32 | total) — the host polls it instead of
 // waiting for a copy and a stream synchronisation (the ply loop's only round trip to the host)
+// hostflag[1] receives the number of games started so far (*next_game; written before hostflag[0]).
 __global__ __launch_bounds__(1024) void k_scan_alive(const uint32_t* alive, uint32_t* newslot, int L, uint32_t* count,
-                                                     unsigned long long* hostflag, uint32_t seq) {
+                                                     unsigned long long* hostflag, uint32_t seq, const unsigned long long* next_game = nullptr) {
     __shared__ uint32_t part[16];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int seg = ((L + 1023) / 1024) * 64;                    // flags per wave (a multiple of 64)
@@ -187,17 +208,21 @@ __global__ __launch_bounds__(1024) void k_scan_alive(const uint32_t* alive, uint
     }
     if (t == 0) {
         *count = total;
-        if (hostflag) __hip_atomic_store(hostflag, ((unsigned long long)seq << 32) | total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (hostflag) {
+            if (next_game) __hip_atomic_store(hostflag + 1, *next_game, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(hostflag, ((unsigned long long)seq << 32) | total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
 // re_init (:359-373): move surviving games to their compacted slots
-__global__ void k_compact(const PlyPar T, const uint32_t* newslot, const uint32_t* gid_in, uint32_t* gid_out) {
+__global__ void k_compact(const PlyPar T, const uint32_t* newslot, const uint32_t* gid_in, uint32_t* gid_out, uint32_t* ply_out) {
     int slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= T.L || !T.alive[slot]) return;
     uint32_t ns = newslot[slot];
     T.states[(size_t)ns * T.V] = T.newpos[slot];
     gid_out[ns] = gid_in[slot];
+    ply_out[ns] = T.slot_ply[slot];
 }
 
 // ---------------------------------------------------------------------------------------------------

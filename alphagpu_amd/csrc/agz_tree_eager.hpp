@@ -362,12 +362,13 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
         const int rounds = 1 + (nwl > free0 ? (int)((nwl - free0 + (uint32_t)(NG - 1)) / (uint32_t)NG) : 0);
         ItemRows<KPR> R;
         const uint32_t gid = live ? T.game_id[slot] : 0u;
+        const uint32_t stp = live ? T.slot_ply[slot] : 0u;           // the game's ply: part of the key of its uniforms
         {   // the uniforms of the rows this call makes: U(seed; game, step, rollout whose leaf is expanded / backed up, depth);
             // lane sub draws depths 4 sub .. 4 sub + 3 (and 4 (sub + G) .. in a narrow group; deeper nodes, rare: drawn where they are needed)
 #pragma unroll
             for (int b = 0; b < 8 / G; ++b) {
                 float uq[4];
-                uniform_search4(T.seed, gid, T.step, SF.rollout - 1u, (uint32_t)(sub + b * G), uq);
+                uniform_search4(T.seed, gid, stp, SF.rollout - 1u, (uint32_t)(sub + b * G), uq);
                 *reinterpret_cast<float4*>(utab + g * 32 + 4 * (sub + b * G)) = make_float4(uq[0], uq[1], uq[2], uq[3]);
             }
         }
@@ -514,7 +515,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
             float total;
             const float st0 = grp_ordered_start<KPR, true, G>(xr, sub, total, nlr);
             const int Dl = (int)((spw >> 16) & 0xffu);                // depth of the leaf = expanded nodes above it
-            const float ul = Dl < 32 ? utab[g * 32 + Dl] : uniform_search(T.seed, gid, T.step, SF.rollout - 1u, (uint32_t)Dl);
+            const float ul = Dl < 32 ? utab[g * 32 + Dl] : uniform_search(T.seed, gid, stp, SF.rollout - 1u, (uint32_t)Dl);
             ChildWords<KPR> nocd;
 #pragma unroll
             for (int j = 0; j < KPR / 4; ++j) nocd.w[j] = 0u;
@@ -738,7 +739,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
             STAMPW(7);
             float dummy;
             const float st = grp_ordered_start<KPR, false, G>(pol, sub, dummy, nlr);
-            const float u = dpt < 32 ? utab[gi * 32 + dpt] : uniform_search(TI.seed, TI.game_id[valid ? slot_base + gi : sl], TI.step, SF.rollout - 1u, (uint32_t)dpt);
+            const float u = dpt < 32 ? utab[gi * 32 + dpt] : uniform_search(TI.seed, TI.game_id[valid ? slot_base + gi : sl], TI.slot_ply[valid ? slot_base + gi : sl], SF.rollout - 1u, (uint32_t)dpt);
             const uint32_t nx = sample_next(pol, st, u, cdk, rkw, move, (uint32_t)ileaf);
             if (valid && lead) *reinterpret_cast<uint4*>(rec) = make_uint4(__float_as_uint(prem_raw), nx, auxz, 0u);
             STAMPW(8);

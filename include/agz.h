@@ -45,7 +45,7 @@ typedef struct {
     uint64_t seed;          /* Philox key: search uniforms (CUDA.rand, mcts_gpu.jl:397) and move sampling (:520) */
     uint32_t game_id_base;  /* global id of slot 0; results depend on game ids, never on slot/GPU placement */
     int32_t  nn_mode;       /* agz_nn_mode */
-    int32_t  sample_capacity_games; /* games whose samples are retained by agz_selfplay (0 = max_games) */
+    int32_t  sample_capacity_games; /* games whose samples are retained by agz_selfplay (0 = max_games); the most games one agz_selfplay call may play */
     int32_t  reserved[3];
 } agz_config;
 
@@ -126,6 +126,10 @@ typedef struct {
     double  search_seconds; /* HIP-event time inside mcts_single ("temps mcts" :566) */
     double  total_seconds;  /* wall time of the call */
 } agz_selfplay_stats;
+/* ngames may exceed max_games (up to sample_capacity_games): the first max_games games start together and a slot whose game has ended
+ * takes the next game that has not started yet, so that every search runs on a full batch.  Each game's samples are exactly those of a
+ * lock-step run over ngames slots (results are keyed by game id and the game's own ply, never by slot or by the round a game started in);
+ * stats->plies then counts the rounds of the loop. */
 int  agz_selfplay(agz_engine *h, int ngames, int V, float cpuct, int tau_plies, agz_selfplay_stats *stats);
 /* duelnetwork half: mcts(actor1,actor2,visits,ngames;cpuct) :581-651; first = actor to move at ply 0 */
 int  agz_duel(agz_engine *h, int ngames, int V, float cpuct, int tau_plies, int first, int64_t wdl[3]);

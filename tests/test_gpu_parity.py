@@ -810,7 +810,8 @@ def test_whole_search_kernel_with_narrow_lane_groups_agrees_bitwise(name, L, V, 
     monkeypatch.delenv("AGZ_SMALL4_MAXL")
     monkeypatch.setenv("AGZ_NARROW_MINL", "0")
     for grp in groups:
-        for env in ({"AGZ_NARROW_OCC": "0"}, {"AGZ_NARROW_OCC": "1"}, {"AGZ_NARROW_OCC": "0", "AGZ_WL_LDS_BYTES": "16"}):
+        # (32 trees per wave: a workgroup's tables take more than half a CU's LDS — one workgroup per CU, the one-wave-per-SIMD build only)
+        for env in ({"AGZ_NARROW_OCC": "0"}, {"AGZ_NARROW_OCC": "1"}, {"AGZ_NARROW_OCC": "0" if grp == "4" else "1", "AGZ_WL_LDS_BYTES": "16"}):
             monkeypatch.delenv("AGZ_WL_LDS_BYTES", raising=False)
             monkeypatch.setenv("AGZ_NARROW", grp)
             for k, v in env.items():
@@ -840,3 +841,38 @@ def test_generation_with_narrow_lane_groups_equals_the_oracle(name, n, V, grp, m
     assert ref["n"] == len(s["ply"])
     for k in ("game_id", "ply", "move", "player", "state", "fstate", "value", "policy"):
         assert parity.same_bits(s[k], ref[k]), f"{name} G={grp}: {k}"
+
+
+# ---- more games than slots: finished games' slots are refilled --------------------------------------------------------------
+@pytest.mark.parametrize("name,slots,ngames,V,mode", [("tictactoe", 16, 100, 8, "exact"), ("gobang9", 24, 70, 16, "bf16"), ("connect4", 40, 150, 12, "bf16"),
+                                                      ("reversi6", 16, 50, 8, "exact"), ("hex5", 8, 40, 16, "bf16")])
+def test_selfplay_with_more_games_than_slots_equals_the_lockstep_oracle(name, slots, ngames, V, mode):
+    """agz_selfplay(ngames > max_games): a slot whose game has ended takes the next game that has not started yet (k_advance), every game
+    keeps its own ply (key of its uniforms, tau rule, sample index) — sample for sample the generation the oracle plays in lock step
+    over ngames slots, in PoolSample order (ply-major, then game id)."""
+    g, og = spec(name)
+    net, onet = nets(g, og, 32, 1) if mode == "exact" else (ag.SNetwork2.random(g, 128, 2), O.OracleNet(og, 128, 2))
+    ref = O.selfplay(og, onet if mode == "exact" else onet.bf16(), ngames, V, 1.5, 25, 9, 1000)
+    with M.Engine(g, slots, V, seed=9, game_id_base=1000, nn_mode=M.NN_EXACT if mode == "exact" else M.NN_BF16, sample_capacity_games=ngames) as e:
+        e.set_network(net)
+        st = e.selfplay(ngames, V, cpuct=1.5, tau_plies=25)
+        s = e.samples()
+        assert st["valid"] and st["nsamples"] == ref["n"] and st["wins"] + st["draws"] + st["losses"] == ngames
+        assert (st["wins"], st["draws"], st["losses"], st["total_plies"]) == (ref["wins"], ref["draws"], ref["losses"], ref["total_plies"])
+        for key in ("game_id", "ply", "move", "player", "state", "fstate", "policy", "value"):
+            assert_same_bits(s[key], ref[key], key)
+        # ... and the engine is reusable: a lock-step generation afterwards (fewer games than slots)
+        st2 = e.selfplay(slots // 2, V, cpuct=1.5, tau_plies=25)
+        s2 = e.samples()
+    ref2 = O.selfplay(og, onet if mode == "exact" else onet.bf16(), slots // 2, V, 1.5, 25, 9, 1000)
+    assert st2["valid"] and st2["nsamples"] == ref2["n"]
+    for key in ("game_id", "ply", "move", "policy", "value"):
+        assert_same_bits(s2[key], ref2[key], key + " (second call)")
+
+
+def test_selfplay_refill_needs_sample_capacity():
+    g, _ = spec("tictactoe")
+    with M.Engine(g, 8, 8, seed=1, nn_mode=M.NN_BF16) as e:
+        e.set_network(ag.SNetwork2.random(g, 128, 2))
+        with pytest.raises(Exception):
+            e.selfplay(20, 8)

@@ -361,28 +361,32 @@ def test_bench_gpus_2_over_rccl(tmp_path):
 # are keyed by game id, so the samples of a contiguous slice of game ids — chosen across a 64-game workgroup boundary in the
 # middle of the batch — must equal, record for record and through ALL plies, the oracle playing just those 16 games.
 FULL_GEN_CASES = [
-    # name,      H,   T, V
-    ("gobang9", 128, 6, 64),        # the headline configuration
-    ("connect4", 128, 6, 64),       # BASELINE config 2
-    ("gobang9", 512, 1, 64),        # k_search_big (config 3's trunk width; one tower keeps the oracle's bit-level MFMA model cheap)
-    ("reversi8", 512, 1, 64),       # config 5's game and trunk width: pass moves, 152-byte positions
-    ("hex9", 128, 6, 128),          # config 4's game and rollout count
+    # name,      H,   T, V, games
+    ("gobang9", 128, 6, 64, 32768),        # the headline configuration
+    ("connect4", 128, 6, 64, 32768),       # BASELINE config 2
+    ("gobang9", 512, 1, 64, 32768),        # k_search_big (config 3's trunk width; one tower keeps the oracle's bit-level MFMA model cheap)
+    ("reversi8", 512, 1, 64, 32768),       # config 5's game and trunk width: pass moves, 152-byte positions
+    ("hex9", 128, 6, 128, 32768),          # config 4's game and rollout count
+    ("gobang9", 128, 6, 64, 81920),        # 2.5 generations' worth of games on 32768 slots: finished games' slots are refilled (what bench.py times)
+    ("connect4", 128, 6, 64, 65536),
 ]
 
 
-@pytest.mark.parametrize("name,H,T,V", FULL_GEN_CASES)
-def test_full_size_generation_slice_equals_the_oracle_through_all_plies(name, H, T, V):
-    L, base, n, seed = 32768, 16380, 16, 3
+@pytest.mark.parametrize("name,H,T,V,ngames", FULL_GEN_CASES)
+def test_full_size_generation_slice_equals_the_oracle_through_all_plies(name, H, T, V, ngames):
+    L, n, seed = 32768, 16, 3
+    bases = [16380] if ngames <= L else [16380, ngames - 9000]       # (refill: also games that start in a slot another game has left)
     g, og = spec(name)
     net, onet = ag.SNetwork2.random(g, H, T), O.OracleNet(og, H, T)
-    with M.Engine(g, L, V, seed=seed, nn_mode=M.NN_BF16) as e:
+    with M.Engine(g, L, V, seed=seed, nn_mode=M.NN_BF16, sample_capacity_games=ngames) as e:
         e.set_network(net)
-        st = e.selfplay(L, V, cpuct=1.5, tau_plies=25)
+        st = e.selfplay(ngames, V, cpuct=1.5, tau_plies=25)
         assert st["valid"] and st["faults"] == 0
         s = e.samples()
-    assert len(s["ply"]) == st["nsamples"] and st["wins"] + st["draws"] + st["losses"] == L
-    keep = (s["game_id"] >= base) & (s["game_id"] < base + n)
-    ref = O.selfplay(og, onet.bf16(), n, V, 1.5, 25, seed, base)
-    assert ref["rc"] == 0 and int(keep.sum()) == ref["n"], (int(keep.sum()), ref["n"])
-    for k in ("game_id", "ply", "move", "player", "state", "fstate", "value", "policy"):
-        assert parity.same_bits(s[k][keep], ref[k]), f"{name} {H}x{T}: {k} of games {base}..{base + n - 1} differs from the oracle"
+    assert len(s["ply"]) == st["nsamples"] and st["wins"] + st["draws"] + st["losses"] == ngames
+    for base in bases:
+        keep = (s["game_id"] >= base) & (s["game_id"] < base + n)
+        ref = O.selfplay(og, onet.bf16(), n, V, 1.5, 25, seed, base)
+        assert ref["rc"] == 0 and int(keep.sum()) == ref["n"], (int(keep.sum()), ref["n"])
+        for k in ("game_id", "ply", "move", "player", "state", "fstate", "value", "policy"):
+            assert parity.same_bits(s[k][keep], ref[k]), f"{name} {H}x{T}: {k} of games {base}..{base + n - 1} differs from the oracle"
