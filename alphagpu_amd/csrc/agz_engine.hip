@@ -136,7 +136,7 @@ struct agz_engine {
     // budgets for two / one wave per SIMD.  narrow_mode (AGZ_NARROW): -1 never, 0 by batch size (from narrow_minl games on), 4 / 2: only
     // that group width (A/B).
     struct Narrow { int g = 0, kpl = 0, kpr = 0; small_fn k[2] = {nullptr, nullptr}; };
-    Narrow nar[8]; int nnar = 0, narrow_mode = 0, narrow_minl = 1 << 30, narrow_occ = -1;   // narrow_occ (AGZ_NARROW_OCC, tests): force the 2 (0) / 1 (1) waves-per-SIMD build
+    Narrow nar[8]; int nnar = 0, narrow_mode = 0, narrow_minl = -1, narrow_occ = -1;   // narrow_occ (AGZ_NARROW_OCC, tests): force the 2 (0) / 1 (1) waves-per-SIMD build
     // record geometry of the LAST search (the narrow builds of games with few actions lay their records out for their own row width):
     // what the root read-back kernels use
     uint32_t rd_rec_bytes = 0, rd_off_rk = 0, rd_off_el = 0, rd_off_vis = 0;
@@ -838,10 +838,14 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
     {   // narrow lane-groups (4 or 2 lanes per tree): big batches of the 128-wide trunk, every game resident at once
         DevNet& n = h->net[which];
         const agz_engine::Narrow* nk = nullptr;
-        if (h->narrow_mode >= 0 && h->cfg.nn_mode == AGZ_NN_BF16 && n.H == 128 && n.w16w && h->L >= h->narrow_minl && h->V <= 128 && (h->V & 3) == 0 && !h->no_fused_nn)
+        if (h->narrow_mode >= 0 && h->cfg.nn_mode == AGZ_NN_BF16 && n.H == 128 && n.w16w && h->L >= (h->narrow_minl >= 0 ? h->narrow_minl : 112 * h->cus) && h->V <= 128 && (h->V & 3) == 0 && !h->no_fused_nn)
             for (int i = 0; i < h->nnar; ++i) {
                 const agz_engine::Narrow& c = h->nar[i];
                 if (h->narrow_mode > 0 && c.g != h->narrow_mode) continue;
+                // by default only where it was measured faster: games with few actions (Connect4: 4 lanes x 4 actions per tree, 2.54 vs 2.84 ms
+                // per search at 32768 games; 2.41 vs 2.24 at 24576) — on a 9x9 board 4 lanes x 24 actions halve the vector instructions and
+                // the waves, and the launch takes as long as before (4.35 vs 4.21 ms): it is bound by the waves' dependent chains, not by issue
+                if (h->narrow_mode == 0 && (c.kpl > 4 || c.g != 4)) continue;
                 if (c.g * c.kpl > h->LGS) continue;                                   // (the lean tree step reads whole blocks of logits)
                 if (c.kpr && (h->no_compact || h->legal_bound > c.g * c.kpr || 2 * h->V < c.g * c.kpr)) continue;
                 const int wgs = (h->L + 4 * (64 / c.g) - 1) / (4 * (64 / c.g));

@@ -50,8 +50,8 @@ class PendingGather:
     HOST (the engine writes the source buffer on its own stream, so stream-ordered completion in torch's sense is not
     enough to reuse it)."""
 
-    def __init__(self, ex, work, out, src, sent):
-        self.ex, self.work, self.out, self.src, self.sent = ex, work, out, src, sent
+    def __init__(self, ex, work, out, src, sent, units=1):
+        self.ex, self.work, self.out, self.src, self.sent, self.units = ex, work, out, src, sent, units
         self.result = None
 
     def wait(self):
@@ -84,7 +84,7 @@ class PendingGather:
                 parts.append(self.out[r, HEADER: HEADER + n * rb])
             else:
                 parts.append(torch.cat([self.out[r, HEADER: HEADER + self.sent * rb], tail[r, : (n - self.sent) * rb]]))
-        ex._observe(max_n)
+        ex._observe(max_n, self.units)
         self.work = self.src = None
         self.result = (parts, counts)
         return self.result
@@ -112,26 +112,29 @@ class RecordExchange:
         """A send buffer: the engine writes its packed records at data_ptr() + HEADER (agz_get_samples_packed)."""
         return torch.zeros(self.buffer_bytes(), dtype=torch.uint8, device=device)
 
-    def agreed_count(self):
+    def agreed_count(self, units=1):
         if self.seen_max is None:
             return self.cap
-        n = self.seen_max + int(self.seen_max * self.slack) + 64
+        n = int(self.seen_max * units * (1.0 + self.slack)) + 64
         return min(self.cap, (n + 255) & ~255)
 
-    def _observe(self, max_n):
-        self.seen_max = max_n if self.seen_max is None else max(self.seen_max, max_n)
+    def _observe(self, max_n, units=1):
+        r = max_n / float(units)
+        self.seen_max = r if self.seen_max is None else max(self.seen_max, r)
 
-    def start(self, buf, n_local):
-        """buf: a new_buffer() tensor whose records region holds n_local records; it must not be modified until wait()."""
+    def start(self, buf, n_local, units=1):
+        """buf: a new_buffer() tensor whose records region holds n_local records; it must not be modified until wait().
+        units: what the record count scales with (games of the generation; the same on every rank): the agreed size is predicted
+        from the largest count PER UNIT seen so far, so that calls of different sizes share one prediction."""
         world = dist.get_world_size(self.group)
         if n_local > self.cap:
             raise ValueError(f"{n_local} records exceed the exchange capacity {self.cap}")
         buf[:8].view(torch.int64).fill_(int(n_local))          # (a fill with a scalar argument: nothing is read back, no host buffer)
-        sent = self.agreed_count()
+        sent = self.agreed_count(units)
         nbytes = HEADER + sent * self.rb
         out = torch.empty(world, nbytes, dtype=torch.uint8, device=buf.device)
         work = dist.all_gather_into_tensor(out.view(-1), buf[:nbytes], group=self.group, async_op=True)
-        return PendingGather(self, work, out, buf, sent)
+        return PendingGather(self, work, out, buf, sent, units)
 
 
 def unpack_records(buf, n, game):

@@ -110,6 +110,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-delivery", action="store_true", help="skip the extra (untimed) generation that measures sample delivery to the host")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI); gloo only for single-GPU smoke tests of the N>1 path")
+    ap.add_argument("--lockstep", action="store_true", help="K separate lock-step generations of --games games (the reference's call pattern: the batch "
+                    "shrinks as games end) instead of ONE call that plays K x --games games on --games slots, finished games' slots refilled")
+    ap.add_argument("--gens-per-call", type=int, default=4, help="generations' worth of games one agz_selfplay call plays on the engine's slots (bounds the "
+                    "sample store: ~1 GB per generation of Gobang 9x9)")
     ap.add_argument("--dump-records", default="", help="rank 0 writes the gathered samples of the LAST timed generation (PoolSample order) to this .npz")
     args = ap.parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -150,22 +154,32 @@ def main():
     game = ag.GameSpec(args.game, args.n, args.nvict)
     net = ag.SNetwork2.random(game, args.filters, args.towers)
     G, V = args.games, args.rollouts
-    eng = M.Engine(game, G, V, device=dev, seed=1, game_id_base=shard.shard_base(rank, G),
-                   nn_mode=M.NN_BF16 if args.mode == "bf16" else M.NN_EXACT)
+    # scheduling of the K timed generations: by default ONE agz_selfplay call plays K x G games on the engine's G slots — a slot whose game
+    # has ended takes the next game that has not started yet, so every mcts_single of the timed region runs on a full batch of G games
+    # (the configuration the metric names) instead of the shrinking batches of a generation's tail.  Every game's samples are exactly those
+    # of lock-step generations (results are keyed by game id and the game's own ply; tests/test_gpu_scale_parity.py checks slices of such a
+    # run against the oracle).  --lockstep: K separate calls of G games; the line carries that number too (value_lockstep_generations).
+    gens_cap = 1 if args.lockstep else max(1, min(args.gens_per_call, max(args.steps, args.warmup, 1)))
+
+    def calls(k):                           # K generations as calls of at most gens_cap generations each
+        return [gens_cap] * (k // gens_cap) + ([k % gens_cap] if k % gens_cap else [])
+
+    eng = M.Engine(game, G, V, device=dev, seed=1, game_id_base=shard.shard_base(rank, gens_cap * G),
+                   nn_mode=M.NN_BF16 if args.mode == "bf16" else M.NN_EXACT, sample_capacity_games=gens_cap * G)
     eng.set_network(net)
     rb = game.rec_bytes
     # the exchange of generation k overlaps generation k+1: two sample buffers, at most two collectives in flight; a collective is
     # issued without any read-back (the rank's record count travels in the buffer's header: shard.RecordExchange)
-    ex = shard.RecordExchange(G * game.max_plies, rb) if world > 1 else None
+    ex = shard.RecordExchange(gens_cap * G * game.max_plies, rb) if world > 1 else None
     sample_bufs = [ex.new_buffer("cuda") for _ in range(2)] if world > 1 else None
     host_bufs = [ex.new_buffer("cpu").pin_memory() for _ in range(2)] if world > 1 and args.backend != "nccl" else None
     inflight = [None, None]
     last_gather = [None]
     nstep = [0]
 
-    def step():
-        eng.set_seed(1 + nstep[0])              # a fresh Philox key per generation, as the reference's unseeded draws
-        st = eng.selfplay(G, V, cpuct=args.cpuct, tau_plies=25)
+    def step(ngen=1):
+        eng.set_seed(1 + nstep[0])              # a fresh Philox key per call, as the reference's unseeded draws
+        st = eng.selfplay(ngen * G, V, cpuct=args.cpuct, tau_plies=25)
         if not st["valid"]:
             raise SystemExit("illegal move sampled ('faute')")
         k = nstep[0] & 1
@@ -173,13 +187,13 @@ def main():
         if world > 1:                       # the one exchange step: all-gather of the generated samples
             if inflight[k] is not None:
                 inflight[k].wait()          # the collective that read sample_bufs[k] two generations ago
-            n = eng.samples_packed_into(sample_bufs[k].data_ptr() + shard.HEADER, G * game.max_plies)
+            n = eng.samples_packed_into(sample_bufs[k].data_ptr() + shard.HEADER, gens_cap * G * game.max_plies)
             if args.backend == "nccl":
-                inflight[k] = ex.start(sample_bufs[k], n)
+                inflight[k] = ex.start(sample_bufs[k], n, units=ngen)
             else:                               # gloo smoke path: stage through host memory
                 lo, hi = shard.HEADER, shard.HEADER + n * rb
                 host_bufs[k][lo:hi].copy_(sample_bufs[k][lo:hi])
-                inflight[k] = ex.start(host_bufs[k], n)
+                inflight[k] = ex.start(host_bufs[k], n, units=ngen)
             last_gather[0] = inflight[k]
         return st
 
@@ -198,8 +212,8 @@ def main():
     # launch.  Two kernels per rollout (wide trunks, V > 64): events around ~10^4 launches cost ~10 % of a generation, so only
     # every 4th search is instrumented (profiling bit 2); the fractions are taken over the instrumented searches.
     eng.set_profiling(1)
-    for _ in range(max(args.warmup, 0)):
-        step()
+    for ng in calls(max(args.warmup, 0)):
+        step(ng)
     # the kernel the roofline object names is the one the FIRST ply (all G games alive) dispatches to -- the plies of the tail
     # run smaller-batch variants of the same kernel (agz_get_search_form reports the last search): one untimed probe search
     eng.set_roots(None, L=G)
@@ -214,8 +228,8 @@ def main():
     search_s = 0.0
     plies = 0
     nsamples = 0
-    for _ in range(args.steps):
-        st = step()
+    for ng in calls(args.steps):
+        st = step(ng)
         rollouts += st["rollouts"]
         search_s += st["search_seconds"]
         plies += st["plies"]
@@ -261,6 +275,7 @@ def main():
         h3 = time.perf_counter()
         host = {"generation_s": h1 - h0, "packed_records_to_pinned_host_s": h2 - h1, "samples_into_PoolSample_s": h3 - h2,
                 "bytes": int(recs.size), "samples": int(recs.shape[0]),
+                "lockstep_generation_rollouts_per_s": st["rollouts"] / (h1 - h0),
                 "rollouts_per_s_with_host_delivery": st["rollouts"] / (h2 - h0),
                 "rollouts_per_s_with_delivery_into_PoolSample_serial": st["rollouts"] / (h1 - h0 + h3 - h2)}
         # (b) pipelined
@@ -290,7 +305,7 @@ def main():
 
         th = threading.Thread(target=deliver, daemon=True)
         th.start()
-        gens = max(2, args.steps)
+        gens = 6                            # (the delivery of the last generation is not hidden: amortised over six)
         p_rollouts = 0
         p0 = time.perf_counter()
         for i in range(gens):
@@ -402,6 +417,10 @@ def main():
             "roofline": nn_obj if nn_dominant else tree_obj,
             "roofline_other": tree_obj if nn_dominant else nn_obj,
             "roofline_valu": valu_obj,
+            "scheduling": ("lock-step: K separate generations of G games, the batch shrinks as games end (the reference's call pattern)" if args.lockstep else
+                           f"agz_selfplay calls of {gens_cap} x G games on G slots: a slot whose game has ended takes the next game that has not started "
+                           "(every search runs on a full batch of G games; per-game samples identical to lock-step generations)"),
+            "value_lockstep_generations": (rollouts / dt if args.lockstep else (host or {}).get("lockstep_generation_rollouts_per_s")),
             "value_with_host_delivery": (host or {}).get("rollouts_per_s_with_delivery_into_PoolSample"),
             "rank0": {"search_only_rollouts_per_s": rollouts / search_s if search_s > 0 else None,
                       "search_kernel_ms": tree_ms, "network_kernel_ms": nn_ms, "search_ms": search_s * 1e3,
