@@ -117,6 +117,7 @@ struct agz_engine {
     double tree_ms = 0, nn_ms = 0, tree_busy_ms = 0; int64_t tree_launches = 0;
     hipEvent_t ev_ref = nullptr; bool ev_ref_live = false;
     hipEvent_t ev_ply0 = nullptr, ev_ply1 = nullptr; uint32_t* hcount = nullptr;   // ply loop: search timing, pinned alive count
+    hipEvent_t ev_adv = nullptr; bool ply_sleep = true;   // ply loop: the host thread SLEEPS (blocking event) until the ply's k_advance has run, then polls the scan's word for a few microseconds (AGZ_PLY_SPIN=1: spin all the way)
     unsigned long long* hflag = nullptr; unsigned long long* hflag_dev = nullptr; uint32_t ply_seq = 0;   // ... host-visible (seq, count) word the scan kernel publishes
     uint32_t* d_order = nullptr; int64_t sp_nsamples = 0; int sp_maxplies = 0;   // PoolSample order of the last generation (device), its length, its longest game
     uint8_t *stage_dev = nullptr, *stage_host = nullptr; size_t stage_cap = 0;     // agz_get_samples: packed records on the device / in pinned host memory (kept)
@@ -276,6 +277,7 @@ void agz_destroy(agz_engine* h) {
     if (h->ev_ref) hipEventDestroy(h->ev_ref);
     if (h->ev_ply0) hipEventDestroy(h->ev_ply0);
     if (h->ev_ply1) hipEventDestroy(h->ev_ply1);
+    if (h->ev_adv) hipEventDestroy(h->ev_adv);
     if (h->hcount) hipHostFree(h->hcount);
     if (h->hflag) hipHostFree(h->hflag);
     for (int c = 0; c < agz_engine::KCH - 1; ++c) { if (h->aux[c]) hipStreamDestroy(h->aux[c]); if (h->ev_join[c]) hipEventDestroy(h->ev_join[c]); }
@@ -321,6 +323,8 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     const GamePar& P = h->G;
     h->Lmax = cfg->max_games; h->V = cfg->max_visits;
     if (!bind_kernels(h)) { h->fail("no kernel instantiation for this game shape"); return bail(AGZ_ERR_UNSUPPORTED); }
+    h->ply_sleep = getenv("AGZ_PLY_SPIN") == nullptr;
+    if (hipEventCreateWithFlags(&h->ev_adv, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) h->ev_adv = nullptr;
     if (hipEventCreate(&h->ev_ply0) != hipSuccess || hipEventCreate(&h->ev_ply1) != hipSuccess ||
         hipHostMalloc((void**)&h->hcount, 4, 0) != hipSuccess) { h->fail("cannot create the ply-loop events / pinned counter"); return bail(AGZ_ERR_HIP); }
     if (!getenv("AGZ_NO_HOST_FLAG") && hipHostMalloc((void**)&h->hflag, 16, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
@@ -1304,6 +1308,7 @@ static int run_games(agz_engine* h, int ngames, int V, float cpuct, int tau_plie
         PlyPar T; fill_plypar(h, T, ply, tau_plies, duel);
         T.refill_total = refill ? (uint32_t)ngames : 0u;
         hipLaunchKernelGGL(h->k_adv, dim3((unsigned)((h->L + 3) / 4)), dim3(256), 0, h->stream, T);          // :513-549
+        const bool sleep = h->ply_sleep && h->ev_adv && hipEventRecord(h->ev_adv, h->stream) == hipSuccess;
         const uint32_t seq = ++h->ply_seq ? h->ply_seq : ++h->ply_seq;        // (never 0)
         hipLaunchKernelGGL(k_scan_alive, dim3(1), dim3(1024), 0, h->stream, (const uint32_t*)h->alive, h->newslot, h->L, h->d_count, h->hflag_dev, seq,
                            (const unsigned long long*)(h->d_stats + 6));
@@ -1314,6 +1319,9 @@ static int run_games(agz_engine* h, int ngames, int V, float cpuct, int tau_plie
             // the number of games left, as soon as the scan kernel has it: polled from host-visible memory while the compaction still runs
             // (the next search is queued behind it on the stream); a stream that ends without the word falls back to the copy below
             volatile unsigned long long* const f = h->hflag;
+            // the search takes milliseconds: the host thread sleeps through it (a blocking event after k_advance — no core is burnt
+            // per engine) and polls only for the scan that follows (~10 us)
+            if (sleep) (void)hipEventSynchronize(h->ev_adv);
             for (uint32_t spin = 0;; ++spin) {
                 const unsigned long long w = __atomic_load_n(f, __ATOMIC_ACQUIRE);
                 if ((uint32_t)(w >> 32) == seq) { *hcount = (uint32_t)w; started = __atomic_load_n(f + 1, __ATOMIC_RELAXED); have = true; break; }

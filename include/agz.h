@@ -195,6 +195,8 @@ int  agz_set_profiling(agz_engine *h, int mode);       /* HIP events per launch:
  *   AGZ_NO_COMPACT=1       the ply loop keeps node rows by action on Gobang / Hex 9x9 (default: rows by the root's legal rank from ply 17 on,
  *                          same results; root statistics cannot be read back after such a search)
  *   AGZ_NO_FASTDIV=1       IEEE '/' everywhere in the tree kernel (agz_fastdiv.hpp off)
+ *   AGZ_PLY_SPIN=1         ply loop: the host thread spins on the scan's host-visible word through the whole search instead of sleeping on a
+ *                          blocking event until the ply's k_advance has run
  *   AGZ_NO_HOST_FLAG=1     ply loop: fetch the number of games left with a copy + stream synchronisation instead of polling the
  *                          host-visible word the scan kernel publishes
  *   AGZ_BIG_MT=2|4|8       256 / 512-wide trunk, stand-alone network launches: 16-leaf tiles per workgroup (default by launch size)
