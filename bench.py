@@ -112,7 +112,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI); gloo only for single-GPU smoke tests of the N>1 path")
     ap.add_argument("--lockstep", action="store_true", help="K separate lock-step generations of --games games (the reference's call pattern: the batch "
                     "shrinks as games end) instead of ONE call that plays K x --games games on --games slots, finished games' slots refilled")
-    ap.add_argument("--gens-per-call", type=int, default=4, help="generations' worth of games one agz_selfplay call plays on the engine's slots (bounds the "
+    ap.add_argument("--gens-per-call", type=int, default=8, help="generations' worth of games one agz_selfplay call plays on the engine's slots (bounds the "
                     "sample store: ~1 GB per generation of Gobang 9x9)")
     ap.add_argument("--dump-records", default="", help="rank 0 writes the gathered samples of the LAST timed generation (PoolSample order) to this .npz")
     args = ap.parse_args()
