@@ -146,9 +146,6 @@ struct agz_engine {
     small_fn k_small8 = nullptr; int tw8 = 0;
     big_fn k_big8 = nullptr, k_big8x = nullptr; int big8 = 0;   // k_big8x: two such workgroups per CU (128 registers) above 64 games per CU   // k_search_big with 64-game workgroups (eight tree waves, one workgroup per CU) above 32 games per CU: AGZ_BIG8
     int legal_bound = 1 << 30, tree_kpr = 0;
-    // ply classes of the batch (ply loop, k_scan_alive): the first cls_n[0] slots hold games that need rows by action, the next cls_n[1] games whose
-    // roots fit the rows of level cls_lv[0], the rest those of level cls_lv[1] (-1: no such level); cls_use: the coming search goes by them
-    bool cls_use = false; int cls_n[2] = {0, 0}, cls_lv[2] = {-1, -1}; uint32_t cls_t[2] = {0xffffffffu, 0xffffffffu};
     bool no_compact = false;            // AGZ_NO_COMPACT (A/B, tests)
     advance_fn k_spread = nullptr;      // policy_final rows from rank order back to action order after such a search
     small_fn k_small4[3] = {nullptr, nullptr, nullptr};   // the same with 32 games per workgroup, register budgets for 2 / 3 / 4 workgroups per SIMD set
@@ -329,9 +326,9 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     h->ply_sleep = getenv("AGZ_PLY_SPIN") == nullptr;
     if (hipEventCreateWithFlags(&h->ev_adv, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) h->ev_adv = nullptr;
     if (hipEventCreate(&h->ev_ply0) != hipSuccess || hipEventCreate(&h->ev_ply1) != hipSuccess ||
-        hipHostMalloc((void**)&h->hcount, 16, 0) != hipSuccess) { h->fail("cannot create the ply-loop events / pinned counter"); return bail(AGZ_ERR_HIP); }
-    if (!getenv("AGZ_NO_HOST_FLAG") && hipHostMalloc((void**)&h->hflag, 32, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
-        h->hflag[0] = 0; h->hflag[1] = 0; h->hflag[2] = 0; h->hflag[3] = 0;
+        hipHostMalloc((void**)&h->hcount, 4, 0) != hipSuccess) { h->fail("cannot create the ply-loop events / pinned counter"); return bail(AGZ_ERR_HIP); }
+    if (!getenv("AGZ_NO_HOST_FLAG") && hipHostMalloc((void**)&h->hflag, 16, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+        h->hflag[0] = 0; h->hflag[1] = 0;
         if (hipHostGetDevicePointer((void**)&h->hflag_dev, h->hflag, 0) != hipSuccess) { hipHostFree(h->hflag); h->hflag = nullptr; h->hflag_dev = nullptr; }
     }
     hipError_t fa = hipSuccess;                                     // first failure of the attribute / memset calls below
@@ -930,16 +927,19 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
             const bool t8 = h->k_small8 && tw == 4 && occ == 2 && (h->tw8 > 0 || (h->tw8 == 0 && h->reg_kpl == 12 && h->G.fam != F_REV));   // (Connect4 +1 %, Reversi 8x8 0 .. +2 %, 11x11 / 13x13 -0.5 .. -1.6 %: not by default)
             if (t8) tw = 8;
             // rows by the root's legal rank once no root can have more legal actions than they hold (the ply loop knows: A - ply); the
-            // expansion compacts through the group's edge table, 2 V >= 8 KPR floats.  Games at different plies (refilled slots): the ply
-            // loop has partitioned the slots into up to three classes by the rows their games may use (k_scan_alive) and every class is
-            // one launch of its own build on its own range of slots, side by side on parallel streams.
+            // expansion compacts through the group's edge table, 2 V >= 8 KPR floats
+            const int lv = cmp_level(h);                          // the narrowest rows that hold every root's legal actions, or -1
+            const bool cmp = lv >= 0;
+            const small_fn kfn = t8 ? (cmp ? h->cmp[lv].s8 : h->k_small8)
+                                    : (cmp ? (tw == 2 ? h->cmp[lv].s2 : h->cmp[lv].s4[occ]) : (tw == 2 ? h->k_small : h->k_small4[occ]));
+            h->tree_kpr = cmp ? h->cmp[lv].kpr : 0;
             SmallPar S;
             S.T = h->tp;
-            S.T.step = h->step; S.T.cpuct = h->cpuct; S.T.training = h->training;
+            S.T.L = h->L; S.T.slot0 = 0; S.T.step = h->step; S.T.cpuct = h->cpuct; S.T.training = h->training;
             S.T.fastdiv = fastdiv_range(h);
             S.T.inject = 0; S.T.capture = 0; S.T.rollout = 0; S.T.do_reset = 1; S.T.do_expand = 0; S.T.do_select = 1; S.T.last = 0;
             S.F.planes = (const uint16_t*)h->planes; S.F.INP = n.INP; S.F.w16 = n.w16w; S.F.bias_head = n.bias_head;
-            S.F.logits = h->logits; S.F.LGS = h->LGS; S.F.vout = h->v_eval; S.F.T = n.T; S.F.A = h->G.A; S.F.AOP = n.AOP;
+            S.F.logits = h->logits; S.F.LGS = h->LGS; S.F.vout = h->v_eval; S.F.L = h->L; S.F.T = n.T; S.F.A = h->G.A; S.F.AOP = n.AOP;
             // few games: sparse waves — a rollout lasts as long as the deepest descent among the games of a workgroup, and with
             // <= 2 workgroups per CU idle lanes cost nothing: 1 / 2 games per tree wave up to 4 / 8 games per CU (measured per ply:
             // 2.9 vs 4.0 ms at 256 games, 3.1 vs 3.9 at 1024, 3.5 vs 3.9 at 2048; no gain from 4 games per wave at 4096)
@@ -968,46 +968,18 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
             const size_t room = (size_t)(160 * 1024) / (size_t)wgs_per_cu > shared ? (size_t)(160 * 1024) / (size_t)wgs_per_cu - shared : 0;
             S.wl_off = (int)shared; S.wl_bytes = (int)std::min({(size_t)(8 * h->V * 4), (room / (size_t)tw) & ~(size_t)15, (size_t)h->wl_lds_max});
             const size_t lds = shared + (size_t)tw * S.wl_bytes;
-            // the slot ranges of this search: one ([0, L), level by the bound on the roots' legal actions) or the ply loop's classes
-            struct Range { int s0, s1, lv; } rg[3]; int nrg = 0;
-            const int gwg = S.T.gpw * tw;                              // games per workgroup: class boundaries fall on workgroup boundaries
-            if (h->cls_use && !h->no_compact) {
-                // (a class's first games may sit in the last workgroup of the class before it: rows by action / by a wider rank hold them too)
-                int b1 = std::min(h->L, (h->cls_n[0] + gwg - 1) / gwg * gwg);
-                int b2 = std::min(h->L, std::max(b1, (h->cls_n[0] + h->cls_n[1] + gwg - 1) / gwg * gwg));
-                if (h->cls_lv[0] < 0) b1 = b2 = h->L;
-                else if (h->cls_lv[1] < 0) b2 = h->L;
-                if (b1 > 0) rg[nrg++] = {0, b1, -1};
-                if (b2 > b1) rg[nrg++] = {b1, b2, h->cls_lv[0]};
-                if (h->L > b2) rg[nrg++] = {b2, h->L, h->cls_lv[1]};
-            } else rg[nrg++] = {0, h->L, cmp_level(h)};
-            h->tree_kpr = 0;
-            if (nrg > 1) HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
-            std::string forms;
-            for (int r = 0; r < nrg; ++r) {
-                const int lv = rg[r].lv;
-                const bool cmp = lv >= 0;
-                hipStream_t st = r == 0 ? h->stream : h->aux[r - 1];
-                if (r > 0) HIPCHK(h, hipStreamWaitEvent(st, h->ev_fork, 0));
-                const small_fn kfn = t8 ? (cmp ? h->cmp[lv].s8 : h->k_small8)
-                                        : (cmp ? (tw == 2 ? h->cmp[lv].s2 : h->cmp[lv].s4[occ]) : (tw == 2 ? h->k_small : h->k_small4[occ]));
-                if (cmp) h->tree_kpr = h->cmp[lv].kpr;
-                S.T.slot0 = rg[r].s0; S.T.L = rg[r].s1; S.F.L = rg[r].s1;
-                std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
-                if ((h->profiling & 1) && h->prof_this) { ev = next_events(h, h->ev_tree, h->ev_tree_used); hipEventRecord(ev->first, st); }
-                hipLaunchKernelGGL(kfn, dim3((unsigned)((rg[r].s1 - rg[r].s0 + gwg - 1) / gwg)), dim3(64 * (tw == 8 ? 8 : NW_WAVES)), lds, st, S);
-                if (cmp) {   // policy_final back to action order (one wave per game, in place)
-                    PlyPar Q; memset(&Q, 0, sizeof Q);
-                    Q.G = h->G; Q.slot0 = rg[r].s0; Q.L = rg[r].s1; Q.V = h->V; Q.states = h->states; Q.policy_final = h->policy_final;
-                    hipLaunchKernelGGL(h->k_spread, dim3((unsigned)((rg[r].s1 - rg[r].s0 + 3) / 4)), dim3(256), 0, st, Q);
-                }
-                if (ev) hipEventRecord(ev->second, st);
-                if (r > 0) { HIPCHK(h, hipEventRecord(h->ev_join[r - 1], st)); HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join[r - 1], 0)); }
-                { char kb[64] = ""; if (cmp) snprintf(kb, sizeof kb, ",rows by legal rank KPR=%d", h->cmp[lv].kpr);
-                  char b[240]; snprintf(b, sizeof b, "%sk_search_small<KPL=%d,H=128,TW=%d,WV=%d%s>", r ? " + " : "", h->reg_kpl, tw, tw == 2 ? 2 : 2 + occ, kb); forms += b; }
+            std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
+            if ((h->profiling & 1) && h->prof_this) { ev = next_events(h, h->ev_tree, h->ev_tree_used); hipEventRecord(ev->first, h->stream); }
+            hipLaunchKernelGGL(kfn, dim3((unsigned)((h->L + S.T.gpw * tw - 1) / (S.T.gpw * tw))), dim3(64 * (tw == 8 ? 8 : NW_WAVES)), lds, h->stream, S);
+            if (cmp) {   // policy_final back to action order (one wave per game, in place)
+                PlyPar Q; memset(&Q, 0, sizeof Q);
+                Q.G = h->G; Q.L = h->L; Q.V = h->V; Q.states = h->states; Q.policy_final = h->policy_final;
+                hipLaunchKernelGGL(h->k_spread, dim3((unsigned)((h->L + 3) / 4)), dim3(256), 0, h->stream, Q);
             }
-            { char b[200]; snprintf(b, sizeof b, " (whole mcts_single per launch, %d games per workgroup, %d per tree wave%s)", S.T.gpw * tw, S.T.gpw,
-                                    nrg > 1 ? "; one launch per ply class of the batch, side by side" : ""); h->form_tree = forms + b; h->form_nn = "inside k_search_small (mlp_wave_body<128>)"; }
+            { char kb[48] = ""; if (cmp) snprintf(kb, sizeof kb, ",rows by legal rank KPR=%d", h->tree_kpr);
+              char b[200]; snprintf(b, sizeof b, "k_search_small<KPL=%d,H=128,TW=%d,WV=%d%s> (whole mcts_single per launch, %d games per workgroup, %d per tree wave)",
+                                    h->reg_kpl, tw, tw == 2 ? 2 : 2 + occ, kb, S.T.gpw * tw, S.T.gpw); h->form_tree = b; h->form_nn = "inside k_search_small (mlp_wave_body<128>)"; }
+            if (ev) hipEventRecord(ev->second, h->stream);
             HIPCHK(h, hipGetLastError());
             h->cnt_live = true;
             h->need_reset = true; h->injected = false;
@@ -1320,21 +1292,6 @@ static int run_games(agz_engine* h, int ngames, int V, float cpuct, int tau_plie
     int first_all = refill ? -1 : 0;                                            // round in which the last started game is at ply 0 (-1: games still start)
     unsigned long long started = (unsigned long long)slots;
     h->in_ply_loop = true;
-    // ply classes for the 128-wide trunk's one-launch search (rows by legal rank per class of slots): the two widest levels of rows by rank
-    // that this game shape has; a game at ply p has p stones on the board, so its root has at most A - p legal actions
-    h->cls_use = false; h->cls_lv[0] = h->cls_lv[1] = -1; h->cls_t[0] = h->cls_t[1] = 0xffffffffu;
-    if (!duel && !h->no_compact && (h->G.fam == F_LINE || h->G.fam == F_HEX) && h->ncmp > 0) {
-        int order[4] = {0, 1, 2, 3};
-        std::sort(order, order + h->ncmp, [&](int a, int b) { return h->cmp[a].kpr > h->cmp[b].kpr; });
-        int k = 0;
-        for (int i = 0; i < h->ncmp && k < 2; ++i) {
-            const int r = h->cmp[order[i]].kpr;
-            if (2 * h->V < 8 * r || 8 * r >= h->G.A) continue;                 // (the compaction buffer is the group's edge table: 2 V floats)
-            h->cls_lv[k] = order[i]; h->cls_t[k] = (uint32_t)(h->G.A - 8 * r); ++k;
-        }
-        h->cls_use = k > 0;
-        h->cls_n[0] = slots; h->cls_n[1] = 0;                                   // every game starts at ply 0
-    }
     while (h->L > 0) {                                                          // :494
         const int which = duel ? ((ply & 1) == 0 ? duel_first : 1 - duel_first) : 0;   // :592-596
         if (hipEventRecord(e0, h->stream) != hipSuccess) { h->fail("hipEventRecord failed"); rc = AGZ_ERR_HIP; break; }
@@ -1354,7 +1311,7 @@ static int run_games(agz_engine* h, int ngames, int V, float cpuct, int tau_plie
         const bool sleep = h->ply_sleep && h->ev_adv && hipEventRecord(h->ev_adv, h->stream) == hipSuccess;
         const uint32_t seq = ++h->ply_seq ? h->ply_seq : ++h->ply_seq;        // (never 0)
         hipLaunchKernelGGL(k_scan_alive, dim3(1), dim3(1024), 0, h->stream, (const uint32_t*)h->alive, h->newslot, h->L, h->d_count, h->hflag_dev, seq,
-                           (const unsigned long long*)(h->d_stats + 6), (const uint32_t*)h->slot_ply, h->cls_t[0], h->cls_t[1]);
+                           (const unsigned long long*)(h->d_stats + 6));
         hipLaunchKernelGGL(k_compact, dim3((unsigned)((h->L + 255) / 256)), dim3(256), 0, h->stream, T, (const uint32_t*)h->newslot,
                            (const uint32_t*)h->game_id, h->game_id2, h->slot_ply2);           // :550-561
         bool have = false;
@@ -1367,8 +1324,7 @@ static int run_games(agz_engine* h, int ngames, int V, float cpuct, int tau_plie
             if (sleep) (void)hipEventSynchronize(h->ev_adv);
             for (uint32_t spin = 0;; ++spin) {
                 const unsigned long long w = __atomic_load_n(f, __ATOMIC_ACQUIRE);
-                if ((uint32_t)(w >> 32) == seq) { *hcount = (uint32_t)w; started = __atomic_load_n(f + 1, __ATOMIC_RELAXED);
-                                                  hcount[1] = (uint32_t)__atomic_load_n(f + 2, __ATOMIC_RELAXED); hcount[2] = (uint32_t)__atomic_load_n(f + 3, __ATOMIC_RELAXED); have = true; break; }
+                if ((uint32_t)(w >> 32) == seq) { *hcount = (uint32_t)w; started = __atomic_load_n(f + 1, __ATOMIC_RELAXED); have = true; break; }
 #if defined(__x86_64__) || defined(__i386__)
                 __builtin_ia32_pause();                                            // (a polite spin: the core is shared with the host's other threads)
 #else
@@ -1382,7 +1338,7 @@ static int run_games(agz_engine* h, int ngames, int V, float cpuct, int tau_plie
             if (have && hipEventSynchronize(e1) != hipSuccess) have = false;   // (the search's end event is long past)
         }
         if (!have) {
-            if (hipMemcpyAsync(hcount, h->d_count, 12, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+            if (hipMemcpyAsync(hcount, h->d_count, 4, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
                 hipMemcpyAsync(&started, h->d_stats + 6, 8, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
                 hipStreamSynchronize(h->stream) != hipSuccess) { h->fail("ply loop failed: %s", hipGetErrorString(hipGetLastError())); rc = AGZ_ERR_HIP; break; }
         }
@@ -1391,13 +1347,12 @@ static int run_games(agz_engine* h, int ngames, int V, float cpuct, int tau_plie
         { uint32_t* s = h->game_id; h->game_id = h->game_id2; h->game_id2 = s; h->tp.game_id = h->game_id; }
         { uint32_t* s = h->slot_ply; h->slot_ply = h->slot_ply2; h->slot_ply2 = s; h->tp.slot_ply = h->slot_ply; }
         h->L = (int)*hcount;
-        h->cls_n[0] = (int)hcount[1]; h->cls_n[1] = (int)hcount[2];
         ++ply;
         if (first_all < 0 && started >= (unsigned long long)ngames) first_all = ply;   // the last game was started in this round's k_advance: ply 0 in the next search
         if (ply > 255 && !refill) { h->fail("game exceeded 255 plies"); rc = AGZ_ERR_STATE; break; }
         if (ply > 255 * ((ngames + slots - 1) / slots + 1)) { h->fail("ply loop does not end"); rc = AGZ_ERR_STATE; break; }
     }
-    h->in_ply_loop = false; h->cls_use = false;
+    h->in_ply_loop = false;
     if (rc) return rc;
     unsigned long long hs[8];
     HIPCHK(h, hipMemcpy(hs, h->d_stats, sizeof hs, hipMemcpyDeviceToHost));

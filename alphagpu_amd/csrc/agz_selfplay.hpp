@@ -9,7 +9,6 @@ namespace agz {
 
 struct PlyPar {
     GamePar G;
-    int32_t slot0;            // k_spread_policy: first slot of the range [slot0, L) it works on
     int32_t L, V, ply, tau_plies, all_actions;   // ply: the round of the lock-step loop (diagnostics; every game's own ply is slot_ply[slot])
     uint64_t seed;
     uint32_t game_id_base;
@@ -142,7 +141,7 @@ __global__ __launch_bounds__(256) void k_spread_policy(const PlyPar T) {
     using G = Game<FAM, NC>;
     const GamePar& P = T.G;
     const int lane = lane_id();
-    const int slot = T.slot0 + ufirst((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    const int slot = ufirst((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
     if (slot >= T.L) return;
     const int A = P.A;
     const WPos<NC> root = load_pos<NC>(T.states + (size_t)slot * T.V);
@@ -169,65 +168,48 @@ __global__ __launch_bounds__(256) void k_fold_counters(const uint32_t* cnt_p, co
     if ((threadIdx.x & 63) == 0) { atomicAdd(&acc[0], a); atomicAdd(&acc[1], b); }
 }
 
-// Compaction map of a ply: the surviving games keep their order (deleteat! semantics, :550-553) — and, when the games of the batch are at
-// different plies (slots refilled with new games), they are PARTITIONED by the row width their next search may use: class 0 = ply < t1
-// (rows by action), class 1 = t1 <= ply < t2, class 2 = ply >= t2 (rows by the root's legal rank, agz_tree_eager.hpp KPR_: a game at ply p
-// has p stones on the board), each class in slot order, class 0 first.  A lock-step generation has one class per ply and the map is the
-// plain exclusive scan of the alive flags.  One workgroup of 1024 threads: wave w owns a contiguous segment and walks it 64 flags at a
-// time (coalesced loads, counts by ballot): one pass for the segment totals, a 16-entry scan of them, one pass for the slots.
-// hostflag (may be null): four 64-bit words in host-visible memory: [1] games started so far (*next_game), [2] class-0 count, [3] class-1
-// count, then [0] = (seq << 32 | total), which the host polls instead of waiting for a copy and a stream synchronisation.
+// exclusive scan of the 0/1 flags alive[0..L) by one workgroup of 1024 threads -> newslot[], total -> *count.  Wave w owns a
+// contiguous segment and walks it 64 flags at a time (coalesced loads, counts by ballot): one pass for the segment totals, a
+// 16-entry scan of them, one pass for the slots.
+// hostflag (may be null): a 64-bit word in host-visible memory that receives (seq << 32 | total) — the host polls it instead of
+// waiting for a copy and a stream synchronisation (the ply loop's only round trip to the host)
+// hostflag[1] receives the number of games started so far (*next_game; written before hostflag[0]).
 __global__ __launch_bounds__(1024) void k_scan_alive(const uint32_t* alive, uint32_t* newslot, int L, uint32_t* count,
-                                                     unsigned long long* hostflag, uint32_t seq, const unsigned long long* next_game = nullptr,
-                                                     const uint32_t* ply = nullptr, uint32_t t1 = 0xffffffffu, uint32_t t2 = 0xffffffffu) {
-    __shared__ uint32_t part[16][3];
+                                                     unsigned long long* hostflag, uint32_t seq, const unsigned long long* next_game = nullptr) {
+    __shared__ uint32_t part[16];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int seg = ((L + 1023) / 1024) * 64;                    // flags per wave (a multiple of 64)
     const int b = w * seg, e = (b + seg < L) ? b + seg : L;
     const uint64_t below = (1ull << lane) - 1ull;
-    auto cls = [&](int k) -> uint32_t {                           // 0..2: class of a surviving game, 3: the game has ended
-        if (k >= e || alive[k] == 0u) return 3u;
-        const uint32_t p = ply ? ply[k] : 0u;
-        return p >= t2 ? 2u : (p >= t1 ? 1u : 0u);
-    };
-    uint32_t s0 = 0, s1 = 0, s2 = 0;
+    uint32_t s = 0;
     for (int i = b; i < e; i += 256) {                            // four chunks per turn: their loads are in flight together
         uint32_t a[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) a[j] = cls(i + 64 * j + lane);
+        for (int j = 0; j < 4; ++j) { const int k = i + 64 * j + lane; a[j] = k < e ? alive[k] : 0u; }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { s0 += (uint32_t)__popcll(__ballot(a[j] == 0u)); s1 += (uint32_t)__popcll(__ballot(a[j] == 1u)); s2 += (uint32_t)__popcll(__ballot(a[j] == 2u)); }
+        for (int j = 0; j < 4; ++j) s += (uint32_t)__popcll(__ballot(a[j] != 0u));
     }
-    if (lane == 0) { part[w][0] = s0; part[w][1] = s1; part[w][2] = s2; }
+    if (lane == 0) part[w] = s;
     __syncthreads();
-    uint32_t base[3] = {0, 0, 0}, tot[3] = {0, 0, 0};
+    uint32_t base = 0, total = 0;
 #pragma unroll
-    for (int j = 0; j < 16; ++j)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { const uint32_t v = part[j][c]; base[c] += j < w ? v : 0u; tot[c] += v; }
-    base[1] += tot[0]; base[2] += tot[0] + tot[1];
+    for (int j = 0; j < 16; ++j) { const uint32_t v = part[j]; base += j < w ? v : 0u; total += v; }
     for (int i = b; i < e; i += 256) {
         uint32_t a[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) a[j] = cls(i + 64 * j + lane);
+        for (int j = 0; j < 4; ++j) { const int k = i + 64 * j + lane; a[j] = k < e ? alive[k] : 0u; }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+            const uint64_t m = __ballot(a[j] != 0u);
             const int k = i + 64 * j + lane;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const uint64_t m = __ballot(a[j] == (uint32_t)c);
-                if (k < e && a[j] == (uint32_t)c) newslot[k] = base[c] + (uint32_t)__popcll(m & below);
-                base[c] += (uint32_t)__popcll(m);
-            }
+            if (k < e) newslot[k] = base + (uint32_t)__popcll(m & below);
+            base += (uint32_t)__popcll(m);
         }
     }
     if (t == 0) {
-        const uint32_t total = tot[0] + tot[1] + tot[2];
-        *count = total; count[1] = tot[0]; count[2] = tot[1];
+        *count = total;
         if (hostflag) {
             if (next_game) __hip_atomic_store(hostflag + 1, *next_game, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(hostflag + 2, (unsigned long long)tot[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(hostflag + 3, (unsigned long long)tot[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(hostflag, ((unsigned long long)seq << 32) | total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }

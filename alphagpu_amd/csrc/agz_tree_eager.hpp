@@ -181,10 +181,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
     constexpr int A2 = G * KPR;
     constexpr int OFF_P = 16, OFF_RK = 16 + 4 * A2, OFF_CID = 16 + 5 * A2, OFF_EL = 16 + 6 * A2;   // aux, per-action rows, then the edge list by rank ...
     const int A = P.A, V = T.V;
-    // ... and the visit bytes by rank.  The STRIDE of the records is that of rows by action whatever the row width of this build: launches
-    // with rows by action and with rows by legal rank then share one record buffer slot by slot (the games of a batch at different
-    // plies are searched by different builds, each on its own range of slots)
-    const uint32_t OFF_VIS = (uint32_t)(OFF_EL + 8 * eager_vl(V, A2)), ROWS = (uint32_t)eager_rec_bytes(G * KPL, V);
+    const uint32_t OFF_VIS = (uint32_t)(OFF_EL + 8 * eager_vl(V, A2)), ROWS = (uint32_t)eager_rec_bytes(A2, V);   // ... and the visit bytes by rank
     const EagerLds LO = eager_lds_layout(V, NG);
     float2* const tab = reinterpret_cast<float2*>(lds + (size_t)g * LO.tstride + LO.tab);   // tab[-1] = {0, 0}
     float4* const valtab = reinterpret_cast<float4*>(lds + LO.val);
@@ -211,7 +208,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
     //   Newton      top / bot, -top / bot^2: same bounds;  newerr / g: newerr in [1e-3, 2^25] and then |g| in [2^-10, 2^39]
     // The backup's own quotient (vis q + 1 - v) / (vis + 1) keeps '/': a value head output may be arbitrarily small.
     const bool FD = T.fastdiv && !inject && !exact;
-    const int wl_block = T.slot0 / GPW + __builtin_amdgcn_readfirstlane(bidx);   // (the wave's index among the waves of ALL launches of this search: slot ranges start at multiples of GPW)
+    const int wl_block = T.slot0 / NG + __builtin_amdgcn_readfirstlane(bidx);
     uint32_t* const wl_g = T.wl + (size_t)wl_block * (size_t)T.wl_cap * (size_t)(NG / 8);   // this wave's work list (global form; wl_cap entries per 8 games)
     // the wave's 8 games lie next to each other in every per-node array: ONE wave-uniform base per array (scalar registers) and
     // 32-bit offsets (game-in-wave, node) from it — every load / store of the item loop is base + 32-bit offset + immediate,
