@@ -584,9 +584,9 @@ int agz_set_network_slot(agz_engine* h, int which, int H, int T, const float* W0
             HIPCHK(h, dmalloc(&n.w16, b16.size()));
             HIPCHK(h, hipMemcpy(n.w16, b16.data(), b16.size() * 2, hipMemcpyHostToDevice));
             if (H == 256 || H == 512) {   // agz_nn_big.hpp: layer 0 padded to an even row count, 2 rows of slack
-                const int k0r = (KT0b + 1) / 2 * 2;
+                const int k0r = (KT0b + 3) / 4 * 4;                 // (zero rows pad layer 0: the network body walks four k-rows per turn)
                 const size_t row = (size_t)NTb * 512;
-                std::vector<uint16_t> bb(((size_t)k0r + (size_t)T * KThb + 2) * row, 0);
+                std::vector<uint16_t> bb(((size_t)k0r + (size_t)T * KThb + 4) * row, 0);   // (+ 4 rows of slack: the prefetch runs four rows ahead)
                 std::copy(b16.begin(), b16.begin() + s0, bb.begin());
                 std::copy(b16.begin() + s0, b16.begin() + (s0 + sr * T), bb.begin() + (size_t)k0r * row);
                 HIPCHK(h, dmalloc(&n.wbig, bb.size()));

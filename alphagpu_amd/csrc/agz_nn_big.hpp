@@ -31,7 +31,11 @@ struct BigPar {
 // the launch is bound by one workgroup's own chain of layers and a quarter of the work per workgroup is ~4x faster.
 // mlp_big_body: the 8-wave workgroup's forward for the leaves of tile rows 0 .. 16 MT - 1, slot_of(row) = leaf (game slot) of a
 // row or a value >= P.L (also called from k_search_big, agz_search_big.hpp); contains workgroup barriers.
-template <int H, int MT, typename SlotOf>
+// PIPE (builds with register room: one workgroup per CU): FOUR k-rows of weight fragments in flight — a fragment is requested three k-steps
+// (~1.5 K cycles of matrix work) before the matrix core needs it; with two rows the request of a row went out when the row before
+// it had just been used up, and its L2 latency stood in front of every second k-step — and the B operand of leaf tile i + 2 is read from
+// LDS while the MFMAs of tile i issue (explicit schedule groups).  Same MFMA instruction, same k order per accumulator: same bits.
+template <int H, int MT, bool PIPE = false, typename SlotOf>
 __device__ __forceinline__ void mlp_big_body(const BigPar& P, uint8_t* const act, SlotOf slot_of) {
     constexpr int NT = H / 16, KTH = H / 32, NTW = NT / 8;       // neuron tiles per layer / k-rows per layer / neuron tiles per wave
     constexpr int MB = 16 * MT;                                  // leaves per workgroup
@@ -43,13 +47,14 @@ __device__ __forceinline__ void mlp_big_body(const BigPar& P, uint8_t* const act
     const int lrow = lane & 15, q4 = lane >> 4;
     const AGZ_GLB v4u* wsrc = (const AGZ_GLB v4u*)P.wh + (size_t)wave * NTW * 64 + lane;   // this wave's tiles of k-row 0
 
-    bf16x8 A0[NTW], A1[NTW];
+    bf16x8 A0[NTW], A1[NTW], A2[PIPE ? NTW : 1], A3[PIPE ? NTW : 1];
 #define NB_LOADROW(buf)                                                                                 \
     do {                                                                                                \
         _Pragma("unroll") for (int t = 0; t < NTW; ++t) { const v4u w_ = wsrc[t * 64]; buf[t] = *reinterpret_cast<const bf16x8*>(&w_); } \
         wsrc += NT * 64;                                                                                \
     } while (0)
     NB_LOADROW(A0); NB_LOADROW(A1);
+    if constexpr (PIPE) { NB_LOADROW(A2); NB_LOADROW(A3); }
 
     {   // input planes -> columns [0, 32*K0R) of the activation tile, zero beyond INP
         const int segs = P.K0R * 4, isegs = P.INP / 8;
@@ -82,8 +87,31 @@ __device__ __forceinline__ void mlp_big_body(const BigPar& P, uint8_t* const act
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int t = 0; t < NTW; ++t) { acc[mt][t][0] = 0.0f; acc[mt][t][1] = 0.0f; acc[mt][t][2] = 0.0f; acc[mt][t][3] = 0.0f; }
+        if constexpr (PIPE) {
+#define NB_STEP4(buf, kt)                                                                               \
+    do {                                                                                                \
+        bf16x8 b_[MT];                                                                                  \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) b_[mt] = *reinterpret_cast<const bf16x8*>(brow + (size_t)mt * 16 * ROWB + (kt) * 64); \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                               \
+            _Pragma("unroll") for (int t = 0; t < NTW; ++t)                                             \
+                acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(buf[t], b_[mt], acc[mt][t], 0, 0, 0); \
+        NB_LOADROW(buf);                                          /* k-row + 4 */                       \
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);        /* the B operands of two leaf tiles up front ... */ \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                                \
+            __builtin_amdgcn_sched_group_barrier(0x008, NTW, 0);  /* ... then NTW MFMAs per tile, */    \
+            if (i + 2 < MT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   /* each followed by the read for tile i + 2 */ \
+        }                                                                                               \
+        __builtin_amdgcn_sched_group_barrier(0x020, NTW, 0);      /* the weight fragments of row + 4 */ \
+    } while (0)
+            // (at the loop's back edge the compiler waits for ALL outstanding weight requests — vmcnt(0) — instead of the four oldest:
+            //  once per four k-steps; unrolling a layer's loop in full removes that wait and spills ~390 registers)
 #pragma unroll 1
-        for (int kt = 0; kt < KTl; kt += 2) { NB_STEP(A0, kt); NB_STEP(A1, kt + 1); }
+            for (int kt = 0; kt < KTl; kt += 4) { NB_STEP4(A0, kt); NB_STEP4(A1, kt + 1); NB_STEP4(A2, kt + 2); NB_STEP4(A3, kt + 3); }
+#undef NB_STEP4
+        } else {
+#pragma unroll 1
+            for (int kt = 0; kt < KTl; kt += 2) { NB_STEP(A0, kt); NB_STEP(A1, kt + 1); }
+        }
         __syncthreads();                                          // every wave has read the layer's input
         const bool res = l > 0;
 #pragma unroll
@@ -150,7 +178,7 @@ template <int H, int MT>
 __global__ __launch_bounds__(NB_THREADS, 1) void k_mlp_big(const BigPar P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t act_big[];   // [16 MT][ROWB]
     const int leaf0 = (int)blockIdx.x * 16 * MT;
-    mlp_big_body<H, MT>(P, act_big, [&](int row) { return leaf0 + row; });
+    mlp_big_body<H, MT, true>(P, act_big, [&](int row) { return leaf0 + row; });
 }
 
 }  // namespace agz

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(NB_THREADS, 2 * WG) void k_search_big(const BigSear
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             const BigSearchPar& S = par();
             const int gpw = S.T.gpw, L = S.T.L;
-            mlp_big_body<H, TW / 2>(S.B, lds_bigs, [&](int row) { return (row & 7) < gpw ? (bx * TW + (row >> 3)) * gpw + (row & 7) : L; });
+            mlp_big_body<H, TW / 2, (WG < 2)>(S.B, lds_bigs, [&](int row) { return (row & 7) < gpw ? (bx * TW + (row >> 3)) * gpw + (row & 7) : L; });
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __syncthreads();                                      // logits and values are visible to the tree waves
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");

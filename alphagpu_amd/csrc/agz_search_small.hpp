@@ -12,6 +12,10 @@
 #include "agz_tree_eager.hpp"
 #include "agz_nn_wave.hpp"
 
+#ifndef AGZ_PFM_LOW
+#define AGZ_PFM_LOW 1       // item prefetch of the builds without register room (agz_tree_eager.hpp PFM): 1 = touch only, 3 = first part into registers
+#endif
+
 namespace agz {
 
 struct SmallPar {
@@ -91,7 +95,7 @@ __global__ __launch_bounds__(64 * (TW == 8 ? 8 : NW_WAVES), WV) void k_search_sm
             }
         } else {
             const StepFlags SF = {(uint32_t)k, k == 0, k > 0, k < S.V, k == S.V - 1, k == S.V};
-            if (wave < TW) rollout_eager_body<FAM, NC, KPL, true, ((G < 8 || WV < 3 || (WV == 3 && KPL <= 16) || KPL <= 4) ? 2 : 1), true, ROLE_ALL, KPR, G>(SF, tree_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
+            if (wave < TW) rollout_eager_body<FAM, NC, KPL, true, ((G < 8 || WV < 3 || (WV == 3 && KPL <= 16) || KPL <= 4) ? 2 : AGZ_PFM_LOW), true, ROLE_ALL, KPR, G>(SF, tree_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
                                                                                    io_blk, S.io_prowb, S.io_lgs);
         }
 #ifdef AGZ_STAMPS

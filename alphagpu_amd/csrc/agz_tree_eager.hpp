@@ -275,7 +275,12 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
     };
 
     // one work item's rows -> registers (zeros for a lane-group without an item).  entry: node | move << 8 | depth << 16 | game << 24
-    auto item_fetch = [&](ItemRows<KPR>& R, const int r, const uint32_t nwl) {
+    // part: 0 = everything; 1 = what the round needs FIRST (the entry, aux words, the edge taken, the rank bytes, the head of the edge
+    // list: the backup and the edge table), 2 = the rest (priors and child bytes, used after Newton) of the item whose first part R holds.
+    // PFM = 3 prefetches part 1 a round ahead into registers (19 instead of 34) and requests part 2 at the head of the round, where the
+    // backup and Newton cover its latency.
+    auto item_fetch = [&](ItemRows<KPR>& R, const int r, const uint32_t nwl, const int part = 0) {
+        if (part != 2) {
         R.ent = 0u; R.gi = g; R.valid = false;
         // round 0: the lane-groups that own a game take its special item, the others (sparse waves: g >= GPW) already take list entries
         if (r == 0 && g < GPW) { R.ent = C.spw; R.valid = live && (C.spw & SP_VALID); }
@@ -286,6 +291,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
                 R.valid = true; R.gi = (int)(R.ent >> 24) & (NG - 1);
             }
         }
+        }
         // entry: node | mr << 8 | ...: mr = the ACTION of a new edge (special item with SP_CREATED), else the creation rank + 1 of
         // the edge taken
         const uint32_t node = R.ent & 0xffu, mr = (R.ent >> 8) & 0xffu;
@@ -295,16 +301,19 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
         // nothing it computes is stored.  The loads are unconditional (no branch, no zero fill of 30 registers per round).
         const uint32_t nd = (uint32_t)((R.valid ? R.gi : gl) * V) + node;
         const uint8_t* const rec = wrecs + __umul24(nd, ROWS);
-        {
-            const uint4 ax = *reinterpret_cast<const uint4*>(rec);
-            R.ax_x = ax.x; R.ax_z = ax.z;                             // (raw: nothing here may wait for a load — the item body masks them)
+        if (part != 1) {
 #pragma unroll
             for (int j = 0; j < KPR; j += 4) {
                 const float4 a = *reinterpret_cast<const float4*>(rec + OFF_P + (uint32_t)(r0 + j) * 4u);
                 R.p[j] = a.x; R.p[j + 1] = a.y; R.p[j + 2] = a.z; R.p[j + 3] = a.w;
-                R.rk[j / 4] = *reinterpret_cast<const uint32_t*>(rec + OFF_RK + (uint32_t)(r0 + j));
                 R.cd[j / 4] = *reinterpret_cast<const uint32_t*>(rec + OFF_CID + (uint32_t)(r0 + j));
             }
+        }
+        if (part != 2) {
+            const uint4 ax = *reinterpret_cast<const uint4*>(rec);
+            R.ax_x = ax.x; R.ax_z = ax.z;                             // (raw: nothing here may wait for a load — the item body masks them)
+#pragma unroll
+            for (int j = 0; j < KPR; j += 4) R.rk[j / 4] = *reinterpret_cast<const uint32_t*>(rec + OFF_RK + (uint32_t)(r0 + j));
             // the edge taken: an existing one is entry mr - 1 of the list; a new one has q = 0, no visit, and the prior of its action
             const uint32_t er = (crt || mr == 0u) ? 0u : mr - 1u;
             const float2 em = *reinterpret_cast<const float2*>(rec + OFF_EL + er * 8u);
@@ -324,7 +333,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
         }
     };
 
-    constexpr bool PF = PFM == 2;
+    constexpr bool PF = PFM == 2, PF3 = PFM == 3;
     // touch the record (and the aux word) of the item of round r: one dword per cache line
     auto item_touch = [&](const int r, const uint32_t nwl) -> uint32_t {
         uint32_t ent = 0u; int gi = g; bool valid = false;
@@ -373,7 +382,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
             }
         }
         uint32_t sink = 0u;
-        if constexpr (PFM == 1 && ROLE != ROLE_EXPAND) sink = item_touch(0, nwl);   // the first item's record starts travelling towards L2 now
+        if constexpr ((PFM == 1 || PFM == 3) && ROLE != ROLE_EXPAND) sink = item_touch(0, nwl);   // the first item's record starts travelling towards L2 now
         // ---------------------------------------------------------------------------- expand (lane-group g = game g)
         const int lf = (int)C.leafn;
         uint32_t ml = live ? (LEAN ? C.leaf_meta : gmeta[lf]) : (uint32_t)M_TERM;   // (one memory round trip less on the rollout's chain)
@@ -508,7 +517,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
             }
             npos = grp_sum<G>(npos);                                  // "A" of :125-131 never changes after the expansion
         }
-        if constexpr (PF && ROLE != ROLE_EXPAND) item_fetch(R, 0, nwl);   // the first round's rows travel while the leaf's rows are written
+        if constexpr ((PF || PF3) && ROLE != ROLE_EXPAND) item_fetch(R, 0, nwl, PF3 ? 1 : 0);   // the first round's rows travel while the leaf's rows are written
         if (ROLE != ROLE_ITEMS && doexp) {
             // policy = prior (:297-299): the first revisit samples from these running sums; their total is prior_rem (:120-124, no   // PHASE expand: running sums + write rows
             // child yet)
@@ -554,7 +563,8 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
         const bool recompute = !(TI.final_ || SF.fin);                 // after the last rollout of a search nobody descends again   // PHASE items: loop control
 #pragma unroll 1
         for (int r = 0; r < (ROLE == ROLE_EXPAND ? 0 : rounds); ++r) {
-            if constexpr (!PF) item_fetch(R, r, nwl);
+            if constexpr (!PF && !PF3) item_fetch(R, r, nwl);
+            if constexpr (PF3) item_fetch(R, r, nwl, 2);              // priors and child bytes of THIS item: used after Newton
             const bool valid = R.valid, special = r == 0 && g < GPW;
             const int gi = R.gi;   // PHASE items: fetch item
             const int node = (int)(R.ent & 0xffu), mr = (int)((R.ent >> 8) & 0xffu), dpt_e = (int)((R.ent >> 16) & 0xffu);
@@ -614,7 +624,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
             const bool FDr = FD && !__ballot(ax_z & AUX_SLOW);      // (wave-uniform)
             if (!recompute) {
                 if (valid && lead) *reinterpret_cast<uint4*>(rec) = make_uint4(__float_as_uint(prem_raw), 0u, auxz, 0u);
-                if constexpr (PF) { if (r + 1 < rounds) item_fetch(R, r + 1, nwl); }
+                if constexpr (PF || PF3) { if (r + 1 < rounds) item_fetch(R, r + 1, nwl, PF3 ? 1 : 0); }
                 continue;
             }
             STAMPW(4);
@@ -707,7 +717,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
             // the 128-register build touches the next item's record HERE, not at the head of the round: a full round ahead, the lines
             // touched by the 512 waves of an XCD (5.2 MB per round) do not survive in its 4 MB L2 until they are read; half a round
             // (~6 us) still covers an HBM miss (first ply at 32768 games 4.22 -> 4.15 ms)
-            if constexpr (PFM == 1) {
+            if constexpr (PFM == 1 || PFM == 3) {
                 asm volatile("" :: "v"(sink));                        // (keeps the touch loads alive; they completed long ago)
                 if (r + 1 < rounds) sink = item_touch(r + 1, nwl);
             }
@@ -728,7 +738,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
             // the rows of this item are dead: the next item's start travelling now (its table entries are written after the
             // AGZ_WSYNC below)
             AGZ_WSYNC();
-            if constexpr (PF) { if (r + 1 < rounds) item_fetch(R, r + 1, nwl); }
+            if constexpr (PF || PF3) { if (r + 1 < rounds) item_fetch(R, r + 1, nwl, PF3 ? 1 : 0); }
             if (__builtin_expect(__ballot(valid && node == 0 && SF.last) != 0, 0)) {     // copy_pol (:330-339): the row the last descent samples from
                 if (valid && node == 0) {
 #pragma unroll

@@ -278,14 +278,17 @@ def main():
                 "lockstep_generation_rollouts_per_s": st["rollouts"] / (h1 - h0),
                 "rollouts_per_s_with_host_delivery": st["rollouts"] / (h2 - h0),
                 "rollouts_per_s_with_delivery_into_PoolSample_serial": st["rollouts"] / (h1 - h0 + h3 - h2)}
-        # (b) pipelined
-        cap = G * game.max_plies
+        # (b) pipelined: calls of `gp` generations' worth of games (refilled slots, as in the timed region); the records of call k travel
+        # and are unpacked while call k + 1 runs
+        gp = min(gens_cap, 2)
+        cap = gp * G * game.max_plies
         dbuf = [torch.empty(cap * rb, dtype=torch.uint8, device="cuda") for _ in range(2)]
         hbuf = [torch.empty(cap * rb, dtype=torch.uint8).pin_memory() for _ in range(2)]
         side = torch.cuda.Stream()
         free = [threading.Semaphore(1), threading.Semaphore(1)]
         jobs = queue.Queue()
         err = []
+        d_copy, d_unpack = [], []
 
         def deliver():
             try:
@@ -294,10 +297,13 @@ def main():
                     if job is None:
                         return
                     k, n = job
+                    c0 = time.perf_counter()
                     with torch.cuda.stream(side):
                         hbuf[k][: n * rb].copy_(dbuf[k][: n * rb], non_blocking=True)
                     side.synchronize()
+                    c1 = time.perf_counter()
                     buf.push_packed(hbuf[k][: n * rb].numpy(), n)
+                    d_copy.append(c1 - c0); d_unpack.append(time.perf_counter() - c1)
                     free[k].release()
             except Exception as e:          # noqa: BLE001 — reported by the main thread
                 err.append(e)
@@ -305,13 +311,13 @@ def main():
 
         th = threading.Thread(target=deliver, daemon=True)
         th.start()
-        gens = 6                            # (the delivery of the last generation is not hidden: amortised over six)
+        ncalls = 4                          # (the delivery of the last call is not hidden: amortised over four calls)
         p_rollouts = 0
         p0 = time.perf_counter()
-        for i in range(gens):
+        for i in range(ncalls):
             k = i & 1
-            free[k].acquire()               # the delivery of generation i - 2 has left buffer k
-            st = step()
+            free[k].acquire()               # the delivery of call i - 2 has left buffer k
+            st = step(gp)
             n = eng.samples_packed_into(dbuf[k].data_ptr(), cap)
             jobs.put((k, n))
             p_rollouts += st["rollouts"]
@@ -320,7 +326,10 @@ def main():
         p1 = time.perf_counter()
         if err:
             raise err[0]
-        host["pipelined_generations"] = gens
+        host["pipelined_generations"] = ncalls * gp
+        host["pipelined_calls"] = ncalls
+        host["pipelined_copy_s_per_call"] = d_copy
+        host["pipelined_unpack_s_per_call"] = d_unpack
         host["pipelined_wall_s"] = p1 - p0
         host["rollouts_per_s_with_delivery_into_PoolSample"] = p_rollouts / (p1 - p0)
         host["poolsample_length_after"] = buf.length_buffer()
