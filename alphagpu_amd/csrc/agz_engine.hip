@@ -734,7 +734,7 @@ static int launch_network(agz_engine* h, int which, int s0 = 0, int s1 = -1, hip
     float* const logits = h->logits + (size_t)s0 * h->LGS; float* const v_eval = h->v_eval + s0;
     std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
     if ((h->profiling & 2) && h->prof_this) { ev = next_events(h, h->ev_nn, h->ev_nn_used); hipEventRecord(ev->first, stream); h->nn_leaves += (uint64_t)L; }
-    const int big_rowb = 2 * std::max(n.H, 32 * n.k0r) + 16;
+    const int big_rowb = (2 * std::max(n.H, 32 * n.k0r) + 255) & ~255;   // (a multiple of the LDS bank row: agz_nn_big.hpp's XOR swizzle)
     if (h->cfg.nn_mode == AGZ_NN_BF16 && n.wbig && (size_t)NB_M * big_rowb <= 160 * 1024 && !h->no_fused_nn) {   // wide trunk: activations resident in LDS, weights streamed from L2
         BigPar B;
         B.planes = (const uint16_t*)planes; B.INP = n.INP; B.wh = n.wbig;
@@ -989,7 +989,7 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
     }
     {   // wide trunk, batch small enough to be latency-bound in the two-kernel form: the whole search in one launch (agz_search_big.hpp)
         DevNet& n = h->net[which];
-        const int big_rowb = 2 * std::max(n.H, 32 * n.k0r) + 16;
+        const int big_rowb = (2 * std::max(n.H, 32 * n.k0r) + 255) & ~255;   // (a multiple of the LDS bank row: agz_nn_big.hpp's XOR swizzle)
         if (h->k_big[0] && h->cfg.nn_mode == AGZ_NN_BF16 && n.H == 512 && n.wbig && h->L > 0 && 8 * h->reg_kpl <= h->LGS &&
             h->V <= 128 && (h->V & 3) == 0 &&                    // (the shapes the lean build of the tree step is tested at, as for k_search_small)
             h->L <= (h->big8 >= 0 && h->k_big8x && h->big_maxl >= 64 * h->cus ? 128 * h->cus : std::min(h->big_maxl, 64 * h->cus)) && !h->no_fused_nn) {

@@ -12,6 +12,10 @@
 #pragma once
 #include "agz_nn_wave.hpp"
 
+#ifndef AGZ_BIG_PIPE
+#define AGZ_BIG_PIPE 1      // 0: the two-rows-in-flight k-loop everywhere (A/B)
+#endif
+
 namespace agz {
 
 constexpr int NB_M = 128;                 // leaves per workgroup (MT = 8 leaf tiles; MT = 2 -> 32 leaves for small batches)
@@ -24,7 +28,7 @@ struct BigPar {
     const float* bias_head;
     float* logits; int LGS; float* vout;
     int L, T, A, AOP, K0R;                // K0R = k-rows of layer 0 after padding
-    int ROWB;                             // bytes per activation row in LDS: 2 * max(H, 32*K0R) + 16
+    int ROWB;                             // bytes per activation row in LDS: 2 * max(H, 32*K0R) rounded up to 256 (XOR-swizzled, below)
 };
 
 // MT = 16-leaf tiles per workgroup: 8 (128 leaves) when the batch fills the chip, 2 (32 leaves) below ~8192 leaves, where
@@ -63,17 +67,25 @@ __device__ __forceinline__ void mlp_big_body(const BigPar& P, uint8_t* const act
             const int row = c / segs, seg = c - row * segs, mm = slot_of(row);
             v4u v = {0u, 0u, 0u, 0u};
             if (mm < P.L && seg < isegs) v = *(const AGZ_GLB v4u*)(gp + (size_t)mm * P.INP + seg * 8);
-            *reinterpret_cast<v4u*>(act + (size_t)row * ROWB + seg * 16) = v;
+            *reinterpret_cast<v4u*>(act + (size_t)row * ROWB + ((seg * 16) ^ ((row & 15) << 4))) = v;
         }
     }
     __syncthreads();
 
-    const uint8_t* const brow = act + (size_t)lrow * ROWB + q4 * 16;    // + 16*mt*ROWB + 64*kt
+    // LDS layout of the activation tile: row r at r * ROWB (a multiple of 256 bytes = one bank row), byte b of the row at b ^ ((r & 15) << 4):
+    // the 16-byte slot of a k-chunk is XORed with the row's low bits.  ds_read_b128 is serviced in four groups of 16 lanes
+    // ({0-3, 12-15, 20-27}, ...: MI355X_MICROARCH.md, LDS) whose lanes read 16 different rows at one or two neighbouring k-chunks —
+    // with the XOR every group touches all 16 slots of the bank row once (a padded stride of 256 n + 16 bytes left one slot of every
+    // group busy twice: half the read rate of the B operand, which all eight waves read in full for every layer).
+    const int swz = lrow << 4;
+    const uint8_t* const brow = act + (size_t)lrow * ROWB;               // + 16*mt*ROWB + ((64*kt + 16*q4) ^ swz)
+    const int cx = (q4 * 16) ^ swz;                                      // (64 kt and 16 q4 share no bit: (64 kt + 16 q4) ^ swz = 64 kt ^ cx)
     f32x4 acc[MT][NTW];
 #define NB_STEP(buf, kt)                                                                                \
     do {                                                                                                \
         bf16x8 b_[MT];                                                                                  \
-        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) b_[mt] = *reinterpret_cast<const bf16x8*>(brow + (size_t)mt * 16 * ROWB + (kt) * 64); \
+        const int off_ = ((kt) * 64) ^ cx;                                                              \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) b_[mt] = *reinterpret_cast<const bf16x8*>(brow + (size_t)mt * 16 * ROWB + off_); \
         _Pragma("unroll") for (int t = 0; t < NTW; ++t)                                                 \
             _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                           \
                 acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(buf[t], b_[mt], acc[mt][t], 0, 0, 0); \
@@ -91,7 +103,8 @@ __device__ __forceinline__ void mlp_big_body(const BigPar& P, uint8_t* const act
 #define NB_STEP4(buf, kt)                                                                               \
     do {                                                                                                \
         bf16x8 b_[MT];                                                                                  \
-        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) b_[mt] = *reinterpret_cast<const bf16x8*>(brow + (size_t)mt * 16 * ROWB + (kt) * 64); \
+        const int off_ = ((kt) * 64) ^ cx;                                                              \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) b_[mt] = *reinterpret_cast<const bf16x8*>(brow + (size_t)mt * 16 * ROWB + off_); \
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                               \
             _Pragma("unroll") for (int t = 0; t < NTW; ++t)                                             \
                 acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(buf[t], b_[mt], acc[mt][t], 0, 0, 0); \
@@ -116,13 +129,13 @@ __device__ __forceinline__ void mlp_big_body(const BigPar& P, uint8_t* const act
         const bool res = l > 0;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            uint8_t* const orow = act + (size_t)(mt * 16 + lrow) * ROWB;
+            uint8_t* const orow = act + (size_t)(mt * 16 + lrow) * ROWB;   // (this lane's row: its bytes at b ^ swz)
 #pragma unroll
             for (int t = 0; t < NTW; ++t) {
                 const int n = 16 * (wave * NTW + t) + 4 * q4;     // acc[mt][t][r] = out[neuron n + r][leaf 16 mt + lrow]
                 float x0 = acc[mt][t][0] > 0.0f ? acc[mt][t][0] : 0.0f, x1 = acc[mt][t][1] > 0.0f ? acc[mt][t][1] : 0.0f;
                 float x2 = acc[mt][t][2] > 0.0f ? acc[mt][t][2] : 0.0f, x3 = acc[mt][t][3] > 0.0f ? acc[mt][t][3] : 0.0f;
-                uint2* dst = reinterpret_cast<uint2*>(orow + n * 2);
+                uint2* dst = reinterpret_cast<uint2*>(orow + ((n * 2) ^ swz));
                 if (res) {                                        // b = relu(b + relu(W b))
                     const uint2 o = *dst;
                     x0 += __uint_as_float(o.x << 16); x1 += __uint_as_float(o.x & 0xffff0000u);
@@ -150,7 +163,7 @@ __device__ __forceinline__ void mlp_big_body(const BigPar& P, uint8_t* const act
                 const bf16x8 w = *reinterpret_cast<const bf16x8*>(&w_);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
-                    const bf16x8 x = *reinterpret_cast<const bf16x8*>(brow + (size_t)mt * 16 * ROWB + kt * 64);
+                    const bf16x8 x = *reinterpret_cast<const bf16x8*>(brow + (size_t)mt * 16 * ROWB + ((kt * 64 + q4 * 16) ^ swz));
                     hacc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, w, hacc[mt], 0, 0, 0);
                 }
             }
@@ -178,7 +191,7 @@ template <int H, int MT>
 __global__ __launch_bounds__(NB_THREADS, 1) void k_mlp_big(const BigPar P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t act_big[];   // [16 MT][ROWB]
     const int leaf0 = (int)blockIdx.x * 16 * MT;
-    mlp_big_body<H, MT, true>(P, act_big, [&](int row) { return leaf0 + row; });
+    mlp_big_body<H, MT, (AGZ_BIG_PIPE != 0)>(P, act_big, [&](int row) { return leaf0 + row; });
 }
 
 }  // namespace agz

@@ -77,31 +77,33 @@ class PoolSample:
     def push_packed(self, records, n=None):
         """Packed sample records of a generation in HOST memory (agz_get_samples_packed layout, PoolSample order: uint8 array
         [n, rec_bytes] or flat) unpacked straight into the ring at the write position (agz_unpack_records: host threads, no
-        device) — what a host loop calls on the pinned copy of generation k while generation k + 1 runs."""
+        device) — what a host loop calls on the pinned copy of generation k while generation k + 1 runs.  A write that reaches the
+        end of the ring continues at its start (two or more contiguous segments, each unpacked in place); of more records than the
+        ring holds the last `length` survive, at the positions the reference's one-by-one pushes would leave them."""
         import ctypes as C
         from . import lib as _lib
         rb = self.game.rec_bytes
         records = np.ascontiguousarray(records).reshape(-1)
         n = records.size // rb if n is None else int(n)
-        start = self.currentIndex - 1
         L = _lib.load_library()
         p = lambda a: a.ctypes.data_as(C.c_void_p)
-        if n > self.length - start:                                       # the write would wrap: unpack aside, then the general path
-            g = self.game
-            s = dict(state=np.zeros((n, 2 * g.VS), np.int8), policy=np.zeros((n, g.A), np.float32), player=np.zeros(n, np.int8),
-                     value=np.zeros(n, np.float32), fstate=np.zeros((n, g.FS), np.int8))
-            rc = L.agz_unpack_records(C.byref(g.info), p(records), n, p(s["state"]), p(s["policy"]), p(s["player"]), p(s["value"]),
-                                      p(s["fstate"]), None, None, None)
+        first = self.currentIndex                                          # 1-based index of the first record's slot
+        done = 0
+        if n > self.length:                                               # the first n - length records would be overwritten by this very push
+            done = n - self.length
+        pos = (self.currentIndex - 1 + done) % self.length
+        while done < n:
+            m = min(n - done, self.length - pos)
+            seg = records[done * rb:(done + m) * rb]
+            rc = L.agz_unpack_records(C.byref(self.game.info), p(seg), m, p(self.state[pos:pos + m]), p(self.policy[pos:pos + m]),
+                                      p(self.player[pos:pos + m]), p(self.value[pos:pos + m]), p(self.fstate[pos:pos + m]), None, None, None)
             assert rc == 0
-            return self.push_generation(s)
-        rc = L.agz_unpack_records(C.byref(self.game.info), p(records), n, p(self.state[start:start + n]), p(self.policy[start:start + n]),
-                                  p(self.player[start:start + n]), p(self.value[start:start + n]), p(self.fstate[start:start + n]),
-                                  None, None, None)
-        assert rc == 0
-        if start + n >= self.length:
+            done += m
+            pos = (pos + m) % self.length
+        if self.currentIndex - 1 + n >= self.length:
             self.full = True
-        self.currentIndex = int((start + n) % self.length) + 1
-        return start + 1 + np.arange(n)
+        self.currentIndex = int((self.currentIndex - 1 + n) % self.length) + 1
+        return (first - 1 + np.arange(n)) % self.length + 1
 
     def length_buffer(self):                                              # mainGobang.jl:82
         return self.length if self.full else self.currentIndex - 1

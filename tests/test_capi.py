@@ -140,3 +140,24 @@ def test_every_environment_switch_is_documented_in_the_header():
     documented = set(re.findall(r"\b(AGZ_[A-Z0-9_]+)\b", block))
     assert used and used <= documented, sorted(used - documented)
     assert documented <= used, sorted(documented - used)
+
+
+def test_push_packed_equals_push_generation_with_wrap_and_overflow():
+    """PoolSample.push_packed (agz_unpack_records: host-only, straight into the ring's arrays, segment by segment across the end of the
+    ring) == push_generation of the same samples — also when the write wraps and when one push brings more samples than the ring holds."""
+    import alphagpu_amd as ag
+    import oracle_lib as O
+    from test_shard_gloo import _pack
+    game = ag.GameSpec("gobang", 3, 3)
+    og = O.make_game("gobang", 3, 3)
+    s = O.selfplay(og, O.OracleNet(og, 16, 1), 40, 8, 1.5, 25, 3, 0)
+    recs = _pack(s, game)
+    n = s["n"]
+    for length in (n + 50, n - 7, n // 2 + 3, n // 3):
+        a, b = ag.PoolSample(game, length), ag.PoolSample(game, length)
+        for _ in range(3):
+            ia = a.push_packed(recs, n)
+            ib = b.push_generation({k: s[k] for k in ("state", "policy", "player", "value", "fstate")})
+            assert np.array_equal(ia, ib) and a.currentIndex == b.currentIndex and a.full == b.full
+            for k in ("state", "policy", "player", "value", "fstate"):
+                assert np.array_equal(getattr(a, k), getattr(b, k)), (length, k)
