@@ -303,15 +303,18 @@ def mcts_single(actor, visits, engine, training=True, cpuct=2.0, step=0):
     engine.search(visits, cpuct=cpuct, training=training, step=step)
 
 
-def mcts(actor, visits, ngames, buffer, game=None, cpuct=2.0, engine=None, tau_plies=25, seed=None, **kw):
+def mcts(actor, visits, ngames, buffer, game=None, cpuct=2.0, engine=None, tau_plies=25, seed=None, slots=None, **kw):
     """mcts(actor, visits, ngames, buffer::PoolSample; cpuct) — mcts_gpu.jl:477-579.
     Plays `ngames` self-play games to the end, pushes every (state, policy, player, value, fstate) sample into
     `buffer` in the reference's order and returns (data, valid) like the reference's named tuple.
-    seed=None draws a fresh Philox key per call (the reference's randomness is unseeded); pass a seed to reproduce."""
+    seed=None draws a fresh Philox key per call (the reference's randomness is unseeded); pass a seed to reproduce.
+    slots < ngames: only `slots` games are in flight at a time and a slot whose game has ended takes the next game that has not
+    started (every search on a full batch); the samples are those of the lock-step run over ngames slots."""
     own = engine is None
     seed = fresh_seed() if seed is None else int(seed)
     if own:
-        engine = Engine(game if game is not None else buffer.game, ngames, visits, seed=seed, **kw)
+        nslots = ngames if slots is None else min(int(slots), int(ngames))
+        engine = Engine(game if game is not None else buffer.game, nslots, visits, seed=seed, sample_capacity_games=ngames, **kw)
     else:
         engine.set_seed(seed)
     try:

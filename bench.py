@@ -112,8 +112,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI); gloo only for single-GPU smoke tests of the N>1 path")
     ap.add_argument("--lockstep", action="store_true", help="K separate lock-step generations of --games games (the reference's call pattern: the batch "
                     "shrinks as games end) instead of ONE call that plays K x --games games on --games slots, finished games' slots refilled")
-    ap.add_argument("--gens-per-call", type=int, default=8, help="generations' worth of games one agz_selfplay call plays on the engine's slots (bounds the "
-                    "sample store: ~1 GB per generation of Gobang 9x9)")
+    ap.add_argument("--gens-per-call", type=int, default=0, help="generations' worth of games one agz_selfplay call plays on the engine's slots (bounds the "
+                    "sample store: ~1 GB per generation of Gobang 9x9); 0 = up to 32 on one GPU, up to 8 per rank with several (the exchange buffers "
+                    "scale with it)")
     ap.add_argument("--dump-records", default="", help="rank 0 writes the gathered samples of the LAST timed generation (PoolSample order) to this .npz")
     args = ap.parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -159,7 +160,9 @@ def main():
     # (the configuration the metric names) instead of the shrinking batches of a generation's tail.  Every game's samples are exactly those
     # of lock-step generations (results are keyed by game id and the game's own ply; tests/test_gpu_scale_parity.py checks slices of such a
     # run against the oracle).  --lockstep: K separate calls of G games; the line carries that number too (value_lockstep_generations).
-    gens_cap = 1 if args.lockstep else max(1, min(args.gens_per_call, max(args.steps, args.warmup, 1)))
+    world_ = int(os.environ.get("WORLD_SIZE", "1"))
+    gpc = args.gens_per_call if args.gens_per_call > 0 else (32 if world_ == 1 else 8)
+    gens_cap = 1 if args.lockstep else max(1, min(gpc, max(args.steps, args.warmup, 1)))
 
     def calls(k):                           # K generations as calls of at most gens_cap generations each
         return [gens_cap] * (k // gens_cap) + ([k % gens_cap] if k % gens_cap else [])

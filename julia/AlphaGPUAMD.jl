@@ -36,8 +36,8 @@ fresh_seed() = rand(UInt64) >> 1 | UInt64(1)
 set_seed!(e::Engine, seed) = check(e, ccall((:agz_set_seed, libagz), Cint, (Ptr{Cvoid}, UInt64), e.h, seed))
 
 # game ids: 0 Gobang, 1 Connect4, 2 Hex, 3 Reversi 8x8, 4 Reversi 6x6 — set by the main*.jl that includes the plugin
-function init(positions::Vector{Position}, visits; game::Integer, N::Integer=0, Nvict::Integer=0, device=0, seed=fresh_seed(), nn_mode=0)
-    cfg = Ref(AgzConfig(game, N, Nvict, length(positions), visits, device, seed, 0, nn_mode, 0, (0, 0, 0)))
+function init(positions::Vector{Position}, visits; game::Integer, N::Integer=0, Nvict::Integer=0, device=0, seed=fresh_seed(), nn_mode=0, sample_capacity=0)
+    cfg = Ref(AgzConfig(game, N, Nvict, length(positions), visits, device, seed, 0, nn_mode, sample_capacity, (0, 0, 0)))
     h = Ref{Ptr{Cvoid}}(C_NULL)
     rc = ccall((:agz_create, libagz), Cint, (Ref{AgzConfig}, Ref{Ptr{Cvoid}}), cfg, h)
     rc == 0 || error(unsafe_string(ccall((:agz_last_error, libagz), Cstring, (Ptr{Cvoid},), C_NULL)))
@@ -74,8 +74,10 @@ function mcts_single(actor, visits, e::Engine; training=true, cpuct=2f0, step=0)
     policy, batch                                  # == Array(vnodesStats.policy_final), Array(vnodesStats.batch)
 end
 
-function mcts(actor, visits, ngames, buffer::PoolSample; θ=1, cpuct=2.0, noise=Float32(1 / maxActions), game, N=0, Nvict=0, seed=fresh_seed())
-    e = init(ngames, visits; game=game, N=N, Nvict=Nvict, seed=seed)
+# slots < ngames: the engine keeps `slots` games in flight and a slot whose game has ended takes the next game that has not started
+# (every search on a full batch; each game's samples are those of the lock-step run, agz.h agz_selfplay)
+function mcts(actor, visits, ngames, buffer::PoolSample; θ=1, cpuct=2.0, noise=Float32(1 / maxActions), game, N=0, Nvict=0, seed=fresh_seed(), slots=ngames)
+    e = init(min(slots, ngames), visits; game=game, N=N, Nvict=Nvict, seed=seed, sample_capacity=ngames)
     try
     set_network!(e, actor)
     st = Ref{AgzStats}()
