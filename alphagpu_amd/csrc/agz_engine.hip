@@ -117,6 +117,7 @@ struct agz_engine {
     double tree_ms = 0, nn_ms = 0, tree_busy_ms = 0; int64_t tree_launches = 0;
     hipEvent_t ev_ref = nullptr; bool ev_ref_live = false;
     hipEvent_t ev_ply0 = nullptr, ev_ply1 = nullptr; uint32_t* hcount = nullptr;   // ply loop: search timing, pinned alive count
+    hipStream_t fold_stream = nullptr; hipEvent_t ev_fold = nullptr;   // ply loop with profiling: the descent counters of a search are folded beside the ply kernels, not in front of them
     hipEvent_t ev_adv = nullptr; bool ply_sleep = true;   // ply loop: the host thread SLEEPS (blocking event) until the ply's k_advance has run, then polls the scan's word for a few microseconds (AGZ_PLY_SPIN=1: spin all the way)
     unsigned long long* hflag = nullptr; unsigned long long* hflag_dev = nullptr; uint32_t ply_seq = 0;   // ... host-visible (seq, count) word the scan kernel publishes
     uint32_t* d_order = nullptr; int64_t sp_nsamples = 0; int sp_maxplies = 0;   // PoolSample order of the last generation (device), its length, its longest game
@@ -278,6 +279,8 @@ void agz_destroy(agz_engine* h) {
     if (h->ev_ply0) hipEventDestroy(h->ev_ply0);
     if (h->ev_ply1) hipEventDestroy(h->ev_ply1);
     if (h->ev_adv) hipEventDestroy(h->ev_adv);
+    if (h->ev_fold) hipEventDestroy(h->ev_fold);
+    if (h->fold_stream) hipStreamDestroy(h->fold_stream);
     if (h->hcount) hipHostFree(h->hcount);
     if (h->hflag) hipHostFree(h->hflag);
     for (int c = 0; c < agz_engine::KCH - 1; ++c) { if (h->aux[c]) hipStreamDestroy(h->aux[c]); if (h->ev_join[c]) hipEventDestroy(h->ev_join[c]); }
@@ -324,6 +327,9 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     h->Lmax = cfg->max_games; h->V = cfg->max_visits;
     if (!bind_kernels(h)) { h->fail("no kernel instantiation for this game shape"); return bail(AGZ_ERR_UNSUPPORTED); }
     h->ply_sleep = getenv("AGZ_PLY_SPIN") == nullptr;
+    if (hipStreamCreateWithFlags(&h->fold_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_fold, hipEventDisableTiming) != hipSuccess) {
+        h->fold_stream = nullptr; h->ev_fold = nullptr;
+    }
     if (hipEventCreateWithFlags(&h->ev_adv, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) h->ev_adv = nullptr;
     if (hipEventCreate(&h->ev_ply0) != hipSuccess || hipEventCreate(&h->ev_ply1) != hipSuccess ||
         hipHostMalloc((void**)&h->hcount, 4, 0) != hipSuccess) { h->fail("cannot create the ply-loop events / pinned counter"); return bail(AGZ_ERR_HIP); }
@@ -1258,7 +1264,7 @@ static void fill_plypar(agz_engine* h, PlyPar& T, int ply, int tau_plies, bool a
     T.all_actions = all_actions ? 1 : 0;
     T.G = h->G; T.L = h->L; T.V = h->V; T.ply = ply; T.tau_plies = tau_plies; T.seed = h->cfg.seed; T.game_id_base = h->cfg.game_id_base;
     T.states = h->states; T.game_id = h->game_id; T.slot_ply = h->slot_ply; T.policy_final = h->policy_final; T.newpos = h->newpos; T.alive = h->alive;
-    T.next_game = h->d_stats + 6;
+    T.next_game = h->d_stats + 6; T.identity = h->d_count;
     T.sample_games = h->sample_games; T.max_plies = h->G.max_plies;
     T.s_boards = h->s_boards; T.s_policy = h->s_policy; T.s_move = h->s_move; T.g_nplies = h->g_nplies; T.g_result = h->g_result;
     T.g_final = h->g_final; T.stats = h->d_stats;
@@ -1283,7 +1289,6 @@ static int run_games(agz_engine* h, int ngames, int V, float cpuct, int tau_plie
         HIPCHK(h, hipMemcpyAsync(h->d_stats + 6, &started0, 8, hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream)); }
     h->sp_games = ngames; h->sp_nsamples = 0; h->sp_maxplies = 0;
-    const hipEvent_t e0 = h->ev_ply0, e1 = h->ev_ply1;
     double search_ms = 0; int64_t rollouts = 0; int ply = 0;
     uint32_t* const hcount = h->hcount;
     const bool refill = ngames > slots;
@@ -1291,9 +1296,22 @@ static int run_games(agz_engine* h, int ngames, int V, float cpuct, int tau_plie
     // first_all) -> every root of round r holds at least r - first_all stones
     int first_all = refill ? -1 : 0;                                            // round in which the last started game is at ply 0 (-1: games still start)
     unsigned long long started = (unsigned long long)slots;
+    bool fold_pending = false;
+    // Run-ahead: while games still start, a ply cannot change the number of games in flight as long as more games are waiting than
+    // slots exist (every game that ends is replaced) — the host then queues the next ply WITHOUT waiting for this one's count (up to 8
+    // plies ahead; the search timings of those plies are read from their own event pairs at the next wait).  `started_ub` bounds the
+    // games started so far from above between two waits.
+    unsigned long long started_ub = started;
+    int ahead = 0; bool any_fold = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> tpool;                       // search-timing event pairs of the plies not yet waited for
+    size_t tused = 0;
+    tpool.push_back({h->ev_ply0, h->ev_ply1});
     h->in_ply_loop = true;
     while (h->L > 0) {                                                          // :494
         const int which = duel ? ((ply & 1) == 0 ? duel_first : 1 - duel_first) : 0;   // :592-596
+        if (fold_pending) { hipStreamWaitEvent(h->stream, h->ev_fold, 0); fold_pending = false; }   // (the counters of the last search are folded before this one overwrites them)
+        if (tused == tpool.size()) { hipEvent_t a = nullptr, b = nullptr; if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { h->fail("hipEventCreate failed"); rc = AGZ_ERR_HIP; break; } tpool.push_back({a, b}); }
+        const hipEvent_t e0 = tpool[tused].first, e1 = tpool[tused].second; ++tused;
         if (hipEventRecord(e0, h->stream) != hipSuccess) { h->fail("hipEventRecord failed"); rc = AGZ_ERR_HIP; break; }
         h->legal_bound = ((h->G.fam == F_LINE || h->G.fam == F_HEX) && first_all >= 0) ? h->G.A - (ply - first_all) : 1 << 30;   // every game started from Position(): a game at ply p has p stones on the board
         rc = agz_search_actor(h, which, V, cpuct, training, (uint32_t)ply);      // :503
@@ -1301,19 +1319,32 @@ static int run_games(agz_engine* h, int ngames, int V, float cpuct, int tau_plie
         if (rc) break;
         if (hipEventRecord(e1, h->stream) != hipSuccess) { h->fail("hipEventRecord failed"); rc = AGZ_ERR_HIP; break; }
         rollouts += (int64_t)h->L * V;
-        const bool fold = h->profiling && h->prof_this;                         // descent counters of this search -> d_acc (queued before the
-        if (fold)                                                               // ply kernels: nothing is launched between the sync and the next search)
-            hipLaunchKernelGGL(k_fold_counters, dim3((unsigned)std::min(64, (h->L + 255) / 256)), dim3(256), 0, h->stream, (const uint32_t*)h->cnt_p,
+        const bool fold = h->profiling && h->prof_this;                         // descent counters of this search -> d_acc: beside the ply kernels, on a
+        if (fold) {                                                             // stream of its own (the next search waits for it, long after it has run)
+            hipStream_t fs = h->fold_stream ? h->fold_stream : h->stream;
+            if (h->fold_stream) hipStreamWaitEvent(fs, e1, 0);
+            hipLaunchKernelGGL(k_fold_counters, dim3((unsigned)std::min(64, (h->L + 255) / 256)), dim3(256), 0, fs, (const uint32_t*)h->cnt_p,
                                (const uint32_t*)h->cnt_new, h->L, h->d_acc);
+            if (h->fold_stream) { hipEventRecord(h->ev_fold, fs); fold_pending = true; }
+            any_fold = true;
+        }
         PlyPar T; fill_plypar(h, T, ply, tau_plies, duel);
         T.refill_total = refill ? (uint32_t)ngames : 0u;
         hipLaunchKernelGGL(h->k_adv, dim3((unsigned)((h->L + 3) / 4)), dim3(256), 0, h->stream, T);          // :513-549
         const bool sleep = h->ply_sleep && h->ev_adv && hipEventRecord(h->ev_adv, h->stream) == hipSuccess;
         const uint32_t seq = ++h->ply_seq ? h->ply_seq : ++h->ply_seq;        // (never 0)
         hipLaunchKernelGGL(k_scan_alive, dim3(1), dim3(1024), 0, h->stream, (const uint32_t*)h->alive, h->newslot, h->L, h->d_count, h->hflag_dev, seq,
-                           (const unsigned long long*)(h->d_stats + 6));
+                           (const unsigned long long*)(h->d_stats + 6), h->d_stats + 7);
         hipLaunchKernelGGL(k_compact, dim3((unsigned)((h->L + 255) / 256)), dim3(256), 0, h->stream, T, (const uint32_t*)h->newslot,
                            (const uint32_t*)h->game_id, h->game_id2, h->slot_ply2);           // :550-561
+        if (refill && ahead < 8 && started_ub + 2ull * (unsigned long long)h->L <= (unsigned long long)ngames) {
+            // this ply and the next cannot exhaust the games that wait: the batch stays as it is — queue the next ply now
+            started_ub += (unsigned long long)h->L; ++ahead;
+            { uint32_t* s = h->game_id; h->game_id = h->game_id2; h->game_id2 = s; h->tp.game_id = h->game_id; }
+            { uint32_t* s = h->slot_ply; h->slot_ply = h->slot_ply2; h->slot_ply2 = s; h->tp.slot_ply = h->slot_ply; }
+            ++ply;
+            continue;
+        }
         bool have = false;
         if (h->hflag_dev) {
             // the number of games left, as soon as the scan kernel has it: polled from host-visible memory while the compaction still runs
@@ -1342,8 +1373,9 @@ static int run_games(agz_engine* h, int ngames, int V, float cpuct, int tau_plie
                 hipMemcpyAsync(&started, h->d_stats + 6, 8, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
                 hipStreamSynchronize(h->stream) != hipSuccess) { h->fail("ply loop failed: %s", hipGetErrorString(hipGetLastError())); rc = AGZ_ERR_HIP; break; }
         }
-        float ms = 0; hipEventElapsedTime(&ms, e0, e1); search_ms += ms;
-        if (fold) { h->cnt_live = false; drain_events(h); }
+        for (size_t i = 0; i < tused; ++i) { float ms = 0; if (hipEventElapsedTime(&ms, tpool[i].first, tpool[i].second) == hipSuccess) search_ms += ms; }
+        tused = 0; ahead = 0; started_ub = started;
+        if (any_fold) { h->cnt_live = false; drain_events(h); any_fold = false; }
         { uint32_t* s = h->game_id; h->game_id = h->game_id2; h->game_id2 = s; h->tp.game_id = h->game_id; }
         { uint32_t* s = h->slot_ply; h->slot_ply = h->slot_ply2; h->slot_ply2 = s; h->tp.slot_ply = h->slot_ply; }
         h->L = (int)*hcount;
@@ -1353,6 +1385,8 @@ static int run_games(agz_engine* h, int ngames, int V, float cpuct, int tau_plie
         if (ply > 255 * ((ngames + slots - 1) / slots + 1)) { h->fail("ply loop does not end"); rc = AGZ_ERR_STATE; break; }
     }
     h->in_ply_loop = false;
+    if (fold_pending) hipStreamWaitEvent(h->stream, h->ev_fold, 0);
+    for (size_t i = 1; i < tpool.size(); ++i) { hipEventDestroy(tpool[i].first); hipEventDestroy(tpool[i].second); }
     if (rc) return rc;
     unsigned long long hs[8];
     HIPCHK(h, hipMemcpy(hs, h->d_stats, sizeof hs, hipMemcpyDeviceToHost));

@@ -20,6 +20,7 @@ struct PlyPar {
     // (0: no refill).  Results are keyed by game id and ply, never by slot or by the round a game happens to start in.
     uint32_t refill_total;
     unsigned long long* next_game;   // games started so far (device counter)
+    const uint32_t* identity; // k_compact: k_scan_alive's count words ([1] != 0: every slot keeps its place)
     const float* policy_final;// [L][A]
     // per-slot scratch
     Pos* newpos;              // [L]
@@ -32,7 +33,7 @@ struct PlyPar {
     int32_t* g_nplies;        // [G]
     int8_t* g_result;         // [G]
     Pos* g_final;             // [G]
-    unsigned long long* stats;// [0] wins [1] draws [2] losses [3] total_plies [4] faults
+    unsigned long long* stats;// [0] wins [1] draws [2] losses [3] total_plies [4] faults ... [7] slots left without a game by this ply's k_advance (reset by k_scan_alive)
 };
 
 // one wavefront per slot
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(256) void k_advance(const PlyPar T) {
         fault = !ok;
     }
     if (fault) {
-        if (lane == 0) { atomicAdd(&T.stats[4], 1ull); T.alive[slot] = 0; if (keep) T.s_move[(size_t)g * T.max_plies + ply] = (int16_t)c; if (in_range) { T.g_nplies[g] = np_end; T.g_result[g] = 0; T.g_final[g] = pack(root); } }
+        if (lane == 0) { atomicAdd(&T.stats[4], 1ull); atomicAdd(&T.stats[7], 1ull); T.alive[slot] = 0; if (keep) T.s_move[(size_t)g * T.max_plies + ply] = (int16_t)c; if (in_range) { T.g_nplies[g] = np_end; T.g_result[g] = 0; T.g_final[g] = pack(root); } }
         return;
     }
     WPos<NC> np = G::play(P, root, c);
@@ -127,6 +128,7 @@ __global__ __launch_bounds__(256) void k_advance(const PlyPar T) {
                 }
             }
         }
+        if (!alive) atomicAdd(&T.stats[7], 1ull);
         T.newpos[slot] = next;
         T.alive[slot] = alive;
         T.slot_ply[slot] = nply;
@@ -174,10 +176,23 @@ __global__ __launch_bounds__(256) void k_fold_counters(const uint32_t* cnt_p, co
 // hostflag (may be null): a 64-bit word in host-visible memory that receives (seq << 32 | total) — the host polls it instead of
 // waiting for a copy and a stream synchronisation (the ply loop's only round trip to the host)
 // hostflag[1] receives the number of games started so far (*next_game; written before hostflag[0]).
+// dead (may be null): the number of slots this ply's k_advance left without a game.  0 — every game goes on or its slot was refilled, the
+// usual case while games still start — makes the compaction the identity: the scan is skipped, count[1] = 1 tells k_compact so.
 __global__ __launch_bounds__(1024) void k_scan_alive(const uint32_t* alive, uint32_t* newslot, int L, uint32_t* count,
-                                                     unsigned long long* hostflag, uint32_t seq, const unsigned long long* next_game = nullptr) {
+                                                     unsigned long long* hostflag, uint32_t seq, const unsigned long long* next_game = nullptr,
+                                                     unsigned long long* dead = nullptr) {
     __shared__ uint32_t part[16];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    if (dead && ufirst((uint32_t)(*dead == 0ull)) != 0u) {        // (the word is stable: k_advance has finished; only this kernel resets it)
+        if (t == 0) {
+            *count = (uint32_t)L; count[1] = 1u;
+            if (hostflag) {
+                if (next_game) __hip_atomic_store(hostflag + 1, *next_game, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(hostflag, ((unsigned long long)seq << 32) | (unsigned long long)(uint32_t)L, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        return;
+    }
     const int seg = ((L + 1023) / 1024) * 64;                    // flags per wave (a multiple of 64)
     const int b = w * seg, e = (b + seg < L) ? b + seg : L;
     const uint64_t below = (1ull << lane) - 1ull;
@@ -207,7 +222,8 @@ __global__ __launch_bounds__(1024) void k_scan_alive(const uint32_t* alive, uint
         }
     }
     if (t == 0) {
-        *count = total;
+        *count = total; count[1] = 0u;
+        if (dead) *dead = 0ull;
         if (hostflag) {
             if (next_game) __hip_atomic_store(hostflag + 1, *next_game, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(hostflag, ((unsigned long long)seq << 32) | total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -219,7 +235,7 @@ __global__ __launch_bounds__(1024) void k_scan_alive(const uint32_t* alive, uint
 __global__ void k_compact(const PlyPar T, const uint32_t* newslot, const uint32_t* gid_in, uint32_t* gid_out, uint32_t* ply_out) {
     int slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= T.L || !T.alive[slot]) return;
-    uint32_t ns = newslot[slot];
+    uint32_t ns = T.identity[1] ? (uint32_t)slot : newslot[slot];    // (k_scan_alive: nothing to compact this ply)
     T.states[(size_t)ns * T.V] = T.newpos[slot];
     gid_out[ns] = gid_in[slot];
     ply_out[ns] = T.slot_ply[slot];

@@ -29,7 +29,8 @@ for name, n, V, H, T, seed in cases:
     exact = os.environ.get("FUZZ_EXACT") == "1"                # the bit-exact fp32 mode instead of the benchmarked bf16 mode
     ref = O.selfplay(og, onet if exact else onet.bf16(), n, V, 1.5, 25, seed, 1000 * seed)
     t1 = time.perf_counter()
-    with M.Engine(g, n, V, seed=seed, game_id_base=1000 * seed, nn_mode=M.NN_EXACT if exact else M.NN_BF16) as e:
+    slots = max(8, n // int(os.environ.get("FUZZ_SLOT_DIV", "1")))   # FUZZ_SLOT_DIV=3: a third of the games in flight, finished games' slots refilled
+    with M.Engine(g, min(slots, n), V, seed=seed, game_id_base=1000 * seed, nn_mode=M.NN_EXACT if exact else M.NN_BF16, sample_capacity_games=n) as e:
         e.set_network(net)
         st = e.selfplay(n, V, cpuct=1.5, tau_plies=25)
         s = e.samples()

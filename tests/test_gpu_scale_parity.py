@@ -95,10 +95,12 @@ def test_full_size_first_ply_slice_matches_oracle(label, name, H, T, V, n_each, 
 def test_workgroup_shapes_of_the_full_batch_match_oracle(name, tw8, form):
     if tw8 is not None:
         os.environ["AGZ_TW8"] = tw8
+    os.environ["AGZ_NARROW"] = "-1"                  # (the 8-lane forms: Connect4's default at this size is 4 lanes per tree)
     try:
         run_slice_case(name, 128, 2, 32, 32768, 8, form, "inside k_search_small", step=1)
     finally:
         os.environ.pop("AGZ_TW8", None)
+        os.environ.pop("AGZ_NARROW", None)
 
 
 @pytest.mark.parametrize("name,H,T,V,n", [("gobang9", 512, 1, 32, 24000), ("hex9", 128, 1, 32, 32768)])
