@@ -301,7 +301,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
         // nothing it computes is stored.  The loads are unconditional (no branch, no zero fill of 30 registers per round).
         const uint32_t nd = (uint32_t)((R.valid ? R.gi : gl) * V) + node;
         const uint8_t* const rec = wrecs + __umul24(nd, ROWS);
-        if (part != 1) {
+        if (part == 2) {
 #pragma unroll
             for (int j = 0; j < KPR; j += 4) {
                 const float4 a = *reinterpret_cast<const float4*>(rec + OFF_P + (uint32_t)(r0 + j) * 4u);
@@ -313,7 +313,14 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
             const uint4 ax = *reinterpret_cast<const uint4*>(rec);
             R.ax_x = ax.x; R.ax_z = ax.z;                             // (raw: nothing here may wait for a load — the item body masks them)
 #pragma unroll
-            for (int j = 0; j < KPR; j += 4) R.rk[j / 4] = *reinterpret_cast<const uint32_t*>(rec + OFF_RK + (uint32_t)(r0 + j));
+            for (int j = 0; j < KPR; j += 4) {
+                if (part == 0) {
+                    const float4 a = *reinterpret_cast<const float4*>(rec + OFF_P + (uint32_t)(r0 + j) * 4u);
+                    R.p[j] = a.x; R.p[j + 1] = a.y; R.p[j + 2] = a.z; R.p[j + 3] = a.w;
+                }
+                R.rk[j / 4] = *reinterpret_cast<const uint32_t*>(rec + OFF_RK + (uint32_t)(r0 + j));
+                if (part == 0) R.cd[j / 4] = *reinterpret_cast<const uint32_t*>(rec + OFF_CID + (uint32_t)(r0 + j));
+            }
             // the edge taken: an existing one is entry mr - 1 of the list; a new one has q = 0, no visit, and the prior of its action
             const uint32_t er = (crt || mr == 0u) ? 0u : mr - 1u;
             const float2 em = *reinterpret_cast<const float2*>(rec + OFF_EL + er * 8u);
@@ -931,7 +938,11 @@ __global__ __launch_bounds__(64, WV) void k_rollout_eager(const TreePar) {
     const TreePar& T = tree_par();
     const StepFlags SF = {T.rollout, T.do_reset, T.do_expand, T.do_select, T.last, T.final_};
     EagerCarry C; uint32_t wcount = 0;
-    rollout_eager_body<FAM, NC, KPL, false, (WV < 4 ? 2 : 1)>(SF, lds_eager, (int)blockIdx.x, C, nullptr, 0u, wcount);
+    // (register prefetch of the item rows in the 3-waves-per-SIMD build up to 16 actions per lane: with 24 the build spills ~20 registers
+    //  with it, and THAT build — and only that one — lost a node-count increment in a rare position after a change that does not alter a
+    //  single value (the record stride written as a rounded-up expression): `scratch/repro_13.py`, the 13x13 cases of
+    //  tests/test_gpu_parity.py test_two_kernel_generation_* pin the shape.  Treated as a code-generation hazard of the spilling build.)
+    rollout_eager_body<FAM, NC, KPL, false, ((WV < 4 && KPL <= 16) ? 2 : 1)>(SF, lds_eager, (int)blockIdx.x, C, nullptr, 0u, wcount);
 }
 
 }  // namespace agz

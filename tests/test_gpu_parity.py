@@ -876,3 +876,23 @@ def test_selfplay_refill_needs_sample_capacity():
         e.set_network(ag.SNetwork2.random(g, 128, 2))
         with pytest.raises(Exception):
             e.selfplay(20, 8)
+
+
+# ---- the two-kernel form on the big boards (rows of 16 / 24 actions per lane) -------------------------------------------------
+@pytest.mark.parametrize("name,n,V,H,T,mode,seed", [("gobang13", 16, 64, 256, 3, "exact", 42), ("gobang13", 24, 32, 256, 2, "bf16", 5),
+                                                    ("hex11", 16, 48, 256, 2, "exact", 7)])
+def test_two_kernel_generation_on_big_boards_equals_the_oracle(name, n, V, H, T, mode, seed):
+    """k_rollout_eager<KPL = 24 / 16> + the stand-alone network kernels over a whole generation.  The first case is the one the round-4
+    fuzz run (profiles/r04_fuzz_parity.txt, set 2) caught: the 3-waves-per-SIMD build with the register prefetch of 24-action rows lost
+    one node-count increment at ply 7 of game 42010 (the build now prefetches through registers up to 16 actions per lane only)."""
+    g, og = spec(name)
+    net, onet = ag.SNetwork2.random(g, H, T, 0x5EED + seed), O.OracleNet(og, H, T, 0x5EED + seed)
+    with M.Engine(g, n, V, seed=seed, game_id_base=1000 * seed, nn_mode=M.NN_EXACT if mode == "exact" else M.NN_BF16) as e:
+        e.set_network(net)
+        st = e.selfplay(n, V, cpuct=1.5, tau_plies=25)
+        assert e.search_form()[0].startswith("k_rollout_eager"), e.search_form()
+        s = e.samples()
+    ref = O.selfplay(og, onet if mode == "exact" else onet.bf16(), n, V, 1.5, 25, seed, 1000 * seed)
+    assert st["valid"] and st["nsamples"] == ref["n"]
+    for key in ("game_id", "ply", "move", "player", "state", "fstate", "policy", "value"):
+        assert_same_bits(s[key], ref[key], f"{name} {mode}: {key}")
