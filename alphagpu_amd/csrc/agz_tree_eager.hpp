@@ -932,17 +932,22 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
 #endif
 }
 
+#ifndef AGZ_EAGER_PF24
+#define AGZ_EAGER_PF24 0    // 1: the register prefetch also with 24 actions per lane (the build the note below is about)
+#endif
 template <int FAM, int NC, int KPL, int WV = 4>
 __global__ __launch_bounds__(64, WV) void k_rollout_eager(const TreePar) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_eager[];
     const TreePar& T = tree_par();
     const StepFlags SF = {T.rollout, T.do_reset, T.do_expand, T.do_select, T.last, T.final_};
     EagerCarry C; uint32_t wcount = 0;
-    // (register prefetch of the item rows in the 3-waves-per-SIMD build up to 16 actions per lane: with 24 the build spills ~20 registers
-    //  with it, and THAT build — and only that one — lost a node-count increment in a rare position after a change that does not alter a
-    //  single value (the record stride written as a rounded-up expression): `scratch/repro_13.py`, the 13x13 cases of
-    //  tests/test_gpu_parity.py test_two_kernel_generation_* pin the shape.  Treated as a code-generation hazard of the spilling build.)
-    rollout_eager_body<FAM, NC, KPL, false, ((WV < 4 && KPL <= 16) ? 2 : 1)>(SF, lds_eager, (int)blockIdx.x, C, nullptr, 0u, wcount);
+    // (register prefetch of the item rows in the 3-waves-per-SIMD build up to 16 actions per lane.  With 24 the build spills 19 vector
+    //  registers, and this compiler placed four of the spill stores — the node count among them — at the head of the block that JOINS
+    //  the expansion's `if (doexp)`, in front of its `s_or_b64 exec`: they ran for the games whose leaf was being expanded only, the item
+    //  loop then reused the registers in every lane, and a game with a terminal leaf got back what an earlier launch had left in its
+    //  scratch slot — one node-count increment lost (round-4 fuzz, Gobang 13x13; scratch/repro_13.py).  tests/test_code_objects.py scans
+    //  every kernel of the library for that placement (scratch/spill_exec_check.py); -DAGZ_EAGER_PF24=1 rebuilds the case.)
+    rollout_eager_body<FAM, NC, KPL, false, ((WV < 4 && (KPL <= 16 || AGZ_EAGER_PF24)) ? 2 : 1)>(SF, lds_eager, (int)blockIdx.x, C, nullptr, 0u, wcount);
 }
 
 }  // namespace agz

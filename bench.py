@@ -94,8 +94,8 @@ def launch_ranks(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20, help="timed generations (the default is what the round driver passes; 20 generations of the headline config take 3 s)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=0, help="BASELINE.json configs[k-1] (1..5); 0 = the headline metric config")
     ap.add_argument("--game", default="gobang", choices=["gobang", "connect4", "hex", "reversi8", "reversi6"])
     ap.add_argument("--games", type=int, default=32768, help="games per GPU (--samples, mainGobang.jl:96)")

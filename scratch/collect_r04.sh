@@ -5,11 +5,11 @@
 #   refilled call of every config
 out=gpurun_out/$1; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-python bench.py --steps 8 --warmup 2 > $out/bench_headline.json 2> $out/bench_headline.err
+python bench.py --steps 20 --warmup 5 > $out/bench_headline.json 2> $out/bench_headline.err
 python bench.py --steps 4 --warmup 1 --lockstep --no-host-delivery > $out/bench_headline_lockstep.json 2> $out/bench_headline_lockstep.err
 python bench.py --steps 2 --warmup 1 --mode exact --no-cpu-baseline --no-host-delivery > $out/bench_headline_exact.json 2> $out/bench_headline_exact.err
-for c in 2 3 4 5; do timeout 900 python bench.py --config $c --steps 4 --warmup 1 > $out/bench_config$c.json 2> $out/bench_config$c.err; done
-timeout 600 rocprofv3 --kernel-trace --stats -d $out/stats -o x --output-format csv -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-host-delivery > $out/bench_under_rocprof.json 2> $out/stats.log
+for c in 2 3 4 5; do timeout 900 python bench.py --config $c --steps 20 --warmup 5 > $out/bench_config$c.json 2> $out/bench_config$c.err; done
+timeout 600 rocprofv3 --kernel-trace --stats -d $out/stats -o x --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-host-delivery > $out/bench_under_rocprof.json 2> $out/stats.log
 for cfg in 0 2 3 4 5; do
   for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_MFMA SQ_WAVES"; do
     n=$(echo $c | cut -c1-12 | tr " " _)

@@ -79,3 +79,34 @@ def test_benchmarked_kernels_do_not_spill_vector_registers():
         assert md[f"k_search_small<0, 2, 24, 128, 4, 1, {kpr}, 4>"]["vgpr_spill_count"] == 0
     assert md["k_search_small<1, 1, 4, 128, 4, 2, 0, 4>"]["vgpr_spill_count"] == 0
     assert md["k_search_small<1, 1, 4, 128, 4, 1, 0, 2>"]["vgpr_spill_count"] == 0
+
+
+@pytest.mark.skipif(not (OBJS and all(os.path.exists(LLVM + t) for t in ("clang-offload-bundler", "llvm-objdump", "llvm-objcopy"))),
+                    reason="needs the built objects and the ROCm LLVM tools")
+def test_no_spill_code_in_front_of_an_exec_restore():
+    """The compiler of this ROCm release can put the spill stores of the block that joins a divergent branch in front of the block's
+    `s_or_b64 exec`: they then cover the lanes of the branch only while the registers are reused by all lanes afterwards (the cause of the
+    round-4 fuzz miss in k_rollout_eager<F_LINE,3,24,3>).  No kernel of the library may contain that placement."""
+    import spill_exec_check as sc
+    hits = []
+    for obj in OBJS:
+        hits += [(os.path.basename(obj), name, hex(a), t) for name, a, t in sc.check(sc.disassemble(obj))]
+    assert not hits, hits[:8]
+
+
+def test_spill_check_recognises_the_faulty_placement():
+    """the scanner itself, on the listing of the faulty build (four spill stores at the head of the joining block) and on a legitimate use
+    of scratch inside a branch"""
+    import spill_exec_check as sc
+    bad = """0000000000001000 <kern>:
+\ts_and_saveexec_b64 s[0:1], vcc   // 000000001000: BE80206A
+\ts_cbranch_execz 3                // 000000001004: BF880003 <kern+0x14>
+\tv_mov_b32_e32 v82, 1             // 000000001008: 7EA40281
+\ts_mov_b32 s26, s24               // 000000001014: BE9A0018
+\tscratch_store_dwordx2 off, v[82:83], off offset:16 // 000000001018: DC740010 007F5200
+\ts_or_b64 exec, exec, s[0:1]      // 000000001020: 87FE007E
+\ts_endpgm                         // 000000001024: BF810000
+"""
+    assert len(sc.check(bad)) == 1
+    good = bad.replace("s_mov_b32 s26, s24               // 000000001014", "v_add_u32_e32 v82, 1, v82         // 000000001014")
+    assert sc.check(good) == []
