@@ -283,8 +283,11 @@ def main():
                 "rollouts_per_s_with_delivery_into_PoolSample_serial": st["rollouts"] / (h1 - h0 + h3 - h2)}
         # (b) pipelined: calls of `gp` generations' worth of games (refilled slots, as in the timed region); the records of call k travel
         # and are unpacked while call k + 1 runs
-        gp = min(gens_cap, 2)
-        cap = gp * G * game.max_plies
+        # (gp generations per call: every call ends with the plies in which its last games run out, ~60 ms for the headline config — four
+        #  generations per call spread them thinner than two did; the buffers are sized by one untimed call, not by the longest game possible)
+        gp = min(gens_cap, 4)
+        step(gp)
+        cap = min(gp * G * game.max_plies, int(eng.num_samples() * 1.2) + 4096)
         dbuf = [torch.empty(cap * rb, dtype=torch.uint8, device="cuda") for _ in range(2)]
         hbuf = [torch.empty(cap * rb, dtype=torch.uint8).pin_memory() for _ in range(2)]
         side = torch.cuda.Stream()
