@@ -1444,7 +1444,7 @@ int agz_get_samples_packed(agz_engine* h, void* dev_out, int64_t capacity_record
     T.game_id_base = h->cfg.game_id_base; T.s_boards = h->s_boards; T.s_policy = h->s_policy; T.s_move = h->s_move;
     T.g_nplies = h->g_nplies; T.g_result = h->g_result; T.g_final = h->g_final; T.order = h->d_order; T.n = n;
     T.out = (uint8_t*)dev_out;
-    hipLaunchKernelGGL(k_pack_samples, dim3((unsigned)n), dim3(64), 0, h->stream, T);
+    hipLaunchKernelGGL(k_pack_samples, dim3((unsigned)std::min<int64_t>((n + 3) / 4, (int64_t)h->cus * 32)), dim3(256), 0, h->stream, T);
     HIPCHK(h, hipGetLastError());
     const hipError_t e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) { h->fail("k_pack_samples failed: %s", hipGetErrorString(e)); return AGZ_ERR_HIP; }

@@ -286,39 +286,43 @@ struct PackPar {
     int64_t n;
     uint8_t* out;
 };
-__global__ void k_pack_samples(const PackPar T) {
-    int64_t s = blockIdx.x;
-    if (s >= T.n) return;
-    uint32_t key = T.order[s];
-    int g = (int)(key >> 8), ply = (int)(key & 0xff);
-    uint8_t* rec = T.out + (size_t)s * T.rec_bytes;
-    const size_t sidx = (size_t)g * T.max_plies + ply;
-    const int player = (ply & 1) ? -1 : 1;                  // Position().player == 1 and play() flips it
-    const int res = T.g_result[g];
-    if (threadIdx.x == 0) {
-        reinterpret_cast<uint32_t*>(rec)[0] = T.game_id_base + (uint32_t)g;
-        reinterpret_cast<int32_t*>(rec)[1] = ply;
-        reinterpret_cast<int32_t*>(rec)[2] = T.s_move[sidx];
-        reinterpret_cast<float*>(rec)[3] = (float)((1 + res * player) / 2.0);      // mainGobang.jl:76
-        reinterpret_cast<int8_t*>(rec)[16] = (int8_t)player;
-        rec[17] = rec[18] = rec[19] = 0;
+// One WAVE per record, a grid-stride loop over the records (a workgroup per record — 25 million of them for a call of 20 generations — was
+// bound by the rate at which workgroups are dispatched: 27.7 ms for 5.1 M records of 592 bytes).
+__global__ __launch_bounds__(256) void k_pack_samples(const PackPar T) {
+    const int lane = (int)(threadIdx.x & 63);
+    const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t s = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); s < T.n; s += nw) {
+        uint32_t key = T.order[s];
+        int g = (int)(key >> 8), ply = (int)(key & 0xff);
+        uint8_t* rec = T.out + (size_t)s * T.rec_bytes;
+        const size_t sidx = (size_t)g * T.max_plies + ply;
+        const int player = (ply & 1) ? -1 : 1;                  // Position().player == 1 and play() flips it
+        const int res = T.g_result[g];
+        if (lane == 0) {
+            reinterpret_cast<uint32_t*>(rec)[0] = T.game_id_base + (uint32_t)g;
+            reinterpret_cast<int32_t*>(rec)[1] = ply;
+            reinterpret_cast<int32_t*>(rec)[2] = T.s_move[sidx];
+            reinterpret_cast<float*>(rec)[3] = (float)((1 + res * player) / 2.0);      // mainGobang.jl:76
+            reinterpret_cast<int8_t*>(rec)[16] = (int8_t)player;
+            rec[17] = rec[18] = rec[19] = 0;
+        }
+        float* pol = reinterpret_cast<float*>(rec + 20);
+        int8_t* st = reinterpret_cast<int8_t*>(rec + 20 + 4 * T.A);
+        int8_t* fs = st + 2 * T.VS;
+        const Pos fin = T.g_final[g];
+        for (int k = lane; k < T.A; k += 64) pol[k] = T.s_policy[sidx * T.A + k];
+        for (int j = lane; j < 2 * T.VS; j += 64) {
+            int b = j < T.VS ? j : j - T.VS;
+            uint64_t w = T.s_boards[sidx * 6 + (j < T.VS ? 0 : 3) + (b >> 6)];
+            st[j] = (int8_t)((w >> (b & 63)) & 1);
+        }
+        for (int j = lane; j < T.FS; j += 64) {
+            int bit = (int)((fin.p[j >> 6] >> (j & 63)) & 1);
+            int v = bit ? fin.player : -fin.player;                                    // decode :464-474
+            fs[j] = (int8_t)(v * player);                                              // fstate * player :77
+        }
+        for (int j = 20 + 4 * T.A + 2 * T.VS + T.FS + lane; j < T.rec_bytes; j += 64) rec[j] = 0;
     }
-    float* pol = reinterpret_cast<float*>(rec + 20);
-    int8_t* st = reinterpret_cast<int8_t*>(rec + 20 + 4 * T.A);
-    int8_t* fs = st + 2 * T.VS;
-    const Pos fin = T.g_final[g];
-    for (int k = threadIdx.x; k < T.A; k += blockDim.x) pol[k] = T.s_policy[sidx * T.A + k];
-    for (int j = threadIdx.x; j < 2 * T.VS; j += blockDim.x) {
-        int b = j < T.VS ? j : j - T.VS;
-        uint64_t w = T.s_boards[sidx * 6 + (j < T.VS ? 0 : 3) + (b >> 6)];
-        st[j] = (int8_t)((w >> (b & 63)) & 1);
-    }
-    for (int j = threadIdx.x; j < T.FS; j += blockDim.x) {
-        int bit = (int)((fin.p[j >> 6] >> (j & 63)) & 1);
-        int v = bit ? fin.player : -fin.player;                                    // decode :464-474
-        fs[j] = (int8_t)(v * player);                                              // fstate * player :77
-    }
-    for (int j = 20 + 4 * T.A + 2 * T.VS + T.FS + threadIdx.x; j < T.rec_bytes; j += blockDim.x) rec[j] = 0;
 }
 
 // ---- known-answer test of the game plugins ON THE DEVICE (agz_perft): one level of a breadth-first perft ------------------------

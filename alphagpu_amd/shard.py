@@ -93,8 +93,9 @@ class PendingGather:
 class RecordExchange:
     """The exchange step of a generation as one asynchronous all-gather, issued without reading anything back.
 
-    Every rank sends `HEADER + sent * rec_bytes` bytes where `sent` is a record count ALL ranks agree on without talking to
-    each other: the capacity (games x max plies) for the first generation, afterwards the largest count any rank has produced
+    Every rank sends `HEADER + sent * rec_bytes` bytes where `sent` is a record count ALL ranks agree on — for the first exchange
+    of a run the largest count of that exchange (one blocking gather of the counts), from then on without talking to each other:
+    the largest count any rank has produced
     in a generation whose collective has been waited for, plus a slack, rounded up — derived only from gathered counts, which
     are identical on every rank, and updated inside wait(), which every rank calls in the same order.  A rank that produces
     more than `sent` records is completed by a second (blocking) collective inside wait().  The record count of the rank
@@ -130,7 +131,15 @@ class RecordExchange:
         if n_local > self.cap:
             raise ValueError(f"{n_local} records exceed the exchange capacity {self.cap}")
         buf[:8].view(torch.int64).fill_(int(n_local))          # (a fill with a scalar argument: nothing is read back, no host buffer)
-        sent = self.agreed_count(units)
+        if self.seen_max is None:
+            # the FIRST exchange of a run has no count to predict from: the ranks gather their counts (the one blocking read of the run)
+            # and send exactly the largest — not the capacity, which for calls of several generations is W x 12 GB of gathered records
+            cnt = torch.tensor([int(n_local)], dtype=torch.int64, device=buf.device)
+            counts = torch.zeros(world, dtype=torch.int64, device=buf.device)
+            dist.all_gather_into_tensor(counts, cnt, group=self.group)
+            sent = min(self.cap, (int(counts.max()) + 255) & ~255)
+        else:
+            sent = self.agreed_count(units)
         nbytes = HEADER + sent * self.rb
         out = torch.empty(world, nbytes, dtype=torch.uint8, device=buf.device)
         work = dist.all_gather_into_tensor(out.view(-1), buf[:nbytes], group=self.group, async_op=True)

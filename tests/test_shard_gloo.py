@@ -42,7 +42,7 @@ def _worker(rank, world, port, q):
     merged = shard.merge_poolsample_order(parts)
     # the pipelined form (what bench.py runs): one asynchronous collective per generation, the count in the buffer's header, no
     # read-back when it is issued.  Four "generations", each waited for after the next one was issued (double buffering): the first two
-    # are sent at full capacity, the next two with the count agreed from the gathered counts of the first; the last outgrows that
+    # are sent with the largest count of their own exchange (gathered first: nothing to predict from yet), the next two with the count agreed from the gathered counts of the first; the last outgrows that
     # prediction on rank 1 only and is completed by the second (blocking) step inside wait() -- every one must deliver exactly the records each rank packed.
     rb = game.rec_bytes
     ex = shard.RecordExchange(40 * game.max_plies, rb, slack=0.0)
@@ -88,10 +88,11 @@ def test_two_rank_allgather_equals_unsharded_run():
     assert all(r["ok"] for r in res)
     r0 = [r for r in res if "merged" in r][0]
     merged = r0["merged"]
-    # generations 0 and 1 travel at full capacity (nothing has been waited for when they are issued), 2 and 3 with the count
-    # agreed from the gathered counts; only generation 3 needs the second step
+    # generations 0 and 1 are issued before any collective has been waited for: the ranks gather their counts first (the blocking step of
+    # a run's first exchanges) and send the largest, not the capacity; 2 and 3 travel with the count agreed from the gathered counts
+    # without any read-back; only generation 3 needs the second step
     cap, sent = r0["cap"], r0["sent"]
-    assert sent[0] == cap and sent[1] == cap and sent[2] < cap and sent[3] == sent[2] and r0["tails"] == 1, (sent, cap, r0["tails"])
+    assert 0 < sent[0] < cap and 0 < sent[1] < cap and sent[2] < cap and sent[3] == sent[2] and r0["tails"] == 1, (sent, cap, r0["tails"])
     og = O.make_game("gobang", 3, 3)
     ref = O.selfplay(og, O.OracleNet(og, 16, 1), 12, 8, 1.5, 25, 11, 0)
     assert len(merged["ply"]) == ref["n"]
