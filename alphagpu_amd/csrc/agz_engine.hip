@@ -460,7 +460,7 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     T.slot_ply = h->slot_ply;
     h->rd_rec_bytes = rec_bytes; h->rd_off_rk = 16 + A2 * 4; h->rd_off_el = T.off_q; h->rd_off_vis = T.off_vis;
     FA_(hipMemsetAsync(h->wl_n, 0, wl_blocks * 4, h->stream)); hipMemsetAsync(h->sp, 0, Lm * 4, h->stream);
-#ifdef AGZ_STAMPS
+#if defined(AGZ_STAMPS) || defined(AGZ_BIGSTAMPS)
     { unsigned long long* d = nullptr; hipMalloc((void**)&d, (size_t)65536 * 16 * 8); hipMemset(d, 0, (size_t)65536 * 16 * 8); T.dbg = d; }
 #endif
 #undef FA_
@@ -486,7 +486,7 @@ int agz_get_info(const agz_engine* h, agz_game_info* out) {
     *out = h->info; return AGZ_OK;
 }
 void* agz_stream(agz_engine* h) { return h ? (void*)h->stream : nullptr; }
-#ifdef AGZ_STAMPS
+#if defined(AGZ_STAMPS) || defined(AGZ_BIGSTAMPS)
 // out[0..15]: the tree step's phases (blocks below 32768), out[16..31]: the network body's (blocks from 32768 on)
 extern "C" int agz_debug_stamps(agz_engine* h, unsigned long long* out, int reset) {
     hipStreamSynchronize(h->stream);

@@ -51,7 +51,13 @@ __global__ __launch_bounds__(NB_THREADS, 2 * WG) void k_search_big(const BigSear
     constexpr int PF_ = WG < 2 ? 2 : 1;
     constexpr bool SPLIT = WG < 2 && TW == 4;
     const int V_ = S.V;
+#ifdef AGZ_BIGSTAMPS
+    unsigned long long st_tree = 0, st_wait = 0, st_net = 0, st_join = 0;   // cycles of wave 0: tree step, barrier in front of the pass, network pass, barrier behind it
+#endif
     for (int k = 0; k <= V_; ++k) {
+#ifdef AGZ_BIGSTAMPS
+        const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+#endif
         int bx = (int)blockIdx.x;
         asm volatile("" : "+s"(bx));                              // (see k_search_small)
         const BigSearchPar& S = par();
@@ -75,17 +81,35 @@ __global__ __launch_bounds__(NB_THREADS, 2 * WG) void k_search_big(const BigSear
                 rollout_eager_body<FAM, NC, KPL, true, PF_, false, ROLE_EXPAND, KPR>(SS, own_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
                                                                              nullptr, 0, 0, xch);
             }
+#ifdef AGZ_BIGSTAMPS
+            const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+#endif
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __syncthreads();                                      // the planes of the 32 leaves are written
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#ifdef AGZ_BIGSTAMPS
+            const unsigned long long c2 = __builtin_amdgcn_s_memtime();
+#endif
             const BigSearchPar& S = par();
             const int gpw = S.T.gpw, L = S.T.L;
             mlp_big_body<H, TW / 2, (WG < 2)>(S.B, lds_bigs, [&](int row) { return (row & 7) < gpw ? (bx * TW + (row >> 3)) * gpw + (row & 7) : L; });
+#ifdef AGZ_BIGSTAMPS
+            const unsigned long long c3 = __builtin_amdgcn_s_memtime();
+#endif
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __syncthreads();                                      // logits and values are visible to the tree waves
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#ifdef AGZ_BIGSTAMPS
+            st_tree += c1 - c0; st_wait += c2 - c1; st_net += c3 - c2; st_join += __builtin_amdgcn_s_memtime() - c3;
+#endif
         }
     }
+#ifdef AGZ_BIGSTAMPS
+    if (threadIdx.x == 0 && S.T.dbg) {
+        unsigned long long* d = S.T.dbg + (size_t)(32768 + (blockIdx.x & 32767)) * 16;
+        d[0] += st_tree; d[1] += st_wait; d[2] += st_net; d[3] += st_join; d[4] += 1;
+    }
+#endif
 }
 
 #define AGZ_BIG_VARIANTS(F, C, K, KW)                                        \
