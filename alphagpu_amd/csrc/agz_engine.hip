@@ -147,6 +147,11 @@ struct agz_engine {
     small_fn k_small8 = nullptr; int tw8 = 0;
     big_fn k_big8 = nullptr, k_big8x = nullptr; int big8 = 0;   // k_big8x: two such workgroups per CU (128 registers) above 64 games per CU   // k_search_big with 64-game workgroups (eight tree waves, one workgroup per CU) above 32 games per CU: AGZ_BIG8
     int legal_bound = 1 << 30, tree_kpr = 0;
+    // chained self-play calls (agz_selfplay_chain): the slots keep the games a call leaves in flight; chain_k0 = games handed to the earlier
+    // calls of the chain (= the number of the next call's first game), chain_started = games started so far, chain_early = games of the
+    // next call that have already finished, chain_L = slots in flight when the last call returned
+    bool chain_live = false; unsigned long long chain_k0 = 0, chain_started = 0, chain_early = 0; int chain_L = 0;
+    uint32_t sp_ring0 = 0, sp_k0 = 0;      // where the games of the last call sit in the per-game sample arrays / in the chain
     bool no_compact = false;            // AGZ_NO_COMPACT (A/B, tests)
     advance_fn k_spread = nullptr;      // policy_final rows from rank order back to action order after such a search
     small_fn k_small4[3] = {nullptr, nullptr, nullptr};   // the same with 32 games per workgroup, register budgets for 2 / 3 / 4 workgroups per SIMD set
@@ -333,8 +338,8 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     if (hipEventCreateWithFlags(&h->ev_adv, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) h->ev_adv = nullptr;
     if (hipEventCreate(&h->ev_ply0) != hipSuccess || hipEventCreate(&h->ev_ply1) != hipSuccess ||
         hipHostMalloc((void**)&h->hcount, 4, 0) != hipSuccess) { h->fail("cannot create the ply-loop events / pinned counter"); return bail(AGZ_ERR_HIP); }
-    if (!getenv("AGZ_NO_HOST_FLAG") && hipHostMalloc((void**)&h->hflag, 16, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
-        h->hflag[0] = 0; h->hflag[1] = 0;
+    if (!getenv("AGZ_NO_HOST_FLAG") && hipHostMalloc((void**)&h->hflag, 32, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+        h->hflag[0] = 0; h->hflag[1] = 0; h->hflag[2] = 0; h->hflag[3] = 0;
         if (hipHostGetDevicePointer((void**)&h->hflag_dev, h->hflag, 0) != hipSuccess) { hipHostFree(h->hflag); h->hflag = nullptr; h->hflag_dev = nullptr; }
     }
     hipError_t fa = hipSuccess;                                     // first failure of the attribute / memset calls below
@@ -430,7 +435,7 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     A_(dmalloc(&h->logits, Lm * h->LGS));
     A_(dmalloc(&h->prior_eval, Lm * P.A + 64)); A_(dmalloc(&h->v_eval, Lm)); A_(dmalloc(&h->policy_final, Lm * P.A));
     A_(dmalloc(&h->newpos, Lm)); A_(dmalloc(&h->alive, Lm)); A_(dmalloc(&h->newslot, Lm)); A_(dmalloc(&h->d_count, 4));
-    A_(dmalloc(&h->d_stats, 8)); A_(dmalloc(&h->d_acc, 2));
+    A_(dmalloc(&h->d_stats, 16)); A_(dmalloc(&h->d_acc, 2));
     FA_(hipMemset(h->d_acc, 0, 16));
     A_(dmalloc(&h->scratch_f, Lm * (size_t)((P.A > 2 * P.VS) ? P.A : 2 * P.VS)));
     h->sample_games = cfg->sample_capacity_games > 0 ? cfg->sample_capacity_games : h->Lmax;
@@ -478,6 +483,8 @@ int agz_get_search_form(agz_engine* h, char* tree_kernel, char* nn_kernel, int c
 }
 int agz_set_seed(agz_engine* h, uint64_t seed) {
     if (!h) return AGZ_ERR_ARG;
+    if (h->chain_live && h->chain_L > 0 && seed != h->cfg.seed) {   // (the games in flight draw from the key they started with)
+        h->fail("agz_set_seed: %d games of a chain of self-play calls are in flight (end the chain with next_ngames = 0 first)", h->chain_L); return AGZ_ERR_STATE; }
     h->cfg.seed = seed; h->tp.seed = seed;
     return AGZ_OK;
 }
@@ -663,7 +670,7 @@ int agz_set_roots(agz_engine* h, const void* positions, int format, const uint32
         HIPCHK(h, hipMemcpy2D(h->states, (size_t)h->V * sizeof(Pos), roots.data(), sizeof(Pos), sizeof(Pos), (size_t)L, hipMemcpyHostToDevice));
         HIPCHK(h, hipMemcpy(h->game_id, ids.data(), (size_t)L * 4, hipMemcpyHostToDevice));
     }
-    h->L = L; h->need_reset = true;
+    h->L = L; h->need_reset = true; h->chain_live = false;     // (new roots end a chain of self-play calls)
     return AGZ_OK;
 }
 
@@ -1270,32 +1277,75 @@ static void fill_plypar(agz_engine* h, PlyPar& T, int ply, int tau_plies, bool a
     T.g_final = h->g_final; T.stats = h->d_stats;
 }
 
+// next_games < 0: a call of its own (agz_selfplay, agz_duel).  next_games >= 0: a call of a CHAIN (agz_selfplay_chain): game ids run on from
+// the previous call of the chain, the call returns when ITS ngames games have finished, and while they run out it starts up to next_games
+// games of the next call in the slots that come free — they stay in flight when the call returns and the next call goes on with them, so
+// only the last call of a chain (next_games = 0) ends on a batch that runs out.
 static int run_games(agz_engine* h, int ngames, int V, float cpuct, int tau_plies, int training, int duel_first, bool duel,
-                     agz_selfplay_stats* st) {
+                     agz_selfplay_stats* st, int next_games = -1) {
     int rc = check_search_args(h, V); if (rc) return rc;
+    const bool chain = next_games >= 0;
+    const bool cont = chain && h->chain_live;                                   // the chain goes on (possibly with games in flight)
+    const unsigned long long k0 = cont ? h->chain_k0 : 0ull;                    // this call's games: k0 .. k0 + ngames - 1 of the chain
+    const unsigned long long pool_end = k0 + (unsigned long long)ngames + (unsigned long long)(chain ? next_games : 0);   // games that may be started
     // more games than slots (self-play only): the first Lmax games start together, and a slot whose game has ended takes the next game
     // that has not started yet (k_advance) until all ngames have been started — the batch stays full, every search of the generation
     // runs at the size the chip is filled by, and each game's samples are the ones a lock-step run over ngames slots gives (results are
     // keyed by game id and the game's own ply)
-    const int slots = ngames < h->Lmax ? ngames : h->Lmax;
+    const long long want = chain ? (long long)ngames + next_games : (long long)ngames;
+    const int slots = want < h->Lmax ? (int)want : h->Lmax;
     if (ngames < 1 || (duel && ngames > h->Lmax)) { h->fail("ngames=%d outside [1,%d]", ngames, h->Lmax); return AGZ_ERR_ARG; }
     if (ngames > slots && ngames > h->sample_games) { h->fail("ngames=%d exceeds the sample capacity of the engine (%d games: agz_config.sample_capacity_games)", ngames, h->sample_games); return AGZ_ERR_ARG; }
+    if (chain && want > h->sample_games) { h->fail("agz_selfplay_chain: ngames + next_ngames = %lld exceeds the sample capacity of the engine (%d games: agz_config.sample_capacity_games)", want, h->sample_games); return AGZ_ERR_ARG; }
+    if (chain && pool_end + (unsigned long long)h->cfg.game_id_base > 0xffffffffull) { h->fail("agz_selfplay_chain: game ids exhausted"); return AGZ_ERR_ARG; }
     auto t0 = std::chrono::steady_clock::now();
-    rc = agz_set_roots(h, nullptr, 0, nullptr, slots); if (rc) return rc;       // Position() for every game (:479)
-    HIPCHK(h, hipMemsetAsync(h->d_stats, 0, 8 * sizeof(unsigned long long), h->stream));
-    HIPCHK(h, hipMemsetAsync(h->g_nplies, 0, (size_t)h->sample_games * 4, h->stream));
-    HIPCHK(h, hipMemsetAsync(h->slot_ply, 0, (size_t)slots * 4, h->stream));
-    {   const unsigned long long started0 = (unsigned long long)slots;
-        HIPCHK(h, hipMemcpyAsync(h->d_stats + 6, &started0, 8, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream)); }
+    unsigned long long started = 0, finished = 0;
+    if (!cont) {
+        rc = agz_set_roots(h, nullptr, 0, nullptr, slots); if (rc) return rc;   // Position() for every game (:479)
+        HIPCHK(h, hipMemsetAsync(h->d_stats, 0, 16 * sizeof(unsigned long long), h->stream));
+        HIPCHK(h, hipMemsetAsync(h->g_nplies, 0, (size_t)h->sample_games * 4, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->slot_ply, 0, (size_t)slots * 4, h->stream));
+        started = (unsigned long long)slots;
+        HIPCHK(h, hipMemcpyAsync(h->d_stats + 6, &started, 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    } else {
+        // the games the last call left in flight go on in their slots; per-call counters start over; the games of this call that finished
+        // early (during the last call) are already counted; the ring entries of the games that may start now are cleared
+        HIPCHK(h, hipSetDevice(h->cfg.device));
+        h->L = h->chain_L; h->need_reset = true;
+        started = h->chain_started; finished = h->chain_early;
+        const unsigned long long z[10] = {0, 0, 0, 0, 0, 0, started, 0, finished, 0};
+        HIPCHK(h, hipMemcpyAsync(h->d_stats, z, sizeof z, hipMemcpyHostToDevice, h->stream));
+        const unsigned long long cap = (unsigned long long)h->sample_games;
+        for (unsigned long long a = started; a < pool_end;) {                    // [started, pool_end) in ring order, piece by piece
+            const unsigned long long r = a % cap, n = std::min(pool_end - a, cap - r);
+            HIPCHK(h, hipMemsetAsync(h->g_nplies + r, 0, (size_t)n * 4, h->stream));
+            a += n;
+        }
+        // slots without a game (the last call's pool ran dry before its games were over) take new games right away
+        const int fill = (int)std::min<unsigned long long>((unsigned long long)(slots > h->L ? slots - h->L : 0), pool_end > started ? pool_end - started : 0ull);
+        if (fill > 0) {
+            std::vector<Pos> roots((size_t)fill, start_pos(h->G));
+            std::vector<uint32_t> ids((size_t)fill), zero((size_t)fill, 0u);
+            for (int i = 0; i < fill; ++i) ids[i] = h->cfg.game_id_base + (uint32_t)(started + (unsigned long long)i);
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            HIPCHK(h, hipMemcpy2D(h->states + (size_t)h->L * h->V, (size_t)h->V * sizeof(Pos), roots.data(), sizeof(Pos), sizeof(Pos), (size_t)fill, hipMemcpyHostToDevice));
+            HIPCHK(h, hipMemcpy(h->game_id + h->L, ids.data(), (size_t)fill * 4, hipMemcpyHostToDevice));
+            HIPCHK(h, hipMemcpy(h->slot_ply + h->L, zero.data(), (size_t)fill * 4, hipMemcpyHostToDevice));
+            h->L += fill; started += (unsigned long long)fill;
+            HIPCHK(h, hipMemcpy(h->d_stats + 6, &started, 8, hipMemcpyHostToDevice));
+        }
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    h->chain_live = false;                                                      // (set again when a chained call returns in good order)
     h->sp_games = ngames; h->sp_nsamples = 0; h->sp_maxplies = 0;
+    h->sp_k0 = (uint32_t)k0; h->sp_ring0 = chain ? (uint32_t)(k0 % (unsigned long long)h->sample_games) : 0u;
     double search_ms = 0; int64_t rollouts = 0; int ply = 0;
     uint32_t* const hcount = h->hcount;
-    const bool refill = ngames > slots;
+    const bool refill = chain ? true : ngames > slots;
     // the youngest game alive bounds every root's stone count from below: all games have started (and the youngest was at ply 0 in round
     // first_all) -> every root of round r holds at least r - first_all stones
-    int first_all = refill ? -1 : 0;                                            // round in which the last started game is at ply 0 (-1: games still start)
-    unsigned long long started = (unsigned long long)slots;
+    int first_all = (refill && started < pool_end) ? -1 : (cont ? -2 : 0);      // round in which the last started game is at ply 0 (-1: games still start; -2: unknown — a chain's games of unknown age, no bound)
     bool fold_pending = false;
     // Run-ahead: while games still start, a ply cannot change the number of games in flight as long as more games are waiting than
     // slots exist (every game that ends is replaced) — the host then queues the next ply WITHOUT waiting for this one's count (up to 8
@@ -1329,15 +1379,16 @@ static int run_games(agz_engine* h, int ngames, int V, float cpuct, int tau_plie
             any_fold = true;
         }
         PlyPar T; fill_plypar(h, T, ply, tau_plies, duel);
-        T.refill_total = refill ? (uint32_t)ngames : 0u;
+        T.refill_total = refill ? (uint32_t)pool_end : 0u;
+        T.ring = chain ? 1 : 0; T.k_cur_end = (uint32_t)(k0 + (unsigned long long)ngames);
         hipLaunchKernelGGL(h->k_adv, dim3((unsigned)((h->L + 3) / 4)), dim3(256), 0, h->stream, T);          // :513-549
         const bool sleep = h->ply_sleep && h->ev_adv && hipEventRecord(h->ev_adv, h->stream) == hipSuccess;
         const uint32_t seq = ++h->ply_seq ? h->ply_seq : ++h->ply_seq;        // (never 0)
         hipLaunchKernelGGL(k_scan_alive, dim3(1), dim3(1024), 0, h->stream, (const uint32_t*)h->alive, h->newslot, h->L, h->d_count, h->hflag_dev, seq,
-                           (const unsigned long long*)(h->d_stats + 6), h->d_stats + 7);
+                           (const unsigned long long*)(h->d_stats + 6), h->d_stats + 7, (const unsigned long long*)(h->d_stats + 8));
         hipLaunchKernelGGL(k_compact, dim3((unsigned)((h->L + 255) / 256)), dim3(256), 0, h->stream, T, (const uint32_t*)h->newslot,
                            (const uint32_t*)h->game_id, h->game_id2, h->slot_ply2);           // :550-561
-        if (refill && ahead < 8 && started_ub + 2ull * (unsigned long long)h->L <= (unsigned long long)ngames) {
+        if (refill && ahead < 8 && started_ub + 2ull * (unsigned long long)h->L <= pool_end) {
             // this ply and the next cannot exhaust the games that wait: the batch stays as it is — queue the next ply now
             started_ub += (unsigned long long)h->L; ++ahead;
             { uint32_t* s = h->game_id; h->game_id = h->game_id2; h->game_id2 = s; h->tp.game_id = h->game_id; }
@@ -1355,7 +1406,7 @@ static int run_games(agz_engine* h, int ngames, int V, float cpuct, int tau_plie
             if (sleep) (void)hipEventSynchronize(h->ev_adv);
             for (uint32_t spin = 0;; ++spin) {
                 const unsigned long long w = __atomic_load_n(f, __ATOMIC_ACQUIRE);
-                if ((uint32_t)(w >> 32) == seq) { *hcount = (uint32_t)w; started = __atomic_load_n(f + 1, __ATOMIC_RELAXED); have = true; break; }
+                if ((uint32_t)(w >> 32) == seq) { *hcount = (uint32_t)w; started = __atomic_load_n(f + 1, __ATOMIC_RELAXED); finished = __atomic_load_n(f + 2, __ATOMIC_RELAXED); have = true; break; }
 #if defined(__x86_64__) || defined(__i386__)
                 __builtin_ia32_pause();                                            // (a polite spin: the core is shared with the host's other threads)
 #else
@@ -1371,16 +1422,21 @@ static int run_games(agz_engine* h, int ngames, int V, float cpuct, int tau_plie
         if (!have) {
             if (hipMemcpyAsync(hcount, h->d_count, 4, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
                 hipMemcpyAsync(&started, h->d_stats + 6, 8, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+                hipMemcpyAsync(&finished, h->d_stats + 8, 8, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
                 hipStreamSynchronize(h->stream) != hipSuccess) { h->fail("ply loop failed: %s", hipGetErrorString(hipGetLastError())); rc = AGZ_ERR_HIP; break; }
         }
         for (size_t i = 0; i < tused; ++i) { float ms = 0; if (hipEventElapsedTime(&ms, tpool[i].first, tpool[i].second) == hipSuccess) search_ms += ms; }
+        // (k_advance draws a number for every slot that comes free, also when the pool has run dry: the counter overshoots the pool then,
+        //  and the next call of a chain sets it back to what was really started)
+        if (started > pool_end) started = pool_end;
         tused = 0; ahead = 0; started_ub = started;
         if (any_fold) { h->cnt_live = false; drain_events(h); any_fold = false; }
         { uint32_t* s = h->game_id; h->game_id = h->game_id2; h->game_id2 = s; h->tp.game_id = h->game_id; }
         { uint32_t* s = h->slot_ply; h->slot_ply = h->slot_ply2; h->slot_ply2 = s; h->tp.slot_ply = h->slot_ply; }
         h->L = (int)*hcount;
         ++ply;
-        if (first_all < 0 && started >= (unsigned long long)ngames) first_all = ply;   // the last game was started in this round's k_advance: ply 0 in the next search
+        if (first_all == -1 && started >= pool_end) first_all = ply;          // the last game was started in this round's k_advance: ply 0 in the next search
+        if (chain && finished >= (unsigned long long)ngames) break;            // this call's games are all over; what is in flight belongs to the next call
         if (ply > 255 && !refill) { h->fail("game exceeded 255 plies"); rc = AGZ_ERR_STATE; break; }
         if (ply > 255 * ((ngames + slots - 1) / slots + 1)) { h->fail("ply loop does not end"); rc = AGZ_ERR_STATE; break; }
     }
@@ -1388,13 +1444,27 @@ static int run_games(agz_engine* h, int ngames, int V, float cpuct, int tau_plie
     if (fold_pending) hipStreamWaitEvent(h->stream, h->ev_fold, 0);
     for (size_t i = 1; i < tpool.size(); ++i) { hipEventDestroy(tpool[i].first); hipEventDestroy(tpool[i].second); }
     if (rc) return rc;
-    unsigned long long hs[8];
+    unsigned long long hs[16];
     HIPCHK(h, hipMemcpy(hs, h->d_stats, sizeof hs, hipMemcpyDeviceToHost));
     {   // nsamples = sum of plies per game; kept (with the longest game) for agz_get_samples_packed
         std::vector<int32_t> np((size_t)(ngames < h->sample_games ? ngames : h->sample_games));
-        HIPCHK(h, hipMemcpy(np.data(), h->g_nplies, np.size() * 4, hipMemcpyDeviceToHost));
+        std::vector<int8_t> res(chain ? np.size() : 0);
+        const size_t cap = (size_t)h->sample_games, r0 = (size_t)h->sp_ring0;
+        for (size_t a = 0; a < np.size();) {                                    // the call's games in ring order (one piece unless the ring wraps)
+            const size_t r = (r0 + a) % cap, n = std::min(np.size() - a, cap - r);
+            HIPCHK(h, hipMemcpy(np.data() + a, h->g_nplies + r, n * 4, hipMemcpyDeviceToHost));
+            if (chain) HIPCHK(h, hipMemcpy(res.data() + a, h->g_result + r, n, hipMemcpyDeviceToHost));
+            a += n;
+        }
         int64_t n = 0; int mx = 0; for (int32_t x : np) { n += x; mx = x > mx ? x : mx; }
         h->sp_nsamples = n; h->sp_maxplies = mx;
+        if (chain) {
+            // the device counters of a chained call mix this call's games with the early ones of the next: W / D / L and the plies of
+            // THIS call's games come from their own entries (mcts_gpu.jl:535: tot_length += round, the ply of the last move)
+            hs[0] = hs[1] = hs[2] = hs[3] = 0;
+            for (size_t i = 0; i < np.size(); ++i) { hs[res[i] == 1 ? 0 : (res[i] == 0 ? 1 : 2)] += 1; hs[3] += (unsigned long long)(np[i] > 0 ? np[i] - 1 : 0); }
+            h->chain_live = true; h->chain_k0 = k0 + (unsigned long long)ngames; h->chain_started = started; h->chain_early = hs[9]; h->chain_L = h->L;
+        }
     }
     if (st) {
         memset(st, 0, sizeof *st);
@@ -1413,6 +1483,13 @@ int agz_selfplay(agz_engine* h, int ngames, int V, float cpuct, int tau_plies, a
     HIPCHK(h, hipSetDevice(h->cfg.device));
     if (!h->net[0].loaded) { h->fail("no network loaded"); return AGZ_ERR_STATE; }
     return run_games(h, ngames, V, cpuct, tau_plies, 1, 0, false, stats);
+}
+int agz_selfplay_chain(agz_engine* h, int ngames, int next_ngames, int V, float cpuct, int tau_plies, agz_selfplay_stats* stats) {
+    if (!h) return AGZ_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (!h->net[0].loaded) { h->fail("no network loaded"); return AGZ_ERR_STATE; }
+    if (next_ngames < 0) { h->fail("agz_selfplay_chain: next_ngames=%d", next_ngames); return AGZ_ERR_ARG; }
+    return run_games(h, ngames, V, cpuct, tau_plies, 1, 0, false, stats, next_ngames);
 }
 int agz_duel(agz_engine* h, int ngames, int V, float cpuct, int tau_plies, int first, int64_t wdl[3]) {
     if (!h || !wdl) return AGZ_ERR_ARG;
@@ -1438,11 +1515,12 @@ int agz_get_samples_packed(agz_engine* h, void* dev_out, int64_t capacity_record
     if (n == 0) return AGZ_OK;
     const int G = h->sp_games < h->sample_games ? h->sp_games : h->sample_games;
     hipLaunchKernelGGL(k_sample_order, dim3((unsigned)h->sp_maxplies), dim3(1024), 0, h->stream, (const int32_t*)h->g_nplies, G, h->d_order,
-                       (unsigned long long*)nullptr);
+                       (unsigned long long*)nullptr, h->sp_ring0, (uint32_t)h->sample_games);
     PackPar T;
     T.A = h->G.A; T.VS = h->G.VS; T.FS = h->G.FS; T.max_plies = h->G.max_plies; T.rec_bytes = h->info.rec_bytes;
     T.game_id_base = h->cfg.game_id_base; T.s_boards = h->s_boards; T.s_policy = h->s_policy; T.s_move = h->s_move;
     T.g_nplies = h->g_nplies; T.g_result = h->g_result; T.g_final = h->g_final; T.order = h->d_order; T.n = n;
+    T.ring0 = h->sp_ring0; T.cap = (uint32_t)h->sample_games; T.k0 = h->sp_k0;
     T.out = (uint8_t*)dev_out;
     hipLaunchKernelGGL(k_pack_samples, dim3((unsigned)std::min<int64_t>((n + 3) / 4, (int64_t)h->cus * 32)), dim3(256), 0, h->stream, T);
     HIPCHK(h, hipGetLastError());

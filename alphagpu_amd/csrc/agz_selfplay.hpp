@@ -20,6 +20,10 @@ struct PlyPar {
     // (0: no refill).  Results are keyed by game id and ply, never by slot or by the round a game happens to start in.
     uint32_t refill_total;
     unsigned long long* next_game;   // games started so far (device counter)
+    // chained calls (agz_selfplay_chain): game ids run on from call to call (game k of the chain has id game_id_base + k), the sample store
+    // is a RING over k (k mod sample_games), and a call may start games of the NEXT call in slots that would otherwise idle.  k_cur_end:
+    // the games k < k_cur_end belong to the call that is running (a finished one counts in stats[8], a later one in stats[9]).
+    int32_t ring; uint32_t k_cur_end;
     const uint32_t* identity; // k_compact: k_scan_alive's count words ([1] != 0: every slot keeps its place)
     const float* policy_final;// [L][A]
     // per-slot scratch
@@ -46,12 +50,13 @@ __global__ __launch_bounds__(256) void k_advance(const PlyPar T) {
     if (slot >= T.L) return;
     const int A = P.A;
     const uint32_t gid = ufirst(T.game_id[slot]);
-    const int g = (int)(gid - T.game_id_base);
+    const uint32_t kg = gid - T.game_id_base;                      // the game's number in the call (in the chain of calls)
+    const int g = T.ring ? (int)(kg % (uint32_t)T.sample_games) : (int)kg;
     WPos<NC> root = load_pos<NC>(T.states + (size_t)slot * T.V);
     const int ply = (int)ufirst(T.slot_ply[slot]);                 // this game's round (:484, :556)
     float pol[NR];
     for (int r = 0; r < NR; ++r) { int k = 64 * r + lane; pol[r] = k < A ? T.policy_final[(size_t)slot * A + k] : 0.0f; }
-    const bool in_range = g >= 0 && g < T.sample_games;
+    const bool in_range = T.ring || (g >= 0 && g < T.sample_games);
     const bool keep = in_range && ply < T.max_plies;
     const int np_end = ply + 1 < T.max_plies ? ply + 1 : T.max_plies;
     if (keep) {                                                     // push_buffer: root planes (as boards) + policy
@@ -104,7 +109,7 @@ __global__ __launch_bounds__(256) void k_advance(const PlyPar T) {
         fault = !ok;
     }
     if (fault) {
-        if (lane == 0) { atomicAdd(&T.stats[4], 1ull); atomicAdd(&T.stats[7], 1ull); T.alive[slot] = 0; if (keep) T.s_move[(size_t)g * T.max_plies + ply] = (int16_t)c; if (in_range) { T.g_nplies[g] = np_end; T.g_result[g] = 0; T.g_final[g] = pack(root); } }
+        if (lane == 0) { atomicAdd(&T.stats[4], 1ull); atomicAdd(&T.stats[7], 1ull); if (T.ring) atomicAdd(&T.stats[kg < T.k_cur_end ? 8 : 9], 1ull); T.alive[slot] = 0; if (keep) T.s_move[(size_t)g * T.max_plies + ply] = (int16_t)c; if (in_range) { T.g_nplies[g] = np_end; T.g_result[g] = 0; T.g_final[g] = pack(root); } }
         return;
     }
     WPos<NC> np = G::play(P, root, c);
@@ -117,6 +122,7 @@ __global__ __launch_bounds__(256) void k_advance(const PlyPar T) {
             if (in_range) { T.g_nplies[g] = np_end; T.g_result[g] = (int8_t)res; T.g_final[g] = pack(np); }
             atomicAdd(&T.stats[res == 1 ? 0 : (res == 0 ? 1 : 2)], 1ull);     // :541-547
             atomicAdd(&T.stats[3], (unsigned long long)ply);                   // tot_length += round (:535)
+            if (T.ring) atomicAdd(&T.stats[kg < T.k_cur_end ? 8 : 9], 1ull);
             if (T.refill_total) {                                              // the slot takes the next game that has not started yet
                 const unsigned long long k = atomicAdd(T.next_game, 1ull);
                 if (k < (unsigned long long)T.refill_total) {
@@ -180,7 +186,7 @@ __global__ __launch_bounds__(256) void k_fold_counters(const uint32_t* cnt_p, co
 // usual case while games still start — makes the compaction the identity: the scan is skipped, count[1] = 1 tells k_compact so.
 __global__ __launch_bounds__(1024) void k_scan_alive(const uint32_t* alive, uint32_t* newslot, int L, uint32_t* count,
                                                      unsigned long long* hostflag, uint32_t seq, const unsigned long long* next_game = nullptr,
-                                                     unsigned long long* dead = nullptr) {
+                                                     unsigned long long* dead = nullptr, const unsigned long long* finished = nullptr) {
     __shared__ uint32_t part[16];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     if (dead && ufirst((uint32_t)(*dead == 0ull)) != 0u) {        // (the word is stable: k_advance has finished; only this kernel resets it)
@@ -188,6 +194,7 @@ __global__ __launch_bounds__(1024) void k_scan_alive(const uint32_t* alive, uint
             *count = (uint32_t)L; count[1] = 1u;
             if (hostflag) {
                 if (next_game) __hip_atomic_store(hostflag + 1, *next_game, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (finished) __hip_atomic_store(hostflag + 2, *finished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 __hip_atomic_store(hostflag, ((unsigned long long)seq << 32) | (unsigned long long)(uint32_t)L, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
@@ -226,6 +233,7 @@ __global__ __launch_bounds__(1024) void k_scan_alive(const uint32_t* alive, uint
         if (dead) *dead = 0ull;
         if (hostflag) {
             if (next_game) __hip_atomic_store(hostflag + 1, *next_game, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (finished) __hip_atomic_store(hostflag + 2, *finished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(hostflag, ((unsigned long long)seq << 32) | total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
@@ -248,12 +256,14 @@ __global__ void k_compact(const PlyPar T, const uint32_t* newslot, const uint32_
 // PoolSample order of the generation's samples (mcts_gpu.jl:513-516: one push per ply and per game still running, ply-major, games
 // in slot = game-id order) built on the device: block p takes ply p — its first record is the number of samples of earlier plies,
 // sum over games of min(nplies, p), then the games with nplies > p in order (ballot ranks).  order[s] = game << 8 | ply.
-__global__ __launch_bounds__(1024) void k_sample_order(const int32_t* nplies, int G, uint32_t* order, unsigned long long* total) {
+// ring0 / cap: game g of the call sits at entry (ring0 + g) mod cap of the per-game arrays (chained calls; 0 / anything >= G otherwise)
+__global__ __launch_bounds__(1024) void k_sample_order(const int32_t* nplies, int G, uint32_t* order, unsigned long long* total, uint32_t ring0 = 0,
+                                                       uint32_t cap = 0xffffffffu) {
     __shared__ unsigned long long red[16];
     __shared__ uint32_t part[16];
     const int p = (int)blockIdx.x, t = (int)threadIdx.x, lane = t & 63, w = t >> 6;
     unsigned long long b = 0;
-    for (int g = t; g < G; g += 1024) { const int n = nplies[g]; b += (unsigned long long)(n < p ? n : p); }
+    for (int g = t; g < G; g += 1024) { const int n = nplies[(ring0 + (uint32_t)g) % cap]; b += (unsigned long long)(n < p ? n : p); }
     for (int o = 32; o > 0; o >>= 1) b += __shfl_down(b, o, 64);
     if (lane == 0) red[w] = b;
     __syncthreads();
@@ -263,7 +273,7 @@ __global__ __launch_bounds__(1024) void k_sample_order(const int32_t* nplies, in
     const uint64_t below = (1ull << lane) - 1ull;
     for (int g0 = 0; g0 < G; g0 += 1024) {
         const int g = g0 + t;
-        const bool in = g < G && nplies[g] > p;
+        const bool in = g < G && nplies[(ring0 + (uint32_t)g) % cap] > p;
         const uint64_t m = __ballot(in);
         __syncthreads();                                           // (part of the previous chunk has been read)
         if (lane == 0) part[w] = (uint32_t)__popcll(m);
@@ -283,6 +293,7 @@ struct PackPar {
     const uint64_t* s_boards; const float* s_policy; const int16_t* s_move;
     const int32_t* g_nplies; const int8_t* g_result; const Pos* g_final;
     const uint32_t* order;   // [n] (g << 8 | ply)  PoolSample order
+    uint32_t ring0, cap, k0; // chained calls: game g of the call is entry (ring0 + g) mod cap of the per-game arrays and game k0 + g of the chain
     int64_t n;
     uint8_t* out;
 };
@@ -293,13 +304,14 @@ __global__ __launch_bounds__(256) void k_pack_samples(const PackPar T) {
     const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
     for (int64_t s = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); s < T.n; s += nw) {
         uint32_t key = T.order[s];
-        int g = (int)(key >> 8), ply = (int)(key & 0xff);
+        const int gl = (int)(key >> 8), ply = (int)(key & 0xff);
+        const int g = (int)((T.ring0 + (uint32_t)gl) % T.cap);
         uint8_t* rec = T.out + (size_t)s * T.rec_bytes;
         const size_t sidx = (size_t)g * T.max_plies + ply;
         const int player = (ply & 1) ? -1 : 1;                  // Position().player == 1 and play() flips it
         const int res = T.g_result[g];
         if (lane == 0) {
-            reinterpret_cast<uint32_t*>(rec)[0] = T.game_id_base + (uint32_t)g;
+            reinterpret_cast<uint32_t*>(rec)[0] = T.game_id_base + T.k0 + (uint32_t)gl;
             reinterpret_cast<int32_t*>(rec)[1] = ply;
             reinterpret_cast<int32_t*>(rec)[2] = T.s_move[sidx];
             reinterpret_cast<float*>(rec)[3] = (float)((1 + res * player) / 2.0);      // mainGobang.jl:76

@@ -78,6 +78,7 @@ def load_library():
         getattr(L, "agz_get_" + n).argtypes = [vp, vp]
     L.agz_get_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.agz_selfplay.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.c_int, C.POINTER(SelfplayStats)]
+    L.agz_selfplay_chain.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.POINTER(SelfplayStats)]
     L.agz_duel.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.POINTER(C.c_int64 * 3)]
     L.agz_get_samples.argtypes = [vp] + [vp] * 8
     L.agz_get_samples_packed.argtypes = [vp, vp, C.c_int64, C.POINTER(C.c_int64)]

@@ -232,6 +232,20 @@ class Engine:
         stats["valid"] = True
         return stats
 
+    def selfplay_chain(self, ngames, next_ngames, visits, cpuct=2.0, tau_plies=25):
+        """agz_selfplay_chain: one call of a chain of self-play calls — returns when its own `ngames` games are over, having started up to
+        `next_ngames` games of the next call in the slots that came free (they stay in flight; the last call of a chain passes 0)."""
+        st = _lib.SelfplayStats()
+        rc = self.L.agz_selfplay_chain(self.h, int(ngames), int(next_ngames), int(visits), float(cpuct), int(tau_plies), C.byref(st))
+        self.nslots = 0
+        stats = {f: getattr(st, f) for f, _ in _lib.SelfplayStats._fields_}
+        if rc == -5:
+            stats["valid"] = False
+            return stats
+        self._chk(rc)
+        stats["valid"] = True
+        return stats
+
     def duel(self, ngames, visits, cpuct=2.0, tau_plies=15, first=0):
         wdl = (C.c_int64 * 3)()
         self._chk(self.L.agz_duel(self.h, int(ngames), int(visits), float(cpuct), int(tau_plies), int(first), C.byref(wdl)))

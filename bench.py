@@ -115,6 +115,8 @@ def main():
     ap.add_argument("--gens-per-call", type=int, default=0, help="generations' worth of games one agz_selfplay call plays on the engine's slots (bounds the "
                     "sample store: ~1 GB per generation of Gobang 9x9); 0 = up to 32 on one GPU, up to 8 per rank with several (the exchange buffers "
                     "scale with it)")
+    ap.add_argument("--no-chain", action="store_true", help="every agz_selfplay call on its own (ends on a batch that runs out) instead of a chain of "
+                    "calls in which a call starts the next call's games in the slots it leaves free (agz_selfplay_chain)")
     ap.add_argument("--dump-records", default="", help="rank 0 writes the gathered samples of the LAST timed generation (PoolSample order) to this .npz")
     args = ap.parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -167,8 +169,16 @@ def main():
     def calls(k):                           # K generations as calls of at most gens_cap generations each
         return [gens_cap] * (k // gens_cap) + ([k % gens_cap] if k % gens_cap else [])
 
-    eng = M.Engine(game, G, V, device=dev, seed=1, game_id_base=shard.shard_base(rank, gens_cap * G),
-                   nn_mode=M.NN_BF16 if args.mode == "bf16" else M.NN_EXACT, sample_capacity_games=gens_cap * G)
+    # The calls of a run form a CHAIN (agz_selfplay_chain, include/agz.h): game ids run on from call to call under one seed, and while a
+    # call's last games run out the slots that come free start games of the NEXT call (up to FILL generations' worth), which stay in flight
+    # when the call returns — no call of the run ends on a batch that runs out, the untimed last one aside.  The timed region therefore
+    # completes its K generations' worth of games on full batches from its first search to its last; it inherits the games the warm-up left in
+    # flight and leaves as many in flight itself, and `value` counts the rollouts EXECUTED inside it, whichever game they belong to.
+    chain = not args.lockstep and not args.no_chain
+    FILL = 2
+    gens_run = max(1, args.warmup + args.steps)
+    eng = M.Engine(game, G, V, device=dev, seed=1, game_id_base=shard.shard_base(rank, (gens_run if chain else gens_cap) * G),
+                   nn_mode=M.NN_BF16 if args.mode == "bf16" else M.NN_EXACT, sample_capacity_games=(gens_cap + (FILL if chain else 0)) * G)
     eng.set_network(net)
     rb = game.rec_bytes
     # the exchange of generation k overlaps generation k+1: two sample buffers, at most two collectives in flight; a collective is
@@ -180,9 +190,12 @@ def main():
     last_gather = [None]
     nstep = [0]
 
-    def step(ngen=1):
-        eng.set_seed(1 + nstep[0])              # a fresh Philox key per call, as the reference's unseeded draws
-        st = eng.selfplay(ngen * G, V, cpuct=args.cpuct, tau_plies=25)
+    def step(ngen=1, nxt=None):
+        if chain and nxt is not None:           # a call of the run's chain: `nxt` generations' worth of the next call's games may start early
+            st = eng.selfplay_chain(ngen * G, min(nxt, FILL) * G, V, cpuct=args.cpuct, tau_plies=25)
+        else:
+            eng.set_seed(1 + nstep[0])          # a fresh Philox key per call, as the reference's unseeded draws
+            st = eng.selfplay(ngen * G, V, cpuct=args.cpuct, tau_plies=25)
         if not st["valid"]:
             raise SystemExit("illegal move sampled ('faute')")
         k = nstep[0] & 1
@@ -214,15 +227,19 @@ def main():
     # which kernels does this configuration run?  One launch per ply (whole mcts_single in k_search_small): events around every
     # launch.  Two kernels per rollout (wide trunks, V > 64): events around ~10^4 launches cost ~10 % of a generation, so only
     # every 4th search is instrumented (profiling bit 2); the fractions are taken over the instrumented searches.
-    eng.set_profiling(1)
-    for ng in calls(max(args.warmup, 0)):
-        step(ng)
     # the kernel the roofline object names is the one the FIRST ply (all G games alive) dispatches to -- the plies of the tail
     # run smaller-batch variants of the same kernel (agz_get_search_form reports the last search): one untimed probe search
+    eng.set_profiling(1)
     eng.set_roots(None, L=G)
     eng.search(V, cpuct=args.cpuct, training=True, step=0)
     form_tree, form_nn = eng.search_form()
     whole = form_tree.startswith("k_search_small") or form_tree.startswith("k_search_big")   # one launch per ply at every size
+    plan = [(ng, False) for ng in calls(max(args.warmup, 0))] + [(ng, True) for ng in calls(args.steps)]   # (generations, timed) per call of the run
+    nxt_of = [plan[i + 1][0] if i + 1 < len(plan) else FILL for i in range(len(plan))]                     # (the last call announces games that nobody will ask for)
+    eng.set_seed(1)
+    for i, (ng, timed) in enumerate(plan):
+        if not timed:
+            step(ng, nxt_of[i])
     eng.set_profiling(1 if whole else 7)
     eng.kernel_times(reset=True)
     fence()
@@ -231,8 +248,10 @@ def main():
     search_s = 0.0
     plies = 0
     nsamples = 0
-    for ng in calls(args.steps):
-        st = step(ng)
+    for i, (ng, timed) in enumerate(plan):
+        if not timed:
+            continue
+        st = step(ng, nxt_of[i])
         rollouts += st["rollouts"]
         search_s += st["search_seconds"]
         plies += st["plies"]
@@ -244,6 +263,8 @@ def main():
     sum_p, sum_new, r_cnt = eng.counters()
     nn_leaves = eng.nn_leaves()
 
+    if chain:
+        eng.set_roots(None, L=0)            # the chain ends here: the games the timed region left in flight are dropped
     if args.dump_records:                   # (tests: the samples of the last timed generation as the host sees them)
         import numpy as np
         if world > 1:
@@ -285,8 +306,10 @@ def main():
         # and are unpacked while call k + 1 runs
         # (gp generations per call: every call ends with the plies in which its last games run out, ~60 ms for the headline config — four
         #  generations per call spread them thinner than two did; the buffers are sized by one untimed call, not by the longest game possible)
-        gp = min(gens_cap, 4)
-        step(gp)
+        # (a chain of calls of two generations each, as a trainer's loop would run them; without chaining four generations per call, so that
+        #  the ~60 ms in which a call's last games run out are spread thinner)
+        gp = min(gens_cap, 2 if chain else 4)
+        step(gp, gp)
         cap = min(gp * G * game.max_plies, int(eng.num_samples() * 1.2) + 4096)
         dbuf = [torch.empty(cap * rb, dtype=torch.uint8, device="cuda") for _ in range(2)]
         hbuf = [torch.empty(cap * rb, dtype=torch.uint8).pin_memory() for _ in range(2)]
@@ -317,13 +340,13 @@ def main():
 
         th = threading.Thread(target=deliver, daemon=True)
         th.start()
-        ncalls = 4                          # (the delivery of the last call is not hidden: amortised over four calls)
+        ncalls = 16 // gp if gp in (1, 2, 4) else 4   # (the delivery of the last call is not hidden: amortised over the calls)
         p_rollouts = 0
         p0 = time.perf_counter()
         for i in range(ncalls):
             k = i & 1
             free[k].acquire()               # the delivery of call i - 2 has left buffer k
-            st = step(gp)
+            st = step(gp, gp)
             n = eng.samples_packed_into(dbuf[k].data_ptr(), cap)
             jobs.put((k, n))
             p_rollouts += st["rollouts"]
@@ -332,6 +355,8 @@ def main():
         p1 = time.perf_counter()
         if err:
             raise err[0]
+        if chain:
+            eng.set_roots(None, L=0)
         host["pipelined_generations"] = ncalls * gp
         host["pipelined_calls"] = ncalls
         host["pipelined_copy_s_per_call"] = d_copy
@@ -433,8 +458,14 @@ def main():
             "roofline_other": tree_obj if nn_dominant else nn_obj,
             "roofline_valu": valu_obj,
             "scheduling": ("lock-step: K separate generations of G games, the batch shrinks as games end (the reference's call pattern)" if args.lockstep else
-                           f"agz_selfplay calls of {gens_cap} x G games on G slots: a slot whose game has ended takes the next game that has not started "
-                           "(every search runs on a full batch of G games; per-game samples identical to lock-step generations)"),
+                           (f"a chain of agz_selfplay_chain calls of {gens_cap} x G games on G slots: a slot whose game has ended takes the next game that has "
+                            f"not started — of this call or, once those have all started, of the next one (up to {FILL} x G of them, left in flight when the "
+                            "call returns): every search of the timed region runs on a full batch of G games; it completes its K x G games, inherits the games "
+                            "the warm-up left in flight and leaves as many in flight; value = rollouts executed / time; every game's samples are those of a "
+                            "lock-step run over the run's games (keyed by game id and the game's own ply)" if chain else
+                            f"agz_selfplay calls of {gens_cap} x G games on G slots, each on its own: a slot whose game has ended takes the next game that has "
+                            "not started (per-game samples identical to lock-step generations); a call ends on the batch of its last games running out")),
+            "value_calls_on_their_own": None if chain else rollouts / dt,
             "value_lockstep_generations": (rollouts / dt if args.lockstep else (host or {}).get("lockstep_generation_rollouts_per_s")),
             "value_with_host_delivery": (host or {}).get("rollouts_per_s_with_delivery_into_PoolSample"),
             "rank0": {"search_only_rollouts_per_s": rollouts / search_s if search_s > 0 else None,

@@ -131,6 +131,17 @@ typedef struct {
  * lock-step run over ngames slots (results are keyed by game id and the game's own ply, never by slot or by the round a game started in);
  * stats->plies then counts the rounds of the loop. */
 int  agz_selfplay(agz_engine *h, int ngames, int V, float cpuct, int tau_plies, agz_selfplay_stats *stats);
+/* A CHAIN of self-play calls (a host loop that calls mcts(actor, visits, ngames, buffer) generation after generation, selfplay.jl:34):
+ * like agz_selfplay, but the caller says how many games its NEXT call will play.  Game ids run on from call to call (game k of the chain
+ * has id game_id_base + k, this call returns games k0 .. k0 + ngames - 1), and while this call's games run out the slots that come
+ * free start up to next_ngames games of the next call instead of idling; they stay in flight when the call returns — as soon as its own
+ * ngames games are over — and the next call of the chain goes on with them.  Only the last call of a chain (next_ngames = 0) ends on a
+ * batch that runs out.  Every game's samples are those of one lock-step run over all the chain's games with the engine's seed (keyed by
+ * game id and the game's own ply): the seed must stay the same while games are in flight (agz_set_seed fails otherwise), the network may
+ * change between calls.  Needs sample_capacity_games >= ngames + next_ngames; fetch a call's samples before the next call of the chain
+ * (their storage is reused).  agz_selfplay, agz_duel, agz_set_roots end a chain (games in flight are dropped).
+ * stats: nsamples / wins / draws / losses / total_plies of THIS call's games; rollouts, plies, seconds of the work done inside the call. */
+int  agz_selfplay_chain(agz_engine *h, int ngames, int next_ngames, int V, float cpuct, int tau_plies, agz_selfplay_stats *stats);
 /* duelnetwork half: mcts(actor1,actor2,visits,ngames;cpuct) :581-651; first = actor to move at ply 0 */
 int  agz_duel(agz_engine *h, int ngames, int V, float cpuct, int tau_plies, int first, int64_t wdl[3]);
 

@@ -84,21 +84,40 @@ function mcts(actor, visits, ngames, buffer::PoolSample; θ=1, cpuct=2.0, noise=
     rc = ccall((:agz_selfplay, libagz), Cint, (Ptr{Cvoid}, Cint, Cint, Cfloat, Cint, Ref{AgzStats}), e.h, ngames, visits, cpuct, 25, st)
     rc == -5 && return (data=[], valid=false)      # "faute"
     check(e, rc)
-    n = st[].nsamples
+    push_samples!(e, st[], buffer)
+    return (data=[], valid=true)
+    finally
+        destroy!(e)
+    end
+end
+
+# the samples of the last self-play call -> the PoolSample, in the order the reference pushes them (ply-major, slot order)
+function push_samples!(e::Engine, st::AgzStats, buffer::PoolSample)
+    n = st.nsamples
     state = Matrix{Int8}(undef, 2VectorizedState, n); policy = Matrix{Float32}(undef, maxActions, n)
     player = Vector{Int8}(undef, n); value = Vector{Float32}(undef, n); fstate = Matrix{Int8}(undef, FeatureSize, n)
     check(e, ccall((:agz_get_samples, libagz), Cint,
                    (Ptr{Cvoid}, Ptr{Int8}, Ptr{Float32}, Ptr{Int8}, Ptr{Float32}, Ptr{Int8}, Ptr{UInt32}, Ptr{Int32}, Ptr{Int32}),
                    e.h, state, policy, player, value, fstate, C_NULL, C_NULL, C_NULL))
-    for i in 1:n                                   # same order the reference pushes them (ply-major, slot order)
+    for i in 1:n
         idx = Main.push_buffer(buffer, state, policy, player[i], i)
         buffer.pool[idx].value = value[i]; buffer.pool[idx].fstate .= @view fstate[:, i]
     end
-    println("victoires,nul,défaites", [st[].wins, st[].draws, st[].losses])
+    println("victoires,nul,défaites", [st.wins, st.draws, st.losses])
+end
+
+# A host loop that plays generation after generation (selfplay.jl:34 inside trainingPipeline) keeps ONE engine (init(...; sample_capacity =
+# ngames + next_ngames)) and calls this instead of mcts: the call returns its own ngames games and starts up to next_ngames games of the
+# next call in the slots that come free meanwhile, so that no generation ends on a batch that runs out (agz.h agz_selfplay_chain; the
+# last call of the loop passes next_ngames = 0).  The network may change from call to call (set_network! inside).
+function mcts_chain!(e::Engine, actor, visits, ngames, next_ngames, buffer::PoolSample; cpuct=2.0)
+    set_network!(e, actor)
+    st = Ref{AgzStats}()
+    rc = ccall((:agz_selfplay_chain, libagz), Cint, (Ptr{Cvoid}, Cint, Cint, Cint, Cfloat, Cint, Ref{AgzStats}), e.h, ngames, next_ngames, visits, cpuct, 25, st)
+    rc == -5 && return (data=[], valid=false)      # "faute"
+    check(e, rc)
+    push_samples!(e, st[], buffer)
     return (data=[], valid=true)
-    finally
-        destroy!(e)
-    end
 end
 
 function duelnetwork(actor1, actor2, visits, ngames, conv=2; game, N=0, Nvict=0, seed=fresh_seed())

@@ -6,6 +6,7 @@
 out=gpurun_out/$1; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 python bench.py --steps 20 --warmup 5 > $out/bench_headline.json 2> $out/bench_headline.err
+python bench.py --steps 20 --warmup 5 --no-chain --no-cpu-baseline --no-host-delivery > $out/bench_headline_nochain.json 2> $out/bench_headline_nochain.err
 python bench.py --steps 4 --warmup 1 --lockstep --no-host-delivery > $out/bench_headline_lockstep.json 2> $out/bench_headline_lockstep.err
 python bench.py --steps 2 --warmup 1 --mode exact --no-cpu-baseline --no-host-delivery > $out/bench_headline_exact.json 2> $out/bench_headline_exact.err
 for c in 2 3 4 5; do timeout 900 python bench.py --config $c --steps 20 --warmup 5 > $out/bench_config$c.json 2> $out/bench_config$c.err; done

@@ -6,7 +6,7 @@ call from the device counters.   usage: install_r04.py gpurun_out/r04p r04"""
 import glob, json, os, re, shutil, sys
 src, pre = sys.argv[1], sys.argv[2]
 P = "profiles"
-for f in ("bench_headline", "bench_headline_lockstep", "bench_headline_exact", "bench_config2", "bench_config3", "bench_config4", "bench_config5", "bench_under_rocprof"):
+for f in ("bench_headline", "bench_headline_nochain", "bench_headline_lockstep", "bench_headline_exact", "bench_config2", "bench_config3", "bench_config4", "bench_config5", "bench_under_rocprof"):
     if os.path.exists(os.path.join(src, f + ".json")) and os.path.getsize(os.path.join(src, f + ".json")) > 0:
         shutil.copy(os.path.join(src, f + ".json"), os.path.join(P, f"{pre}_{f}.json"))
 st = glob.glob(os.path.join(src, "stats", "*kernel_stats.csv")) + glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))

@@ -896,3 +896,55 @@ def test_two_kernel_generation_on_big_boards_equals_the_oracle(name, n, V, H, T,
     assert st["valid"] and st["nsamples"] == ref["n"]
     for key in ("game_id", "ply", "move", "player", "state", "fstate", "policy", "value"):
         assert_same_bits(s[key], ref[key], f"{name} {mode}: {key}")
+
+
+# ---- chains of self-play calls: the next call's games start in the slots the running call leaves free -----------------------------
+@pytest.mark.parametrize("name,slots,N,V,mode", [("tictactoe", 16, 60, 8, "exact"), ("gobang9", 24, 50, 16, "bf16"), ("connect4", 32, 90, 12, "bf16"),
+                                                 ("reversi6", 16, 40, 8, "exact")])
+def test_chain_of_selfplay_calls_returns_the_oracles_games_call_by_call(name, slots, N, V, mode):
+    """agz_selfplay_chain: three calls of a chain (N, N and N / 2 games; the first two announce the size of the next one, the last one 0).
+    Every call returns exactly ITS games — ids running on through the chain — sample for sample as the oracle's lock-step generation over
+    all the chain's games has them (PoolSample order within the call), although most of a call's games were started, and some finished,
+    while the call before it was still running; the sample store is a ring that wraps in the third call."""
+    g, og = spec(name)
+    net, onet = nets(g, og, 32, 1) if mode == "exact" else (ag.SNetwork2.random(g, 128, 2), O.OracleNet(og, 128, 2))
+    calls = [(N, N), (N, N // 2), (N // 2, 0)]
+    total = sum(n for n, _ in calls)
+    ref = O.selfplay(og, onet if mode == "exact" else onet.bf16(), total, V, 1.5, 25, 9, 700)
+    with M.Engine(g, slots, V, seed=9, game_id_base=700, nn_mode=M.NN_EXACT if mode == "exact" else M.NN_BF16, sample_capacity_games=2 * N + 7) as e:
+        e.set_network(net)
+        k0, rollouts = 0, 0
+        for i, (n, nxt) in enumerate(calls):
+            st = e.selfplay_chain(n, nxt, V, cpuct=1.5, tau_plies=25)
+            s = e.samples()
+            sel = (ref["game_id"] >= 700 + k0) & (ref["game_id"] < 700 + k0 + n)
+            assert st["valid"] and st["nsamples"] == int(sel.sum()) == len(s["ply"]), (i, st["nsamples"], int(sel.sum()))
+            for key in ("game_id", "ply", "move", "player", "state", "fstate", "policy", "value"):
+                assert_same_bits(s[key], ref[key][sel], f"call {i}: {key}")
+            first = sel & (ref["ply"] == 0)                      # the side to move at ply 0 is player +1: value = (1 + res) / 2
+            res = np.rint(2.0 * ref["value"][first] - 1.0).astype(int)
+            assert (st["wins"], st["draws"], st["losses"]) == (int((res == 1).sum()), int((res == 0).sum()), int((res == -1).sum()))
+            assert st["total_plies"] == int(sel.sum()) - n
+            if nxt:                                              # games of the next call are in flight: their key must not change
+                with pytest.raises(Exception):
+                    e.set_seed(1234)
+            k0 += n
+            rollouts += st["rollouts"]
+        # ... the work of the chain is the work of its games, no more (nothing is searched twice or dropped)
+        assert rollouts >= V * len(ref["ply"])
+        # a call of its own afterwards starts over (ids from game_id_base, a fresh batch)
+        st = e.selfplay(slots, V, cpuct=1.5, tau_plies=25)
+        s = e.samples()
+    ref2 = O.selfplay(og, onet if mode == "exact" else onet.bf16(), slots, V, 1.5, 25, 9, 700)
+    assert st["valid"] and st["nsamples"] == ref2["n"]
+    for key in ("game_id", "ply", "move", "policy", "value"):
+        assert_same_bits(s[key], ref2[key], key + " (call of its own after the chain)")
+
+
+def test_chain_needs_sample_capacity_for_both_calls():
+    g, _ = spec("tictactoe")
+    with M.Engine(g, 8, 8, seed=1, nn_mode=M.NN_BF16, sample_capacity_games=20) as e:
+        e.set_network(ag.SNetwork2.random(g, 128, 2))
+        with pytest.raises(Exception):
+            e.selfplay_chain(16, 16, 8)
+        assert e.selfplay_chain(12, 8, 8)["valid"] and e.selfplay_chain(8, 0, 8)["valid"]

@@ -392,3 +392,30 @@ def test_full_size_generation_slice_equals_the_oracle_through_all_plies(name, H,
         assert ref["rc"] == 0 and int(keep.sum()) == ref["n"], (int(keep.sum()), ref["n"])
         for k in ("game_id", "ply", "move", "player", "state", "fstate", "value", "policy"):
             assert parity.same_bits(s[k][keep], ref[k]), f"{name} {H}x{T}: {k} of games {base}..{base + n - 1} differs from the oracle"
+
+
+@pytest.mark.parametrize("name,H,T,V", [("gobang9", 128, 6, 64), ("gobang9", 512, 1, 64)])
+def test_full_size_chain_of_calls_slices_equal_the_oracle(name, H, T, V):
+    """agz_selfplay_chain at the benchmarked size (what bench.py times since round 4): three calls of 65536, 32768 and 32768 games on 32768
+    slots, each announcing the next (the last one 0).  The batch stays full across the call boundaries (the host's run-ahead, the ring of the
+    sample store and the early finishers are all at work); 16 games of every call — started in the call before it, in a refilled slot, at
+    the very start — equal the oracle's lock-step games of the same ids, sample for sample."""
+    L, n, seed = 32768, 16, 5
+    g, og = spec(name)
+    net, onet = ag.SNetwork2.random(g, H, T), O.OracleNet(og, H, T)
+    calls = [(65536, 32768), (32768, 32768), (32768, 0)]
+    with M.Engine(g, L, V, seed=seed, nn_mode=M.NN_BF16, sample_capacity_games=65536 + 32768 + 1000) as e:
+        e.set_network(net)
+        k0 = 0
+        for i, (ng, nxt) in enumerate(calls):
+            st = e.selfplay_chain(ng, nxt, V, cpuct=1.5, tau_plies=25)
+            assert st["valid"] and st["faults"] == 0 and st["wins"] + st["draws"] + st["losses"] == ng
+            s = e.samples()
+            assert len(s["ply"]) == st["nsamples"] and int(s["game_id"].min()) == k0 and int(s["game_id"].max()) == k0 + ng - 1
+            for base in (k0 + 5, k0 + ng // 2, k0 + ng - n - 3):
+                keep = (s["game_id"] >= base) & (s["game_id"] < base + n)
+                ref = O.selfplay(og, onet.bf16(), n, V, 1.5, 25, seed, base)
+                assert ref["rc"] == 0 and int(keep.sum()) == ref["n"], (i, base, int(keep.sum()), ref["n"])
+                for k in ("game_id", "ply", "move", "player", "state", "fstate", "value", "policy"):
+                    assert parity.same_bits(s[k][keep], ref[k]), f"{name} {H}x{T} call {i}: {k} of games {base}..{base + n - 1} differs from the oracle"
+            k0 += ng
