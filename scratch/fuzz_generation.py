@@ -32,8 +32,18 @@ for name, n, V, H, T, seed in cases:
     slots = max(8, n // int(os.environ.get("FUZZ_SLOT_DIV", "1")))   # FUZZ_SLOT_DIV=3: a third of the games in flight, finished games' slots refilled
     with M.Engine(g, min(slots, n), V, seed=seed, game_id_base=1000 * seed, nn_mode=M.NN_EXACT if exact else M.NN_BF16, sample_capacity_games=n) as e:
         e.set_network(net)
-        st = e.selfplay(n, V, cpuct=1.5, tau_plies=25)
-        s = e.samples()
+        if os.environ.get("FUZZ_CHAIN") == "1":                # the n games as a chain of three calls (agz_selfplay_chain), merged back into PoolSample order
+            parts, st, sizes = [], None, [n // 2, n // 4, n - n // 2 - n // 4]
+            for i, ng in enumerate(sizes):
+                sti = e.selfplay_chain(ng, sizes[i + 1] if i + 1 < len(sizes) else 0, V, cpuct=1.5, tau_plies=25)
+                parts.append(e.samples())
+                st = sti if st is None else {k: (st[k] + sti[k] if k in ("nsamples", "wins", "draws", "losses", "rollouts", "total_plies") else (st[k] and sti[k] if k == "valid" else sti[k])) for k in sti}
+            cat = {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
+            order = np.lexsort((cat["game_id"], cat["ply"]))
+            s = {k: v[order] for k, v in cat.items()}
+        else:
+            st = e.selfplay(n, V, cpuct=1.5, tau_plies=25)
+            s = e.samples()
     ok = st["valid"] and ref["rc"] == 0 and st["nsamples"] == ref["n"]
     diff = {}
     if ok:
