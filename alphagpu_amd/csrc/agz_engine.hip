@@ -1313,15 +1313,25 @@ static int run_games(agz_engine* h, int ngames, int V, float cpuct, int tau_plie
         // early (during the last call) are already counted; the ring entries of the games that may start now are cleared
         HIPCHK(h, hipSetDevice(h->cfg.device));
         h->L = h->chain_L; h->need_reset = true;
-        started = h->chain_started; finished = h->chain_early;
-        const unsigned long long z[10] = {0, 0, 0, 0, 0, 0, started, 0, finished, 0};
-        HIPCHK(h, hipMemcpyAsync(h->d_stats, z, sizeof z, hipMemcpyHostToDevice, h->stream));
+        started = h->chain_started;
         const unsigned long long cap = (unsigned long long)h->sample_games;
         for (unsigned long long a = started; a < pool_end;) {                    // [started, pool_end) in ring order, piece by piece
             const unsigned long long r = a % cap, n = std::min(pool_end - a, cap - r);
             HIPCHK(h, hipMemsetAsync(h->g_nplies + r, 0, (size_t)n * 4, h->stream));
             a += n;
         }
+        {   // the games of THIS call that are already over (they ran, early, while the call before it was busy): their entries say so
+            std::vector<int32_t> np((size_t)ngames);
+            for (size_t a = 0; a < np.size();) {
+                const size_t r = (size_t)((k0 + a) % cap), n = std::min(np.size() - a, (size_t)cap - r);
+                HIPCHK(h, hipMemcpyAsync(np.data() + a, h->g_nplies + r, n * 4, hipMemcpyDeviceToHost, h->stream));
+                a += n;
+            }
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            finished = 0; for (int32_t x : np) finished += x > 0 ? 1ull : 0ull;
+        }
+        const unsigned long long z[10] = {0, 0, 0, 0, 0, 0, started, 0, finished, 0};
+        HIPCHK(h, hipMemcpyAsync(h->d_stats, z, sizeof z, hipMemcpyHostToDevice, h->stream));
         // slots without a game (the last call's pool ran dry before its games were over) take new games right away
         const int fill = (int)std::min<unsigned long long>((unsigned long long)(slots > h->L ? slots - h->L : 0), pool_end > started ? pool_end - started : 0ull);
         if (fill > 0) {
@@ -1426,9 +1436,6 @@ static int run_games(agz_engine* h, int ngames, int V, float cpuct, int tau_plie
                 hipStreamSynchronize(h->stream) != hipSuccess) { h->fail("ply loop failed: %s", hipGetErrorString(hipGetLastError())); rc = AGZ_ERR_HIP; break; }
         }
         for (size_t i = 0; i < tused; ++i) { float ms = 0; if (hipEventElapsedTime(&ms, tpool[i].first, tpool[i].second) == hipSuccess) search_ms += ms; }
-        // (k_advance draws a number for every slot that comes free, also when the pool has run dry: the counter overshoots the pool then,
-        //  and the next call of a chain sets it back to what was really started)
-        if (started > pool_end) started = pool_end;
         tused = 0; ahead = 0; started_ub = started;
         if (any_fold) { h->cnt_live = false; drain_events(h); any_fold = false; }
         { uint32_t* s = h->game_id; h->game_id = h->game_id2; h->game_id2 = s; h->tp.game_id = h->game_id; }

@@ -124,7 +124,11 @@ __global__ __launch_bounds__(256) void k_advance(const PlyPar T) {
             atomicAdd(&T.stats[3], (unsigned long long)ply);                   // tot_length += round (:535)
             if (T.ring) atomicAdd(&T.stats[kg < T.k_cur_end ? 8 : 9], 1ull);
             if (T.refill_total) {                                              // the slot takes the next game that has not started yet
+                // (a draw past the end of the pool is given back: once the launch is over the counter IS the number of games started, and a
+                //  chain's later calls go on from it with a larger pool.  Draws below refill_total are unique: a failed draw only happens once
+                //  all of them have been handed out.  One add per finished game — a compare-and-swap loop on this one address cost 2 ms per ply.)
                 const unsigned long long k = atomicAdd(T.next_game, 1ull);
+                if (k >= (unsigned long long)T.refill_total) atomicAdd(T.next_game, ~0ull);
                 if (k < (unsigned long long)T.refill_total) {
                     for (int i = 0; i < 3; ++i) { next.p[i] = P.start_p[i]; next.o[i] = P.start_o[i]; next.lg[i] = P.start_lg[i]; }
                     next.player = (int8_t)P.start_player; next.aux = (int8_t)P.start_aux;
