@@ -368,11 +368,11 @@ def main():
 
     cdev = "cuda" if args.backend == "nccl" else "cpu"
     tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
-    tot = torch.tensor([float(rollouts)], dtype=torch.float64, device=cdev)
+    tot = torch.tensor([float(rollouts), float(nsamples)], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    dt_max, total_rollouts = float(tmax.item()), float(tot.item())
+    dt_max, total_rollouts, nsamples_all = float(tmax.item()), float(tot[0].item()), float(tot[1].item())
 
     if rank == 0:
         S = game.pos_image_bytes
@@ -466,6 +466,10 @@ def main():
                             f"agz_selfplay calls of {gens_cap} x G games on G slots, each on its own: a slot whose game has ended takes the next game that has "
                             "not started (per-game samples identical to lock-step generations); a call ends on the batch of its last games running out")),
             "value_calls_on_their_own": None if chain else rollouts / dt,
+            # value = rollouts EXECUTED in the timed region / its time.  With chained calls the region also works on games it does not return
+            # (the ones it leaves in flight) and returns games it did not play in full (the ones it inherited): the rollouts of the games it
+            # RETURNED (their samples x V) over the same time are given beside it — the two meet as the run gets longer.
+            "value_by_returned_games": nsamples_all * V / dt_max,
             "value_lockstep_generations": (rollouts / dt if args.lockstep else (host or {}).get("lockstep_generation_rollouts_per_s")),
             "value_with_host_delivery": (host or {}).get("rollouts_per_s_with_delivery_into_PoolSample"),
             "rank0": {"search_only_rollouts_per_s": rollouts / search_s if search_s > 0 else None,
