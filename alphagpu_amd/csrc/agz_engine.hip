@@ -148,9 +148,9 @@ struct agz_engine {
     big_fn k_big8 = nullptr, k_big8x = nullptr; int big8 = 0;   // k_big8x: two such workgroups per CU (128 registers) above 64 games per CU   // k_search_big with 64-game workgroups (eight tree waves, one workgroup per CU) above 32 games per CU: AGZ_BIG8
     int legal_bound = 1 << 30, tree_kpr = 0;
     // chained self-play calls (agz_selfplay_chain): the slots keep the games a call leaves in flight; chain_k0 = games handed to the earlier
-    // calls of the chain (= the number of the next call's first game), chain_started = games started so far, chain_early = games of the
-    // next call that have already finished, chain_L = slots in flight when the last call returned
-    bool chain_live = false; unsigned long long chain_k0 = 0, chain_started = 0, chain_early = 0; int chain_L = 0;
+    // calls of the chain (= the number of the next call's first game), chain_started = games started so far, chain_L = slots in flight
+    // when the last call returned (which of a call's games are already over when it begins is read from their own entries)
+    bool chain_live = false; unsigned long long chain_k0 = 0, chain_started = 0; int chain_L = 0;
     uint32_t sp_ring0 = 0, sp_k0 = 0;      // where the games of the last call sit in the per-game sample arrays / in the chain
     bool no_compact = false;            // AGZ_NO_COMPACT (A/B, tests)
     advance_fn k_spread = nullptr;      // policy_final rows from rank order back to action order after such a search
@@ -1470,7 +1470,7 @@ static int run_games(agz_engine* h, int ngames, int V, float cpuct, int tau_plie
             // THIS call's games come from their own entries (mcts_gpu.jl:535: tot_length += round, the ply of the last move)
             hs[0] = hs[1] = hs[2] = hs[3] = 0;
             for (size_t i = 0; i < np.size(); ++i) { hs[res[i] == 1 ? 0 : (res[i] == 0 ? 1 : 2)] += 1; hs[3] += (unsigned long long)(np[i] > 0 ? np[i] - 1 : 0); }
-            h->chain_live = true; h->chain_k0 = k0 + (unsigned long long)ngames; h->chain_started = started; h->chain_early = hs[9]; h->chain_L = h->L;
+            h->chain_live = true; h->chain_k0 = k0 + (unsigned long long)ngames; h->chain_started = started; h->chain_L = h->L;
         }
     }
     if (st) {

@@ -22,7 +22,7 @@ struct PlyPar {
     unsigned long long* next_game;   // games started so far (device counter)
     // chained calls (agz_selfplay_chain): game ids run on from call to call (game k of the chain has id game_id_base + k), the sample store
     // is a RING over k (k mod sample_games), and a call may start games of the NEXT call in slots that would otherwise idle.  k_cur_end:
-    // the games k < k_cur_end belong to the call that is running (a finished one counts in stats[8], a later one in stats[9]).
+    // the games k < k_cur_end belong to the call that is running (a finished one counts in stats[8] — what the call waits for —, a later one in stats[9]).
     int32_t ring; uint32_t k_cur_end;
     const uint32_t* identity; // k_compact: k_scan_alive's count words ([1] != 0: every slot keeps its place)
     const float* policy_final;// [L][A]
