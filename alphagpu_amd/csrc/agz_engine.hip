@@ -151,6 +151,7 @@ struct agz_engine {
     // calls of the chain (= the number of the next call's first game), chain_started = games started so far, chain_L = slots in flight
     // when the last call returned (which of a call's games are already over when it begins is read from their own entries)
     bool chain_live = false; unsigned long long chain_k0 = 0, chain_started = 0; int chain_L = 0;
+    int run_ahead = 8;                    // plies the ply loop may queue before it waits for a ply's counters (AGZ_RUN_AHEAD; while the pool cannot run dry)
     uint32_t sp_ring0 = 0, sp_k0 = 0;      // where the games of the last call sit in the per-game sample arrays / in the chain
     bool no_compact = false;            // AGZ_NO_COMPACT (A/B, tests)
     advance_fn k_spread = nullptr;      // policy_final rows from rank order back to action order after such a search
@@ -332,6 +333,7 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     h->Lmax = cfg->max_games; h->V = cfg->max_visits;
     if (!bind_kernels(h)) { h->fail("no kernel instantiation for this game shape"); return bail(AGZ_ERR_UNSUPPORTED); }
     h->ply_sleep = getenv("AGZ_PLY_SPIN") == nullptr;
+    { const char* ra = getenv("AGZ_RUN_AHEAD"); if (ra && atoi(ra) >= 0 && atoi(ra) <= 64) h->run_ahead = atoi(ra); }
     if (hipStreamCreateWithFlags(&h->fold_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_fold, hipEventDisableTiming) != hipSuccess) {
         h->fold_stream = nullptr; h->ev_fold = nullptr;
     }
@@ -1398,7 +1400,7 @@ static int run_games(agz_engine* h, int ngames, int V, float cpuct, int tau_plie
                            (const unsigned long long*)(h->d_stats + 6), h->d_stats + 7, (const unsigned long long*)(h->d_stats + 8));
         hipLaunchKernelGGL(k_compact, dim3((unsigned)((h->L + 255) / 256)), dim3(256), 0, h->stream, T, (const uint32_t*)h->newslot,
                            (const uint32_t*)h->game_id, h->game_id2, h->slot_ply2);           // :550-561
-        if (refill && ahead < 8 && started_ub + 2ull * (unsigned long long)h->L <= pool_end) {
+        if (refill && ahead < h->run_ahead && started_ub + 2ull * (unsigned long long)h->L <= pool_end) {
             // this ply and the next cannot exhaust the games that wait: the batch stays as it is — queue the next ply now
             started_ub += (unsigned long long)h->L; ++ahead;
             { uint32_t* s = h->game_id; h->game_id = h->game_id2; h->game_id2 = s; h->tp.game_id = h->game_id; }

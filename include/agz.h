@@ -208,6 +208,7 @@ int  agz_set_profiling(agz_engine *h, int mode);       /* HIP events per launch:
  *   AGZ_NO_FASTDIV=1       IEEE '/' everywhere in the tree kernel (agz_fastdiv.hpp off)
  *   AGZ_PLY_SPIN=1         ply loop: the host thread spins on the scan's host-visible word through the whole search instead of sleeping on a
  *                          blocking event until the ply's k_advance has run
+ *   AGZ_RUN_AHEAD=n        ply loop with refilled slots: plies queued before the host waits for a ply's counters (default 8; 8 and 32 measure the same)
  *   AGZ_NO_HOST_FLAG=1     ply loop: fetch the number of games left with a copy + stream synchronisation instead of polling the
  *                          host-visible word the scan kernel publishes
  *   AGZ_BIG_MT=2|4|8       256 / 512-wide trunk, stand-alone network launches: 16-leaf tiles per workgroup (default by launch size)
