@@ -5,7 +5,7 @@
 # maintainer of fabricerosay/AlphaGPU would add.  See INTEGRATION.md.
 module mcts_gpu
 
-export mcts, duelnetwork, mcts_single, init, re_init
+export mcts, mcts_chain!, duelnetwork, mcts_single, init, re_init
 
 using ..Game            # Position, canPlay, play, isOver, VectorizedState, FeatureSize, maxActions, maxLengthGame, PoolSample
 
