@@ -4,8 +4,14 @@
 A step = ONE whole self-play generation: `--games` games per GPU x `--rollouts` rollouts per move, random-init snetwork2
 `--filters` x `--towers`, bf16 MFMA network + fp32 strict-IEEE tree arithmetic, all games played to the end on the device
 (mcts(), mcts_gpu.jl:477-579).  Inputs (start positions, weights) are resident in HBM before the timed region.
-value = rollouts of all ranks / max-over-ranks time.  With N > 1 ranks each rank plays its own shard of game ids and the
-step ends with the RCCL all-gather of the packed sample records.
+value = rollouts executed by all ranks in the timed region / max-over-ranks time.  With N > 1 ranks each rank plays its own shard
+of game ids and every call ends with the RCCL all-gather of its packed sample records.
+
+Scheduling of the K timed steps (what the "scheduling" field of the line spells out): by default the warm-up and timed calls are ONE
+chain of agz_selfplay_chain calls on `--games` slots — a slot whose game has ended takes the next game that has not started, of the
+running call or of the next one — so every search runs on a full batch; `--no-chain` plays each call on its own (it ends on the
+batch of its last games running out), `--lockstep` plays K separate generations the way the reference does (the batch shrinks as
+games end).  Every game's samples are the same in all three (keyed by game id and the game's own ply; parity-tested).
 
 The default is the configuration the metric is quoted on (Gobang 9x9 Nvict=5, 32768 x 64, 128x6).  `--config k` selects
 BASELINE.json configs[k-1] (2: Connect4 128x6, 3: Gobang 9x9 512x8, 4: Hex 9x9 V=128 512x8, 5: Reversi 8x8 512x8 — the
