@@ -950,3 +950,7 @@ def test_chain_needs_sample_capacity_for_both_calls():
         with pytest.raises(Exception):
             e.selfplay_chain(16, 16, 8)
         assert e.selfplay_chain(12, 8, 8)["valid"] and e.selfplay_chain(8, 0, 8)["valid"]
+        # the chain has run dry (nothing announced, nothing in flight): a further call of it starts its games itself, ids running on
+        st = e.selfplay_chain(6, 0, 8)
+        ids = np.unique(e.samples()["game_id"])
+        assert st["valid"] and list(ids) == list(range(20, 26)) and st["wins"] + st["draws"] + st["losses"] == 6
