@@ -26,6 +26,7 @@
 #include "agz_search_small.hpp"
 #include "agz_search_big.hpp"
 #include "agz_selfplay.hpp"
+#include "agz_selfplay_small.hpp"
 
 using namespace agz;
 
@@ -54,9 +55,13 @@ struct DevNet {
 typedef void (*rollout_fn)(const TreePar);
 typedef void (*small_fn)(const SmallPar);
 typedef void (*big_fn)(const BigSearchPar);
+typedef void (*persist_fn)(const PersistPar);
 namespace agz {
-#define X(F, C, K) AGZ_SMALL_VARIANTS(F, C, K, extern) AGZ_BIG_VARIANTS(F, C, K, extern)
+#define X(F, C, K) AGZ_SMALL_VARIANTS(F, C, K, extern) AGZ_BIG_VARIANTS(F, C, K, extern) AGZ_PERSIST_VARIANTS(F, C, K, extern)
 AGZ_SMALL_SHAPES(X)          // defined in agz_small_inst.hip
+#undef X
+#define X(F, C, K, GG) AGZ_PERSIST_NARROW_VARIANTS(F, C, K, GG, extern)
+AGZ_PERSIST_NARROW_SHAPES(X)
 #undef X
 #define X(F, C, K, R) AGZ_SMALL_CMP_VARIANTS(F, C, K, R, extern) AGZ_BIG_CMP_VARIANTS(F, C, K, R, extern)
 AGZ_SMALL_CMP_SHAPES(X)
@@ -98,7 +103,8 @@ struct agz_engine {
     // selfplay
     Pos* newpos = nullptr; uint32_t *alive = nullptr, *newslot = nullptr, *d_count = nullptr;
     int sample_games = 0;
-    uint64_t* s_boards = nullptr; float* s_policy = nullptr; int16_t* s_move = nullptr;
+    uint64_t* s_boards = nullptr; float* s_policy = nullptr; int16_t* s_move = nullptr; uint8_t* s_net = nullptr;
+    uint32_t net_tag = 0;      // agz_set_network_tag: stored with every sample (which network searched the ply)
     int32_t* g_nplies = nullptr; int8_t* g_result = nullptr; Pos* g_final = nullptr;
     unsigned long long* d_stats = nullptr;
     unsigned long long* d_acc = nullptr;   // device-side sums of cnt_p / cnt_new over the instrumented plies of a generation
@@ -151,6 +157,11 @@ struct agz_engine {
     // calls of the chain (= the number of the next call's first game), chain_started = games started so far, chain_L = slots in flight
     // when the last call returned (which of a call's games are already over when it begins is read from their own entries)
     bool chain_live = false; unsigned long long chain_k0 = 0, chain_started = 0; int chain_L = 0;
+    // the persistent self-play kernels (agz_selfplay_small.hpp): one launch per agz_selfplay / agz_selfplay_chain call, a workgroup keeps its
+    // slots and loops over the plies of its games by itself.  persist: AGZ_PERSIST = 1 wherever a kernel exists (tests), 0 never, default
+    // (-1): calls with refilled slots on an engine of more than 96 slots per CU.  chain_persist: the running chain's slots are not compacted.
+    persist_fn k_persist = nullptr, k_persist_nar = nullptr; int persist_nar_g = 0, persist_nar_kpl = 0;
+    int persist = -1; bool chain_persist = false; unsigned long long* d_pacc = nullptr;
     int run_ahead = 8;                    // plies the ply loop may queue before it waits for a ply's counters (AGZ_RUN_AHEAD; while the pool cannot run dry)
     uint32_t sp_ring0 = 0, sp_k0 = 0;      // where the games of the last call sit in the per-game sample arrays / in the chain
     bool no_compact = false;            // AGZ_NO_COMPACT (A/B, tests)
@@ -191,8 +202,12 @@ static bool bind_kernels(agz_engine* h) {
     const int kpl = P.A <= 32 ? 4 : (P.A <= 64 ? 8 : (P.A <= 96 ? 12 : (P.A <= 128 ? 16 : (P.A <= 192 ? 24 : 0))));
 #define Z(F, C, K) if (P.fam == F && P.NC == C && kpl == K) { h->k_eager = k_rollout_eager<F, C, K, 4>; h->k_eager3 = k_rollout_eager<F, C, K, 3>; \
         h->k_small = k_search_small<F, C, K, 128, 2, 2>; h->k_small4[0] = k_search_small<F, C, K, 128, 4, 2>; h->k_small4[1] = k_search_small<F, C, K, 128, 4, 3>; \
-        h->k_small4[2] = k_search_small<F, C, K, 128, 4, 4>; h->k_small8 = k_search_small<F, C, K, 128, 8, 4>; h->k_big[0] = k_search_big<F, C, K, 512, 1>; h->k_big[1] = k_search_big<F, C, K, 512, 2>; h->k_big8 = k_search_big<F, C, K, 512, 1, 0, 8>; h->k_big8x = k_search_big<F, C, K, 512, 2, 0, 8>; h->reg_kpl = K; }
+        h->k_small4[2] = k_search_small<F, C, K, 128, 4, 4>; h->k_small8 = k_search_small<F, C, K, 128, 8, 4>; h->k_big[0] = k_search_big<F, C, K, 512, 1>; h->k_big[1] = k_search_big<F, C, K, 512, 2>; h->k_big8 = k_search_big<F, C, K, 512, 1, 0, 8>; h->k_big8x = k_search_big<F, C, K, 512, 2, 0, 8>; h->reg_kpl = K; \
+        h->k_persist = k_selfplay_small<F, C, K, 128, 8, 4>; }
     AGZ_SMALL_SHAPES(Z)
+#undef Z
+#define Z(F, C, K, GG) if (P.fam == F && P.NC == C && GG * K >= P.A && GG * K <= 8 * kpl) { h->k_persist_nar = k_selfplay_small<F, C, K, 128, 4, 2, GG>; h->persist_nar_g = GG; h->persist_nar_kpl = K; }
+    AGZ_PERSIST_NARROW_SHAPES(Z)
 #undef Z
 #define Z(F, C, K, R) if (P.fam == F && P.NC == C && kpl == K && h->ncmp < 4) { agz_engine::CmpLevel& c = h->cmp[h->ncmp++]; c.kpr = R; \
         c.s2 = k_search_small<F, C, K, 128, 2, 2, R>; c.s4[0] = k_search_small<F, C, K, 128, 4, 2, R>; c.s4[1] = k_search_small<F, C, K, 128, 4, 3, R>; \
@@ -273,8 +288,8 @@ void agz_destroy(agz_engine* h) {
     hipFree(h->game_id2); hipFree(h->slot_ply); hipFree(h->slot_ply2); hipFree(h->cnt_p); hipFree(h->cnt_new); hipFree(h->planes); hipFree(h->logits);
     hipFree(h->prior_eval); hipFree(h->v_eval); hipFree(h->policy_final); hipFree(h->act0); hipFree(h->act1);
     hipFree(h->actf0); hipFree(h->actf1); hipFree(h->newpos); hipFree(h->alive); hipFree(h->newslot); hipFree(h->d_count);
-    hipFree(h->s_boards); hipFree(h->s_policy); hipFree(h->s_move); hipFree(h->g_nplies); hipFree(h->g_result);
-    hipFree(h->g_final); hipFree(h->d_stats); hipFree(h->d_acc); hipFree(h->scratch_f);
+    hipFree(h->s_boards); hipFree(h->s_policy); hipFree(h->s_move); hipFree(h->s_net); hipFree(h->g_nplies); hipFree(h->g_result);
+    hipFree(h->g_final); hipFree(h->d_stats); hipFree(h->d_acc); hipFree(h->d_pacc); hipFree(h->scratch_f);
     hipFree(h->wl); hipFree(h->wl_n); hipFree(h->sp);
     hipFree(h->d_order);
     hipFree(h->stage_dev); if (h->stage_host) hipHostFree(h->stage_host);
@@ -399,6 +414,10 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
         e3 = getenv("AGZ_NARROW_OCC");
         if (e3 && (atoi(e3) == 0 || atoi(e3) == 1)) h->narrow_occ = atoi(e3);
         for (int i = 0; i < h->nnar; ++i) for (int j = 0; j < 2; ++j) FA_(hipFuncSetAttribute((const void*)h->nar[i].k[j], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        e3 = getenv("AGZ_PERSIST");
+        if (e3) h->persist = atoi(e3) > 0 ? 1 : 0;
+        if (h->k_persist) FA_(hipFuncSetAttribute((const void*)h->k_persist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if (h->k_persist_nar) FA_(hipFuncSetAttribute((const void*)h->k_persist_nar, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         e3 = getenv("AGZ_SMALL4_OCC");
         if (e3 && atoi(e3) >= 0 && atoi(e3) <= 2) h->small4_occ = atoi(e3);
         if (h->k_small) FA_(hipFuncSetAttribute((const void*)h->k_small, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -437,12 +456,12 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     A_(dmalloc(&h->logits, Lm * h->LGS));
     A_(dmalloc(&h->prior_eval, Lm * P.A + 64)); A_(dmalloc(&h->v_eval, Lm)); A_(dmalloc(&h->policy_final, Lm * P.A));
     A_(dmalloc(&h->newpos, Lm)); A_(dmalloc(&h->alive, Lm)); A_(dmalloc(&h->newslot, Lm)); A_(dmalloc(&h->d_count, 4));
-    A_(dmalloc(&h->d_stats, 16)); A_(dmalloc(&h->d_acc, 2));
+    A_(dmalloc(&h->d_stats, 16)); A_(dmalloc(&h->d_acc, 2)); A_(dmalloc(&h->d_pacc, 8));
     FA_(hipMemset(h->d_acc, 0, 16));
     A_(dmalloc(&h->scratch_f, Lm * (size_t)((P.A > 2 * P.VS) ? P.A : 2 * P.VS)));
     h->sample_games = cfg->sample_capacity_games > 0 ? cfg->sample_capacity_games : h->Lmax;
     const size_t SG = (size_t)h->sample_games, MP = (size_t)P.max_plies;
-    A_(dmalloc(&h->s_boards, SG * MP * 6)); A_(dmalloc(&h->s_policy, SG * MP * P.A)); A_(dmalloc(&h->s_move, SG * MP));
+    A_(dmalloc(&h->s_boards, SG * MP * 6)); A_(dmalloc(&h->s_policy, SG * MP * P.A)); A_(dmalloc(&h->s_move, SG * MP)); A_(dmalloc(&h->s_net, SG * MP));
     A_(dmalloc(&h->g_nplies, SG)); A_(dmalloc(&h->g_result, SG)); A_(dmalloc(&h->g_final, SG));
     A_(dmalloc(&h->d_order, SG * MP));
     if (e != hipSuccess) { h->fail("device allocation failed: %s", hipGetErrorString(e)); return bail(AGZ_ERR_NOMEM); }
@@ -467,7 +486,7 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     T.slot_ply = h->slot_ply;
     h->rd_rec_bytes = rec_bytes; h->rd_off_rk = 16 + A2 * 4; h->rd_off_el = T.off_q; h->rd_off_vis = T.off_vis;
     FA_(hipMemsetAsync(h->wl_n, 0, wl_blocks * 4, h->stream)); hipMemsetAsync(h->sp, 0, Lm * 4, h->stream);
-#if defined(AGZ_STAMPS) || defined(AGZ_BIGSTAMPS)
+#if defined(AGZ_STAMPS) || defined(AGZ_BIGSTAMPS) || defined(AGZ_WGTIME)
     { unsigned long long* d = nullptr; hipMalloc((void**)&d, (size_t)65536 * 16 * 8); hipMemset(d, 0, (size_t)65536 * 16 * 8); T.dbg = d; }
 #endif
 #undef FA_
@@ -490,11 +509,24 @@ int agz_set_seed(agz_engine* h, uint64_t seed) {
     h->cfg.seed = seed; h->tp.seed = seed;
     return AGZ_OK;
 }
+int agz_set_network_tag(agz_engine* h, uint32_t tag) {
+    if (!h) return AGZ_ERR_ARG;
+    if (tag > 255u) { h->fail("agz_set_network_tag: tag=%u outside [0,255]", tag); return AGZ_ERR_ARG; }
+    h->net_tag = tag;
+    return AGZ_OK;
+}
 int agz_get_info(const agz_engine* h, agz_game_info* out) {
     if (!h || !out) return AGZ_ERR_ARG;
     *out = h->info; return AGZ_OK;
 }
 void* agz_stream(agz_engine* h) { return h ? (void*)h->stream : nullptr; }
+#if defined(AGZ_WGTIME)
+// start / end times (100 MHz) of the workgroups of the last 256 searches: out[(step & 255)][workgroup < 512][2]
+extern "C" int agz_debug_wgtimes(agz_engine* h, unsigned long long* out) {
+    hipStreamSynchronize(h->stream);
+    return hipMemcpy(out, h->tp.dbg, (size_t)256 * 512 * 2 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif
 #if defined(AGZ_STAMPS) || defined(AGZ_BIGSTAMPS)
 // out[0..15]: the tree step's phases (blocks below 32768), out[16..31]: the network body's (blocks from 32768 on)
 extern "C" int agz_debug_stamps(agz_engine* h, unsigned long long* out, int reset) {
@@ -844,6 +876,8 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
     int rc = check_search_args(h, V); if (rc) return rc;
     if (which < 0 || which > 1 || !h->net[which].loaded) { h->fail("no network loaded in slot %d", which); return AGZ_ERR_STATE; }
     HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (h->chain_live && h->chain_L > 0 && !h->in_ply_loop) {   // (a search on those slots would overwrite the plies of the games in flight)
+        h->fail("agz_search: %d games of a chain of self-play calls are in flight (end the chain with next_ngames = 0, or set new roots)", h->chain_L); return AGZ_ERR_STATE; }
     h->cpuct = cpuct; h->training = training; h->step = step;
     if (!h->in_ply_loop && h->L > 0) HIPCHK(h, hipMemsetD32Async((hipDeviceptr_t)h->slot_ply, (int)step, (size_t)h->L, h->stream));   // every slot's game is at ply `step`
     h->rd_rec_bytes = h->tp.rec_bytes; h->rd_off_rk = 16 + h->tp.A2 * 4; h->rd_off_el = h->tp.off_q; h->rd_off_vis = h->tp.off_vis;
@@ -1099,6 +1133,7 @@ int agz_search(agz_engine* h, int V, float cpuct, int training, uint32_t step) {
 // ---- stepwise (teacher-forced parity) ---------------------------------------------------------------
 int agz_search_begin(agz_engine* h, float cpuct, int training, uint32_t step) {
     if (!h) return AGZ_ERR_ARG;
+    if (h->chain_live && h->chain_L > 0) { h->fail("agz_search_begin: %d games of a chain of self-play calls are in flight (end the chain with next_ngames = 0, or set new roots)", h->chain_L); return AGZ_ERR_STATE; }
     h->cpuct = cpuct; h->training = training; h->step = step; h->need_reset = true; h->injected = false; h->step_last = false; h->tree_kpr = 0;
     if (h->L > 0) { HIPCHK(h, hipSetDevice(h->cfg.device)); HIPCHK(h, hipMemsetD32Async((hipDeviceptr_t)h->slot_ply, (int)step, (size_t)h->L, h->stream)); }
     h->rd_rec_bytes = h->tp.rec_bytes; h->rd_off_rk = 16 + h->tp.A2 * 4; h->rd_off_el = h->tp.off_q; h->rd_off_vis = h->tp.off_vis;
@@ -1275,7 +1310,7 @@ static void fill_plypar(agz_engine* h, PlyPar& T, int ply, int tau_plies, bool a
     T.states = h->states; T.game_id = h->game_id; T.slot_ply = h->slot_ply; T.policy_final = h->policy_final; T.newpos = h->newpos; T.alive = h->alive;
     T.next_game = h->d_stats + 6; T.identity = h->d_count;
     T.sample_games = h->sample_games; T.max_plies = h->G.max_plies;
-    T.s_boards = h->s_boards; T.s_policy = h->s_policy; T.s_move = h->s_move; T.g_nplies = h->g_nplies; T.g_result = h->g_result;
+    T.s_boards = h->s_boards; T.s_policy = h->s_policy; T.s_move = h->s_move; T.s_net = h->s_net; T.net_tag = h->net_tag; T.g_nplies = h->g_nplies; T.g_result = h->g_result;
     T.g_final = h->g_final; T.stats = h->d_stats;
 }
 
@@ -1283,11 +1318,28 @@ static void fill_plypar(agz_engine* h, PlyPar& T, int ply, int tau_plies, bool a
 // the previous call of the chain, the call returns when ITS ngames games have finished, and while they run out it starts up to next_games
 // games of the next call in the slots that come free — they stay in flight when the call returns and the next call goes on with them, so
 // only the last call of a chain (next_games = 0) ends on a batch that runs out.
+static int finish_call(agz_engine* h, int ngames, bool chain, unsigned long long k0, unsigned long long started, int in_flight, bool persist,
+                       int64_t rollouts, int ply, double search_ms, std::chrono::steady_clock::time_point t0, agz_selfplay_stats* st);
+static bool persist_shape(const agz_engine* h);
+static int run_games_persist(agz_engine* h, int ngames, int V, float cpuct, int tau_plies, agz_selfplay_stats* st, int next_games);
+
 static int run_games(agz_engine* h, int ngames, int V, float cpuct, int tau_plies, int training, int duel_first, bool duel,
                      agz_selfplay_stats* st, int next_games = -1) {
     int rc = check_search_args(h, V); if (rc) return rc;
     const bool chain = next_games >= 0;
     const bool cont = chain && h->chain_live;                                   // the chain goes on (possibly with games in flight)
+    if (!duel && training) {
+        // one launch per call (agz_selfplay_small.hpp) where the kernel exists: by default for calls that refill their slots on an engine whose
+        // every workgroup is resident at more than 96 slots per CU (the batch the eight-wave workgroups are the fastest form of); a chain
+        // stays in the form it began in (the persistent form does not compact its slots)
+        const long long want_ = chain ? (long long)ngames + next_games : (long long)ngames;
+        const bool refill_ = chain || want_ > h->Lmax;
+        const bool use = cont ? h->chain_persist : (persist_shape(h) && (h->persist > 0 || (h->persist < 0 && refill_ && h->Lmax > 96 * h->cus)));
+        if (use) {
+            if (!persist_shape(h)) { h->fail("the chain's games are in flight in uncompacted slots (persistent form) and the engine's network / mode no longer allows that form"); return AGZ_ERR_STATE; }
+            return run_games_persist(h, ngames, V, cpuct, tau_plies, st, next_games);
+        }
+    }
     const unsigned long long k0 = cont ? h->chain_k0 : 0ull;                    // this call's games: k0 .. k0 + ngames - 1 of the chain
     const unsigned long long pool_end = k0 + (unsigned long long)ngames + (unsigned long long)(chain ? next_games : 0);   // games that may be started
     // more games than slots (self-play only): the first Lmax games start together, and a slot whose game has ended takes the next game
@@ -1453,6 +1505,13 @@ static int run_games(agz_engine* h, int ngames, int V, float cpuct, int tau_plie
     if (fold_pending) hipStreamWaitEvent(h->stream, h->ev_fold, 0);
     for (size_t i = 1; i < tpool.size(); ++i) { hipEventDestroy(tpool[i].first); hipEventDestroy(tpool[i].second); }
     if (rc) return rc;
+    return finish_call(h, ngames, chain, k0, started, h->L, false, rollouts, ply, search_ms, t0, st);
+}
+
+// the end of a self-play / duel call, shared by the ply loop above and the persistent form below: the call's sample count and longest
+// game, W / D / L, the chain's bookkeeping, the statistics, the faults
+static int finish_call(agz_engine* h, int ngames, bool chain, unsigned long long k0, unsigned long long started, int in_flight, bool persist,
+                       int64_t rollouts, int ply, double search_ms, std::chrono::steady_clock::time_point t0, agz_selfplay_stats* st) {
     unsigned long long hs[16];
     HIPCHK(h, hipMemcpy(hs, h->d_stats, sizeof hs, hipMemcpyDeviceToHost));
     {   // nsamples = sum of plies per game; kept (with the longest game) for agz_get_samples_packed
@@ -1472,7 +1531,8 @@ static int run_games(agz_engine* h, int ngames, int V, float cpuct, int tau_plie
             // THIS call's games come from their own entries (mcts_gpu.jl:535: tot_length += round, the ply of the last move)
             hs[0] = hs[1] = hs[2] = hs[3] = 0;
             for (size_t i = 0; i < np.size(); ++i) { hs[res[i] == 1 ? 0 : (res[i] == 0 ? 1 : 2)] += 1; hs[3] += (unsigned long long)(np[i] > 0 ? np[i] - 1 : 0); }
-            h->chain_live = true; h->chain_k0 = k0 + (unsigned long long)ngames; h->chain_started = started; h->chain_L = h->L;
+            h->chain_live = true; h->chain_k0 = k0 + (unsigned long long)ngames; h->chain_started = persist ? hs[6] : started; h->chain_L = in_flight;
+            h->chain_persist = persist;
         }
     }
     if (st) {
@@ -1485,6 +1545,129 @@ static int run_games(agz_engine* h, int ngames, int V, float cpuct, int tau_plie
     if (hs[5]) { h->fail("%llu expansion(s) found a root with more legal actions than the rows by legal rank hold (legal_bound violated)", hs[5]); return AGZ_ERR_STATE; }
     if (hs[4]) { h->fail("%llu illegal sampled move(s) (\"faute\", mcts_gpu.jl:526-529)", hs[4]); return AGZ_ERR_ILLEGAL_MOVE; }
     return AGZ_OK;
+}
+
+// ---- one launch per call: the persistent self-play kernel (agz_selfplay_small.hpp) -------------------------------------------------
+static bool persist_shape(const agz_engine* h) {
+    const DevNet& n = h->net[0];
+    if (h->persist == 0 || !(h->k_persist || h->k_persist_nar) || h->cfg.nn_mode != AGZ_NN_BF16 || !n.loaded || n.H != 128 || !n.w16w) return false;
+    if (h->V > 128 || (h->V & 3) != 0 || h->no_fused_nn || 8 * h->reg_kpl > h->LGS) return false;
+    return (h->Lmax + 63) / 64 <= 2 * h->cus;                                  // every workgroup resident: two 64-game workgroups per CU
+}
+
+static int run_games_persist(agz_engine* h, int ngames, int V, float cpuct, int tau_plies, agz_selfplay_stats* st, int next_games) {
+    const bool chain = next_games >= 0;
+    const bool cont = chain && h->chain_live;
+    const unsigned long long k0 = cont ? h->chain_k0 : 0ull;
+    const unsigned long long pool_end = k0 + (unsigned long long)ngames + (unsigned long long)(chain ? next_games : 0);
+    const long long want = chain ? (long long)ngames + next_games : (long long)ngames;
+    const int slots = want < h->Lmax ? (int)want : h->Lmax;
+    if (ngames < 1) { h->fail("ngames=%d outside [1,%d]", ngames, h->sample_games); return AGZ_ERR_ARG; }
+    if (ngames > slots && ngames > h->sample_games) { h->fail("ngames=%d exceeds the sample capacity of the engine (%d games: agz_config.sample_capacity_games)", ngames, h->sample_games); return AGZ_ERR_ARG; }
+    if (chain && want > h->sample_games) { h->fail("agz_selfplay_chain: ngames + next_ngames = %lld exceeds the sample capacity of the engine (%d games: agz_config.sample_capacity_games)", want, h->sample_games); return AGZ_ERR_ARG; }
+    if (chain && pool_end + (unsigned long long)h->cfg.game_id_base > 0xffffffffull) { h->fail("agz_selfplay_chain: game ids exhausted"); return AGZ_ERR_ARG; }
+    auto t0 = std::chrono::steady_clock::now();
+    unsigned long long started = 0, finished = 0;
+    int rc;
+    if (!cont) {
+        rc = agz_set_roots(h, nullptr, 0, nullptr, slots); if (rc) return rc;   // Position() for every game (:479), ids game_id_base + slot
+        HIPCHK(h, hipMemsetAsync(h->d_stats, 0, 16 * sizeof(unsigned long long), h->stream));
+        HIPCHK(h, hipMemsetAsync(h->g_nplies, 0, (size_t)h->sample_games * 4, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->slot_ply, 0, (size_t)h->Lmax * 4, h->stream));
+        HIPCHK(h, hipMemsetD32Async((hipDeviceptr_t)h->alive, 1, (size_t)slots, h->stream));
+        if (slots < h->Lmax) HIPCHK(h, hipMemsetD32Async((hipDeviceptr_t)(h->alive + slots), 0, (size_t)(h->Lmax - slots), h->stream));
+        started = (unsigned long long)slots;
+        HIPCHK(h, hipMemcpyAsync(h->d_stats + 6, &started, 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    } else {
+        // the games the last call left in flight go on in their slots (alive[]); per-call counters start over; the games of this call that
+        // finished early are already counted; the ring entries of the games that may start now are cleared; slots without a game take the
+        // games that wait when the kernel starts
+        HIPCHK(h, hipSetDevice(h->cfg.device));
+        started = h->chain_started;
+        const unsigned long long cap = (unsigned long long)h->sample_games;
+        for (unsigned long long a = started; a < pool_end;) {
+            const unsigned long long r = a % cap, n = std::min(pool_end - a, cap - r);
+            HIPCHK(h, hipMemsetAsync(h->g_nplies + r, 0, (size_t)n * 4, h->stream));
+            a += n;
+        }
+        {
+            std::vector<int32_t> np((size_t)ngames);
+            for (size_t a = 0; a < np.size();) {
+                const size_t r = (size_t)((k0 + a) % cap), n = std::min(np.size() - a, (size_t)cap - r);
+                HIPCHK(h, hipMemcpyAsync(np.data() + a, h->g_nplies + r, n * 4, hipMemcpyDeviceToHost, h->stream));
+                a += n;
+            }
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            finished = 0; for (int32_t x : np) finished += x > 0 ? 1ull : 0ull;
+        }
+        const unsigned long long z[10] = {0, 0, 0, 0, 0, 0, started, 0, finished, 0};
+        HIPCHK(h, hipMemcpyAsync(h->d_stats, z, sizeof z, hipMemcpyHostToDevice, h->stream));
+    }
+    h->L = h->Lmax;                                                             // the launch covers every slot; alive[] says which hold a game
+    h->need_reset = true; h->tree_kpr = 0;
+    h->chain_live = false;
+    h->sp_games = ngames; h->sp_nsamples = 0; h->sp_maxplies = 0;
+    h->sp_k0 = (uint32_t)k0; h->sp_ring0 = chain ? (uint32_t)(k0 % (unsigned long long)h->sample_games) : 0u;
+    h->cpuct = cpuct; h->training = 1; h->step = 0;
+    HIPCHK(h, hipMemsetAsync(h->d_pacc, 0, 8 * sizeof(unsigned long long), h->stream));
+    // ---- the launch: the search parameters of k_search_small's 64-game workgroups (agz_search_actor), the ply step's, the call's pool
+    DevNet& n = h->net[0];
+    const bool nar = h->k_persist_nar && h->narrow_mode >= 0;                   // few-action games: 4 lanes per tree, 16 trees per wave, four waves
+    if (!nar && !h->k_persist) { h->fail("no persistent self-play kernel for this game shape"); return AGZ_ERR_UNSUPPORTED; }
+    const int G = nar ? h->persist_nar_g : 8, NG = 64 / G, tw = nar ? 4 : 8, gpwg = tw * NG;
+    PersistPar Q; memset(&Q, 0, sizeof Q);
+    SmallPar& S = Q.S;
+    S.T = h->tp;
+    S.T.L = h->Lmax; S.T.slot0 = 0; S.T.step = 0; S.T.cpuct = cpuct; S.T.training = 1;
+    S.T.fastdiv = fastdiv_range(h);
+    S.T.inject = 0; S.T.capture = 0; S.T.rollout = 0; S.T.do_reset = 1; S.T.do_expand = 0; S.T.do_select = 1; S.T.last = 0;
+    S.T.gpw = NG;
+    S.F.planes = (const uint16_t*)h->planes; S.F.INP = n.INP; S.F.w16 = n.w16w; S.F.bias_head = n.bias_head;
+    S.F.logits = h->logits; S.F.LGS = h->LGS; S.F.vout = h->v_eval; S.F.L = h->Lmax; S.F.T = n.T; S.F.A = h->G.A; S.F.AOP = n.AOP;
+    S.F.gpw = 0; S.F.tw = tw; S.F.rb = NG;
+    S.V = V; S.tree_lds = nar ? eager_lds_layout(h->V, NG).total : (int)h->reg_lds;
+    const int kth = n.H / 32, g0 = (n.INP / 32 + kth - 1) / kth;
+    const int prowb = g0 * kth * 64 + 16;
+    const int rs = (std::max(prowb, 4 * n.AOP) + 15) & ~15;
+    S.io_prowb = rs; S.io_lgs = rs / 4; S.io_bw = NG * rs;
+    S.io_off = (int)((std::max((size_t)tw * (size_t)S.tree_lds, (size_t)gpwg * 2 * (n.H * 2 + 16)) + 15) & ~(size_t)15);
+    S.xch_off = S.io_off + tw * S.io_bw;
+    const size_t shared = (size_t)S.xch_off + (size_t)tw * (16 * NG + 16) + 16;   // ... + the workgroup's two flag words
+    Q.flag_off = (int)shared - 16;
+    const size_t cu_lds = (size_t)(160 * 1024) / 2;
+    const size_t room = cu_lds > shared ? cu_lds - shared : 0;
+    S.wl_off = (int)shared; S.wl_bytes = (int)std::min({(size_t)(NG * h->V * 4), (room / (size_t)tw) & ~(size_t)15, (size_t)h->wl_lds_max});
+    const size_t lds = shared + (size_t)tw * S.wl_bytes;
+    if (lds > cu_lds) { h->fail("persistent self-play kernel: %zu bytes of LDS per workgroup", lds); return AGZ_ERR_UNSUPPORTED; }
+    fill_plypar(h, Q.P, 0, tau_plies, false);
+    Q.P.L = h->Lmax;
+    Q.P.refill_total = (chain || (long long)ngames > (long long)slots) ? (uint32_t)pool_end : 0u;
+    Q.P.ring = chain ? 1 : 0; Q.P.k_cur_end = (uint32_t)(k0 + (unsigned long long)ngames);
+    Q.ngames_cur = chain ? (uint32_t)ngames : 0u;
+    Q.acc = h->d_pacc;
+    const unsigned wgs = (unsigned)((h->Lmax + gpwg - 1) / gpwg);
+    h->rd_rec_bytes = nar ? (uint32_t)eager_rec_bytes(G * h->persist_nar_kpl, h->V) : h->tp.rec_bytes;
+    h->in_ply_loop = true;
+    hipEventRecord(h->ev_ply0, h->stream);
+    hipLaunchKernelGGL(nar ? h->k_persist_nar : h->k_persist, dim3(wgs), dim3(64 * tw), lds, h->stream, Q);
+    hipEventRecord(h->ev_ply1, h->stream);
+    const bool sleep = h->ply_sleep && h->ev_adv && hipEventRecord(h->ev_adv, h->stream) == hipSuccess;
+    hipError_t le = hipGetLastError();
+    if (le == hipSuccess) le = sleep ? hipEventSynchronize(h->ev_adv) : hipSuccess;   // (a blocking event: the host thread sleeps through the call)
+    if (le == hipSuccess) le = hipStreamSynchronize(h->stream);
+    h->in_ply_loop = false;
+    if (le != hipSuccess) { h->fail("persistent self-play launch failed: %s", hipGetErrorString(le)); return AGZ_ERR_HIP; }
+    float ms = 0; hipEventElapsedTime(&ms, h->ev_ply0, h->ev_ply1);
+    unsigned long long acc[8];
+    HIPCHK(h, hipMemcpy(acc, h->d_pacc, sizeof acc, hipMemcpyDeviceToHost));
+    const int64_t rollouts = (int64_t)acc[2] * V;
+    { char b[220]; snprintf(b, sizeof b, "k_selfplay_small<KPL=%d,H=128,TW=%d,WV=%d,G=%d> (persistent: one launch per self-play call, a workgroup loops over the plies of its %d games)",
+                            nar ? h->persist_nar_kpl : h->reg_kpl, tw, nar ? 2 : 4, G, gpwg); h->form_tree = b; h->form_nn = "inside k_selfplay_small (mlp_wave_body<128>)"; }
+    h->acc_p += acc[0]; h->acc_new += acc[1]; h->total_rollouts += (uint64_t)rollouts; h->cnt_live = false;
+    h->tree_ms += ms; h->tree_busy_ms += ms; h->tree_launches += 1;
+    const int rounds = (int)((acc[2] + (unsigned long long)h->Lmax - 1) / (unsigned long long)h->Lmax);   // searches per slot, rounded up
+    return finish_call(h, ngames, chain, k0, started, (int)acc[3], true, rollouts, rounds, (double)ms, t0, st);
 }
 
 int agz_selfplay(agz_engine* h, int ngames, int V, float cpuct, int tau_plies, agz_selfplay_stats* stats) {
@@ -1527,7 +1710,7 @@ int agz_get_samples_packed(agz_engine* h, void* dev_out, int64_t capacity_record
                        (unsigned long long*)nullptr, h->sp_ring0, (uint32_t)h->sample_games);
     PackPar T;
     T.A = h->G.A; T.VS = h->G.VS; T.FS = h->G.FS; T.max_plies = h->G.max_plies; T.rec_bytes = h->info.rec_bytes;
-    T.game_id_base = h->cfg.game_id_base; T.s_boards = h->s_boards; T.s_policy = h->s_policy; T.s_move = h->s_move;
+    T.game_id_base = h->cfg.game_id_base; T.s_boards = h->s_boards; T.s_policy = h->s_policy; T.s_move = h->s_move; T.s_net = h->s_net;
     T.g_nplies = h->g_nplies; T.g_result = h->g_result; T.g_final = h->g_final; T.order = h->d_order; T.n = n;
     T.ring0 = h->sp_ring0; T.cap = (uint32_t)h->sample_games; T.k0 = h->sp_k0;
     T.out = (uint8_t*)dev_out;

@@ -70,6 +70,9 @@ __global__ __launch_bounds__(64 * (TW == 8 ? 8 : NW_WAVES), WV) void k_search_sm
     uint8_t* const own_lds = lds_small + (size_t)(SPLIT ? wave : wave % TW) * S.tree_lds;   // (a helper wave has tables of its own)
     uint32_t* const xch = reinterpret_cast<uint32_t*>(lds_small + S.xch_off + (size_t)(wave % TW) * (16 * NG + 16));
     const int V_ = S.V;
+#ifdef AGZ_WGTIME
+    const unsigned long long wg_t0 = wall_clock64();
+#endif
     for (int k = 0; k <= V_; ++k) {
         // the workgroup index is made opaque once per rollout: otherwise every per-game address of both bodies is hoisted out
         // of this loop and kept alive across them (hundreds of registers, spills)
@@ -121,6 +124,13 @@ __global__ __launch_bounds__(64 * (TW == 8 ? 8 : NW_WAVES), WV) void k_search_sm
         if ((threadIdx.x & 63) == 0 && wave < TW && S.T.dbg) S.T.dbg[(size_t)(bx * TW + wave) * 16 + 15] += __builtin_amdgcn_s_memtime() - t_nn0;
 #endif
     }
+#ifdef AGZ_WGTIME
+    // diagnostic: when did this workgroup start and end (100 MHz clock), per launch (step & 255) and workgroup
+    if (threadIdx.x == 0 && par().T.dbg && blockIdx.x < 512) {
+        unsigned long long* d = par().T.dbg + ((size_t)(par().T.step & 255u) * 512 + blockIdx.x) * 2;
+        d[0] = wg_t0; d[1] = wall_clock64();
+    }
+#endif
 }
 
 // The instantiated shapes (game family, bitboard chunks, actions per lane): agz_small_inst.hip compiles them in four

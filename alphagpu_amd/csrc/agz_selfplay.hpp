@@ -4,145 +4,16 @@
 // in a single-threaded host loop with a 32 MB D2H + H2D per ply; here only one 4-byte count crosses PCIe.
 #pragma once
 #include "agz_device.hpp"
+#include "agz_plystep.hpp"
 
 namespace agz {
-
-struct PlyPar {
-    GamePar G;
-    int32_t L, V, ply, tau_plies, all_actions;   // ply: the round of the lock-step loop (diagnostics; every game's own ply is slot_ply[slot])
-    uint64_t seed;
-    uint32_t game_id_base;
-    Pos* states;              // [L][V] roots at node 0
-    uint32_t* game_id;        // [L]
-    uint32_t* slot_ply;       // [L] plies played so far by the slot's game (the reference's `round`, mcts_gpu.jl:484,556, per game)
-    // more games than slots (agz_selfplay with ngames > max_games): a slot whose game has ended takes the next game that has not
-    // started yet — game id game_id_base + k for the k-th start, Position(), ply 0 — until refill_total games have been started
-    // (0: no refill).  Results are keyed by game id and ply, never by slot or by the round a game happens to start in.
-    uint32_t refill_total;
-    unsigned long long* next_game;   // games started so far (device counter)
-    // chained calls (agz_selfplay_chain): game ids run on from call to call (game k of the chain has id game_id_base + k), the sample store
-    // is a RING over k (k mod sample_games), and a call may start games of the NEXT call in slots that would otherwise idle.  k_cur_end:
-    // the games k < k_cur_end belong to the call that is running (a finished one counts in stats[8] — what the call waits for —, a later one in stats[9]).
-    int32_t ring; uint32_t k_cur_end;
-    const uint32_t* identity; // k_compact: k_scan_alive's count words ([1] != 0: every slot keeps its place)
-    const float* policy_final;// [L][A]
-    // per-slot scratch
-    Pos* newpos;              // [L]
-    uint32_t* alive;          // [L]
-    // sample store, indexed by local game g = game_id - game_id_base (< sample_games)
-    int32_t sample_games, max_plies;
-    uint64_t* s_boards;       // [G][max_plies][6]  bplayer[3], bopponent[3] of the root
-    float* s_policy;          // [G][max_plies][A]
-    int16_t* s_move;          // [G][max_plies]
-    int32_t* g_nplies;        // [G]
-    int8_t* g_result;         // [G]
-    Pos* g_final;             // [G]
-    unsigned long long* stats;// [0] wins [1] draws [2] losses [3] total_plies [4] faults ... [7] slots left without a game by this ply's k_advance (reset by k_scan_alive)
-};
 
 // one wavefront per slot
 template <int FAM, int NR, int NC>
 __global__ __launch_bounds__(256) void k_advance(const PlyPar T) {
-    using G = Game<FAM, NC>;
-    const GamePar& P = T.G;
-    const int lane = lane_id();
     const int slot = ufirst((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
     if (slot >= T.L) return;
-    const int A = P.A;
-    const uint32_t gid = ufirst(T.game_id[slot]);
-    const uint32_t kg = gid - T.game_id_base;                      // the game's number in the call (in the chain of calls)
-    const int g = T.ring ? (int)(kg % (uint32_t)T.sample_games) : (int)kg;
-    WPos<NC> root = load_pos<NC>(T.states + (size_t)slot * T.V);
-    const int ply = (int)ufirst(T.slot_ply[slot]);                 // this game's round (:484, :556)
-    float pol[NR];
-    for (int r = 0; r < NR; ++r) { int k = 64 * r + lane; pol[r] = k < A ? T.policy_final[(size_t)slot * A + k] : 0.0f; }
-    const bool in_range = T.ring || (g >= 0 && g < T.sample_games);
-    const bool keep = in_range && ply < T.max_plies;
-    const int np_end = ply + 1 < T.max_plies ? ply + 1 : T.max_plies;
-    if (keep) {                                                     // push_buffer: root planes (as boards) + policy
-        size_t sidx = (size_t)g * T.max_plies + ply;
-        for (int r = 0; r < NR; ++r) { int k = 64 * r + lane; if (k < A) T.s_policy[sidx * A + k] = pol[r]; }
-        if (lane < 6) {
-            uint64_t w = 0;
-            for (int i = 0; i < NC; ++i) { if (lane == i) w = root.p.c[i]; if (lane == 3 + i) w = root.o.c[i]; }
-            T.s_boards[sidx * 6 + lane] = w;
-        }
-    }
-    // ---- move choice (:518-524)
-    int c = -1;
-    if (ply < T.tau_plies) {
-        // sample(lp, Weights(pol[lp])): t = u * sum(w), first index whose running sum >= t (source order)
-        float total = 0.0f; bool st = false; uint64_t nzm[NR]; float run[NR];   // run: the running sum up to and including the lane's action
-        for (int r = 0; r < NR; ++r) {
-            nzm[r] = __ballot(64 * r + lane < A && pol[r] != 0.0f);
-            run[r] = chain64(pol[r], nzm[r], total, false, 0.0f, st);
-        }
-        const float u = ufirst(uniform_move(T.seed, gid, (uint32_t)ply));
-        const float tt = u * total;
-        // duel (:606): sample(1:maxActions, Weights(policy)) walks ALL actions, zero weights included — the same index as the
-        // nonzero-list walk of self-play (:519-520) whenever tt > 0, and u is never 0 (uniform_move): a zero-weight action is never
-        // chosen
-        // (the walk compares the SAME running sums the total came from: one ordered pass over the row, not two)
-        int last = -1;
-        for (int r = 0; r < NR; ++r) {
-            if (!nzm[r]) continue;
-            last = 64 * r + 63 - __builtin_clzll(nzm[r]);
-            if (c >= 0) continue;
-            uint64_t ge = __ballot(((nzm[r] >> lane) & 1ull) && !(run[r] < tt));
-            if (ge) c = 64 * r + __builtin_ctzll(ge);
-        }
-        if (c < 0) c = last;
-    } else {
-        // argmax(pol): first maximum
-        float best = -__builtin_inff();
-        for (int r = 0; r < NR; ++r) { int k = 64 * r + lane; best = (k < A && pol[r] > best) ? pol[r] : best; }
-        best = ufirst(wave_max(best));
-        for (int r = 0; r < NR && c < 0; ++r) {
-            uint64_t eq = __ballot(64 * r + lane < A && pol[r] == best);
-            if (eq) c = 64 * r + __builtin_ctzll(eq);
-        }
-        if (c < 0) c = 0;
-    }
-    bool fault = c < 0;
-    if (!fault) {
-        bool ok = __ballot(lane == 0 && G::canPlay(P, root, c)) != 0;   // "faute" guard (:526-529)
-        fault = !ok;
-    }
-    if (fault) {
-        if (lane == 0) { atomicAdd(&T.stats[4], 1ull); atomicAdd(&T.stats[7], 1ull); if (T.ring) atomicAdd(&T.stats[kg < T.k_cur_end ? 8 : 9], 1ull); T.alive[slot] = 0; if (keep) T.s_move[(size_t)g * T.max_plies + ply] = (int16_t)c; if (in_range) { T.g_nplies[g] = np_end; T.g_result[g] = 0; T.g_final[g] = pack(root); } }
-        return;
-    }
-    WPos<NC> np = G::play(P, root, c);
-    int res; const bool f = G::isOver(P, np, res);
-    if (lane == 0) {
-        if (keep) T.s_move[(size_t)g * T.max_plies + ply] = (int16_t)c;
-        Pos next = pack(np);
-        uint32_t alive = f ? 0u : 1u, nply = (uint32_t)ply + 1u;
-        if (f) {
-            if (in_range) { T.g_nplies[g] = np_end; T.g_result[g] = (int8_t)res; T.g_final[g] = pack(np); }
-            atomicAdd(&T.stats[res == 1 ? 0 : (res == 0 ? 1 : 2)], 1ull);     // :541-547
-            atomicAdd(&T.stats[3], (unsigned long long)ply);                   // tot_length += round (:535)
-            if (T.ring) atomicAdd(&T.stats[kg < T.k_cur_end ? 8 : 9], 1ull);
-            if (T.refill_total) {                                              // the slot takes the next game that has not started yet
-                // (a draw past the end of the pool is given back: once the launch is over the counter IS the number of games started, and a
-                //  chain's later calls go on from it with a larger pool.  Draws below refill_total are unique: a failed draw only happens once
-                //  all of them have been handed out.  One add per finished game — a compare-and-swap loop on this one address cost 2 ms per ply.)
-                const unsigned long long k = atomicAdd(T.next_game, 1ull);
-                if (k >= (unsigned long long)T.refill_total) atomicAdd(T.next_game, ~0ull);
-                if (k < (unsigned long long)T.refill_total) {
-                    for (int i = 0; i < 3; ++i) { next.p[i] = P.start_p[i]; next.o[i] = P.start_o[i]; next.lg[i] = P.start_lg[i]; }
-                    next.player = (int8_t)P.start_player; next.aux = (int8_t)P.start_aux;
-                    for (int i = 0; i < 6; ++i) next.pad[i] = 0;
-                    T.game_id[slot] = T.game_id_base + (uint32_t)k;
-                    alive = 1u; nply = 0u;
-                }
-            }
-        }
-        if (!alive) atomicAdd(&T.stats[7], 1ull);
-        T.newpos[slot] = next;
-        T.alive[slot] = alive;
-        T.slot_ply[slot] = nply;
-    }
+    (void)advance_slot<FAM, NR, NC, false>(T, slot);
 }
 
 // policy_final rows that a search with node rows by the root's legal RANK (agz_tree_eager.hpp KPR_) left in rank order -> action order, in
@@ -294,7 +165,7 @@ __global__ __launch_bounds__(1024) void k_sample_order(const int32_t* nplies, in
 struct PackPar {
     int32_t A, VS, FS, max_plies, rec_bytes;
     uint32_t game_id_base;
-    const uint64_t* s_boards; const float* s_policy; const int16_t* s_move;
+    const uint64_t* s_boards; const float* s_policy; const int16_t* s_move; const uint8_t* s_net;
     const int32_t* g_nplies; const int8_t* g_result; const Pos* g_final;
     const uint32_t* order;   // [n] (g << 8 | ply)  PoolSample order
     uint32_t ring0, cap, k0; // chained calls: game g of the call is entry (ring0 + g) mod cap of the per-game arrays and game k0 + g of the chain
@@ -320,7 +191,8 @@ __global__ __launch_bounds__(256) void k_pack_samples(const PackPar T) {
             reinterpret_cast<int32_t*>(rec)[2] = T.s_move[sidx];
             reinterpret_cast<float*>(rec)[3] = (float)((1 + res * player) / 2.0);      // mainGobang.jl:76
             reinterpret_cast<int8_t*>(rec)[16] = (int8_t)player;
-            rec[17] = rec[18] = rec[19] = 0;
+            rec[17] = T.s_net[sidx];                                                    // the network that searched this ply (agz_set_network_tag)
+            rec[18] = rec[19] = 0;
         }
         float* pol = reinterpret_cast<float*>(rec + 20);
         int8_t* st = reinterpret_cast<int8_t*>(rec + 20 + 4 * T.A);

@@ -7,9 +7,10 @@
 #include "agz_device.hpp"
 #include "agz_search_small.hpp"
 #include "agz_search_big.hpp"
+#include "agz_selfplay_small.hpp"
 
 namespace agz {
-#define X(F, C, K) AGZ_SMALL_VARIANTS(F, C, K, ) AGZ_BIG_VARIANTS(F, C, K, )
+#define X(F, C, K) AGZ_SMALL_VARIANTS(F, C, K, ) AGZ_BIG_VARIANTS(F, C, K, ) AGZ_PERSIST_VARIANTS(F, C, K, )
 #if AGZ_PART == 0
 AGZ_SMALL_SHAPES_0(X)
 #elif AGZ_PART == 1
@@ -23,6 +24,9 @@ AGZ_SMALL_SHAPES_3(X)
 #if AGZ_PART == 7
 #define X(F, C, K, R, GG) AGZ_SMALL_NARROW_VARIANTS(F, C, K, R, GG, )
 AGZ_SMALL_NARROW_SHAPES(X)
+#undef X
+#define X(F, C, K, GG) AGZ_PERSIST_NARROW_VARIANTS(F, C, K, GG, )
+AGZ_PERSIST_NARROW_SHAPES(X)
 #undef X
 #elif AGZ_PART >= 4
 #define X(F, C, K, R) AGZ_SMALL_CMP_VARIANTS(F, C, K, R, ) AGZ_BIG_CMP_VARIANTS(F, C, K, R, )

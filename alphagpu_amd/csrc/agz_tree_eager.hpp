@@ -156,7 +156,7 @@ template <int FAM, int NC, int KPL, bool LEAN, int PFM, bool LIO = false, int RO
 __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* const lds, const int bidx,
                                                    EagerCarry& C, uint32_t* const wl_lds, const uint32_t wl_cap_lds, uint32_t& wcount,
                                                    uint8_t* const io_blk = nullptr, const int io_prowb = 0, const int io_lgs = 0,
-                                                   uint32_t* const xch = nullptr) {
+                                                   uint32_t* const xch = nullptr, const uint32_t dead_mask = 0u) {
     using GM = Game<FAM, NC>;
     constexpr bool REV = FAM == F_REV;
     constexpr int G = G_, NG = 64 / G_;
@@ -174,7 +174,8 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
     const int GPW = T.gpw;
     const int slot_base = T.slot0 + __builtin_amdgcn_readfirstlane(bidx) * GPW;   // (wave-uniform: the wave's arrays get scalar bases)
     const int slot = slot_base + g;
-    const bool live = g < GPW && slot < T.L;
+    // (dead_mask, wave-uniform: bit g set = the wave's slot g holds no game — the persistent self-play kernels, whose slots are never compacted)
+    const bool live = g < GPW && slot < T.L && !((dead_mask >> g) & 1u);
     const bool lead = sub == 0;
     // the row geometry follows from KPL alone (the engine lays the records out with the same formulas): compile-time offsets,
     // so that every load / store of a row is one base address + an immediate

@@ -78,6 +78,11 @@ int  agz_set_seed(agz_engine *h, uint64_t seed);
  * W0 H x in, Wres T consecutive H x H blocks, Wp A x H, bp A, Wv 1 x H, bv 1.  in = 2*VS. */
 int  agz_set_network(agz_engine *h, int H, int T, const float *W0, const float *Wres,
                      const float *Wp, const float *bp, const float *Wv, const float *bv);
+/* The tag (0..255) stored with every sample that later self-play searches produce: byte 17 of a packed record (agz_get_samples_packed),
+ * `net` of agz_get_sample_tags.  A host loop that changes the network between the calls of a chain (agz_selfplay_chain) numbers its
+ * networks with it: the games a call starts early for the NEXT call play their first plies with the network of the running call
+ * (the reference plays every game of a generation with one actor, selfplay.jl:34-56), and the tag of each sample says which.  Default 0. */
+int  agz_set_network_tag(agz_engine *h, uint32_t tag);
 /* second actor for duels (mcts_gpu.jl:581 mcts(actor1,actor2,...)); which = 0 or 1 */
 int  agz_set_network_slot(agz_engine *h, int which, int H, int T, const float *W0, const float *Wres,
                           const float *Wp, const float *bp, const float *Wv, const float *bv);
@@ -152,7 +157,7 @@ int  agz_get_samples(agz_engine *h, int8_t *state, float *policy, int8_t *player
                      int8_t *fstate, uint32_t *game_id, int32_t *ply, int32_t *move);
 /* Packed records in DEVICE memory for the RCCL all-gather: writes n records of rec_bytes
  * (see agz_game_info) to dev_out; returns n via *n_out.  Record: {u32 game_id, i32 ply, i32 move, f32 value,
- * i8 player, i8 pad[3], f32 policy[A], i8 state[2VS], i8 fstate[FS], pad to 16 B}. */
+ * i8 player, u8 net_tag, i8 pad[2], f32 policy[A], i8 state[2VS], i8 fstate[FS], pad to 16 B}   (net_tag: agz_set_network_tag). */
 int  agz_get_samples_packed(agz_engine *h, void *dev_out, int64_t capacity_records, int64_t *n_out);
 /* Host-only helper (no handle, no device): n packed records in HOST memory -> the PoolSample-layout arrays of agz_get_samples
  * (push_buffer / update_buffer, mainGobang.jl:54-80).  Lets a host loop copy the records of generation k to pinned memory on a side
@@ -212,6 +217,10 @@ int  agz_set_profiling(agz_engine *h, int mode);       /* HIP events per launch:
  *   AGZ_NO_HOST_FLAG=1     ply loop: fetch the number of games left with a copy + stream synchronisation instead of polling the
  *                          host-visible word the scan kernel publishes
  *   AGZ_BIG_MT=2|4|8       256 / 512-wide trunk, stand-alone network launches: 16-leaf tiles per workgroup (default by launch size)
+ *   AGZ_PERSIST=1|0        self-play calls as ONE launch (k_selfplay_small: every workgroup loops over the plies of its own games, no kernel
+ *                          boundary, no host wake-up per ply) wherever such a kernel exists — 128-wide trunk, bf16 mode, all slots resident —
+ *                          (1), or never (0); default: calls that refill their slots (agz_selfplay with more games than slots,
+ *                          agz_selfplay_chain) on engines of more than 96 slots per CU
  *   AGZ_WL_LDS_BYTES=n     one-launch forms: at most n bytes of LDS per tree wave for the work list of a rollout (the rest of
  *                          the list lives in global memory; default: what the resident workgroups leave free)
  */

@@ -1,0 +1,113 @@
+"""GPU parity (-m gpu) of the PERSISTENT self-play kernels (alphagpu_amd/csrc/agz_selfplay_small.hpp): one launch per agz_selfplay /
+agz_selfplay_chain call, every workgroup looping over the plies of its own games (search -> root policy -> move choice -> play / isOver ->
+sample capture -> next game) without ever meeting the other workgroups.  Replaces the host-driven ply loop of mcts_gpu.jl:494-561.
+
+Every game's samples must be, bit for bit, those of the oracle's LOCK-STEP generation over all the games (results are keyed by game id
+and the game's own ply, never by slot or by the moment a game is played).  AGZ_PERSIST=1 forces the form at the small sizes the oracle
+finishes in seconds (by default it serves calls with refilled slots on engines of more than 96 slots per CU: the benchmarked shape,
+covered at full size in tests/test_gpu_scale_parity.py)."""
+import numpy as np
+import pytest
+
+import alphagpu_amd as ag
+from alphagpu_amd import mcts_gpu as M
+import oracle_lib as O
+from test_gpu_parity import spec, assert_same_bits
+
+pytestmark = pytest.mark.gpu
+KEYS = ("game_id", "ply", "move", "player", "state", "fstate", "policy", "value")
+
+
+def _nets(name, H=128, T=2):
+    g, og = spec(name)
+    return g, og, ag.SNetwork2.random(g, H, T), O.OracleNet(og, H, T).bf16()
+
+
+@pytest.mark.parametrize("name,slots,ngames,V,narrow", [("gobang9", 24, 70, 16, None), ("gobang9", 200, 520, 8, None), ("connect4", 40, 150, 12, None),
+                                                        ("connect4", 40, 150, 12, "-1"), ("hex5", 8, 40, 16, None), ("reversi6", 16, 50, 8, None),
+                                                        ("tictactoe", 70, 300, 8, None), ("reversi8", 12, 30, 8, None)])
+def test_persistent_selfplay_with_refilled_slots_equals_the_lockstep_oracle(name, slots, ngames, V, narrow, monkeypatch):
+    """agz_selfplay(ngames > max_games) through k_selfplay_small: PoolSample order, W / D / L, plies — the oracle's lock-step generation."""
+    monkeypatch.setenv("AGZ_PERSIST", "1")
+    if narrow:
+        monkeypatch.setenv("AGZ_NARROW", narrow)
+    g, og, net, onet = _nets(name)
+    ref = O.selfplay(og, onet, ngames, V, 1.5, 25, 9, 1000)
+    with M.Engine(g, slots, V, seed=9, game_id_base=1000, nn_mode=M.NN_BF16, sample_capacity_games=ngames) as e:
+        e.set_network(net)
+        st = e.selfplay(ngames, V, cpuct=1.5, tau_plies=25)
+        assert e.search_form()[0].startswith("k_selfplay_small"), e.search_form()
+        if name == "connect4":
+            assert ("G=4" in e.search_form()[0]) == (narrow is None), e.search_form()
+        s = e.samples()
+        assert st["valid"] and st["nsamples"] == ref["n"] and st["wins"] + st["draws"] + st["losses"] == ngames
+        assert (st["wins"], st["draws"], st["losses"], st["total_plies"]) == (ref["wins"], ref["draws"], ref["losses"], ref["total_plies"])
+        assert st["rollouts"] == V * ref["n"]                    # every (game, ply) was searched exactly once
+        for key in KEYS:
+            assert_same_bits(s[key], ref[key], key)
+        # the engine is reusable: a lock-step generation afterwards (fewer games than slots), in the same form
+        st2 = e.selfplay(slots // 2, V, cpuct=1.5, tau_plies=25)
+        s2 = e.samples()
+        # ... and plain searches work again once roots are set
+        e.set_roots(None, L=slots)
+        e.search(V, cpuct=1.5, training=True, step=0)
+        assert (e.root_visits().sum(1) == V - 1).all()
+    ref2 = O.selfplay(og, onet, slots // 2, V, 1.5, 25, 9, 1000)
+    assert st2["valid"] and st2["nsamples"] == ref2["n"]
+    for key in KEYS:
+        assert_same_bits(s2[key], ref2[key], key + " (second call)")
+
+
+@pytest.mark.parametrize("name,slots,N,V", [("gobang9", 24, 50, 16), ("connect4", 32, 90, 12), ("tictactoe", 64, 200, 8), ("hex5", 70, 150, 8)])
+def test_persistent_chain_returns_the_oracles_games_call_by_call(name, slots, N, V, monkeypatch):
+    """agz_selfplay_chain through k_selfplay_small: a call ends when ITS games are over (every workgroup looks at the device counter between
+    two plies), the games of the next call that were started early stay in their slots — uncompacted — and the next launch goes on with
+    them; slots that were left empty take waiting games when that launch starts.  Call by call the oracle's games of the same ids."""
+    monkeypatch.setenv("AGZ_PERSIST", "1")
+    g, og, net, onet = _nets(name)
+    calls = [(N, N), (N, N // 2), (N // 2, 0)] if name != "connect4" else [(N, N), (N // 4, 0), (N // 2, N // 4), (N // 4, 0)]
+    total = sum(n for n, _ in calls)
+    ref = O.selfplay(og, onet, total, V, 1.5, 25, 9, 700)
+    with M.Engine(g, slots, V, seed=9, game_id_base=700, nn_mode=M.NN_BF16, sample_capacity_games=2 * N + 7) as e:
+        e.set_network(net)
+        k0, rollouts = 0, 0
+        for i, (n, nxt) in enumerate(calls):
+            st = e.selfplay_chain(n, nxt, V, cpuct=1.5, tau_plies=25)
+            assert e.search_form()[0].startswith("k_selfplay_small"), e.search_form()
+            s = e.samples()
+            sel = (ref["game_id"] >= 700 + k0) & (ref["game_id"] < 700 + k0 + n)
+            assert st["valid"] and st["nsamples"] == int(sel.sum()) == len(s["ply"]), (i, st["nsamples"], int(sel.sum()))
+            for key in KEYS:
+                assert_same_bits(s[key], ref[key][sel], f"call {i}: {key}")
+            first = sel & (ref["ply"] == 0)
+            res = np.rint(2.0 * ref["value"][first] - 1.0).astype(int)
+            assert (st["wins"], st["draws"], st["losses"]) == (int((res == 1).sum()), int((res == 0).sum()), int((res == -1).sum()))
+            assert st["total_plies"] == int(sel.sum()) - n
+            if nxt and i == 0:
+                with pytest.raises(Exception):                   # games of the next call are in flight: their key must not change ...
+                    e.set_seed(1234)
+                with pytest.raises(Exception):                   # ... and a plain search must not run over their slots
+                    e.search(V, cpuct=1.5, training=True, step=0)
+            k0 += n
+            rollouts += st["rollouts"]
+        assert rollouts == V * len(ref["ply"])                   # the chain's work is the work of its games: nothing searched twice or dropped
+        st = e.selfplay(slots, V, cpuct=1.5, tau_plies=25)       # a call of its own afterwards starts over
+        s = e.samples()
+    ref2 = O.selfplay(og, onet, slots, V, 1.5, 25, 9, 700)
+    assert st["valid"] and st["nsamples"] == ref2["n"]
+    for key in ("game_id", "ply", "move", "policy", "value"):
+        assert_same_bits(s[key], ref2[key], key + " (call of its own after the chain)")
+
+
+def test_persistent_and_ply_loop_forms_return_identical_records(monkeypatch):
+    """The same call through both forms of the self-play loop: byte-identical packed records (what the all-gather ships)."""
+    g, og, net, onet = _nets("gobang9")
+    out = []
+    for persist in ("0", "1"):
+        monkeypatch.setenv("AGZ_PERSIST", persist)
+        with M.Engine(g, 64, 16, seed=5, game_id_base=10, nn_mode=M.NN_BF16, sample_capacity_games=200) as e:
+            e.set_network(net)
+            st = e.selfplay(200, 16, cpuct=1.5, tau_plies=25)
+            assert e.search_form()[0].startswith("k_selfplay_small") == (persist == "1")
+            out.append((st["nsamples"], e.samples_packed_host().tobytes()))
+    assert out[0] == out[1]
