@@ -1662,6 +1662,10 @@ static int run_games_persist(agz_engine* h, int ngames, int V, float cpuct, int 
     unsigned long long acc[8];
     HIPCHK(h, hipMemcpy(acc, h->d_pacc, sizeof acc, hipMemcpyDeviceToHost));
     const int64_t rollouts = (int64_t)acc[2] * V;
+#ifdef AGZ_PSTAMPS
+    fprintf(stderr, "[pstamps] cycles summed over waves: flag/barrier %llu  search %llu  counters %llu  ply step %llu   (ply step share %.2f %%)\n", acc[4], acc[5], acc[6], acc[7],
+            100.0 * (double)acc[7] / (double)(acc[4] + acc[5] + acc[6] + acc[7] + 1));
+#endif
     { char b[220]; snprintf(b, sizeof b, "k_selfplay_small<KPL=%d,H=128,TW=%d,WV=%d,G=%d> (persistent: one launch per self-play call, a workgroup loops over the plies of its %d games)",
                             nar ? h->persist_nar_kpl : h->reg_kpl, tw, nar ? 2 : 4, G, gpwg); h->form_tree = b; h->form_nn = "inside k_selfplay_small (mlp_wave_body<128>)"; }
     h->acc_p += acc[0]; h->acc_new += acc[1]; h->total_rollouts += (uint64_t)rollouts; h->cnt_live = false;

@@ -69,6 +69,12 @@ __global__ __launch_bounds__(64 * (TW == 8 ? 8 : NW_WAVES), WV) void k_selfplay_
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
     if (threadIdx.x == 0) { flag[0] = 0u; flag[1] = 0u; }
+#ifdef AGZ_PSTAMPS
+    unsigned long long ps_t = __builtin_amdgcn_s_memtime(), ps_flag = 0, ps_search = 0, ps_cnt = 0, ps_adv = 0;
+#define PSTAMP(x) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); x += n_ - ps_t; ps_t = n_; } while (0)
+#else
+#define PSTAMP(x) do { } while (0)
+#endif
 #pragma unroll 1
     for (uint32_t it = 0;; ++it) {
         // ---- does the workgroup go on?  Some wave of it still has a game, and the call's own games are not all over
@@ -89,6 +95,7 @@ __global__ __launch_bounds__(64 * (TW == 8 ? 8 : NW_WAVES), WV) void k_selfplay_
             const uint32_t f = ufirst(*fw);
             if (!(f & 1u) || (f & 2u)) break;
         }
+        PSTAMP(ps_flag);
         // ---- mcts_single (:376-462) for the games of this workgroup: the loop of k_search_small
         EagerCarry C = {1u, 0u, 0u, 0u, 0u, 0u, 0u};
         uint32_t wcount = 0;
@@ -113,6 +120,7 @@ __global__ __launch_bounds__(64 * (TW == 8 ? 8 : NW_WAVES), WV) void k_selfplay_
         // (policy_final of this wave's games was written by lanes of this wave: the root's work item of the last-but-one rollout)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        PSTAMP(ps_search);
         // ---- roofline bookkeeping: descent counters of the search (the lead lane of a game's lane-group holds them)
         {
             const PersistPar& Q = par();
@@ -125,6 +133,7 @@ __global__ __launch_bounds__(64 * (TW == 8 ? 8 : NW_WAVES), WV) void k_selfplay_
                 }
             }
         }
+        PSTAMP(ps_cnt);
         // ---- the ply step of each game (:513-561), one after the other, the whole wave on one game
         {
             const PersistPar& Q = par();
@@ -139,7 +148,11 @@ __global__ __launch_bounds__(64 * (TW == 8 ? 8 : NW_WAVES), WV) void k_selfplay_
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the new roots are read by the other lanes of this wave
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
+        PSTAMP(ps_adv);
     }
+#ifdef AGZ_PSTAMPS
+    if (lane == 0 && par().acc) { unsigned long long* a = par().acc; atomicAdd(a + 4, ps_flag); atomicAdd(a + 5, ps_search); atomicAdd(a + 6, ps_cnt); atomicAdd(a + 7, ps_adv); }
+#endif
     {
         const PersistPar& Q = par();
         if (lane == 0 && Q.acc && amask) atomicAdd(Q.acc + 3, (unsigned long long)__builtin_popcount(amask));

@@ -4,7 +4,8 @@
 A step = ONE whole self-play generation: `--games` games per GPU x `--rollouts` rollouts per move, random-init snetwork2
 `--filters` x `--towers`, bf16 MFMA network + fp32 strict-IEEE tree arithmetic, all games played to the end on the device
 (mcts(), mcts_gpu.jl:477-579).  Inputs (start positions, weights) are resident in HBM before the timed region.
-value = rollouts executed by all ranks in the timed region / max-over-ranks time.  With N > 1 ranks each rank plays its own shard
+value = rollouts of the games all ranks RETURNED in the timed region (samples x V; every game played to its end) / max-over-ranks time
+(`value_executed`: the rollouts executed inside the region, whichever game they belong to).  With N > 1 ranks each rank plays its own shard
 of game ids and every call ends with the RCCL all-gather of its packed sample records.
 
 Scheduling of the K timed steps (what the "scheduling" field of the line spells out): by default the warm-up and timed calls are ONE
@@ -179,7 +180,7 @@ def main():
     # call's last games run out the slots that come free start games of the NEXT call (up to FILL generations' worth), which stay in flight
     # when the call returns — no call of the run ends on a batch that runs out, the untimed last one aside.  The timed region therefore
     # completes its K generations' worth of games on full batches from its first search to its last; it inherits the games the warm-up left in
-    # flight and leaves as many in flight itself, and `value` counts the rollouts EXECUTED inside it, whichever game they belong to.
+    # flight and leaves as many in flight itself; `value` counts the rollouts of the games it RETURNS, `value_executed` those executed inside it.
     chain = not args.lockstep and not args.no_chain
     FILL = 2
     gens_run = max(1, args.warmup + args.steps)
@@ -266,6 +267,14 @@ def main():
     dt = time.perf_counter() - t0
     tree_ms, nn_ms, launches = eng.kernel_times()
     busy_ms = eng.tree_busy_ms()      # union of the launch intervals: sub-batch chains run launches side by side
+    # the persistent form (k_selfplay_small: ONE launch per agz_selfplay call, every workgroup loops over the plies of its own games): the
+    # unit the roofline object is quoted per — "a launch" in SURVEY 8(d)'s sense, one mcts_single of G games x V rollouts — is then a
+    # PLY-EQUIVALENT of the persistent launch: kernel time x (G x V) / rollouts executed
+    form_run = eng.search_form()[0]
+    persistent = form_run.startswith("k_selfplay_small")
+    kernel_launches = launches
+    if persistent:
+        form_tree, form_nn = eng.search_form()
     sum_p, sum_new, r_cnt = eng.counters()
     nn_leaves = eng.nn_leaves()
 
@@ -414,6 +423,8 @@ def main():
                             "note": "SQ_INSTS_VALU per (game, rollout) of the committed PMC pass (" + traffic_source + ") x this run's "
                                     "rollouts; 4 cycles per wave-instruction on 1024 SIMDs at 2.4 GHz (the counters show ~2.0 GHz under "
                                     "this load: the real issue utilisation is ~1.2 x higher)"}
+        if persistent:
+            launches = max(r_cnt / float(G * V), 1e-9)                  # ply-equivalents (G games x V rollouts) of the persistent launches
         hbm_achieved = alg / (busy_ms * 1e-3) / 1e9 if busy_ms > 0 else 0.0   # aggregate over the launches in flight together
         if whole or nn_leaves == 0:
             # the network forward runs inside the search kernel: its time is not separable, the fraction is taken against the
@@ -431,7 +442,13 @@ def main():
                     "algorithmic_bytes_per_launch": alg / max(launches, 1), "avg_launch_ms": tree_ms / max(launches, 1),
                     "launches": launches, "launch_concurrency": tree_ms / busy_ms if busy_ms > 0 else None,
                     "mean_depth_p": sum_p / max(r_cnt, 1),
-                    "note": ("one launch = one ply of the generation (all games alive, V rollouts)" if whole else
+                    "kernel_launches": kernel_launches, "kernel_ms_total": tree_ms,
+                    "note": ("PERSISTENT kernel: one launch per agz_selfplay call, every workgroup loops over the plies of its own games (search, move "
+                             "choice, play / isOver, sample capture, refill inside the kernel).  `launches`, `avg_launch_ms` and "
+                             "`algorithmic_bytes_per_launch` are per PLY-EQUIVALENT (G games x V rollouts = one mcts_single of the batch): "
+                             "kernel_ms_total x G x V / rollouts; rocprofv3 shows `kernel_launches` launches of k_selfplay_small whose TOTAL "
+                             "duration is kernel_ms_total" if persistent else
+                             "one launch = one ply of the generation (all games alive, V rollouts)" if whole else
                              "one launch = one rollout of all games alive; busy time = union of the launch intervals of the sub-batch chains")
                             + "; algorithmic bytes are the tree path's (SURVEY 8d)"}
         nn_traffic = None       # HBM bytes per stand-alone network launch (PMC passes of the config's first ply x this run's leaves per launch)
@@ -452,7 +469,10 @@ def main():
             nn_obj["avg_launch_ms"] = tree_ms / max(launches, 1); nn_obj["launches"] = launches
         out = {
             "metric": f"self-play rollouts/sec at {G} games x {V} rollouts, {gname}",
-            "value": total_rollouts / dt_max, "unit": "rollouts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            # value = the rollouts of the games RETURNED in the timed region (their samples x V: every one of them played to its end, K x G games
+            # for K steps) / time.  The rollouts EXECUTED inside the region (`value_executed`) also count work on games the region leaves in flight
+            # for the next call and miss the work done earlier on the games it inherited; the two meet as the run gets longer.
+            "value": nsamples_all * V / dt_max, "unit": "rollouts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt_max * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if args.mode == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": f"{gl}_{G}games_per_gpu_x{V}rollouts_snetwork2_{args.filters}x{args.towers}_full_generation",
@@ -467,14 +487,12 @@ def main():
                            (f"a chain of agz_selfplay_chain calls of {gens_cap} x G games on G slots: a slot whose game has ended takes the next game that has "
                             f"not started — of this call or, once those have all started, of the next one (up to {FILL} x G of them, left in flight when the "
                             "call returns): every search of the timed region runs on a full batch of G games; it completes its K x G games, inherits the games "
-                            "the warm-up left in flight and leaves as many in flight; value = rollouts executed / time; every game's samples are those of a "
+                            "the warm-up left in flight and leaves as many in flight; value = rollouts of the K x G games it RETURNS / time; every game's samples are those of a "
                             "lock-step run over the run's games (keyed by game id and the game's own ply)" if chain else
                             f"agz_selfplay calls of {gens_cap} x G games on G slots, each on its own: a slot whose game has ended takes the next game that has "
                             "not started (per-game samples identical to lock-step generations); a call ends on the batch of its last games running out")),
             "value_calls_on_their_own": None if chain else rollouts / dt,
-            # value = rollouts EXECUTED in the timed region / its time.  With chained calls the region also works on games it does not return
-            # (the ones it leaves in flight) and returns games it did not play in full (the ones it inherited): the rollouts of the games it
-            # RETURNED (their samples x V) over the same time are given beside it — the two meet as the run gets longer.
+            "value_executed": total_rollouts / dt_max,
             "value_by_returned_games": nsamples_all * V / dt_max,
             "value_lockstep_generations": (rollouts / dt if args.lockstep else (host or {}).get("lockstep_generation_rollouts_per_s")),
             "value_with_host_delivery": (host or {}).get("rollouts_per_s_with_delivery_into_PoolSample"),
