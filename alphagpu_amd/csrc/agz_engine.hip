@@ -63,6 +63,9 @@ AGZ_SMALL_SHAPES(X)          // defined in agz_small_inst.hip
 #define X(F, C, K, GG) AGZ_PERSIST_NARROW_VARIANTS(F, C, K, GG, extern)
 AGZ_PERSIST_NARROW_SHAPES(X)
 #undef X
+#define X(F, C, K, R) AGZ_PERSIST_AGE_VARIANTS(F, C, K, R, extern)
+AGZ_PERSIST_AGE_SHAPES(X)
+#undef X
 #define X(F, C, K, R) AGZ_SMALL_CMP_VARIANTS(F, C, K, R, extern) AGZ_BIG_CMP_VARIANTS(F, C, K, R, extern)
 AGZ_SMALL_CMP_SHAPES(X)
 #undef X
@@ -162,7 +165,13 @@ struct agz_engine {
     // (-1): calls with refilled slots on an engine of more than 96 slots per CU.  chain_persist: the running chain's slots are not compacted.
     persist_fn k_persist = nullptr, k_persist_nar = nullptr; int persist_nar_g = 0, persist_nar_kpl = 0;
     int persist = -1; bool chain_persist = false; unsigned long long* d_pacc = nullptr;
+    // ... with age classes (workgroups that prefer old games run rows by legal rank; games migrate through a queue in device memory):
+    // age_kpr rows per lane of the old body, age_on (AGZ_AGE=0 turns it off), age_old16 of 16 CU pairs prefer old games (AGZ_AGE_OLD16),
+    // age_by_block (AGZ_AGE_CLASS=block, tests: odd workgroups prefer old games), age_backlog: the queue's length at which nothing is pushed
+    persist_fn k_persist_age = nullptr; int age_kpr = 0; bool age_on = true, age_by_block = false; int age_old16 = 8, age_backlog = 0;
+    MigEntry* mq_buf = nullptr; unsigned long long* mq_ctr = nullptr; uint32_t mq_cap = 0; bool mq_dirty = false;
     int run_ahead = 8;                    // plies the ply loop may queue before it waits for a ply's counters (AGZ_RUN_AHEAD; while the pool cannot run dry)
+    uint64_t age_ranked_searches = 0, age_searches = 0, age_pushed = 0;   // persistent form since the last agz_get_kernel_times(reset): game-searches with rows by rank / all / games migrated
     uint32_t sp_ring0 = 0, sp_k0 = 0;      // where the games of the last call sit in the per-game sample arrays / in the chain
     bool no_compact = false;            // AGZ_NO_COMPACT (A/B, tests)
     advance_fn k_spread = nullptr;      // policy_final rows from rank order back to action order after such a search
@@ -208,6 +217,9 @@ static bool bind_kernels(agz_engine* h) {
 #undef Z
 #define Z(F, C, K, GG) if (P.fam == F && P.NC == C && GG * K >= P.A && GG * K <= 8 * kpl) { h->k_persist_nar = k_selfplay_small<F, C, K, 128, 4, 2, GG>; h->persist_nar_g = GG; h->persist_nar_kpl = K; }
     AGZ_PERSIST_NARROW_SHAPES(Z)
+#undef Z
+#define Z(F, C, K, R) if (P.fam == F && P.NC == C && kpl == K) { h->k_persist_age = k_selfplay_small<F, C, K, 128, 8, 4, 8, R>; h->age_kpr = R; }
+    AGZ_PERSIST_AGE_SHAPES(Z)
 #undef Z
 #define Z(F, C, K, R) if (P.fam == F && P.NC == C && kpl == K && h->ncmp < 4) { agz_engine::CmpLevel& c = h->cmp[h->ncmp++]; c.kpr = R; \
         c.s2 = k_search_small<F, C, K, 128, 2, 2, R>; c.s4[0] = k_search_small<F, C, K, 128, 4, 2, R>; c.s4[1] = k_search_small<F, C, K, 128, 4, 3, R>; \
@@ -289,7 +301,7 @@ void agz_destroy(agz_engine* h) {
     hipFree(h->prior_eval); hipFree(h->v_eval); hipFree(h->policy_final); hipFree(h->act0); hipFree(h->act1);
     hipFree(h->actf0); hipFree(h->actf1); hipFree(h->newpos); hipFree(h->alive); hipFree(h->newslot); hipFree(h->d_count);
     hipFree(h->s_boards); hipFree(h->s_policy); hipFree(h->s_move); hipFree(h->s_net); hipFree(h->g_nplies); hipFree(h->g_result);
-    hipFree(h->g_final); hipFree(h->d_stats); hipFree(h->d_acc); hipFree(h->d_pacc); hipFree(h->scratch_f);
+    hipFree(h->g_final); hipFree(h->d_stats); hipFree(h->d_acc); hipFree(h->d_pacc); hipFree(h->mq_buf); hipFree(h->mq_ctr); hipFree(h->scratch_f);
     hipFree(h->wl); hipFree(h->wl_n); hipFree(h->sp);
     hipFree(h->d_order);
     hipFree(h->stage_dev); if (h->stage_host) hipHostFree(h->stage_host);
@@ -418,6 +430,15 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
         if (e3) h->persist = atoi(e3) > 0 ? 1 : 0;
         if (h->k_persist) FA_(hipFuncSetAttribute((const void*)h->k_persist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         if (h->k_persist_nar) FA_(hipFuncSetAttribute((const void*)h->k_persist_nar, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if (h->k_persist_age) FA_(hipFuncSetAttribute((const void*)h->k_persist_age, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        e3 = getenv("AGZ_AGE");
+        if (e3) h->age_on = atoi(e3) > 0;
+        e3 = getenv("AGZ_AGE_OLD16");
+        if (e3 && atoi(e3) >= 0 && atoi(e3) <= 16) h->age_old16 = atoi(e3);
+        e3 = getenv("AGZ_AGE_CLASS");
+        if (e3) h->age_by_block = strcmp(e3, "block") == 0;
+        e3 = getenv("AGZ_AGE_BACKLOG");
+        if (e3 && atoi(e3) > 0) h->age_backlog = atoi(e3);
         e3 = getenv("AGZ_SMALL4_OCC");
         if (e3 && atoi(e3) >= 0 && atoi(e3) <= 2) h->small4_occ = atoi(e3);
         if (h->k_small) FA_(hipFuncSetAttribute((const void*)h->k_small, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -456,7 +477,12 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     A_(dmalloc(&h->logits, Lm * h->LGS));
     A_(dmalloc(&h->prior_eval, Lm * P.A + 64)); A_(dmalloc(&h->v_eval, Lm)); A_(dmalloc(&h->policy_final, Lm * P.A));
     A_(dmalloc(&h->newpos, Lm)); A_(dmalloc(&h->alive, Lm)); A_(dmalloc(&h->newslot, Lm)); A_(dmalloc(&h->d_count, 4));
-    A_(dmalloc(&h->d_stats, 16)); A_(dmalloc(&h->d_acc, 2)); A_(dmalloc(&h->d_pacc, 8));
+    A_(dmalloc(&h->d_stats, 16)); A_(dmalloc(&h->d_acc, 2)); A_(dmalloc(&h->d_pacc, 16));
+    if (h->k_persist_age) {                                                     // the migration queue: a ring of at least twice the slots
+        h->mq_cap = 64; while (h->mq_cap < 2u * (uint32_t)h->Lmax) h->mq_cap <<= 1;
+        A_(dmalloc(&h->mq_buf, h->mq_cap)); A_(dmalloc(&h->mq_ctr, 2));
+        if (e == hipSuccess) { FA_(hipMemset(h->mq_buf, 0, (size_t)h->mq_cap * sizeof(MigEntry))); FA_(hipMemset(h->mq_ctr, 0, 16)); }
+    }
     FA_(hipMemset(h->d_acc, 0, 16));
     A_(dmalloc(&h->scratch_f, Lm * (size_t)((P.A > 2 * P.VS) ? P.A : 2 * P.VS)));
     h->sample_games = cfg->sample_capacity_games > 0 ? cfg->sample_capacity_games : h->Lmax;
@@ -1284,10 +1310,16 @@ int agz_get_kernel_times(agz_engine* h, double* tree_ms, double* nn_ms, int64_t*
     if (tree_ms) *tree_ms = h->tree_ms;
     if (nn_ms) *nn_ms = h->nn_ms;
     if (tree_launches) *tree_launches = h->tree_launches;
-    if (reset) { h->nn_leaves = 0; h->tree_ms = h->nn_ms = h->tree_busy_ms = 0; h->tree_launches = 0; h->acc_p = h->acc_new = 0; h->total_rollouts = 0; hipMemsetAsync(h->d_acc, 0, 16, h->stream); }
+    if (reset) { h->nn_leaves = 0; h->tree_ms = h->nn_ms = h->tree_busy_ms = 0; h->tree_launches = 0; h->acc_p = h->acc_new = 0; h->total_rollouts = 0; hipMemsetAsync(h->d_acc, 0, 16, h->stream);
+                 h->age_ranked_searches = h->age_searches = h->age_pushed = 0; }
     return AGZ_OK;
 }
 
+int agz_get_age_stats(agz_engine* h, uint64_t out[3]) {
+    if (!h || !out) return AGZ_ERR_ARG;
+    out[0] = h->age_searches; out[1] = h->age_ranked_searches; out[2] = h->age_pushed;
+    return AGZ_OK;
+}
 int agz_get_nn_leaves(agz_engine* h, uint64_t* leaves) {
     if (!h || !leaves) return AGZ_ERR_ARG;
     *leaves = h->nn_leaves;
@@ -1578,9 +1610,14 @@ static int run_games_persist(agz_engine* h, int ngames, int V, float cpuct, int 
         if (slots < h->Lmax) HIPCHK(h, hipMemsetD32Async((hipDeviceptr_t)(h->alive + slots), 0, (size_t)(h->Lmax - slots), h->stream));
         started = (unsigned long long)slots;
         HIPCHK(h, hipMemcpyAsync(h->d_stats + 6, &started, 8, hipMemcpyHostToDevice, h->stream));
+        if (h->mq_buf && h->mq_dirty) {                                         // games an abandoned chain left on their way between workgroups are dropped
+            HIPCHK(h, hipMemsetAsync(h->mq_buf, 0, (size_t)h->mq_cap * sizeof(MigEntry), h->stream));
+            HIPCHK(h, hipMemsetAsync(h->mq_ctr, 0, 16, h->stream));
+            h->mq_dirty = false;
+        }
         HIPCHK(h, hipStreamSynchronize(h->stream));
     } else {
-        // the games the last call left in flight go on in their slots (alive[]); per-call counters start over; the games of this call that
+        // the games the last call left in flight go on in their slots (alive[]) or wait in the migration queue; per-call counters start over; the games of this call that
         // finished early are already counted; the ring entries of the games that may start now are cleared; slots without a game take the
         // games that wait when the kernel starts
         HIPCHK(h, hipSetDevice(h->cfg.device));
@@ -1610,10 +1647,13 @@ static int run_games_persist(agz_engine* h, int ngames, int V, float cpuct, int 
     h->sp_games = ngames; h->sp_nsamples = 0; h->sp_maxplies = 0;
     h->sp_k0 = (uint32_t)k0; h->sp_ring0 = chain ? (uint32_t)(k0 % (unsigned long long)h->sample_games) : 0u;
     h->cpuct = cpuct; h->training = 1; h->step = 0;
-    HIPCHK(h, hipMemsetAsync(h->d_pacc, 0, 8 * sizeof(unsigned long long), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_pacc, 0, 16 * sizeof(unsigned long long), h->stream));
     // ---- the launch: the search parameters of k_search_small's 64-game workgroups (agz_search_actor), the ply step's, the call's pool
     DevNet& n = h->net[0];
     const bool nar = h->k_persist_nar && h->narrow_mode >= 0;                   // few-action games: 4 lanes per tree, 16 trees per wave, four waves
+    // age classes: stone-placing games on boards whose rows by legal rank are built, V large enough for the expansion's compaction buffer
+    // (2 V >= 8 KPR floats of the lane-group's edge table), refilled slots (a game can only leave a slot that a new game takes)
+    const bool age = !nar && h->k_persist_age && h->age_on && !h->no_compact && 2 * h->V >= 8 * h->age_kpr && (chain || (long long)ngames > (long long)slots);
     if (!nar && !h->k_persist) { h->fail("no persistent self-play kernel for this game shape"); return AGZ_ERR_UNSUPPORTED; }
     const int G = nar ? h->persist_nar_g : 8, NG = 64 / G, tw = nar ? 4 : 8, gpwg = tw * NG;
     PersistPar Q; memset(&Q, 0, sizeof Q);
@@ -1646,11 +1686,20 @@ static int run_games_persist(agz_engine* h, int ngames, int V, float cpuct, int 
     Q.P.ring = chain ? 1 : 0; Q.P.k_cur_end = (uint32_t)(k0 + (unsigned long long)ngames);
     Q.ngames_cur = chain ? (uint32_t)ngames : 0u;
     Q.acc = h->d_pacc;
+    if (h->mq_buf && (age || h->mq_dirty)) {                                    // (a chain that began with age classes keeps the queue: games may wait in it)
+        Q.P.mq.ctr = h->mq_ctr; Q.P.mq.buf = h->mq_buf; Q.P.mq.mask = h->mq_cap - 1u;
+        Q.P.mq.backlog_max = (uint32_t)(h->age_backlog > 0 ? h->age_backlog : std::max(64, h->Lmax / 16));
+        if (Q.P.mq.backlog_max > h->mq_cap / 2u) Q.P.mq.backlog_max = h->mq_cap / 2u;
+        Q.P.mq.age = (uint32_t)std::max(0, h->G.A - 8 * h->age_kpr);
+        Q.old16 = (uint32_t)h->age_old16; Q.class_by_block = h->age_by_block ? 1u : 0u;
+        h->mq_dirty = true;
+    }
+    const bool age_kernel = Q.P.mq.buf != nullptr;
     const unsigned wgs = (unsigned)((h->Lmax + gpwg - 1) / gpwg);
     h->rd_rec_bytes = nar ? (uint32_t)eager_rec_bytes(G * h->persist_nar_kpl, h->V) : h->tp.rec_bytes;
     h->in_ply_loop = true;
     hipEventRecord(h->ev_ply0, h->stream);
-    hipLaunchKernelGGL(nar ? h->k_persist_nar : h->k_persist, dim3(wgs), dim3(64 * tw), lds, h->stream, Q);
+    hipLaunchKernelGGL(nar ? h->k_persist_nar : (age_kernel ? h->k_persist_age : h->k_persist), dim3(wgs), dim3(64 * tw), lds, h->stream, Q);
     hipEventRecord(h->ev_ply1, h->stream);
     const bool sleep = h->ply_sleep && h->ev_adv && hipEventRecord(h->ev_adv, h->stream) == hipSuccess;
     hipError_t le = hipGetLastError();
@@ -1659,19 +1708,24 @@ static int run_games_persist(agz_engine* h, int ngames, int V, float cpuct, int 
     h->in_ply_loop = false;
     if (le != hipSuccess) { h->fail("persistent self-play launch failed: %s", hipGetErrorString(le)); return AGZ_ERR_HIP; }
     float ms = 0; hipEventElapsedTime(&ms, h->ev_ply0, h->ev_ply1);
-    unsigned long long acc[8];
+    unsigned long long acc[16], mqc[2] = {0, 0};
     HIPCHK(h, hipMemcpy(acc, h->d_pacc, sizeof acc, hipMemcpyDeviceToHost));
+    if (age_kernel) HIPCHK(h, hipMemcpy(mqc, h->mq_ctr, sizeof mqc, hipMemcpyDeviceToHost));
+    const int waiting = (int)(mqc[0] - mqc[1]);                                 // games on their way between workgroups: in flight like those in slots
+    h->age_ranked_searches += acc[4]; h->age_searches += acc[2]; h->age_pushed += acc[5];
     const int64_t rollouts = (int64_t)acc[2] * V;
 #ifdef AGZ_PSTAMPS
-    fprintf(stderr, "[pstamps] cycles summed over waves: flag/barrier %llu  search %llu  counters %llu  ply step %llu   (ply step share %.2f %%)\n", acc[4], acc[5], acc[6], acc[7],
-            100.0 * (double)acc[7] / (double)(acc[4] + acc[5] + acc[6] + acc[7] + 1));
+    fprintf(stderr, "[pstamps] cycles summed over waves: flag/barrier %llu  search %llu  counters %llu  ply step %llu   (ply step share %.2f %%)\n", acc[8], acc[9], acc[10], acc[11],
+            100.0 * (double)acc[11] / (double)(acc[8] + acc[9] + acc[10] + acc[11] + 1));
 #endif
-    { char b[220]; snprintf(b, sizeof b, "k_selfplay_small<KPL=%d,H=128,TW=%d,WV=%d,G=%d> (persistent: one launch per self-play call, a workgroup loops over the plies of its %d games)",
-                            nar ? h->persist_nar_kpl : h->reg_kpl, tw, nar ? 2 : 4, G, gpwg); h->form_tree = b; h->form_nn = "inside k_selfplay_small (mlp_wave_body<128>)"; }
+    { char ab[96] = ""; if (age_kernel) snprintf(ab, sizeof ab, "; age classes: rows by legal rank KPR=%d in workgroups whose games are all at ply >= %u", h->age_kpr, Q.P.mq.age);
+      char b[320]; snprintf(b, sizeof b, "k_selfplay_small<KPL=%d,H=128,TW=%d,WV=%d,G=%d%s> (persistent: one launch per self-play call, a workgroup loops over the plies of its %d games%s)",
+                            nar ? h->persist_nar_kpl : h->reg_kpl, tw, nar ? 2 : 4, G, age_kernel ? ",AGE" : "", gpwg, ab); h->form_tree = b; h->form_nn = "inside k_selfplay_small (mlp_wave_body<128>)"; }
     h->acc_p += acc[0]; h->acc_new += acc[1]; h->total_rollouts += (uint64_t)rollouts; h->cnt_live = false;
     h->tree_ms += ms; h->tree_busy_ms += ms; h->tree_launches += 1;
     const int rounds = (int)((acc[2] + (unsigned long long)h->Lmax - 1) / (unsigned long long)h->Lmax);   // searches per slot, rounded up
-    return finish_call(h, ngames, chain, k0, started, (int)acc[3], true, rollouts, rounds, (double)ms, t0, st);
+    if (!chain && waiting) { h->fail("persistent self-play: %d games left in the migration queue at the end of a call of its own", waiting); return AGZ_ERR_STATE; }
+    return finish_call(h, ngames, chain, k0, started, (int)acc[3] + waiting, true, rollouts, rounds, (double)ms, t0, st);
 }
 
 int agz_selfplay(agz_engine* h, int ngames, int V, float cpuct, int tau_plies, agz_selfplay_stats* stats) {

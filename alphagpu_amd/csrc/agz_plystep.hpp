@@ -6,6 +6,16 @@
 
 namespace agz {
 
+// Games that MIGRATE between the workgroups of the persistent self-play kernel (agz_selfplay_small.hpp, age classes): a first-in first-out
+// queue of {root position, game id, ply} in device memory.  ctr[0] = tickets handed to producers (tail), ctr[1] = tickets handed to
+// consumers (head); entry t & mask belongs to ticket t; `ready` == t + 1 once the producer of ticket t has filled it, 0 once its consumer
+// has copied it out.  The entry's words are written and read with agent-scope relaxed atomics (the XCDs' L2s are not coherent with each
+// other for plain accesses inside a launch) around which the wave waits for its own memory operations: no cache-wide write-back or
+// invalidation per game.
+struct MigEntry { uint32_t w[24]; };                               // w[0..19] the Pos, w[20] game id, w[21] ply, w[22] ready, w[23] -
+struct MigQ { unsigned long long* ctr; MigEntry* buf; uint32_t mask, backlog_max, age, rsv; };
+enum { TAKE_POOL = 0, TAKE_POOL_THEN_QUEUE = 1, TAKE_QUEUE = 2, TAKE_QUEUE_THEN_POOL = 3 };
+
 struct PlyPar {
     GamePar G;
     int32_t L, V, ply, tau_plies, all_actions;   // ply: the round of the lock-step loop (diagnostics; every game's own ply is slot_ply[slot])
@@ -39,30 +49,110 @@ struct PlyPar {
     int8_t* g_result;         // [G]
     Pos* g_final;             // [G]
     unsigned long long* stats;// [0] wins [1] draws [2] losses [3] total_plies [4] faults ... [7] slots left without a game by this ply's k_advance (reset by k_scan_alive)
+    MigQ mq;                  // games on their way from one workgroup to another (persistent self-play kernel with age classes); buf == nullptr: none
 };
 
-// A slot without a game takes the next game that has not started yet (game id game_id_base + k for the k-th start, Position(), ply 0),
-// if one waits: lane 0 of the calling wave writes the slot's root, id and ply.  Returns 1 if the slot has a game now (lane 0's value).
+// A slot without a game takes one that waits (the whole wave calls; the result is wave-uniform): from the POOL — the next game that has
+// not started yet: game id game_id_base + k for the k-th start, Position(), ply 0 — or from the migration QUEUE, in the order `order`
+// (TAKE_*).  Writes the slot's root (over states[slot][0] when INPLACE, else to newpos[slot]), game id and ply; returns 1 | the ply of
+// the game << 8 if the slot has a game now, else 0.
 // (a draw past the end of the pool is given back: once nobody draws any more the counter IS the number of games started, and a chain's
 //  later calls go on from it with a larger pool.  Draws below refill_total are unique: a failed draw only happens once all of them have
 //  been handed out.  One add per finished game — a compare-and-swap loop on this one address cost 2 ms per ply.)
-__device__ __forceinline__ uint32_t start_next_game(const PlyPar& T, const int slot, Pos& next) {
-    const GamePar& P = T.G;
-    const unsigned long long k = atomicAdd(T.next_game, 1ull);
-    if (k >= (unsigned long long)T.refill_total) { atomicAdd(T.next_game, ~0ull); return 0u; }
-    for (int i = 0; i < 3; ++i) { next.p[i] = P.start_p[i]; next.o[i] = P.start_o[i]; next.lg[i] = P.start_lg[i]; }
-    next.player = (int8_t)P.start_player; next.aux = (int8_t)P.start_aux;
-    for (int i = 0; i < 6; ++i) next.pad[i] = 0;
-    T.game_id[slot] = T.game_id_base + (uint32_t)k;
-    return 1u;
+__device__ __forceinline__ uint32_t draw_from_pool(const PlyPar& T, unsigned long long& k) {   // lane 0's result, broadcast
+    uint32_t ok = 0u; uint32_t klo = 0u;
+    if (lane_id() == 0) {
+        const unsigned long long kk = atomicAdd(T.next_game, 1ull);
+        if (kk >= (unsigned long long)T.refill_total) atomicAdd(T.next_game, ~0ull); else { ok = 1u; klo = (uint32_t)kk; }
+    }
+    ok = ufirst(ok); k = (unsigned long long)ufirst(klo);          // (game numbers fit 32 bits: agz_selfplay_chain checks)
+    return ok;
+}
+template <bool INPLACE>
+__device__ __forceinline__ void write_start_position(const PlyPar& T, const int slot, const unsigned long long k) {
+    if (lane_id() == 0) {
+        const GamePar& P = T.G;
+        Pos next;
+        for (int i = 0; i < 3; ++i) { next.p[i] = P.start_p[i]; next.o[i] = P.start_o[i]; next.lg[i] = P.start_lg[i]; }
+        next.player = (int8_t)P.start_player; next.aux = (int8_t)P.start_aux;
+        for (int i = 0; i < 6; ++i) next.pad[i] = 0;
+        if (INPLACE) T.states[(size_t)slot * T.V] = next; else T.newpos[slot] = next;
+        T.game_id[slot] = T.game_id_base + (uint32_t)k;
+        T.slot_ply[slot] = 0u;
+    }
+}
+template <bool INPLACE>
+__device__ __forceinline__ uint32_t pop_migrated(const PlyPar& T, const int slot) {
+    const MigQ& q = T.mq;
+    if (!q.buf) return 0u;
+    const int lane = lane_id();
+    uint32_t ok = 0u, hlo = 0u;
+    if (lane == 0) {
+        for (int tries = 0; tries < 4 && !ok; ++tries) {
+            const unsigned long long h = __hip_atomic_load(q.ctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long t = __hip_atomic_load(q.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (h >= t) break;
+            if (atomicCAS(q.ctr + 1, h, h + 1ull) == h) { ok = 1u; hlo = (uint32_t)h; }
+        }
+    }
+    ok = ufirst(ok); hlo = ufirst(hlo);
+    if (!ok) return 0u;
+    MigEntry* const e = q.buf + (hlo & q.mask);
+    // the producer of this ticket may still be writing (it took its ticket before the head could pass it)
+    while (ufirst(__hip_atomic_load(&e->w[22], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != hlo + 1u) __builtin_amdgcn_s_sleep(4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    uint32_t v = 0u;
+    if (lane < 22) v = __hip_atomic_load(&e->w[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane < 20) { uint32_t* d = reinterpret_cast<uint32_t*>(INPLACE ? T.states + (size_t)slot * T.V : T.newpos + slot); d[lane] = v; }
+    if (lane == 20) T.game_id[slot] = v;
+    if (lane == 21) T.slot_ply[slot] = v;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the entry has been read: its place is free again
+    if (lane == 0) __hip_atomic_store(&e->w[22], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return 1u | (rdlane(v, 21) << 8);                              // ... | the game's ply << 8
+}
+template <bool INPLACE>
+__device__ __forceinline__ uint32_t take_game(const PlyPar& T, const int slot, const int order) {
+    if (!T.refill_total) return 0u;
+    unsigned long long k;
+    if (order == TAKE_QUEUE || order == TAKE_QUEUE_THEN_POOL) {
+        const uint32_t r = pop_migrated<INPLACE>(T, slot);
+        if (r) return r;
+        if (order == TAKE_QUEUE) return 0u;
+    }
+    if (draw_from_pool(T, k)) { write_start_position<INPLACE>(T, slot, k); return 1u; }
+    if (order == TAKE_POOL_THEN_QUEUE) return pop_migrated<INPLACE>(T, slot);
+    return 0u;
+}
+// The game of slot `slot` (INPLACE form: root at states[slot][0]) leaves for the queue and the slot starts game k of the pool, which the
+// caller has drawn.  The whole wave calls.
+__device__ __forceinline__ void push_migrating(const PlyPar& T, const int slot, const unsigned long long k) {
+    const MigQ& q = T.mq;
+    const int lane = lane_id();
+    uint32_t tlo = 0u;
+    if (lane == 0) tlo = (uint32_t)atomicAdd(q.ctr, 1ull);
+    tlo = ufirst(tlo);
+    MigEntry* const e = q.buf + (tlo & q.mask);
+    // (the place is free unless the queue has wrapped onto an entry whose consumer is still copying: the backlog is bounded far below the ring)
+    while (ufirst(__hip_atomic_load(&e->w[22], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0u) __builtin_amdgcn_s_sleep(4);
+    uint32_t v = 0u;
+    if (lane < 20) v = reinterpret_cast<const uint32_t*>(T.states + (size_t)slot * T.V)[lane];
+    if (lane == 20) v = T.game_id[slot];
+    if (lane == 21) v = T.slot_ply[slot];
+    if (lane < 22) __hip_atomic_store(&e->w[lane], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the entry is complete (and the slot's old root has been read) ...
+    if (lane == 0) __hip_atomic_store(&e->w[22], tlo + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before it is published
+    write_start_position<true>(T, slot, k);
 }
 
 // The ply step of ONE slot by one wavefront: sample capture, move choice, play / isOver, and — with refilled slots — the next game.
 // INPLACE = false (k_advance, one launch per ply): the slot's next root goes to newpos[] and k_compact moves it to the slot's new place;
 // INPLACE = true (the persistent self-play kernels: a workgroup keeps its slots for the whole call, nothing is compacted): the next
-// root is written over the slot's root.  Returns whether the slot still holds a game (wave-uniform).
+// root is written over the slot's root.  Returns whether the slot still holds a game (wave-uniform) | the ply of that game << 8.
+// ranked: the search left the slot's policy_final row in the order of the root's legal RANKS (node rows by legal rank, agz_tree_eager.hpp
+// KPR_): entry k of the policy is the rank(k)-th entry of the row if action k is legal at the root, else 0 (what k_spread_policy does
+// in place for the one-launch-per-ply form).  order: where a slot whose game has ended looks for its next game (TAKE_*).
 template <int FAM, int NR, int NC, bool INPLACE>
-__device__ __forceinline__ uint32_t advance_slot(const PlyPar& T, const int slot) {
+__device__ __forceinline__ uint32_t advance_slot(const PlyPar& T, const int slot, const bool ranked = false, const int order = TAKE_POOL) {
     using G = Game<FAM, NC>;
     const GamePar& P = T.G;
     const int lane = lane_id();
@@ -73,6 +163,17 @@ __device__ __forceinline__ uint32_t advance_slot(const PlyPar& T, const int slot
     WPos<NC> root = load_pos<NC>(T.states + (size_t)slot * T.V);
     const int ply = (int)ufirst(T.slot_ply[slot]);                 // this game's round (:484, :556)
     float pol[NR];
+    if (ranked) {
+        int base = 0;
+        for (int r = 0; r < NR; ++r) {
+            const int k = 64 * r + lane;
+            const bool legal = k < A && G::canPlay(P, root, k);
+            const uint64_t m = __ballot(legal);
+            const int rank = base + (int)__popcll(m & ((1ull << lane) - 1ull));
+            pol[r] = legal ? T.policy_final[(size_t)slot * A + rank] : 0.0f;
+            base += (int)__popcll(m);
+        }
+    } else
     for (int r = 0; r < NR; ++r) { int k = 64 * r + lane; pol[r] = k < A ? T.policy_final[(size_t)slot * A + k] : 0.0f; }
     const bool in_range = T.ring || (g >= 0 && g < T.sample_games);
     const bool keep = in_range && ply < T.max_plies;
@@ -136,24 +237,26 @@ __device__ __forceinline__ uint32_t advance_slot(const PlyPar& T, const int slot
     uint32_t alive = f ? 0u : 1u;
     if (lane == 0) {
         if (keep) T.s_move[(size_t)g * T.max_plies + ply] = (int16_t)c;
-        Pos next = pack(np);
-        uint32_t nply = (uint32_t)ply + 1u;
         if (f) {
             if (in_range) { T.g_nplies[g] = np_end; T.g_result[g] = (int8_t)res; T.g_final[g] = pack(np); }
             atomicAdd(&T.stats[res == 1 ? 0 : (res == 0 ? 1 : 2)], 1ull);     // :541-547
             atomicAdd(&T.stats[3], (unsigned long long)ply);                   // tot_length += round (:535)
             if (T.ring) atomicAdd(&T.stats[kg < T.k_cur_end ? 8 : 9], 1ull);
-            if (T.refill_total) {                                              // the slot takes the next game that has not started yet
-                alive = start_next_game(T, slot, next);
-                nply = alive ? 0u : nply;
-            }
+        } else {
+            if (INPLACE) T.states[(size_t)slot * T.V] = pack(np); else T.newpos[slot] = pack(np);
+            T.slot_ply[slot] = (uint32_t)ply + 1u;
         }
-        if (!alive) atomicAdd(&T.stats[7], 1ull);
-        if (INPLACE) { if (alive) T.states[(size_t)slot * T.V] = next; } else T.newpos[slot] = next;
-        T.alive[slot] = alive;
-        T.slot_ply[slot] = nply;
     }
-    return ufirst(alive);
+    if (f) {                                                                   // (wave-uniform) the slot takes a game that waits, if there is one
+        alive = take_game<INPLACE>(T, slot, order);                            // (1 | the ply of the game taken << 8)
+        if (!alive && lane == 0) {
+            atomicAdd(&T.stats[7], 1ull);
+            if (!INPLACE) T.newpos[slot] = pack(np);
+            T.slot_ply[slot] = (uint32_t)ply + 1u;
+        }
+    }
+    if (lane == 0) T.alive[slot] = alive & 1u;
+    return f ? alive : (1u | (((uint32_t)ply + 1u) << 8));
 }
 
 }  // namespace agz

@@ -16,17 +16,71 @@
 
 namespace agz {
 
+struct PersistParHead { SmallPar S; };   // (the head of PersistPar: what the search loop reads)
 struct PersistPar {
     SmallPar S;               // the search (S.T at offset 0: rollout_eager_body reads its TreePar from the start of the argument segment);
                               // S.T.L = S.F.L = P.L = the slots of the launch, S.T.game_id / slot_ply / states = P's
-    PlyPar P;                 // the ply step (refill_total = games that may be started, ring / k_cur_end for chained calls)
+    PlyPar P;                 // the ply step (refill_total = games that may be started, ring / k_cur_end for chained calls, the migration queue)
     uint32_t ngames_cur;      // chained call: stop once stats[8] (finished games of the running call) reaches this; 0: run until no slot holds a game
-    int32_t flag_off;         // two LDS words of the workgroup: "some wave still has a game" / "stop"
-    unsigned long long* acc;  // [0] expanded nodes traversed, [1] nodes created (roofline bookkeeping), [2] searches of a game (x V = rollouts), [3] slots with a game at the end
+    int32_t flag_off;         // two LDS words of the workgroup: "some wave still has a game" / "stop" / "some game is young"
+    unsigned long long* acc;  // [0] expanded nodes traversed, [1] nodes created (roofline bookkeeping), [2] searches of a game (x V = rollouts), [3] slots with a game at the end,
+                              // [4] searches with rows by legal rank, [5] games pushed to the migration queue
+    // age classes (AGE builds): a workgroup PREFERS old games (ply >= P.mq.age: rows by legal rank) if hash(its CU pair) < old16 (of 16), young ones otherwise;
+    // class_by_block != 0 (tests): odd workgroups prefer old games
+    uint32_t old16, class_by_block;
 };
 
+// one mcts_single (:376-462) of the workgroup's games inside the persistent kernel: the rollout loop of k_search_small.  KPR: rows per lane
+// by the root's legal rank (0: rows by action); the records keep the stride they were allocated with either way.
+template <int FAM, int NC, int KPL, int H, int TW, int WV, int G, int KPR>
+__device__ __forceinline__ void persist_search(uint8_t* const lds_small, const int wave, const uint32_t amask, EagerCarry& C) {
+    constexpr int NWV = TW == 8 ? 8 : NW_WAVES, NG = 64 / G;
+    constexpr int PFM_ = (G < 8 || WV < 3 || (WV == 3 && KPL <= 16) || KPL <= 4) ? 2 : AGZ_PFM_LOW;
+    typedef const PersistParHead __attribute__((address_space(4)))* KArg;
+    const KArg karg = (KArg)__builtin_amdgcn_kernarg_segment_ptr();
+    const auto spar = [&]() -> const SmallPar& { KArg p = karg; asm volatile("" : "+s"(p)); return ((const PersistParHead*)p)->S; };
+    uint32_t wcount = 0;
+    const int V_ = spar().V;
+#pragma unroll 1
+    for (int k = 0; k <= V_; ++k) {
+        int bx = (int)blockIdx.x;
+        asm volatile("" : "+s"(bx));                              // opaque once per rollout (see k_search_small)
+        const SmallPar& S = spar();
+        uint8_t* const tree_lds = lds_small + (size_t)wave * S.tree_lds;
+        uint32_t* const wl_lds = reinterpret_cast<uint32_t*>(lds_small + S.wl_off + (size_t)wave * S.wl_bytes);
+        uint8_t* const io_blk = lds_small + S.io_off + (size_t)wave * S.io_bw;
+        const StepFlags SF = {(uint32_t)k, k == 0, k > 0, k < S.V, k == S.V - 1, k == S.V};
+        rollout_eager_body<FAM, NC, KPL, true, PFM_, true, ROLE_ALL, KPR, G>(
+            SF, tree_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount, io_blk, S.io_prowb, S.io_lgs, nullptr, ~amask, KPR ? S.T.rec_bytes : 0u);
+        if (k < S.V) {
+            __builtin_amdgcn_s_setprio(3);
+            const SmallPar& S = spar();
+            mlp_wave_body<H, TW * NG / 16, 2, true, true, (WV < 4), (WV < 3), NWV>(S.F, lds_small, bx, lds_small + S.io_off, S.io_bw, S.io_lgs);
+            __syncthreads();
+            __builtin_amdgcn_s_setprio(0);
+        }
+    }
+}
+
 // The same template parameters as k_search_small; only the shapes whose every wave is a full tree wave (TW = 4 or 8, ROLE_ALL) are built.
-template <int FAM, int NC, int KPL, int H, int TW, int WV, int G = 8>
+//
+// KPR2 != 0 — AGE CLASSES (stone-placing games: Gobang, Hex).  A root at ply p has A - p legal actions, and a search whose roots all have
+// at most 8 KPR2 of them may index its node rows by the root's legal RANK (agz_tree_eager.hpp KPR_: a third less arithmetic and traffic per
+// work item on a 9x9 board from ply 17 on; per launch 3.41 instead of 4.07 ms).  With one launch per ply that needs every game of the
+// BATCH to be old — lock-step generations only, the refilled batch is a mix of all ages.  Here it only needs every game of a WORKGROUP
+// to be old, and workgroups trade games: a workgroup that prefers YOUNG games hands a game that has reached ply age = A - 8 KPR2 to a
+// queue in device memory and starts a new game of the pool in its slot; a workgroup that prefers OLD games fills a slot whose game has
+// ended from that queue.  Before every search a workgroup looks at its own games: all of them old -> the body with rows by rank
+// (policy_final then leaves the search in rank order and the ply step reads it through the root's legal mask), else rows by action.
+// The preference is a function of the CU (both workgroups of a CU, and the two CUs that share an instruction cache, run the same body
+// most of the time).  Nothing depends on where a game is played: its uniforms, tau rule and sample index are keyed by (game id, ply).
+//   * a young-preferring workgroup only lets a game go when a new game is there to take the slot (the pool has not run dry) and the
+//     queue holds fewer than backlog_max games; otherwise it keeps the old game (and runs rows by action while it has young ones);
+//   * an old-preferring workgroup takes from the queue only; a wave that has had an empty slot for three plies in a row also takes from
+//     the pool (a run whose games end before they are old must not starve half the chip);
+//   * slots empty at the entry (a chain's next call) and slots of a pool that has run dry take whatever waits, the queue included,
+//     whatever the preference: the queue drains before the launch can end.
+template <int FAM, int NC, int KPL, int H, int TW, int WV, int G = 8, int KPR2 = 0>
 __global__ __launch_bounds__(64 * (TW == 8 ? 8 : NW_WAVES), WV) void k_selfplay_small(const PersistPar) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_small[];
     static_assert(offsetof(PersistPar, S) == 0 && offsetof(SmallPar, T) == 0, "rollout_eager_body reads its TreePar from the start of the argument segment");
@@ -38,12 +92,24 @@ __global__ __launch_bounds__(64 * (TW == 8 ? 8 : NW_WAVES), WV) void k_selfplay_
     constexpr int NWV = TW == 8 ? 8 : NW_WAVES;
     constexpr int NG = 64 / G;                                    // games of a tree wave
     constexpr int NR = (G * KPL + 63) / 64;                       // 64-action rows of the ply step (rows past the game's actions are empty)
+    constexpr bool AGE = KPR2 != 0;
     static_assert(TW == NWV, "tree waves == waves");
+    static_assert(!AGE || G == 8, "age classes: 8 lanes per tree");
     const int lane = lane_id();
-    uint8_t* const tree_lds = lds_small + (size_t)wave * par().S.tree_lds;
-    uint8_t* const nn_lds = lds_small;
-    uint32_t* const wl_lds = reinterpret_cast<uint32_t*>(lds_small + par().S.wl_off + (size_t)wave * par().S.wl_bytes);
-    uint32_t* const flag = reinterpret_cast<uint32_t*>(lds_small + par().flag_off);
+    // ---- which games does this workgroup prefer?  (AGE builds)
+    bool pref_old = false;
+    if constexpr (AGE) {
+        const PersistPar& Q = par();
+        uint32_t hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        // CU_ID[11:8] (the pair 2k, 2k + 1 shares an instruction cache), SH_ID[12], SE_ID[15:13]; XCC_ID[3:0]
+        const uint32_t key = ((xcc & 15u) << 8) | (((hw >> 12) & 15u) << 4) | ((hw >> 9) & 7u);
+        const uint32_t hsh = (key * 2654435761u) >> 28;           // 0 .. 15
+        pref_old = Q.class_by_block ? ((blockIdx.x & 1u) != 0u) : (hsh < Q.old16);
+        pref_old = pref_old && Q.P.mq.buf != nullptr;
+    }
+    uint32_t starve = 0u;                                         // plies in a row this wave has had a slot without a game
     // ---- the games of this wave: slots slot0 .. slot0 + NG - 1; a slot without a game takes one that waits (a chain's next call, or slots
     // the last call left empty when its pool ran dry)
     uint32_t amask = 0u;                                          // bit g: slot slot0 + g holds a game (wave-uniform)
@@ -55,20 +121,19 @@ __global__ __launch_bounds__(64 * (TW == 8 ? 8 : NW_WAVES), WV) void k_selfplay_
             const int slot = slot0 + g;
             if (slot >= Q.P.L) break;
             uint32_t a = ufirst(Q.P.alive[slot]);
-            if (!a && Q.P.refill_total) {
-                if (lane == 0) {
-                    Pos next;
-                    a = start_next_game(Q.P, slot, next);
-                    if (a) { Q.P.states[(size_t)slot * Q.P.V] = next; Q.P.slot_ply[slot] = 0u; Q.P.alive[slot] = 1u; }
-                }
-                a = ufirst(a);
+            if (!a) {
+                a = take_game<true>(Q.P, slot, pref_old ? TAKE_QUEUE_THEN_POOL : TAKE_POOL_THEN_QUEUE) & 1u;
+                if (a && lane == 0) Q.P.alive[slot] = 1u;
             }
             amask |= a << g;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
-    if (threadIdx.x == 0) { flag[0] = 0u; flag[1] = 0u; }
+    {
+        uint32_t* const flag = reinterpret_cast<uint32_t*>(lds_small + par().flag_off);
+        if (threadIdx.x == 0) { flag[0] = 0u; flag[1] = 0u; }
+    }
 #ifdef AGZ_PSTAMPS
     unsigned long long ps_t = __builtin_amdgcn_s_memtime(), ps_flag = 0, ps_search = 0, ps_cnt = 0, ps_adv = 0;
 #define PSTAMP(x) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); x += n_ - ps_t; ps_t = n_; } while (0)
@@ -77,13 +142,21 @@ __global__ __launch_bounds__(64 * (TW == 8 ? 8 : NW_WAVES), WV) void k_selfplay_
 #endif
 #pragma unroll 1
     for (uint32_t it = 0;; ++it) {
-        // ---- does the workgroup go on?  Some wave of it still has a game, and the call's own games are not all over
+        // ---- does the workgroup go on?  Some wave of it still has a game, and the call's own games are not all over.  Are all its games old?
+        bool ranked = false;
         {
             const PersistPar& Q = par();
+            uint32_t* const flag = reinterpret_cast<uint32_t*>(lds_small + Q.flag_off);
             uint32_t* const fw = flag + (it & 1u);
+            uint32_t young = 0u;
+            if constexpr (AGE) {
+                const int slot0 = ((int)blockIdx.x * TW + wave) * NG;
+                const uint32_t p = (lane < NG && ((amask >> lane) & 1u)) ? Q.P.slot_ply[slot0 + lane] : 0xffffffffu;
+                young = __ballot(p < Q.P.mq.age) != 0ull ? 4u : 0u;
+            }
             __syncthreads();                                      // (the word was cleared a whole ply ago / at the entry)
             if (lane == 0) {
-                uint32_t f = amask ? 1u : 0u;
+                uint32_t f = (amask ? 1u : 0u) | young;
                 if (wave == 0 && Q.ngames_cur) {
                     const unsigned long long fin = __hip_atomic_load(Q.P.stats + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (fin >= (unsigned long long)Q.ngames_cur) f |= 2u;
@@ -94,29 +167,16 @@ __global__ __launch_bounds__(64 * (TW == 8 ? 8 : NW_WAVES), WV) void k_selfplay_
             __syncthreads();
             const uint32_t f = ufirst(*fw);
             if (!(f & 1u) || (f & 2u)) break;
+            ranked = AGE && !(f & 4u);
         }
         PSTAMP(ps_flag);
-        // ---- mcts_single (:376-462) for the games of this workgroup: the loop of k_search_small
+        // ---- mcts_single (:376-462) for the games of this workgroup: the loop of k_search_small (one copy per row form: the two tree
+        // bodies inside ONE rollout loop cost 38 spilled registers)
         EagerCarry C = {1u, 0u, 0u, 0u, 0u, 0u, 0u};
-        uint32_t wcount = 0;
-        const int V_ = par().S.V;
-#pragma unroll 1
-        for (int k = 0; k <= V_; ++k) {
-            int bx = (int)blockIdx.x;
-            asm volatile("" : "+s"(bx));                          // opaque once per rollout (see k_search_small)
-            const SmallPar& S = par().S;
-            uint8_t* const io_blk = lds_small + S.io_off + (size_t)wave * S.io_bw;
-            const StepFlags SF = {(uint32_t)k, k == 0, k > 0, k < S.V, k == S.V - 1, k == S.V};
-            rollout_eager_body<FAM, NC, KPL, true, ((G < 8 || WV < 3 || (WV == 3 && KPL <= 16) || KPL <= 4) ? 2 : AGZ_PFM_LOW), true, ROLE_ALL, 0, G>(
-                SF, tree_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount, io_blk, S.io_prowb, S.io_lgs, nullptr, ~amask);
-            if (k < S.V) {
-                __builtin_amdgcn_s_setprio(3);
-                const SmallPar& S = par().S;
-                mlp_wave_body<H, TW * NG / 16, 2, true, true, (WV < 4), (WV < 3), NWV>(S.F, nn_lds, bx, lds_small + S.io_off, S.io_bw, S.io_lgs);
-                __syncthreads();
-                __builtin_amdgcn_s_setprio(0);
-            }
-        }
+        if constexpr (AGE) {
+            if (ranked) persist_search<FAM, NC, KPL, H, TW, WV, G, KPR2>(lds_small, wave, amask, C);
+            else persist_search<FAM, NC, KPL, H, TW, WV, G, 0>(lds_small, wave, amask, C);
+        } else persist_search<FAM, NC, KPL, H, TW, WV, G, 0>(lds_small, wave, amask, C);
         // (policy_final of this wave's games was written by lanes of this wave: the root's work item of the last-but-one rollout)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -130,6 +190,7 @@ __global__ __launch_bounds__(64 * (TW == 8 ? 8 : NW_WAVES), WV) void k_selfplay_
                 if (lane == 0) {
                     atomicAdd(Q.acc + 0, (unsigned long long)ap); atomicAdd(Q.acc + 1, (unsigned long long)an);
                     atomicAdd(Q.acc + 2, (unsigned long long)__builtin_popcount(amask));
+                    if (ranked) atomicAdd(Q.acc + 4, (unsigned long long)__builtin_popcount(amask));
                 }
             }
         }
@@ -138,20 +199,53 @@ __global__ __launch_bounds__(64 * (TW == 8 ? 8 : NW_WAVES), WV) void k_selfplay_
         {
             const PersistPar& Q = par();
             const int slot0 = ((int)blockIdx.x * TW + wave) * NG;
-            uint32_t next_mask = 0u;
+            const bool pool_open = Q.P.refill_total != 0u &&
+                                   __hip_atomic_load(Q.P.next_game, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned long long)Q.P.refill_total;
+            // where a slot whose game ends looks for the next one: see the rules above
+            int order = TAKE_POOL;
+            // (a pool that has run dry is not asked again: every failed draw is two atomic operations on one address)
+            if constexpr (AGE) order = !pool_open ? TAKE_QUEUE : (pref_old ? (starve >= 3u ? TAKE_QUEUE_THEN_POOL : TAKE_QUEUE) : TAKE_POOL_THEN_QUEUE);
+            uint32_t next_mask = 0u, dead = 0u;
 #pragma unroll 1
             for (int g = 0; g < NG; ++g) {
-                if (!((amask >> g) & 1u)) continue;
-                next_mask |= advance_slot<FAM, NR, NC, true>(Q.P, slot0 + g) << g;
+                const int slot = slot0 + g;
+                if (slot >= Q.P.L) break;
+                uint32_t r;
+                if ((amask >> g) & 1u) r = advance_slot<FAM, NR, NC, true>(Q.P, slot, ranked, order);
+                else {                                            // a slot without a game: something may wait for it now
+                    r = AGE ? take_game<true>(Q.P, slot, order) : 0u;
+                    if (r && lane == 0) Q.P.alive[slot] = 1u;
+                }
+                if constexpr (AGE) {
+                    // a young-preferring workgroup lets an old game go — when a new game can take its slot and the queue is not long
+                    if ((r & 1u) && !pref_old && pool_open && Q.P.mq.buf && (r >> 8) >= Q.P.mq.age) {
+                        uint32_t go = 0u;
+                        if (lane == 0) {
+                            const unsigned long long t = __hip_atomic_load(Q.P.mq.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            const unsigned long long h = __hip_atomic_load(Q.P.mq.ctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            go = t - h < (unsigned long long)Q.P.mq.backlog_max ? 1u : 0u;
+                        }
+                        unsigned long long k;
+                        if (ufirst(go) && draw_from_pool(Q.P, k)) {
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // (the root lane 0 has just written is read by lanes 0..19)
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                            push_migrating(Q.P, slot, k);
+                            if (lane == 0 && Q.acc) atomicAdd(Q.acc + 5, 1ull);
+                        }
+                    }
+                }
+                next_mask |= (r & 1u) << g;
+                dead += (r & 1u) ^ 1u;
             }
             amask = next_mask;
+            starve = dead ? starve + 1u : 0u;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the new roots are read by the other lanes of this wave
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
         PSTAMP(ps_adv);
     }
 #ifdef AGZ_PSTAMPS
-    if (lane == 0 && par().acc) { unsigned long long* a = par().acc; atomicAdd(a + 4, ps_flag); atomicAdd(a + 5, ps_search); atomicAdd(a + 6, ps_cnt); atomicAdd(a + 7, ps_adv); }
+    if (lane == 0 && par().acc) { unsigned long long* a = par().acc; atomicAdd(a + 8, ps_flag); atomicAdd(a + 9, ps_search); atomicAdd(a + 10, ps_cnt); atomicAdd(a + 11, ps_adv); }
 #endif
     {
         const PersistPar& Q = par();
@@ -162,6 +256,9 @@ __global__ __launch_bounds__(64 * (TW == 8 ? 8 : NW_WAVES), WV) void k_selfplay_
 // the shapes of AGZ_SMALL_SHAPES in their full-batch form (64-game workgroups of eight tree waves, four waves per SIMD) and the narrow
 // form of the few-action games (Connect4: 4 lanes per tree, 16 trees per wave, workgroups of four waves, two waves per SIMD)
 #define AGZ_PERSIST_VARIANTS(F, C, K, KW) KW template __global__ void k_selfplay_small<F, C, K, 128, 8, 4>(const PersistPar);
+// ... with age classes: (family, chunks, actions per lane, rows per lane by legal rank) — the 9x9 boards (81 actions, old from ply 17 on)
+#define AGZ_PERSIST_AGE_VARIANTS(F, C, K, R, KW) KW template __global__ void k_selfplay_small<F, C, K, 128, 8, 4, 8, R>(const PersistPar);
+#define AGZ_PERSIST_AGE_SHAPES(X) X(F_LINE, 2, 12, 8) X(F_HEX, 2, 12, 8)
 #define AGZ_PERSIST_NARROW_VARIANTS(F, C, K, GG, KW) KW template __global__ void k_selfplay_small<F, C, K, 128, 4, 2, GG>(const PersistPar);
 #define AGZ_PERSIST_NARROW_SHAPES(X) X(F_C4, 1, 4, 4)
 

@@ -32,6 +32,9 @@ AGZ_PERSIST_NARROW_SHAPES(X)
 #define X(F, C, K, R) AGZ_SMALL_CMP_VARIANTS(F, C, K, R, ) AGZ_BIG_CMP_VARIANTS(F, C, K, R, )
 #if AGZ_PART == 4
 AGZ_SMALL_CMP_SHAPES_4(X)
+#undef X
+#define X(F, C, K, R) AGZ_PERSIST_AGE_VARIANTS(F, C, K, R, )
+AGZ_PERSIST_AGE_SHAPES(X)
 #elif AGZ_PART == 5
 AGZ_SMALL_CMP_SHAPES_5(X)
 #else

@@ -156,7 +156,7 @@ template <int FAM, int NC, int KPL, bool LEAN, int PFM, bool LIO = false, int RO
 __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* const lds, const int bidx,
                                                    EagerCarry& C, uint32_t* const wl_lds, const uint32_t wl_cap_lds, uint32_t& wcount,
                                                    uint8_t* const io_blk = nullptr, const int io_prowb = 0, const int io_lgs = 0,
-                                                   uint32_t* const xch = nullptr, const uint32_t dead_mask = 0u) {
+                                                   uint32_t* const xch = nullptr, const uint32_t dead_mask = 0u, const uint32_t rec_stride = 0u) {
     using GM = Game<FAM, NC>;
     constexpr bool REV = FAM == F_REV;
     constexpr int G = G_, NG = 64 / G_;
@@ -182,7 +182,9 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
     constexpr int A2 = G * KPR;
     constexpr int OFF_P = 16, OFF_RK = 16 + 4 * A2, OFF_CID = 16 + 5 * A2, OFF_EL = 16 + 6 * A2;   // aux, per-action rows, then the edge list by rank ...
     const int A = P.A, V = T.V;
-    const uint32_t OFF_VIS = (uint32_t)(OFF_EL + 8 * eager_vl(V, A2)), ROWS = (uint32_t)eager_rec_bytes(A2, V);   // ... and the visit bytes by rank
+    // (rec_stride != 0: the records keep the stride the engine allocated them with although this build's rows are narrower — the persistent
+    //  self-play kernel runs workgroups with rows by action and workgroups with rows by legal rank side by side on one record buffer)
+    const uint32_t OFF_VIS = (uint32_t)(OFF_EL + 8 * eager_vl(V, A2)), ROWS = rec_stride ? rec_stride : (uint32_t)eager_rec_bytes(A2, V);   // ... and the visit bytes by rank
     const EagerLds LO = eager_lds_layout(V, NG);
     float2* const tab = reinterpret_cast<float2*>(lds + (size_t)g * LO.tstride + LO.tab);   // tab[-1] = {0, 0}
     float4* const valtab = reinterpret_cast<float4*>(lds + LO.val);

@@ -91,5 +91,7 @@ def load_library():
     L.agz_set_profiling.argtypes = [vp, C.c_int]
     L.agz_get_tree_busy_ms.argtypes = [vp, C.POINTER(C.c_double)]
     L.agz_get_nn_leaves.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.agz_set_network_tag.argtypes = [vp, C.c_uint32]
+    L.agz_get_age_stats.argtypes = [vp, C.POINTER(C.c_uint64 * 3)]
     _LIB = L
     return L

@@ -219,6 +219,18 @@ class Engine:
     def synchronize(self):
         self._chk(self.L.agz_synchronize(self.h))
 
+    def set_network_tag(self, tag):
+        """The tag (0..255) stored with every sample that later self-play searches produce (agz_set_network_tag): a host loop that changes
+        the network between the calls of a chain numbers its networks with it."""
+        self._chk(self.L.agz_set_network_tag(self.h, int(tag)))
+
+    def age_stats(self):
+        """Persistent self-play kernels since the last kernel_times(reset=True): (searches of a game, those run with node rows by the
+        root's legal rank, games that changed workgroup through the migration queue)."""
+        out = (C.c_uint64 * 3)()
+        self._chk(self.L.agz_get_age_stats(self.h, C.byref(out)))
+        return int(out[0]), int(out[1]), int(out[2])
+
     # -- generation ---------------------------------------------------------------------------------------
     def selfplay(self, ngames, visits, cpuct=2.0, tau_plies=25):
         st = _lib.SelfplayStats()

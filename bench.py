@@ -270,6 +270,7 @@ def main():
     # the persistent form (k_selfplay_small: ONE launch per agz_selfplay call, every workgroup loops over the plies of its own games): the
     # unit the roofline object is quoted per — "a launch" in SURVEY 8(d)'s sense, one mcts_single of G games x V rollouts — is then a
     # PLY-EQUIVALENT of the persistent launch: kernel time x (G x V) / rollouts executed
+    age_searches, age_ranked, age_moved = eng.age_stats()
     form_run = eng.search_form()[0]
     persistent = form_run.startswith("k_selfplay_small")
     kernel_launches = launches
@@ -499,6 +500,8 @@ def main():
             "rank0": {"search_only_rollouts_per_s": rollouts / search_s if search_s > 0 else None,
                       "search_kernel_ms": tree_ms, "network_kernel_ms": nn_ms, "search_ms": search_s * 1e3,
                       "instrumented_rollouts": r_cnt, "plies": plies, "samples": nsamples, "wall_s": dt,
+                      "age_classes": ({"searches_of_a_game": age_searches, "with_rows_by_legal_rank": age_ranked, "fraction": age_ranked / max(age_searches, 1),
+                                       "games_migrated": age_moved} if persistent else None),
                       "host_delivery": host},
         }
         if not args.no_cpu_baseline and world == 1:

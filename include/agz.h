@@ -181,6 +181,10 @@ int  agz_get_kernel_times(agz_engine *h, double *tree_ms, double *nn_ms, int64_t
 int  agz_get_tree_busy_ms(agz_engine *h, double *busy_ms);
 /* leaves evaluated by the stand-alone network launches that agz_get_kernel_times' nn_ms covers (since its last reset) */
 int  agz_get_nn_leaves(agz_engine *h, uint64_t *leaves);
+/* the persistent self-play kernels since the last reset of agz_get_kernel_times: out[0] = searches of a game (one per game and ply),
+ * out[1] = those run with node rows by the root's legal rank (workgroups whose games were all old: the age classes of agz_selfplay_small.hpp),
+ * out[2] = games that changed workgroup through the migration queue */
+int  agz_get_age_stats(agz_engine *h, uint64_t out[3]);
 /* names of the kernels the last search ran (the engine picks the execution form by batch size and network width) */
 int  agz_get_search_form(agz_engine *h, char *tree_kernel, char *nn_kernel, int cap);
 int  agz_set_profiling(agz_engine *h, int mode);       /* HIP events per launch: bit 0 tree kernel, bit 1 network kernel;
@@ -221,6 +225,9 @@ int  agz_set_profiling(agz_engine *h, int mode);       /* HIP events per launch:
  *                          boundary, no host wake-up per ply) wherever such a kernel exists — 128-wide trunk, bf16 mode, all slots resident —
  *                          (1), or never (0); default: calls that refill their slots (agz_selfplay with more games than slots,
  *                          agz_selfplay_chain) on engines of more than 96 slots per CU
+ *   AGZ_AGE=0              persistent self-play without age classes (every workgroup keeps node rows by action; nothing migrates)
+ *   AGZ_AGE_OLD16=n        ... n of 16 CU pairs prefer old games (default 8);  AGZ_AGE_CLASS=block: odd workgroups prefer old games (tests);
+ *                          AGZ_AGE_BACKLOG=n: young-preferring workgroups keep their old games while n games wait in the migration queue
  *   AGZ_WL_LDS_BYTES=n     one-launch forms: at most n bytes of LDS per tree wave for the work list of a rollout (the rest of
  *                          the list lives in global memory; default: what the resident workgroups leave free)
  */

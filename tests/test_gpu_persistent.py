@@ -111,3 +111,77 @@ def test_persistent_and_ply_loop_forms_return_identical_records(monkeypatch):
             assert e.search_form()[0].startswith("k_selfplay_small") == (persist == "1")
             out.append((st["nsamples"], e.samples_packed_host().tobytes()))
     assert out[0] == out[1]
+
+
+# ---- age classes: workgroups whose games are all old run node rows by the root's legal rank; games migrate between workgroups ------------
+@pytest.mark.parametrize("name,slots,ngames,V,backlog", [("gobang9", 256, 700, 32, None), ("hex9", 128, 300, 32, None), ("gobang9", 192, 500, 32, "3")])
+def test_persistent_selfplay_with_age_classes_equals_the_lockstep_oracle(name, slots, ngames, V, backlog, monkeypatch):
+    """k_selfplay_small<..., AGE>: odd workgroups prefer old games (AGZ_AGE_CLASS=block), even ones hand a game that has reached ply
+    A - 64 to the migration queue and start a new one; a workgroup whose games are all old searches with rows by legal rank and reads
+    policy_final through the root's legal mask.  Which workgroup plays a game at which moment changes nothing: the oracle's lock-step
+    generation, sample for sample.  The third case bounds the queue at three games (most old games stay where they are)."""
+    monkeypatch.setenv("AGZ_PERSIST", "1")
+    monkeypatch.setenv("AGZ_AGE_CLASS", "block")
+    if backlog:
+        monkeypatch.setenv("AGZ_AGE_BACKLOG", backlog)
+    g, og, net, onet = _nets(name)
+    ref = O.selfplay(og, onet, ngames, V, 1.5, 25, 9, 1000)
+    with M.Engine(g, slots, V, seed=9, game_id_base=1000, nn_mode=M.NN_BF16, sample_capacity_games=ngames) as e:
+        e.set_network(net)
+        e.kernel_times(reset=True)
+        st = e.selfplay(ngames, V, cpuct=1.5, tau_plies=25)
+        assert e.search_form()[0].startswith("k_selfplay_small") and "AGE" in e.search_form()[0], e.search_form()
+        searches, ranked, moved = e.age_stats()
+        assert searches == ref["n"] and 0 < ranked < searches and moved > 0, (searches, ranked, moved)
+        s = e.samples()
+        assert st["valid"] and st["nsamples"] == ref["n"] and st["rollouts"] == V * ref["n"]
+        assert (st["wins"], st["draws"], st["losses"], st["total_plies"]) == (ref["wins"], ref["draws"], ref["losses"], ref["total_plies"])
+        for key in KEYS:
+            assert_same_bits(s[key], ref[key], key)
+
+
+def test_persistent_chain_with_age_classes_keeps_waiting_games_between_calls(monkeypatch):
+    """A chain whose calls end while games wait in the migration queue: they are in flight like the games in slots, the next launch's
+    empty slots and old-preferring workgroups pick them up, every call returns the oracle's games of its ids."""
+    monkeypatch.setenv("AGZ_PERSIST", "1")
+    monkeypatch.setenv("AGZ_AGE_CLASS", "block")
+    g, og, net, onet = _nets("gobang9")
+    slots, V, calls = 192, 32, [(260, 260), (260, 130), (130, 0)]
+    ref = O.selfplay(og, onet, sum(n for n, _ in calls), V, 1.5, 25, 9, 700)
+    with M.Engine(g, slots, V, seed=9, game_id_base=700, nn_mode=M.NN_BF16, sample_capacity_games=540) as e:
+        e.set_network(net)
+        e.kernel_times(reset=True)
+        k0, rollouts = 0, 0
+        for i, (n, nxt) in enumerate(calls):
+            st = e.selfplay_chain(n, nxt, V, cpuct=1.5, tau_plies=25)
+            s = e.samples()
+            sel = (ref["game_id"] >= 700 + k0) & (ref["game_id"] < 700 + k0 + n)
+            assert st["valid"] and st["nsamples"] == int(sel.sum()) == len(s["ply"]), (i, st["nsamples"], int(sel.sum()))
+            for key in KEYS:
+                assert_same_bits(s[key], ref[key][sel], f"call {i}: {key}")
+            k0 += n
+            rollouts += st["rollouts"]
+        assert rollouts == V * len(ref["ply"])
+        searches, ranked, moved = e.age_stats()
+        assert 0 < ranked < searches and moved > 0, (searches, ranked, moved)
+
+
+def test_network_tag_travels_with_every_sample(monkeypatch):
+    """agz_set_network_tag: byte 17 of a packed record names the network that searched the ply — in a chain whose network changes between
+    calls, the games a call starts early for the next one carry the OLD tag on their first plies and the new one afterwards."""
+    monkeypatch.setenv("AGZ_PERSIST", "1")
+    g, og, net, onet = _nets("gobang9")
+    net2 = ag.SNetwork2.random(g, 128, 2, 77)
+    with M.Engine(g, 64, 16, seed=3, nn_mode=M.NN_BF16, sample_capacity_games=200) as e:
+        e.set_network(net); e.set_network_tag(5)
+        e.selfplay_chain(100, 100, 16, cpuct=1.5, tau_plies=25)
+        r1 = e.samples_packed_host().copy()
+        e.set_network(net2); e.set_network_tag(6)
+        e.selfplay_chain(100, 0, 16, cpuct=1.5, tau_plies=25)
+        r2 = e.samples_packed_host().copy()
+    assert (r1[:, 17] == 5).all()
+    gid, ply, tag = r2[:, 0:4].copy().view(np.uint32)[:, 0], r2[:, 4:8].copy().view(np.int32)[:, 0], r2[:, 17]
+    assert set(np.unique(tag)) == {5, 6}                          # some of the second call's games began under the first network
+    for gme in np.unique(gid):                                    # within a game the tag never goes back
+        t = tag[gid == gme][np.argsort(ply[gid == gme])]
+        assert (np.diff(t.astype(int)) >= 0).all()
