@@ -27,6 +27,7 @@
 #include "agz_search_big.hpp"
 #include "agz_selfplay.hpp"
 #include "agz_selfplay_small.hpp"
+#include "agz_selfplay_big.hpp"
 
 using namespace agz;
 
@@ -56,8 +57,9 @@ typedef void (*rollout_fn)(const TreePar);
 typedef void (*small_fn)(const SmallPar);
 typedef void (*big_fn)(const BigSearchPar);
 typedef void (*persist_fn)(const PersistPar);
+typedef void (*persist_big_fn)(const PersistBigPar);
 namespace agz {
-#define X(F, C, K) AGZ_SMALL_VARIANTS(F, C, K, extern) AGZ_BIG_VARIANTS(F, C, K, extern) AGZ_PERSIST_VARIANTS(F, C, K, extern)
+#define X(F, C, K) AGZ_SMALL_VARIANTS(F, C, K, extern) AGZ_BIG_VARIANTS(F, C, K, extern) AGZ_PERSIST_VARIANTS(F, C, K, extern) AGZ_PERSIST_BIG_VARIANTS(F, C, K, extern)
 AGZ_SMALL_SHAPES(X)          // defined in agz_small_inst.hip
 #undef X
 #define X(F, C, K, GG) AGZ_PERSIST_NARROW_VARIANTS(F, C, K, GG, extern)
@@ -164,6 +166,7 @@ struct agz_engine {
     // slots and loops over the plies of its games by itself.  persist: AGZ_PERSIST = 1 wherever a kernel exists (tests), 0 never, default
     // (-1): calls with refilled slots on an engine of more than 96 slots per CU.  chain_persist: the running chain's slots are not compacted.
     persist_fn k_persist = nullptr, k_persist_nar = nullptr; int persist_nar_g = 0, persist_nar_kpl = 0;
+    persist_big_fn k_persist_big[2] = {nullptr, nullptr};    // 512-wide trunks (agz_selfplay_big.hpp): one / two 64-game workgroups per CU
     int persist = -1; bool chain_persist = false; unsigned long long* d_pacc = nullptr;
     // ... with age classes (workgroups that prefer old games run rows by legal rank; games migrate through a queue in device memory):
     // age_kpr rows per lane of the old body, age_on (AGZ_AGE=0 turns it off), age_old16 of 16 CU pairs prefer old games (AGZ_AGE_OLD16),
@@ -212,7 +215,7 @@ static bool bind_kernels(agz_engine* h) {
 #define Z(F, C, K) if (P.fam == F && P.NC == C && kpl == K) { h->k_eager = k_rollout_eager<F, C, K, 4>; h->k_eager3 = k_rollout_eager<F, C, K, 3>; \
         h->k_small = k_search_small<F, C, K, 128, 2, 2>; h->k_small4[0] = k_search_small<F, C, K, 128, 4, 2>; h->k_small4[1] = k_search_small<F, C, K, 128, 4, 3>; \
         h->k_small4[2] = k_search_small<F, C, K, 128, 4, 4>; h->k_small8 = k_search_small<F, C, K, 128, 8, 4>; h->k_big[0] = k_search_big<F, C, K, 512, 1>; h->k_big[1] = k_search_big<F, C, K, 512, 2>; h->k_big8 = k_search_big<F, C, K, 512, 1, 0, 8>; h->k_big8x = k_search_big<F, C, K, 512, 2, 0, 8>; h->reg_kpl = K; \
-        h->k_persist = k_selfplay_small<F, C, K, 128, 8, 4>; }
+        h->k_persist = k_selfplay_small<F, C, K, 128, 8, 4>; h->k_persist_big[0] = k_selfplay_big<F, C, K, 512, 1>; h->k_persist_big[1] = k_selfplay_big<F, C, K, 512, 2>; }
     AGZ_SMALL_SHAPES(Z)
 #undef Z
 #define Z(F, C, K, GG) if (P.fam == F && P.NC == C && GG * K >= P.A && GG * K <= 8 * kpl) { h->k_persist_nar = k_selfplay_small<F, C, K, 128, 4, 2, GG>; h->persist_nar_g = GG; h->persist_nar_kpl = K; }
@@ -431,6 +434,7 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
         if (h->k_persist) FA_(hipFuncSetAttribute((const void*)h->k_persist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         if (h->k_persist_nar) FA_(hipFuncSetAttribute((const void*)h->k_persist_nar, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         if (h->k_persist_age) FA_(hipFuncSetAttribute((const void*)h->k_persist_age, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        for (int i = 0; i < 2; ++i) if (h->k_persist_big[i]) FA_(hipFuncSetAttribute((const void*)h->k_persist_big[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         e3 = getenv("AGZ_AGE");
         if (e3) h->age_on = atoi(e3) > 0;
         e3 = getenv("AGZ_AGE_OLD16");
@@ -1366,7 +1370,7 @@ static int run_games(agz_engine* h, int ngames, int V, float cpuct, int tau_plie
         // stays in the form it began in (the persistent form does not compact its slots)
         const long long want_ = chain ? (long long)ngames + next_games : (long long)ngames;
         const bool refill_ = chain || want_ > h->Lmax;
-        const bool use = cont ? h->chain_persist : (persist_shape(h) && (h->persist > 0 || (h->persist < 0 && refill_ && h->Lmax > 96 * h->cus)));
+        const bool use = cont ? h->chain_persist : (persist_shape(h) && (h->persist > 0 || (h->persist < 0 && refill_ && h->Lmax > (h->net[0].H == 512 ? 64 : 96) * h->cus)));
         if (use) {
             if (!persist_shape(h)) { h->fail("the chain's games are in flight in uncompacted slots (persistent form) and the engine's network / mode no longer allows that form"); return AGZ_ERR_STATE; }
             return run_games_persist(h, ngames, V, cpuct, tau_plies, st, next_games);
@@ -1582,9 +1586,12 @@ static int finish_call(agz_engine* h, int ngames, bool chain, unsigned long long
 // ---- one launch per call: the persistent self-play kernel (agz_selfplay_small.hpp) -------------------------------------------------
 static bool persist_shape(const agz_engine* h) {
     const DevNet& n = h->net[0];
-    if (h->persist == 0 || !(h->k_persist || h->k_persist_nar) || h->cfg.nn_mode != AGZ_NN_BF16 || !n.loaded || n.H != 128 || !n.w16w) return false;
+    if (h->persist == 0 || h->cfg.nn_mode != AGZ_NN_BF16 || !n.loaded) return false;
     if (h->V > 128 || (h->V & 3) != 0 || h->no_fused_nn || 8 * h->reg_kpl > h->LGS) return false;
-    return (h->Lmax + 63) / 64 <= 2 * h->cus;                                  // every workgroup resident: two 64-game workgroups per CU
+    if ((h->Lmax + 63) / 64 > 2 * h->cus) return false;                        // every workgroup resident: two 64-game workgroups per CU
+    if (n.H == 128) return (h->k_persist || h->k_persist_nar) && n.w16w;
+    if (n.H == 512) return h->k_persist_big[0] && n.wbig && h->big8 >= 0;
+    return false;
 }
 
 static int run_games_persist(agz_engine* h, int ngames, int V, float cpuct, int tau_plies, agz_selfplay_stats* st, int next_games) {
@@ -1648,58 +1655,89 @@ static int run_games_persist(agz_engine* h, int ngames, int V, float cpuct, int 
     h->sp_k0 = (uint32_t)k0; h->sp_ring0 = chain ? (uint32_t)(k0 % (unsigned long long)h->sample_games) : 0u;
     h->cpuct = cpuct; h->training = 1; h->step = 0;
     HIPCHK(h, hipMemsetAsync(h->d_pacc, 0, 16 * sizeof(unsigned long long), h->stream));
-    // ---- the launch: the search parameters of k_search_small's 64-game workgroups (agz_search_actor), the ply step's, the call's pool
+    // ---- the launch: the search parameters of the 64-game workgroups of k_search_small / k_search_big (agz_search_actor), the ply step's,
+    // the call's pool
     DevNet& n = h->net[0];
-    const bool nar = h->k_persist_nar && h->narrow_mode >= 0;                   // few-action games: 4 lanes per tree, 16 trees per wave, four waves
+    const bool big = n.H == 512;
+    const bool nar = !big && h->k_persist_nar && h->narrow_mode >= 0;           // few-action games: 4 lanes per tree, 16 trees per wave, four waves
     // age classes: stone-placing games on boards whose rows by legal rank are built, V large enough for the expansion's compaction buffer
     // (2 V >= 8 KPR floats of the lane-group's edge table), refilled slots (a game can only leave a slot that a new game takes)
-    const bool age = !nar && h->k_persist_age && h->age_on && !h->no_compact && 2 * h->V >= 8 * h->age_kpr && (chain || (long long)ngames > (long long)slots);
-    if (!nar && !h->k_persist) { h->fail("no persistent self-play kernel for this game shape"); return AGZ_ERR_UNSUPPORTED; }
+    const bool age = !big && !nar && h->k_persist_age && h->age_on && !h->no_compact && 2 * h->V >= 8 * h->age_kpr && (chain || (long long)ngames > (long long)slots);
+    if (!big && !nar && !h->k_persist) { h->fail("no persistent self-play kernel for this game shape"); return AGZ_ERR_UNSUPPORTED; }
     const int G = nar ? h->persist_nar_g : 8, NG = 64 / G, tw = nar ? 4 : 8, gpwg = tw * NG;
-    PersistPar Q; memset(&Q, 0, sizeof Q);
-    SmallPar& S = Q.S;
-    S.T = h->tp;
-    S.T.L = h->Lmax; S.T.slot0 = 0; S.T.step = 0; S.T.cpuct = cpuct; S.T.training = 1;
-    S.T.fastdiv = fastdiv_range(h);
-    S.T.inject = 0; S.T.capture = 0; S.T.rollout = 0; S.T.do_reset = 1; S.T.do_expand = 0; S.T.do_select = 1; S.T.last = 0;
-    S.T.gpw = NG;
-    S.F.planes = (const uint16_t*)h->planes; S.F.INP = n.INP; S.F.w16 = n.w16w; S.F.bias_head = n.bias_head;
-    S.F.logits = h->logits; S.F.LGS = h->LGS; S.F.vout = h->v_eval; S.F.L = h->Lmax; S.F.T = n.T; S.F.A = h->G.A; S.F.AOP = n.AOP;
-    S.F.gpw = 0; S.F.tw = tw; S.F.rb = NG;
-    S.V = V; S.tree_lds = nar ? eager_lds_layout(h->V, NG).total : (int)h->reg_lds;
-    const int kth = n.H / 32, g0 = (n.INP / 32 + kth - 1) / kth;
-    const int prowb = g0 * kth * 64 + 16;
-    const int rs = (std::max(prowb, 4 * n.AOP) + 15) & ~15;
-    S.io_prowb = rs; S.io_lgs = rs / 4; S.io_bw = NG * rs;
-    S.io_off = (int)((std::max((size_t)tw * (size_t)S.tree_lds, (size_t)gpwg * 2 * (n.H * 2 + 16)) + 15) & ~(size_t)15);
-    S.xch_off = S.io_off + tw * S.io_bw;
-    const size_t shared = (size_t)S.xch_off + (size_t)tw * (16 * NG + 16) + 16;   // ... + the workgroup's two flag words
-    Q.flag_off = (int)shared - 16;
-    const size_t cu_lds = (size_t)(160 * 1024) / 2;
-    const size_t room = cu_lds > shared ? cu_lds - shared : 0;
-    S.wl_off = (int)shared; S.wl_bytes = (int)std::min({(size_t)(NG * h->V * 4), (room / (size_t)tw) & ~(size_t)15, (size_t)h->wl_lds_max});
-    const size_t lds = shared + (size_t)tw * S.wl_bytes;
-    if (lds > cu_lds) { h->fail("persistent self-play kernel: %zu bytes of LDS per workgroup", lds); return AGZ_ERR_UNSUPPORTED; }
-    fill_plypar(h, Q.P, 0, tau_plies, false);
-    Q.P.L = h->Lmax;
-    Q.P.refill_total = (chain || (long long)ngames > (long long)slots) ? (uint32_t)pool_end : 0u;
-    Q.P.ring = chain ? 1 : 0; Q.P.k_cur_end = (uint32_t)(k0 + (unsigned long long)ngames);
-    Q.ngames_cur = chain ? (uint32_t)ngames : 0u;
-    Q.acc = h->d_pacc;
-    if (h->mq_buf && (age || h->mq_dirty)) {                                    // (a chain that began with age classes keeps the queue: games may wait in it)
-        Q.P.mq.ctr = h->mq_ctr; Q.P.mq.buf = h->mq_buf; Q.P.mq.mask = h->mq_cap - 1u;
-        Q.P.mq.backlog_max = (uint32_t)(h->age_backlog > 0 ? h->age_backlog : std::max(64, h->Lmax / 16));
-        if (Q.P.mq.backlog_max > h->mq_cap / 2u) Q.P.mq.backlog_max = h->mq_cap / 2u;
-        Q.P.mq.age = (uint32_t)std::max(0, h->G.A - 8 * h->age_kpr);
-        Q.old16 = (uint32_t)h->age_old16; Q.class_by_block = h->age_by_block ? 1u : 0u;
+    const unsigned wgs = (unsigned)((h->Lmax + gpwg - 1) / gpwg);
+    PersistTail X; memset(&X, 0, sizeof X);
+    fill_plypar(h, X.P, 0, tau_plies, false);
+    X.P.L = h->Lmax;
+    X.P.refill_total = (chain || (long long)ngames > (long long)slots) ? (uint32_t)pool_end : 0u;
+    X.P.ring = chain ? 1 : 0; X.P.k_cur_end = (uint32_t)(k0 + (unsigned long long)ngames);
+    X.ngames_cur = chain ? (uint32_t)ngames : 0u;
+    X.acc = h->d_pacc;
+    if (h->mq_buf && !big && (age || h->mq_dirty)) {                            // (a chain that began with age classes keeps the queue: games may wait in it)
+        X.P.mq.ctr = h->mq_ctr; X.P.mq.buf = h->mq_buf; X.P.mq.mask = h->mq_cap - 1u;
+        X.P.mq.backlog_max = (uint32_t)(h->age_backlog > 0 ? h->age_backlog : std::max(64, h->Lmax / 16));
+        if (X.P.mq.backlog_max > h->mq_cap / 2u) X.P.mq.backlog_max = h->mq_cap / 2u;
+        X.P.mq.age = (uint32_t)std::max(0, h->G.A - 8 * h->age_kpr);
+        X.old16 = (uint32_t)h->age_old16; X.class_by_block = h->age_by_block ? 1u : 0u;
         h->mq_dirty = true;
     }
-    const bool age_kernel = Q.P.mq.buf != nullptr;
-    const unsigned wgs = (unsigned)((h->Lmax + gpwg - 1) / gpwg);
-    h->rd_rec_bytes = nar ? (uint32_t)eager_rec_bytes(G * h->persist_nar_kpl, h->V) : h->tp.rec_bytes;
+    const bool age_kernel = X.P.mq.buf != nullptr;
+    TreePar T = h->tp;
+    T.L = h->Lmax; T.slot0 = 0; T.step = 0; T.cpuct = cpuct; T.training = 1;
+    T.fastdiv = fastdiv_range(h);
+    T.inject = 0; T.capture = 0; T.rollout = 0; T.do_reset = 1; T.do_expand = 0; T.do_select = 1; T.last = 0;
+    T.gpw = NG;
+    const size_t cu_lds_all = (size_t)(160 * 1024);
+    int wgcu = 2;
     h->in_ply_loop = true;
-    hipEventRecord(h->ev_ply0, h->stream);
-    hipLaunchKernelGGL(nar ? h->k_persist_nar : (age_kernel ? h->k_persist_age : h->k_persist), dim3(wgs), dim3(64 * tw), lds, h->stream, Q);
+    if (big) {
+        PersistBigPar Q; memset(&Q, 0, sizeof Q);
+        BigSearchPar& S = Q.S;
+        S.T = T;
+        const int big_rowb = (2 * std::max(n.H, 32 * n.k0r) + 255) & ~255;
+        BigPar& B = S.B;
+        B.planes = (const uint16_t*)h->planes; B.INP = n.INP; B.wh = n.wbig;
+        B.whead = n.w16 + (size_t)(n.INP / 32) * (n.H / 16) * 512 + (size_t)n.T * (n.H / 32) * (n.H / 16) * 512;
+        B.bias_head = n.bias_head; B.logits = h->logits; B.LGS = h->LGS; B.vout = h->v_eval;
+        B.L = h->Lmax; B.T = n.T; B.A = h->G.A; B.AOP = n.AOP; B.K0R = n.k0r; B.ROWB = big_rowb;
+        wgcu = (int)wgs <= h->cus ? 1 : 2;
+        S.V = V; S.tree_lds = (int)h->reg_lds;
+        S.xch_off = (int)((std::max((size_t)8 * h->reg_lds, (size_t)8 * 8 * big_rowb) + 15) & ~(size_t)15);
+        const size_t shared = (size_t)S.xch_off + 4 * 144 + 16;                  // ... + the workgroup's two flag words
+        Q.X = X; Q.X.flag_off = (int)shared - 16;
+        const size_t cu_lds = cu_lds_all / (size_t)wgcu;
+        const size_t room = cu_lds > shared ? cu_lds - shared : 0;
+        S.wl_off = (int)shared; S.wl_bytes = (int)std::min({(size_t)(8 * h->V * 4), (room / 8) & ~(size_t)15, (size_t)h->wl_lds_max});
+        const size_t lds = shared + (size_t)8 * S.wl_bytes;
+        if (lds > cu_lds) { h->in_ply_loop = false; h->fail("persistent self-play kernel: %zu bytes of LDS per workgroup", lds); return AGZ_ERR_UNSUPPORTED; }
+        h->rd_rec_bytes = h->tp.rec_bytes;
+        hipEventRecord(h->ev_ply0, h->stream);
+        hipLaunchKernelGGL(h->k_persist_big[wgcu - 1], dim3(wgs), dim3(NB_THREADS), lds, h->stream, Q);
+    } else {
+        PersistPar Q; memset(&Q, 0, sizeof Q);
+        SmallPar& S = Q.S;
+        S.T = T;
+        S.F.planes = (const uint16_t*)h->planes; S.F.INP = n.INP; S.F.w16 = n.w16w; S.F.bias_head = n.bias_head;
+        S.F.logits = h->logits; S.F.LGS = h->LGS; S.F.vout = h->v_eval; S.F.L = h->Lmax; S.F.T = n.T; S.F.A = h->G.A; S.F.AOP = n.AOP;
+        S.F.gpw = 0; S.F.tw = tw; S.F.rb = NG;
+        S.V = V; S.tree_lds = nar ? eager_lds_layout(h->V, NG).total : (int)h->reg_lds;
+        const int kth = n.H / 32, g0 = (n.INP / 32 + kth - 1) / kth;
+        const int prowb = g0 * kth * 64 + 16;
+        const int rs = (std::max(prowb, 4 * n.AOP) + 15) & ~15;
+        S.io_prowb = rs; S.io_lgs = rs / 4; S.io_bw = NG * rs;
+        S.io_off = (int)((std::max((size_t)tw * (size_t)S.tree_lds, (size_t)gpwg * 2 * (n.H * 2 + 16)) + 15) & ~(size_t)15);
+        S.xch_off = S.io_off + tw * S.io_bw;
+        const size_t shared = (size_t)S.xch_off + (size_t)tw * (16 * NG + 16) + 16;   // ... + the workgroup's two flag words
+        Q.X = X; Q.X.flag_off = (int)shared - 16;
+        const size_t cu_lds = cu_lds_all / 2;
+        const size_t room = cu_lds > shared ? cu_lds - shared : 0;
+        S.wl_off = (int)shared; S.wl_bytes = (int)std::min({(size_t)(NG * h->V * 4), (room / (size_t)tw) & ~(size_t)15, (size_t)h->wl_lds_max});
+        const size_t lds = shared + (size_t)tw * S.wl_bytes;
+        if (lds > cu_lds) { h->in_ply_loop = false; h->fail("persistent self-play kernel: %zu bytes of LDS per workgroup", lds); return AGZ_ERR_UNSUPPORTED; }
+        h->rd_rec_bytes = nar ? (uint32_t)eager_rec_bytes(G * h->persist_nar_kpl, h->V) : h->tp.rec_bytes;
+        hipEventRecord(h->ev_ply0, h->stream);
+        hipLaunchKernelGGL(nar ? h->k_persist_nar : (age_kernel ? h->k_persist_age : h->k_persist), dim3(wgs), dim3(64 * tw), lds, h->stream, Q);
+    }
     hipEventRecord(h->ev_ply1, h->stream);
     const bool sleep = h->ply_sleep && h->ev_adv && hipEventRecord(h->ev_adv, h->stream) == hipSuccess;
     hipError_t le = hipGetLastError();
@@ -1718,9 +1756,14 @@ static int run_games_persist(agz_engine* h, int ngames, int V, float cpuct, int 
     fprintf(stderr, "[pstamps] cycles summed over waves: flag/barrier %llu  search %llu  counters %llu  ply step %llu   (ply step share %.2f %%)\n", acc[8], acc[9], acc[10], acc[11],
             100.0 * (double)acc[11] / (double)(acc[8] + acc[9] + acc[10] + acc[11] + 1));
 #endif
-    { char ab[96] = ""; if (age_kernel) snprintf(ab, sizeof ab, "; age classes: rows by legal rank KPR=%d in workgroups whose games are all at ply >= %u", h->age_kpr, Q.P.mq.age);
-      char b[320]; snprintf(b, sizeof b, "k_selfplay_small<KPL=%d,H=128,TW=%d,WV=%d,G=%d%s> (persistent: one launch per self-play call, a workgroup loops over the plies of its %d games%s)",
-                            nar ? h->persist_nar_kpl : h->reg_kpl, tw, nar ? 2 : 4, G, age_kernel ? ",AGE" : "", gpwg, ab); h->form_tree = b; h->form_nn = "inside k_selfplay_small (mlp_wave_body<128>)"; }
+    if (big) {
+        char b[320]; snprintf(b, sizeof b, "k_selfplay_big<KPL=%d,H=512,WG=%d> (persistent: one launch per self-play call, a workgroup loops over the plies of its 64 games)", h->reg_kpl, wgcu);
+        h->form_tree = b; h->form_nn = "inside k_selfplay_big (mlp_big_body<512,4>)";
+    } else {
+        char ab[96] = ""; if (age_kernel) snprintf(ab, sizeof ab, "; age classes: rows by legal rank KPR=%d in workgroups whose games are all at ply >= %u", h->age_kpr, X.P.mq.age);
+        char b[320]; snprintf(b, sizeof b, "k_selfplay_small<KPL=%d,H=128,TW=%d,WV=%d,G=%d%s> (persistent: one launch per self-play call, a workgroup loops over the plies of its %d games%s)",
+                              nar ? h->persist_nar_kpl : h->reg_kpl, tw, nar ? 2 : 4, G, age_kernel ? ",AGE" : "", gpwg, ab); h->form_tree = b; h->form_nn = "inside k_selfplay_small (mlp_wave_body<128>)";
+    }
     h->acc_p += acc[0]; h->acc_new += acc[1]; h->total_rollouts += (uint64_t)rollouts; h->cnt_live = false;
     h->tree_ms += ms; h->tree_busy_ms += ms; h->tree_launches += 1;
     const int rounds = (int)((acc[2] + (unsigned long long)h->Lmax - 1) / (unsigned long long)h->Lmax);   // searches per slot, rounded up

@@ -16,11 +16,11 @@
 
 namespace agz {
 
-struct PersistParHead { SmallPar S; };   // (the head of PersistPar: what the search loop reads)
-struct PersistPar {
-    SmallPar S;               // the search (S.T at offset 0: rollout_eager_body reads its TreePar from the start of the argument segment);
-                              // S.T.L = S.F.L = P.L = the slots of the launch, S.T.game_id / slot_ply / states = P's
-    PlyPar P;                 // the ply step (refill_total = games that may be started, ring / k_cur_end for chained calls, the migration queue)
+// what the persistent kernels share beside their search parameters (k_selfplay_small: SmallPar, k_selfplay_big: BigSearchPar — each with its
+// TreePar at offset 0 of the argument segment)
+struct PersistTail {
+    PlyPar P;                 // the ply step (refill_total = games that may be started, ring / k_cur_end for chained calls, the migration queue);
+                              // P.L = the slots of the launch, P.game_id / slot_ply / states = the search's
     uint32_t ngames_cur;      // chained call: stop once stats[8] (finished games of the running call) reaches this; 0: run until no slot holds a game
     int32_t flag_off;         // two LDS words of the workgroup: "some wave still has a game" / "stop" / "some game is young"
     unsigned long long* acc;  // [0] expanded nodes traversed, [1] nodes created (roofline bookkeeping), [2] searches of a game (x V = rollouts), [3] slots with a game at the end,
@@ -29,41 +29,18 @@ struct PersistPar {
     // class_by_block != 0 (tests): odd workgroups prefer old games
     uint32_t old16, class_by_block;
 };
+struct PersistPar { SmallPar S; PersistTail X; };
 
-// one mcts_single (:376-462) of the workgroup's games inside the persistent kernel: the rollout loop of k_search_small.  KPR: rows per lane
-// by the root's legal rank (0: rows by action); the records keep the stride they were allocated with either way.
-template <int FAM, int NC, int KPL, int H, int TW, int WV, int G, int KPR>
-__device__ __forceinline__ void persist_search(uint8_t* const lds_small, const int wave, const uint32_t amask, EagerCarry& C) {
-    constexpr int NWV = TW == 8 ? 8 : NW_WAVES, NG = 64 / G;
-    constexpr int PFM_ = (G < 8 || WV < 3 || (WV == 3 && KPL <= 16) || KPL <= 4) ? 2 : AGZ_PFM_LOW;
-    typedef const PersistParHead __attribute__((address_space(4)))* KArg;
-    const KArg karg = (KArg)__builtin_amdgcn_kernarg_segment_ptr();
-    const auto spar = [&]() -> const SmallPar& { KArg p = karg; asm volatile("" : "+s"(p)); return ((const PersistParHead*)p)->S; };
-    uint32_t wcount = 0;
-    const int V_ = spar().V;
-#pragma unroll 1
-    for (int k = 0; k <= V_; ++k) {
-        int bx = (int)blockIdx.x;
-        asm volatile("" : "+s"(bx));                              // opaque once per rollout (see k_search_small)
-        const SmallPar& S = spar();
-        uint8_t* const tree_lds = lds_small + (size_t)wave * S.tree_lds;
-        uint32_t* const wl_lds = reinterpret_cast<uint32_t*>(lds_small + S.wl_off + (size_t)wave * S.wl_bytes);
-        uint8_t* const io_blk = lds_small + S.io_off + (size_t)wave * S.io_bw;
-        const StepFlags SF = {(uint32_t)k, k == 0, k > 0, k < S.V, k == S.V - 1, k == S.V};
-        rollout_eager_body<FAM, NC, KPL, true, PFM_, true, ROLE_ALL, KPR, G>(
-            SF, tree_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount, io_blk, S.io_prowb, S.io_lgs, nullptr, ~amask, KPR ? S.T.rec_bytes : 0u);
-        if (k < S.V) {
-            __builtin_amdgcn_s_setprio(3);
-            const SmallPar& S = spar();
-            mlp_wave_body<H, TW * NG / 16, 2, true, true, (WV < 4), (WV < 3), NWV>(S.F, lds_small, bx, lds_small + S.io_off, S.io_bw, S.io_lgs);
-            __syncthreads();
-            __builtin_amdgcn_s_setprio(0);
-        }
-    }
-}
+#ifdef AGZ_PSTAMPS
+#define PSTAMP(x) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); x += n_ - ps_t; ps_t = n_; } while (0)
+#else
+#define PSTAMP(x) do { } while (0)
+#endif
 
-// The same template parameters as k_search_small; only the shapes whose every wave is a full tree wave (TW = 4 or 8, ROLE_ALL) are built.
-//
+// The loop of a persistent self-play workgroup.  TW waves, each with the NG = 64 / G games of slots (blockIdx.x TW + wave) NG ...;
+// tail() -> const PersistTail& (read from the kernel-argument segment where it is needed); search(amask, ranked, C): one mcts_single of the
+// workgroup's games (all waves call it; it contains the workgroup barriers of the network phase), C = the games' carry, whose descent
+// counters are read afterwards.
 // KPR2 != 0 — AGE CLASSES (stone-placing games: Gobang, Hex).  A root at ply p has A - p legal actions, and a search whose roots all have
 // at most 8 KPR2 of them may index its node rows by the root's legal RANK (agz_tree_eager.hpp KPR_: a third less arithmetic and traffic per
 // work item on a 9x9 board from ply 17 on; per launch 3.41 instead of 4.07 ms).  With one launch per ply that needs every game of the
@@ -80,26 +57,17 @@ __device__ __forceinline__ void persist_search(uint8_t* const lds_small, const i
 //     the pool (a run whose games end before they are old must not starve half the chip);
 //   * slots empty at the entry (a chain's next call) and slots of a pool that has run dry take whatever waits, the queue included,
 //     whatever the preference: the queue drains before the launch can end.
-template <int FAM, int NC, int KPL, int H, int TW, int WV, int G = 8, int KPR2 = 0>
-__global__ __launch_bounds__(64 * (TW == 8 ? 8 : NW_WAVES), WV) void k_selfplay_small(const PersistPar) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds_small[];
-    static_assert(offsetof(PersistPar, S) == 0 && offsetof(SmallPar, T) == 0, "rollout_eager_body reads its TreePar from the start of the argument segment");
-    static_assert(TW == 4 || TW == 8, "every wave of the workgroup is a tree wave");
-    typedef const PersistPar __attribute__((address_space(4)))* KArg;
-    const KArg karg = (KArg)__builtin_amdgcn_kernarg_segment_ptr();
-    const auto par = [&]() -> const PersistPar& { KArg p = karg; asm volatile("" : "+s"(p)); return *(const PersistPar*)p; };
+template <int FAM, int NC, int KPL, int G, int TW, bool AGE, typename TailFn, typename SearchFn>
+__device__ __forceinline__ void persist_loop(uint8_t* const lds, const TailFn tail, const SearchFn search) {
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    constexpr int NWV = TW == 8 ? 8 : NW_WAVES;
     constexpr int NG = 64 / G;                                    // games of a tree wave
     constexpr int NR = (G * KPL + 63) / 64;                       // 64-action rows of the ply step (rows past the game's actions are empty)
-    constexpr bool AGE = KPR2 != 0;
-    static_assert(TW == NWV, "tree waves == waves");
     static_assert(!AGE || G == 8, "age classes: 8 lanes per tree");
     const int lane = lane_id();
     // ---- which games does this workgroup prefer?  (AGE builds)
     bool pref_old = false;
     if constexpr (AGE) {
-        const PersistPar& Q = par();
+        const PersistTail& Q = tail();
         uint32_t hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -114,7 +82,7 @@ __global__ __launch_bounds__(64 * (TW == 8 ? 8 : NW_WAVES), WV) void k_selfplay_
     // the last call left empty when its pool ran dry)
     uint32_t amask = 0u;                                          // bit g: slot slot0 + g holds a game (wave-uniform)
     {
-        const PersistPar& Q = par();
+        const PersistTail& Q = tail();
         const int slot0 = ((int)blockIdx.x * TW + wave) * NG;
 #pragma unroll 1
         for (int g = 0; g < NG; ++g) {
@@ -131,22 +99,19 @@ __global__ __launch_bounds__(64 * (TW == 8 ? 8 : NW_WAVES), WV) void k_selfplay_
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
     {
-        uint32_t* const flag = reinterpret_cast<uint32_t*>(lds_small + par().flag_off);
+        uint32_t* const flag = reinterpret_cast<uint32_t*>(lds + tail().flag_off);
         if (threadIdx.x == 0) { flag[0] = 0u; flag[1] = 0u; }
     }
 #ifdef AGZ_PSTAMPS
     unsigned long long ps_t = __builtin_amdgcn_s_memtime(), ps_flag = 0, ps_search = 0, ps_cnt = 0, ps_adv = 0;
-#define PSTAMP(x) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); x += n_ - ps_t; ps_t = n_; } while (0)
-#else
-#define PSTAMP(x) do { } while (0)
 #endif
 #pragma unroll 1
     for (uint32_t it = 0;; ++it) {
         // ---- does the workgroup go on?  Some wave of it still has a game, and the call's own games are not all over.  Are all its games old?
         bool ranked = false;
         {
-            const PersistPar& Q = par();
-            uint32_t* const flag = reinterpret_cast<uint32_t*>(lds_small + Q.flag_off);
+            const PersistTail& Q = tail();
+            uint32_t* const flag = reinterpret_cast<uint32_t*>(lds + Q.flag_off);
             uint32_t* const fw = flag + (it & 1u);
             uint32_t young = 0u;
             if constexpr (AGE) {
@@ -170,20 +135,16 @@ __global__ __launch_bounds__(64 * (TW == 8 ? 8 : NW_WAVES), WV) void k_selfplay_
             ranked = AGE && !(f & 4u);
         }
         PSTAMP(ps_flag);
-        // ---- mcts_single (:376-462) for the games of this workgroup: the loop of k_search_small (one copy per row form: the two tree
-        // bodies inside ONE rollout loop cost 38 spilled registers)
+        // ---- mcts_single (:376-462) for the games of this workgroup
         EagerCarry C = {1u, 0u, 0u, 0u, 0u, 0u, 0u};
-        if constexpr (AGE) {
-            if (ranked) persist_search<FAM, NC, KPL, H, TW, WV, G, KPR2>(lds_small, wave, amask, C);
-            else persist_search<FAM, NC, KPL, H, TW, WV, G, 0>(lds_small, wave, amask, C);
-        } else persist_search<FAM, NC, KPL, H, TW, WV, G, 0>(lds_small, wave, amask, C);
+        search(amask, ranked, C);
         // (policy_final of this wave's games was written by lanes of this wave: the root's work item of the last-but-one rollout)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         PSTAMP(ps_search);
         // ---- roofline bookkeeping: descent counters of the search (the lead lane of a game's lane-group holds them)
         {
-            const PersistPar& Q = par();
+            const PersistTail& Q = tail();
             if (Q.acc) {
                 uint32_t ap = (lane % G) == 0 ? C.add_p : 0u, an = (lane % G) == 0 ? C.add_new : 0u;
                 for (int o = 32; o > 0; o >>= 1) { ap += (uint32_t)__shfl_xor((int)ap, o, 64); an += (uint32_t)__shfl_xor((int)an, o, 64); }
@@ -197,13 +158,13 @@ __global__ __launch_bounds__(64 * (TW == 8 ? 8 : NW_WAVES), WV) void k_selfplay_
         PSTAMP(ps_cnt);
         // ---- the ply step of each game (:513-561), one after the other, the whole wave on one game
         {
-            const PersistPar& Q = par();
+            const PersistTail& Q = tail();
             const int slot0 = ((int)blockIdx.x * TW + wave) * NG;
             const bool pool_open = Q.P.refill_total != 0u &&
                                    __hip_atomic_load(Q.P.next_game, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned long long)Q.P.refill_total;
             // where a slot whose game ends looks for the next one: see the rules above
-            int order = TAKE_POOL;
             // (a pool that has run dry is not asked again: every failed draw is two atomic operations on one address)
+            int order = TAKE_POOL;
             if constexpr (AGE) order = !pool_open ? TAKE_QUEUE : (pref_old ? (starve >= 3u ? TAKE_QUEUE_THEN_POOL : TAKE_QUEUE) : TAKE_POOL_THEN_QUEUE);
             uint32_t next_mask = 0u, dead = 0u;
 #pragma unroll 1
@@ -245,12 +206,66 @@ __global__ __launch_bounds__(64 * (TW == 8 ? 8 : NW_WAVES), WV) void k_selfplay_
         PSTAMP(ps_adv);
     }
 #ifdef AGZ_PSTAMPS
-    if (lane == 0 && par().acc) { unsigned long long* a = par().acc; atomicAdd(a + 8, ps_flag); atomicAdd(a + 9, ps_search); atomicAdd(a + 10, ps_cnt); atomicAdd(a + 11, ps_adv); }
+    if (lane == 0 && tail().acc) { unsigned long long* a = tail().acc; atomicAdd(a + 8, ps_flag); atomicAdd(a + 9, ps_search); atomicAdd(a + 10, ps_cnt); atomicAdd(a + 11, ps_adv); }
 #endif
     {
-        const PersistPar& Q = par();
+        const PersistTail& Q = tail();
         if (lane == 0 && Q.acc && amask) atomicAdd(Q.acc + 3, (unsigned long long)__builtin_popcount(amask));
     }
+}
+
+// one mcts_single (:376-462) of the workgroup's games inside the persistent kernel: the rollout loop of k_search_small.  KPR: rows per lane
+// by the root's legal rank (0: rows by action); the records keep the stride they were allocated with either way.
+template <int FAM, int NC, int KPL, int H, int TW, int WV, int G, int KPR>
+__device__ __forceinline__ void persist_search(uint8_t* const lds_small, const uint32_t amask, EagerCarry& C) {
+    constexpr int NWV = TW == 8 ? 8 : NW_WAVES, NG = 64 / G;
+    constexpr int PFM_ = (G < 8 || WV < 3 || (WV == 3 && KPL <= 16) || KPL <= 4) ? 2 : AGZ_PFM_LOW;
+    typedef const PersistPar __attribute__((address_space(4)))* KArg;
+    const KArg karg = (KArg)__builtin_amdgcn_kernarg_segment_ptr();
+    const auto spar = [&]() -> const SmallPar& { KArg p = karg; asm volatile("" : "+s"(p)); return ((const PersistPar*)p)->S; };
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    uint32_t wcount = 0;
+    const int V_ = spar().V;
+#pragma unroll 1
+    for (int k = 0; k <= V_; ++k) {
+        int bx = (int)blockIdx.x;
+        asm volatile("" : "+s"(bx));                              // opaque once per rollout (see k_search_small)
+        const SmallPar& S = spar();
+        uint8_t* const tree_lds = lds_small + (size_t)wave * S.tree_lds;
+        uint32_t* const wl_lds = reinterpret_cast<uint32_t*>(lds_small + S.wl_off + (size_t)wave * S.wl_bytes);
+        uint8_t* const io_blk = lds_small + S.io_off + (size_t)wave * S.io_bw;
+        const StepFlags SF = {(uint32_t)k, k == 0, k > 0, k < S.V, k == S.V - 1, k == S.V};
+        rollout_eager_body<FAM, NC, KPL, true, PFM_, true, ROLE_ALL, KPR, G>(
+            SF, tree_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount, io_blk, S.io_prowb, S.io_lgs, nullptr, ~amask, KPR ? S.T.rec_bytes : 0u);
+        if (k < S.V) {
+            __builtin_amdgcn_s_setprio(3);
+            const SmallPar& S = spar();
+            mlp_wave_body<H, TW * NG / 16, 2, true, true, (WV < 4), (WV < 3), NWV>(S.F, lds_small, bx, lds_small + S.io_off, S.io_bw, S.io_lgs);
+            __syncthreads();
+            __builtin_amdgcn_s_setprio(0);
+        }
+    }
+}
+
+// The same template parameters as k_search_small; only the shapes whose every wave is a full tree wave (TW = 4 or 8, ROLE_ALL) are built.
+// KPR2 != 0: age classes (above).
+template <int FAM, int NC, int KPL, int H, int TW, int WV, int G = 8, int KPR2 = 0>
+__global__ __launch_bounds__(64 * (TW == 8 ? 8 : NW_WAVES), WV) void k_selfplay_small(const PersistPar) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_small[];
+    static_assert(offsetof(PersistPar, S) == 0 && offsetof(SmallPar, T) == 0, "rollout_eager_body reads its TreePar from the start of the argument segment");
+    static_assert(TW == 4 || TW == 8, "every wave of the workgroup is a tree wave");
+    static_assert(TW == (TW == 8 ? 8 : NW_WAVES), "tree waves == waves");
+    constexpr bool AGE = KPR2 != 0;
+    typedef const PersistPar __attribute__((address_space(4)))* KArg;
+    const KArg karg = (KArg)__builtin_amdgcn_kernarg_segment_ptr();
+    const auto tail = [=]() -> const PersistTail& { KArg p = karg; asm volatile("" : "+s"(p)); return ((const PersistPar*)p)->X; };
+    // (one copy of the rollout loop per row form: the two tree bodies inside ONE loop cost 38 spilled registers)
+    persist_loop<FAM, NC, KPL, G, TW, AGE>(lds_small, tail, [&](const uint32_t amask, const bool ranked, EagerCarry& C) {
+        if constexpr (AGE) {
+            if (ranked) persist_search<FAM, NC, KPL, H, TW, WV, G, KPR2>(lds_small, amask, C);
+            else persist_search<FAM, NC, KPL, H, TW, WV, G, 0>(lds_small, amask, C);
+        } else persist_search<FAM, NC, KPL, H, TW, WV, G, 0>(lds_small, amask, C);
+    });
 }
 
 // the shapes of AGZ_SMALL_SHAPES in their full-batch form (64-game workgroups of eight tree waves, four waves per SIMD) and the narrow

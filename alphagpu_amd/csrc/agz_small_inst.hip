@@ -8,9 +8,10 @@
 #include "agz_search_small.hpp"
 #include "agz_search_big.hpp"
 #include "agz_selfplay_small.hpp"
+#include "agz_selfplay_big.hpp"
 
 namespace agz {
-#define X(F, C, K) AGZ_SMALL_VARIANTS(F, C, K, ) AGZ_BIG_VARIANTS(F, C, K, ) AGZ_PERSIST_VARIANTS(F, C, K, )
+#define X(F, C, K) AGZ_SMALL_VARIANTS(F, C, K, ) AGZ_BIG_VARIANTS(F, C, K, ) AGZ_PERSIST_VARIANTS(F, C, K, ) AGZ_PERSIST_BIG_VARIANTS(F, C, K, )
 #if AGZ_PART == 0
 AGZ_SMALL_SHAPES_0(X)
 #elif AGZ_PART == 1

@@ -272,10 +272,11 @@ def main():
     # PLY-EQUIVALENT of the persistent launch: kernel time x (G x V) / rollouts executed
     age_searches, age_ranked, age_moved = eng.age_stats()
     form_run = eng.search_form()[0]
-    persistent = form_run.startswith("k_selfplay_small")
+    persistent = form_run.startswith("k_selfplay_")
     kernel_launches = launches
     if persistent:
         form_tree, form_nn = eng.search_form()
+        whole = True
     sum_p, sum_new, r_cnt = eng.counters()
     nn_leaves = eng.nn_leaves()
 
@@ -468,6 +469,9 @@ def main():
             nn_obj["kernel"] = form_tree + " [" + form_nn + "]"
             nn_obj["traffic"] = traffic; nn_obj["traffic_source"] = traffic_source
             nn_obj["avg_launch_ms"] = tree_ms / max(launches, 1); nn_obj["launches"] = launches
+            nn_obj["kernel_launches"] = kernel_launches; nn_obj["kernel_ms_total"] = tree_ms
+            if persistent:
+                nn_obj["note"] += "; PERSISTENT kernel (one launch per agz_selfplay call): launches / avg_launch_ms are per ply-equivalent (G games x V rollouts)"
         out = {
             "metric": f"self-play rollouts/sec at {G} games x {V} rollouts, {gname}",
             # value = the rollouts of the games RETURNED in the timed region (their samples x V: every one of them played to its end, K x G games

@@ -185,3 +185,32 @@ def test_network_tag_travels_with_every_sample(monkeypatch):
     for gme in np.unique(gid):                                    # within a game the tag never goes back
         t = tag[gid == gme][np.argsort(ply[gid == gme])]
         assert (np.diff(t.astype(int)) >= 0).all()
+
+
+# ---- 512-wide trunks: k_selfplay_big ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,slots,ngames,V", [("gobang9", 70, 160, 16), ("reversi8", 40, 90, 8), ("hex9", 24, 60, 16)])
+def test_persistent_selfplay_with_a_wide_trunk_equals_the_lockstep_oracle(name, slots, ngames, V, monkeypatch):
+    """k_selfplay_big (the rollout loop of k_search_big's 64-game workgroups inside the persistent ply loop): refilled call, then a chain."""
+    monkeypatch.setenv("AGZ_PERSIST", "1")
+    g, og, net, onet = _nets(name, 512, 1)
+    ref = O.selfplay(og, onet, ngames, V, 1.5, 25, 9, 1000)
+    with M.Engine(g, slots, V, seed=9, game_id_base=1000, nn_mode=M.NN_BF16, sample_capacity_games=ngames) as e:
+        e.set_network(net)
+        st = e.selfplay(ngames, V, cpuct=1.5, tau_plies=25)
+        assert e.search_form()[0].startswith("k_selfplay_big"), e.search_form()
+        s = e.samples()
+        assert st["valid"] and st["nsamples"] == ref["n"] and st["rollouts"] == V * ref["n"]
+        assert (st["wins"], st["draws"], st["losses"], st["total_plies"]) == (ref["wins"], ref["draws"], ref["losses"], ref["total_plies"])
+        for key in KEYS:
+            assert_same_bits(s[key], ref[key], key)
+        # a chain of two calls on the same engine: ids start over at game_id_base
+        n1 = ngames // 2
+        k0 = 0
+        for n, nxt in ((n1, ngames - n1), (ngames - n1, 0)):
+            st = e.selfplay_chain(n, nxt, V, cpuct=1.5, tau_plies=25)
+            s = e.samples()
+            sel = (ref["game_id"] >= 1000 + k0) & (ref["game_id"] < 1000 + k0 + n)
+            assert st["valid"] and st["nsamples"] == int(sel.sum())
+            for key in KEYS:
+                assert_same_bits(s[key], ref[key][sel], f"chain call at {k0}: {key}")
+            k0 += n
