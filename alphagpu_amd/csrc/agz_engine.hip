@@ -203,7 +203,7 @@ struct agz_engine {
 #define AGZ_COMBOS(X) \
     X(F_LINE, 1, 1) X(F_LINE, 2, 2) X(F_LINE, 3, 3) X(F_C4, 1, 1) \
     X(F_HEX, 1, 1) X(F_HEX, 1, 2) X(F_HEX, 2, 2) X(F_HEX, 2, 3) X(F_HEX, 3, 3) \
-    X(F_REV, 1, 1) X(F_REV, 2, 1)
+    X(F_REV, 1, 1) X(F_REV, 2, 1) AGZ_EXTRA_COMBOS(X)
 
 static bool bind_kernels(agz_engine* h) {
     const GamePar& P = h->G;

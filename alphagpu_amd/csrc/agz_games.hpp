@@ -13,9 +13,19 @@
 
 namespace agz {
 
-enum { K_GOBANG = 0, K_CONNECT4 = 1, K_HEX = 2, K_REVERSI8 = 3, K_REVERSI6 = 4 };
+enum { K_GOBANG = 0, K_CONNECT4 = 1, K_HEX = 2, K_REVERSI8 = 3, K_REVERSI6 = 4, K_EXTRA = 5 };
 // code families
-enum { F_LINE = 0, F_C4 = 1, F_HEX = 2, F_REV = 3 };
+enum { F_LINE = 0, F_C4 = 1, F_HEX = 2, F_REV = 3, F_EXTRA = 4 };
+// K_EXTRA / F_EXTRA: a game plugin compiled in from OUTSIDE this file — build with -DAGZ_EXTRA_GAME_HPP='"/path/to/mygame.hpp"'
+// (INTEGRATION.md "Adding a game"; tests/plugin/misere34.hpp is the worked example).  The header is included below, after the
+// bitboard operations and before make_game_par; it defines, in namespace agz:
+//     template <int NC> struct Game<F_EXTRA, NC> { static AGZ_HD bool canPlay(const GamePar&, const WPos<NC>&, int a);
+//                                                   static AGZ_HD WPos<NC> play(const GamePar&, const WPos<NC>&, int a);
+//                                                   static AGZ_HD bool isOver(const GamePar&, const WPos<NC>&, int& r); };
+//     inline int extra_game_par(int n, int nvict, GamePar& P);      // geometry, A / VS / FS / ML / max_plies, the start position; 0 = ok
+//     #define AGZ_EXTRA_COMBOS(X)  X(F_EXTRA, NR, NC) ...           // (64-action rows, 64-bit board chunks) of the ply kernels
+//     #define AGZ_EXTRA_SHAPES(X)  X(F_EXTRA, NC, KPL) ...          // (chunks, actions per lane: 4 | 8 | 12 | 16 | 24 with 8 KPL >= A) of the search kernels
+// — the same three functions over the same Position fields (bplayer, bopponent, player: Gobang.jl:16-21) the reference's plugins export.
 
 struct GamePar {
     int32_t kind, fam, n, nvict, d1, d2, len, A, VS, FS, ML, max_plies, NR, NC, pass_action, rev8;
@@ -270,6 +280,18 @@ template <int NC> struct Game<F_REV, NC> {
     }
 };
 
+}  // namespace agz
+#ifdef AGZ_EXTRA_GAME_HPP
+#include AGZ_EXTRA_GAME_HPP
+#endif
+#ifndef AGZ_EXTRA_COMBOS
+#define AGZ_EXTRA_COMBOS(X)
+#endif
+#ifndef AGZ_EXTRA_SHAPES
+#define AGZ_EXTRA_SHAPES(X)
+#endif
+namespace agz {
+
 // ------------------------------------------------------------------------------------------------
 // host-side construction of GamePar and start positions
 inline int make_game_par(int kind, int n, int nvict, GamePar& P) {
@@ -293,6 +315,11 @@ inline int make_game_par(int kind, int n, int nvict, GamePar& P) {
     case K_REVERSI6:
         P.fam = F_REV; P.n = 6; P.d1 = 6; P.d2 = 6; P.len = 36; P.VS = P.FS = 36; P.A = 37; P.ML = 50;
         P.max_plies = 72; P.pass_action = 36; P.rev8 = 0; P.start_player = 1; break;
+#ifdef AGZ_EXTRA_GAME_HPP
+    case K_EXTRA:
+        if (extra_game_par(n, nvict, P) != 0) return -1;
+        P.kind = K_EXTRA; P.fam = F_EXTRA; break;
+#endif
     default: return -1;
     }
     P.NR = (P.A + 63) / 64; P.NC = (P.len + 63) / 64;

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(64 * (TW == 8 ? 8 : NW_WAVES), WV) void k_search_sm
 #define AGZ_SMALL_SHAPES_0(X) X(F_LINE, 1, 4) X(F_LINE, 1, 8) X(F_LINE, 2, 12) X(F_LINE, 2, 16)
 #define AGZ_SMALL_SHAPES_1(X) X(F_LINE, 3, 24) X(F_C4, 1, 4) X(F_HEX, 1, 4) X(F_HEX, 1, 8)
 #define AGZ_SMALL_SHAPES_2(X) X(F_HEX, 2, 8) X(F_HEX, 2, 12) X(F_HEX, 2, 16) X(F_HEX, 3, 16)
-#define AGZ_SMALL_SHAPES_3(X) X(F_HEX, 3, 24) X(F_REV, 1, 12) X(F_REV, 1, 8)
+#define AGZ_SMALL_SHAPES_3(X) X(F_HEX, 3, 24) X(F_REV, 1, 12) X(F_REV, 1, 8) AGZ_EXTRA_SHAPES(X)   // (+ the shapes of a plugged-in game, agz_games.hpp K_EXTRA)
 #define AGZ_SMALL_SHAPES(X) AGZ_SMALL_SHAPES_0(X) AGZ_SMALL_SHAPES_1(X) AGZ_SMALL_SHAPES_2(X) AGZ_SMALL_SHAPES_3(X)
 #define AGZ_SMALL_VARIANTS(F, C, K, KW)                                      \
     KW template __global__ void k_search_small<F, C, K, 128, 2, 2>(const SmallPar); \

@@ -3,7 +3,7 @@ import ctypes as C
 
 from . import lib as _lib
 
-KINDS = {"gobang": 0, "connect4": 1, "hex": 2, "reversi8": 3, "reversi6": 4}
+KINDS = {"gobang": 0, "connect4": 1, "hex": 2, "reversi8": 3, "reversi6": 4, "extra": 5}   # extra: a plugged-in game (INTEGRATION.md "Adding a game")
 
 
 class GameSpec:

@@ -92,6 +92,19 @@ def load_library():
     L.agz_get_tree_busy_ms.argtypes = [vp, C.POINTER(C.c_double)]
     L.agz_get_nn_leaves.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.agz_set_network_tag.argtypes = [vp, C.c_uint32]
+    i64p = C.POINTER(C.c_int64)
+    L.agz_comm_unique_id.argtypes = [vp]
+    L.agz_comm_create.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int64, C.POINTER(vp)]
+    L.agz_comm_destroy.argtypes = [vp]
+    L.agz_comm_destroy.restype = None
+    L.agz_comm_last_error.argtypes = [vp]
+    L.agz_comm_last_error.restype = C.c_char_p
+    L.agz_allgather_samples.argtypes = [vp, vp, i64p]
+    L.agz_allgather_samples_start.argtypes = [vp, vp, C.c_int64]
+    L.agz_allgather_samples_wait.argtypes = [vp, i64p, i64p]
+    L.agz_comm_fetch_records.argtypes = [vp, C.c_int, vp, C.c_int64, C.c_int64]
+    L.agz_comm_records_device.argtypes = [vp, C.c_int]
+    L.agz_comm_records_device.restype = vp
     L.agz_get_age_stats.argtypes = [vp, C.POINTER(C.c_uint64 * 3)]
     _LIB = L
     return L

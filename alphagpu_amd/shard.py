@@ -6,7 +6,12 @@ sample records at generation end (RCCL over xGMI on GPUs: torch.distributed back
 for tests).  Because every uniform is keyed by the global game id, the gathered samples are identical to a
 single-GPU run over all W*G games.
 
-Two forms of the exchange:
+The exchange itself lives behind the C ABI (include/agz.h agz_comm_*: libagz binds RCCL and owns the gather buffers, allocated once);
+`CommExchange` below is a thin caller of it — what a Julia host does through julia/AlphaGPUAMD.jl `mcts_sharded`.  The torch.distributed
+forms remain for the CPU tests (gloo) and as the reference the C-ABI path is compared with.
+
+Forms of the exchange:
+  * `CommExchange`       — through the C ABI (RCCL inside libagz): blocking `allgather()` or pipelined `start()` / `wait()`;
   * `allgather_records`  — blocking: counts, then the records padded to the largest count (tests, one-off callers);
   * `RecordExchange`     — pipelined: ONE asynchronous collective per generation that carries the rank's record count in a
     16-byte header in front of its records, issued WITHOUT any host synchronisation or blocking read (the host never waits
@@ -144,6 +149,88 @@ class RecordExchange:
         out = torch.empty(world, nbytes, dtype=torch.uint8, device=buf.device)
         work = dist.all_gather_into_tensor(out.view(-1), buf[:nbytes], group=self.group, async_op=True)
         return PendingGather(self, work, out, buf, sent, units)
+
+
+class CommExchange:
+    """The exchange step through the C ABI: agz_comm_create / agz_allgather_samples* (RCCL bound by libagz, buffers allocated once:
+    2 x (1 + world) x (16 + capacity x rec_bytes) bytes per rank).  The 128-byte RCCL id is made on rank 0 and shipped to the other ranks
+    by `broadcast` (default: torch.distributed's object broadcast over the initialised process group — any backend — when world > 1).
+
+    allgather()            -> (parts, counts): blocking, counts then records
+    start(units) / wait()  -> pipelined: one collective per call, every rank sends the record count all ranks agree on (predicted from
+                              the counts of the exchanges waited for so far, like RecordExchange); parts[r] are host uint8 arrays."""
+
+    def __init__(self, engine, rank, world, capacity_records, broadcast=None, slack=1.0 / 32):
+        import ctypes as C
+        self.C, self.e, self.L = C, engine, engine.L
+        self.rank, self.world, self.cap, self.rb = int(rank), int(world), int(capacity_records), int(engine.game.rec_bytes)
+        self.slack, self.seen_max, self.units, self.tails = float(slack), None, [], 0
+        uid = (C.c_uint8 * 128)()
+        if self.rank == 0:
+            rc = self.L.agz_comm_unique_id(C.byref(uid))
+            if rc:
+                raise RuntimeError("agz_comm_unique_id: " + (self.L.agz_comm_last_error(None) or b"").decode())
+        blob = bytes(uid)
+        if self.world > 1:
+            if broadcast is None:
+                def broadcast(b):
+                    box = [b]
+                    dist.broadcast_object_list(box, src=0)
+                    return box[0]
+            blob = broadcast(blob)
+        self.h = C.c_void_p()
+        rc = self.L.agz_comm_create(engine.h, self.rank, self.world, blob, self.cap, C.byref(self.h))
+        if rc:
+            raise RuntimeError("agz_comm_create: " + (self.L.agz_comm_last_error(None) or b"").decode())
+
+    def close(self):
+        if self.h:
+            self.L.agz_comm_destroy(self.h)
+            self.h = None
+
+    def _chk(self, rc, what):
+        if rc:
+            raise RuntimeError(what + ": " + (self.L.agz_comm_last_error(self.h) or b"").decode())
+
+    def _parts(self, counts):
+        parts = []
+        for r in range(self.world):
+            a = np.empty(int(counts[r]) * self.rb, np.uint8)
+            self._chk(self.L.agz_comm_fetch_records(self.h, r, a.ctypes.data_as(self.C.c_void_p), 0, int(counts[r])), "agz_comm_fetch_records")
+            parts.append(a)
+        return parts
+
+    def allgather(self):
+        counts = (self.C.c_int64 * self.world)()
+        self._chk(self.L.agz_allgather_samples(self.e.h, self.h, counts), "agz_allgather_samples")
+        counts = np.array(counts[:], np.int64)
+        return self._parts(counts), counts
+
+    def agreed_count(self, units=1):
+        if self.seen_max is None:
+            return self.cap
+        n = int(self.seen_max * units * (1.0 + self.slack)) + 64
+        return min(self.cap, (n + 255) & ~255)
+
+    def start(self, units=1, send_records=None):
+        """Issue the collective for the engine's last self-play call.  The first exchange of a run (nothing to predict from) is the
+        blocking form; its result is kept for wait()."""
+        if self.seen_max is None and send_records is None:
+            self.units.append((units, self.allgather()))
+            return
+        self._chk(self.L.agz_allgather_samples_start(self.e.h, self.h, int(send_records if send_records is not None else self.agreed_count(units))), "agz_allgather_samples_start")
+        self.units.append((units, None))
+
+    def wait(self):
+        units, done = self.units.pop(0)
+        if done is None:
+            counts, mx = (self.C.c_int64 * self.world)(), self.C.c_int64(0)
+            self._chk(self.L.agz_allgather_samples_wait(self.h, counts, self.C.byref(mx)), "agz_allgather_samples_wait")
+            counts = np.array(counts[:], np.int64)
+            done = (self._parts(counts), counts)
+        r = float(done[1].max()) / float(units)
+        self.seen_max = r if self.seen_max is None else max(self.seen_max, r)
+        return done
 
 
 def unpack_records(buf, n, game):

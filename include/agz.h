@@ -27,7 +27,8 @@ enum agz_status {
 };
 
 /* game plugins: Gobang.jl, 4IARow.jl, Hex.jl, Reversi8x8.jl, Reversi6x6.jl */
-enum agz_game_kind { AGZ_GOBANG = 0, AGZ_CONNECT4 = 1, AGZ_HEX = 2, AGZ_REVERSI8 = 3, AGZ_REVERSI6 = 4 };
+enum agz_game_kind { AGZ_GOBANG = 0, AGZ_CONNECT4 = 1, AGZ_HEX = 2, AGZ_REVERSI8 = 3, AGZ_REVERSI6 = 4,
+                     AGZ_EXTRA_GAME = 5 /* a game plugged in at build time: -DAGZ_EXTRA_GAME_HPP, INTEGRATION.md "Adding a game" */ };
 
 /* network evaluation modes */
 enum agz_nn_mode {
@@ -165,6 +166,38 @@ int  agz_get_samples_packed(agz_engine *h, void *dev_out, int64_t capacity_recor
 int  agz_unpack_records(const agz_game_info *info, const void *records, int64_t n, int8_t *state, float *policy, int8_t *player,
                         float *value, int8_t *fstate, uint32_t *game_id, int32_t *ply, int32_t *move);
 
+/* ---- the exchange step of a SHARDED generation: RCCL all-gather, over xGMI, of the packed sample records -------------------
+ * One engine per GPU plays its own shard of game ids (agz_config.game_id_base = rank x games per rank; nothing is exchanged while games
+ * run: every uniform is keyed by the global game id, so the union of the shards IS the single-GPU run over all games).  At the end of a
+ * call the ranks gather their packed records (agz_get_samples_packed layout) and every rank holds the generation's samples, which
+ * mcts(actor, visits, ngames, buffer) pushes into ONE PoolSample (mcts_gpu.jl:513-516; caller selfplay.jl:34).  The reference has no
+ * counterpart (single device).  RCCL is bound at run time (dlopen: AGZ_RCCL_LIB, librccl.so.1); the host ships the 128-byte id from one
+ * rank to the others by its own means (a file, a socket, MPI, torch.distributed).
+ * Memory, allocated once at agz_comm_create: 2 x (1 + world) x (16 + capacity_records x rec_bytes) bytes per rank (two slots: the
+ * exchange of call k overlaps call k + 1).  8 ranks x one Gobang 9x9 generation (32768 games, ~39 plies, 592-byte records: ~0.76 GB per
+ * rank) = 6.1 GB gathered per slot: size capacity_records by the records of ONE call (16 GB of gathered records hold two generations). */
+typedef struct agz_comm agz_comm;
+#define AGZ_COMM_ID_BYTES 128
+int  agz_comm_unique_id(void *id /* [AGZ_COMM_ID_BYTES] */);       /* ncclGetUniqueId: on ONE rank */
+int  agz_comm_create(agz_engine *h, int rank, int world, const void *id, int64_t capacity_records, agz_comm **out);   /* ncclCommInitRank on the engine's device; collective */
+void agz_comm_destroy(agz_comm *c);
+const char *agz_comm_last_error(const agz_comm *c);                /* NULL: the last agz_comm_create / agz_comm_unique_id error of this thread */
+/* Blocking form, as SURVEY §8e states it: all-gather of the ranks' record counts, then of the records of the engine's last self-play
+ * call padded to the largest count.  counts[world] (may be NULL) receives every rank's record count. */
+int  agz_allgather_samples(agz_engine *h, agz_comm *c, int64_t *counts);
+/* Pipelined form: ONE collective per call, issued without waiting for any other rank — every rank sends 16 + send_records x rec_bytes
+ * bytes (its record count travels in the 16-byte header), send_records being a number ALL ranks agree on (0 = the capacity; a host loop
+ * predicts it from the counts of the calls before).  At most two collectives in flight.  _wait returns the counts of the OLDEST one; if a
+ * rank produced more than send_records records, every rank — they all see the same counts — gathers the rest in a second, blocking
+ * collective inside _wait (from the exchange's own copy of the records: the engine may have played on).  *max_count: the largest count. */
+int  agz_allgather_samples_start(agz_engine *h, agz_comm *c, int64_t send_records);
+int  agz_allgather_samples_wait(agz_comm *c, int64_t *counts, int64_t *max_count);
+/* The records of rank `rank` from the exchange last waited for: n records from record `first` on into host memory (-> agz_unpack_records),
+ * or their address in device memory (valid until the next-but-one agz_allgather_samples_start; NULL if the exchange needed its second
+ * collective: the records are then in two pieces). */
+int  agz_comm_fetch_records(agz_comm *c, int rank, void *host_dst, int64_t first, int64_t n);
+const void *agz_comm_records_device(agz_comm *c, int rank);
+
 /* Known-answer test hook: breadth-first perft from Position() computed ON THE DEVICE with the game plugin code the kernels are
  * instantiated from (canPlay / play / isOver: Gobang.jl:25-70, 4IARow.jl:25-81, Hex.jl:37-67, Reversi8x8.jl:84-121).  *nodes = positions
  * after exactly `depth` plies (finished games are not extended); terminal[0..2] (may be NULL) = finished games met at any ply <= depth
@@ -228,6 +261,7 @@ int  agz_set_profiling(agz_engine *h, int mode);       /* HIP events per launch:
  *   AGZ_AGE=0              persistent self-play without age classes (every workgroup keeps node rows by action; nothing migrates)
  *   AGZ_AGE_OLD16=n        ... n of 16 CU pairs prefer old games (default 8);  AGZ_AGE_CLASS=block: odd workgroups prefer old games (tests);
  *                          AGZ_AGE_BACKLOG=n: young-preferring workgroups keep their old games while n games wait in the migration queue
+ *   AGZ_RCCL_LIB=path      the RCCL library agz_comm_* binds (default: an RCCL already in the process, librccl.so.1, /opt/rocm/lib/librccl.so.1)
  *   AGZ_WL_LDS_BYTES=n     one-launch forms: at most n bytes of LDS per tree wave for the work list of a rollout (the rest of
  *                          the list lives in global memory; default: what the resident workgroups leave free)
  */

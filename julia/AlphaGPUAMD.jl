@@ -5,7 +5,7 @@
 # maintainer of fabricerosay/AlphaGPU would add.  See INTEGRATION.md.
 module mcts_gpu
 
-export mcts, mcts_chain!, duelnetwork, mcts_single, init, re_init
+export mcts, mcts_chain!, mcts_sharded!, duelnetwork, mcts_single, init, re_init
 
 using ..Game            # Position, canPlay, play, isOver, VectorizedState, FeatureSize, maxActions, maxLengthGame, PoolSample
 
@@ -117,6 +117,72 @@ function mcts_chain!(e::Engine, actor, visits, ngames, next_ngames, buffer::Pool
     rc == -5 && return (data=[], valid=false)      # "faute"
     check(e, rc)
     push_samples!(e, st[], buffer)
+    return (data=[], valid=true)
+end
+
+# The games a chained call starts early for the NEXT call play their first plies with the network of the running call (the reference
+# plays every game of a generation with one actor, selfplay.jl:34-56).  A host loop that cares numbers its networks: every sample carries
+# the tag of the network that searched it (byte 18 of a packed record, 1-based; agz.h agz_set_network_tag).  next_ngames = 0 in every
+# call gives the reference's semantics exactly (each call's games are played by the call's actor only) at the price of a batch that runs
+# out at the end of each call.
+set_network_tag!(e::Engine, tag::Integer) = check(e, ccall((:agz_set_network_tag, libagz), Cint, (Ptr{Cvoid}, UInt32), e.h, tag))
+
+# ---- game-id shards over several GPUs (BASELINE config 5): one Julia process per GPU, each with its own engine
+# (init(...; device = local rank) and game ids from rank * ngames on: agz_config.game_id_base), nothing exchanged while games run, and ONE
+# RCCL all-gather of the packed sample records at the end of the call (agz.h agz_comm_*; SURVEY 8e).  Every rank then pushes the samples
+# of ALL ranks into its PoolSample — the same samples, in the same order, as one GPU playing world * ngames games.
+mutable struct Comm
+    c::Ptr{Cvoid}; rank::Int; world::Int
+end
+# id: the 128 bytes of comm_unique_id() of rank 0, shipped to the other ranks by the launcher (a file, MPI.jl, Distributed.jl)
+function comm_unique_id()
+    id = zeros(UInt8, 128)
+    ccall((:agz_comm_unique_id, libagz), Cint, (Ptr{UInt8},), id) == 0 || error(unsafe_string(ccall((:agz_comm_last_error, libagz), Cstring, (Ptr{Cvoid},), C_NULL)))
+    id
+end
+function comm_create(e::Engine, rank, world, id::Vector{UInt8}, capacity_records)
+    c = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = ccall((:agz_comm_create, libagz), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{UInt8}, Int64, Ref{Ptr{Cvoid}}), e.h, rank, world, id, capacity_records, c)
+    rc == 0 || error(unsafe_string(ccall((:agz_comm_last_error, libagz), Cstring, (Ptr{Cvoid},), C_NULL)))
+    Comm(c[], rank, world)
+end
+comm_destroy!(c::Comm) = (c.c == C_NULL || ccall((:agz_comm_destroy, libagz), Cvoid, (Ptr{Cvoid},), c.c); c.c = C_NULL)
+
+struct AgzGameInfo
+    A::Int32; VS::Int32; FS::Int32; ML::Int32; max_plies::Int32; pos_image_bytes::Int32; rec_bytes::Int32; reserved::Int32
+end
+
+# mcts(actor, visits, ngames, buffer) of a rank of a sharded run: plays this rank's ngames games (a call of a chain: next_ngames as in
+# mcts_chain!), gathers every rank's records and pushes them all — in PoolSample order: ply-major, then game id — into `buffer`.
+function mcts_sharded!(e::Engine, comm::Comm, actor, visits, ngames, next_ngames, buffer::PoolSample; cpuct=2.0)
+    set_network!(e, actor)
+    st = Ref{AgzStats}()
+    rc = ccall((:agz_selfplay_chain, libagz), Cint, (Ptr{Cvoid}, Cint, Cint, Cint, Cfloat, Cint, Ref{AgzStats}), e.h, ngames, next_ngames, visits, cpuct, 25, st)
+    rc == -5 && return (data=[], valid=false)      # "faute"
+    check(e, rc)
+    counts = zeros(Int64, comm.world)
+    ccall((:agz_allgather_samples, libagz), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Int64}), e.h, comm.c, counts) == 0 ||
+        error(unsafe_string(ccall((:agz_comm_last_error, libagz), Cstring, (Ptr{Cvoid},), comm.c)))
+    info = Ref{AgzGameInfo}()
+    check(e, ccall((:agz_get_info, libagz), Cint, (Ptr{Cvoid}, Ref{AgzGameInfo}), e.h, info))
+    n = sum(counts); rb = Int(info[].rec_bytes)
+    records = Vector{UInt8}(undef, n * rb)
+    off = 0
+    for r in 0:comm.world-1
+        ccall((:agz_comm_fetch_records, libagz), Cint, (Ptr{Cvoid}, Cint, Ptr{UInt8}, Int64, Int64), comm.c, r, pointer(records, off + 1), 0, counts[r+1]) == 0 ||
+            error(unsafe_string(ccall((:agz_comm_last_error, libagz), Cstring, (Ptr{Cvoid},), comm.c)))
+        off += counts[r+1] * rb
+    end
+    state = Matrix{Int8}(undef, 2VectorizedState, n); policy = Matrix{Float32}(undef, maxActions, n)
+    player = Vector{Int8}(undef, n); value = Vector{Float32}(undef, n); fstate = Matrix{Int8}(undef, FeatureSize, n)
+    gid = Vector{UInt32}(undef, n); ply = Vector{Int32}(undef, n)
+    ccall((:agz_unpack_records, libagz), Cint,
+          (Ref{AgzGameInfo}, Ptr{UInt8}, Int64, Ptr{Int8}, Ptr{Float32}, Ptr{Int8}, Ptr{Float32}, Ptr{Int8}, Ptr{UInt32}, Ptr{Int32}, Ptr{Int32}),
+          info, records, n, state, policy, player, value, fstate, gid, ply, C_NULL) == 0 || error("agz_unpack_records failed")
+    for i in sortperm(collect(zip(ply, gid)))      # the order one engine playing all the games would have pushed them in
+        idx = Main.push_buffer(buffer, state, policy, player[i], i)
+        buffer.pool[idx].value = value[i]; buffer.pool[idx].fstate .= @view fstate[:, i]
+    end
     return (data=[], valid=true)
 end
 

@@ -214,3 +214,49 @@ def test_persistent_selfplay_with_a_wide_trunk_equals_the_lockstep_oracle(name, 
             for key in KEYS:
                 assert_same_bits(s[key], ref[key][sel], f"chain call at {k0}: {key}")
             k0 += n
+
+
+# ---- the exchange step behind the C ABI (agz_comm_*: RCCL bound by libagz) ---------------------------------------------------------------
+def test_rccl_exchange_through_the_c_abi_returns_the_engines_records():
+    """One rank over RCCL through include/agz.h (agz_comm_create / agz_allgather_samples / _start / _wait / agz_comm_fetch_records):
+    byte-identical to the engine's own packed records (agz_get_samples_packed) and to the torch.distributed form of the exchange — blocking
+    form, pipelined form with an agreed count, and a count that is too small (the second collective inside _wait)."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from alphagpu_amd import shard
+    g, og, net, onet = _nets("gobang9")
+    with M.Engine(g, 64, 16, seed=5, game_id_base=10, nn_mode=M.NN_BF16, sample_capacity_games=200) as e:
+        e.set_network(net)
+        st = e.selfplay(200, 16, cpuct=1.5, tau_plies=25)
+        n, rb = st["nsamples"], g.rec_bytes
+        want = e.samples_packed_host().copy().reshape(-1)
+        ex = shard.CommExchange(e, 0, 1, n + 100)
+        try:
+            parts, counts = ex.allgather()
+            assert list(counts) == [n] and np.array_equal(parts[0], want), "blocking form"
+            for send in (n + 50, n - 37, 1):                      # enough room; too small (second collective); far too small
+                ex.start(units=1, send_records=send)
+                parts, counts = ex.wait()
+                assert list(counts) == [n] and np.array_equal(parts[0], want), f"pipelined form, {send} records agreed"
+            # two in flight, then a third must be refused until one has been waited for
+            ex.start(units=1, send_records=n); ex.start(units=1, send_records=n)
+            with pytest.raises(RuntimeError):
+                ex.start(units=1, send_records=n)
+            for _ in range(2):
+                parts, counts = ex.wait()
+                assert np.array_equal(parts[0], want)
+        finally:
+            ex.close()
+        # the torch.distributed form of the same exchange (backend "nccl" = RCCL), one rank
+        sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        try:
+            buf = torch.empty((n + 100) * rb, dtype=torch.uint8, device="cuda")
+            assert e.samples_packed_into(buf.data_ptr(), n + 100) == n
+            tparts, tcounts = shard.allgather_records(buf, n, rb)
+            assert int(tcounts[0]) == n and np.array_equal(tparts[0].cpu().numpy(), want)
+        finally:
+            dist.destroy_process_group()

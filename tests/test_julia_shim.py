@@ -56,6 +56,19 @@ def test_selfplay_stats_struct_matches_the_header():
     assert C.sizeof(lib.SelfplayStats) == 72   # agz_selfplay_stats: 6 x i64, 2 x i32, 2 x f64
 
 
+def test_game_info_struct_matches_the_header():
+    same_layout(julia_struct("AgzGameInfo"), lib.GameInfo)
+    assert C.sizeof(lib.GameInfo) == 32        # agz_game_info: 8 x i32
+
+
+def test_the_shim_binds_the_sharded_exchange_and_the_network_tag():
+    """SURVEY 8(e) through the C ABI, from Julia: the calls a rank of a sharded run makes (verdict r4 item 3) and the sample tag (item 5)"""
+    for sym in ("agz_comm_unique_id", "agz_comm_create", "agz_comm_destroy", "agz_allgather_samples", "agz_comm_fetch_records", "agz_unpack_records",
+                "agz_set_network_tag", "agz_selfplay_chain"):
+        assert f"(:{sym}, libagz)" in JL, sym
+    assert "function mcts_sharded!(e::Engine, comm::Comm, actor, visits, ngames, next_ngames, buffer::PoolSample" in JL
+
+
 def test_header_field_order_is_what_the_mirrors_assume():
     """the ctypes mirrors themselves against the header text (names and order of agz_config / agz_selfplay_stats / agz_game_info)"""
     def hdr_fields(tname):

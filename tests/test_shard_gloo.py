@@ -98,3 +98,43 @@ def test_two_rank_allgather_equals_unsharded_run():
     assert len(merged["ply"]) == ref["n"]
     for k in ("game_id", "ply", "move", "player", "state", "fstate", "value", "policy"):
         assert np.array_equal(merged[k], ref[k]), k
+
+
+def _worker8(rank, world, port, q):
+    """eight ranks, blocking exchange only: one shard of Connect4-free TicTacToe games per rank -> the un-sharded run"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    game = ag.GameSpec("gobang", 3, 3)
+    og = O.make_game("gobang", 3, 3)
+    net = O.OracleNet(og, 16, 1)
+    G = 3
+    s = O.selfplay(og, net, G, 8, 1.5, 25, 21, shard.shard_base(rank, G))
+    out, counts = shard.allgather_records(torch.from_numpy(_pack(s, game)), s["n"], game.rec_bytes)
+    if rank == 0:
+        merged = shard.merge_poolsample_order([shard.unpack_records(out[r].numpy(), int(counts[r]), game) for r in range(world)])
+        q.put(dict(merged=dict(merged), counts=[int(c) for c in counts]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_rank_allgather_equals_unsharded_run():
+    """BASELINE config 5's shape of the exchange (8 shards, one all-gather at generation end) on CPU: gloo, world size 8."""
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=300)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    og = O.make_game("gobang", 3, 3)
+    ref = O.selfplay(og, O.OracleNet(og, 16, 1), 24, 8, 1.5, 25, 21, 0)
+    merged = res["merged"]
+    assert sum(res["counts"]) == ref["n"] == len(merged["ply"]) and len(res["counts"]) == 8
+    for k in ("game_id", "ply", "move", "player", "state", "fstate", "value", "policy"):
+        assert np.array_equal(merged[k], ref[k]), k
