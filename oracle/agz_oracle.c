@@ -953,6 +953,16 @@ static int choose_move(const float *pol, int A, int sample, float u) {
 
 int agzo_selfplay(const agzo_game *g, const agzo_net *net, int ngames, int V, float cpuct,
                   int tau_plies, uint64_t seed, uint32_t game_id_base, agzo_samples *out) {
+    return agzo_selfplay_tagged(g, &net, 1, NULL, 0, ngames, V, cpuct, tau_plies, seed, game_id_base, out);
+}
+
+/* The same generation with the actor chosen per (game, ply): tags[k * tag_stride + p] = index into nets[] of the network that searches
+ * ply p of game k (game id game_id_base + k); tags == NULL: nets[0] everywhere.  What a CHAIN of self-play calls whose network changes
+ * between calls plays (include/agz.h agz_selfplay_chain, agz_set_network_tag): the games a call starts early for the next call are
+ * searched by the running call's network on their first plies.  A ply's searches are independent per game, so the round is searched
+ * once per network present and every game takes the result of its own. */
+int agzo_selfplay_tagged(const agzo_game *g, const agzo_net *const *nets, int nnets, const uint8_t *tags, int tag_stride, int ngames, int V,
+                         float cpuct, int tau_plies, uint64_t seed, uint32_t game_id_base, agzo_samples *out) {
     agzo_tree *t = agzo_tree_create(g, ngames, V);
     agzo_pos *positions = malloc((size_t)ngames * sizeof(agzo_pos));
     uint32_t *ids = malloc((size_t)ngames * 4);
@@ -967,9 +977,27 @@ int agzo_selfplay(const agzo_game *g, const agzo_net *net, int ngames, int V, fl
     int L = ngames, round = 0, rc = 0;
     agzo_tree_set_roots(t, positions, ids, L);
     out->nsamples = 0; out->wins = out->draws = out->losses = out->total_plies = out->faults = 0;
+    float *pol_n = nnets > 1 ? malloc((size_t)ngames * g->A * 4) : NULL, *bat_n = nnets > 1 ? malloc((size_t)ngames * 2 * g->VS * 4) : NULL;
     while (L > 0) {                                                       /* :494 */
-        agzo_search(t, net, V, cpuct, 1, seed, (uint32_t)round, NULL, NULL, NULL, NULL); /* :503 */
-        agzo_get_policy(t, policy); agzo_get_root_planes(t, batch);       /* :506 */
+        if (nnets <= 1 || !tags) {
+            agzo_search(t, nets[0], V, cpuct, 1, seed, (uint32_t)round, NULL, NULL, NULL, NULL); /* :503 */
+            agzo_get_policy(t, policy); agzo_get_root_planes(t, batch);   /* :506 */
+        } else {
+            for (int w = 0; w < nnets; ++w) {
+                int any = 0;
+                for (int i = 0; i < L; ++i) { const int tg = round < tag_stride ? tags[(size_t)(ids[i] - game_id_base) * tag_stride + round] : 0; any |= tg == w; }
+                if (!any) continue;
+                agzo_tree_set_roots(t, positions, ids, L);
+                agzo_search(t, nets[w], V, cpuct, 1, seed, (uint32_t)round, NULL, NULL, NULL, NULL);
+                agzo_get_policy(t, pol_n); agzo_get_root_planes(t, bat_n);
+                for (int i = 0; i < L; ++i) {
+                    const int tg = round < tag_stride ? tags[(size_t)(ids[i] - game_id_base) * tag_stride + round] : 0;
+                    if (tg != w) continue;
+                    memcpy(policy + (size_t)i * g->A, pol_n + (size_t)i * g->A, (size_t)g->A * 4);
+                    memcpy(batch + (size_t)i * 2 * g->VS, bat_n + (size_t)i * 2 * g->VS, (size_t)2 * g->VS * 4);
+                }
+            }
+        }
         int nfin = 0;
         for (int i = 0; i < L; ++i) {                                     /* :513-549 */
             long idx = out->nsamples;                                     /* push_buffer mainGobang.jl:54-68 */
@@ -1012,7 +1040,7 @@ int agzo_selfplay(const agzo_game *g, const agzo_net *net, int ngames, int V, fl
     }
 done:
     if (rc != 0) for (int i = 0; i < L; ++i) if (rlen[i] >= 0) free(rtemp[i]);
-    free(rtemp); free(rlen); free(policy); free(batch); free(positions); free(ids);
+    free(rtemp); free(rlen); free(policy); free(batch); free(positions); free(ids); free(pol_n); free(bat_n);
     agzo_tree_destroy(t);
     return rc;
 }

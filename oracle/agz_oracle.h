@@ -137,6 +137,10 @@ agzo_samples *agzo_samples_create(const agzo_game *g, long capacity);
 void agzo_samples_destroy(agzo_samples *s);
 int  agzo_selfplay(const agzo_game *g, const agzo_net *net, int ngames, int V, float cpuct,
                    int tau_plies, uint64_t seed, uint32_t game_id_base, agzo_samples *out);
+/* ... with the actor chosen per (game, ply) (tags: [ngames][tag_stride] indices into nets; NULL: nets[0]) — a chain of calls whose
+ * network changes between calls (include/agz.h agz_selfplay_chain, agz_set_network_tag) */
+int  agzo_selfplay_tagged(const agzo_game *g, const agzo_net *const *nets, int nnets, const uint8_t *tags, int tag_stride, int ngames, int V,
+                          float cpuct, int tau_plies, uint64_t seed, uint32_t game_id_base, agzo_samples *out);
 
 /* ---- duel: mcts(actor1,actor2,visits,ngames;cpuct) mcts_gpu.jl:581-651 (training=false, sample over ALL
  * actions for round < tau_plies (15), argmax after; actor by ply parity).  first = 0: net1 moves first. ---- */

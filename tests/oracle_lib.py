@@ -326,10 +326,21 @@ class OracleTree:
         return p.value, n.value, f
 
 
-def selfplay(g, net, ngames, V, cpuct, tau_plies, seed, game_id_base=0):
+def selfplay(g, net, ngames, V, cpuct, tau_plies, seed, game_id_base=0, nets=None, tags=None):
+    """nets / tags: the actor per (game, ply) — tags[k][p] = index into nets of the network that searches ply p of game k
+    (agzo_selfplay_tagged: a chain of calls whose network changes between calls)."""
     cap = ngames * (2 * g.len + 8)
     s = lib().agzo_samples_create(C.byref(g), cap)
-    rc = lib().agzo_selfplay(C.byref(g), C.byref(net.c), ngames, V, cpuct, tau_plies, seed, game_id_base, s)
+    if nets is None:
+        rc = lib().agzo_selfplay(C.byref(g), C.byref(net.c), ngames, V, cpuct, tau_plies, seed, game_id_base, s)
+    else:
+        tags = np.ascontiguousarray(tags, np.uint8)
+        assert tags.shape[0] == ngames
+        arrp = (C.c_void_p * len(nets))(*[C.addressof(n.c) for n in nets])
+        f = lib().agzo_selfplay_tagged
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_uint64, C.c_uint32, C.c_void_p]
+        f.restype = C.c_int
+        rc = f(C.byref(g), arrp, len(nets), tags.ctypes.data_as(C.c_void_p), tags.shape[1], ngames, V, cpuct, tau_plies, seed, game_id_base, s)
     sc = s.contents
     n = sc.nsamples
 

@@ -260,3 +260,52 @@ def test_rccl_exchange_through_the_c_abi_returns_the_engines_records():
             assert int(tcounts[0]) == n and np.array_equal(tparts[0].cpu().numpy(), want)
         finally:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("persist", ["1", "0"])
+def test_chain_with_a_different_network_per_call_equals_the_oracle_run_the_tags_describe(persist, monkeypatch):
+    """What a chain MEANS when the network changes between calls (include/agz.h agz_selfplay_chain / agz_set_network_tag; the reference
+    plays every game of a generation with one actor, selfplay.jl:34-56): three calls with three networks; every sample's tag names the
+    network that searched it, and the whole chain equals, sample for sample, the oracle's lock-step run in which every (game, ply) is
+    searched by the network its tag names (agzo_selfplay_tagged)."""
+    monkeypatch.setenv("AGZ_PERSIST", persist)
+    g, og = spec("gobang9")
+    seeds = (0x5EED, 77, 78)
+    gnets = [ag.SNetwork2.random(g, 128, 2, sd) for sd in seeds]
+    onets = [O.OracleNet(og, 128, 2, sd).bf16() for sd in seeds]
+    slots, V, N = 48, 16, 60
+    calls = [(N, N), (N, N), (N, 0)]
+    recs = []
+    with M.Engine(g, slots, V, seed=9, game_id_base=700, nn_mode=M.NN_BF16, sample_capacity_games=2 * N) as e:
+        for i, (n, nxt) in enumerate(calls):
+            e.set_network(gnets[i]); e.set_network_tag(i)
+            st = e.selfplay_chain(n, nxt, V, cpuct=1.5, tau_plies=25)
+            assert st["valid"]
+            recs.append(e.samples_packed_host().copy())
+    total = sum(n for n, _ in calls)
+    allr = np.concatenate(recs)
+    gid = allr[:, 0:4].copy().view(np.uint32)[:, 0].astype(np.int64) - 700
+    ply = allr[:, 4:8].copy().view(np.int32)[:, 0]
+    tag = allr[:, 17]
+    tags = np.zeros((total, g.max_plies), np.uint8)
+    for k in range(total):
+        m = gid == k
+        t = np.zeros(g.max_plies, np.uint8)
+        t[ply[m]] = tag[m]
+        last = int(ply[m].max())
+        t[last + 1:] = t[last]
+        tags[k] = t
+    assert len(np.unique(tag)) == 3 and ((tags[:, :1] != tags[:, 1:]).any(axis=1)).sum() > 0, "no game was searched by two networks"
+    call_of = np.repeat(np.arange(len(calls)), [n for n, _ in calls])
+    # a game is searched by the network of the call that returns it or — its first plies, or even all of them — by the one before
+    assert (tags <= call_of[:, None]).all() and (tags >= call_of[:, None] - 1).all() and (tags[:, 0] < call_of).any()
+    assert (np.diff(tags.astype(int), axis=1) >= 0).all()
+    ref = O.selfplay(og, None, total, V, 1.5, 25, 9, 700, nets=onets, tags=tags)
+    from alphagpu_amd import shard
+    k0 = 0
+    for i, (n, _) in enumerate(calls):
+        got = shard.unpack_records(recs[i].reshape(-1), len(recs[i]), g)
+        sel = (ref["game_id"] >= 700 + k0) & (ref["game_id"] < 700 + k0 + n)
+        for key in ("game_id", "ply", "move", "player", "state", "fstate", "policy", "value"):
+            assert_same_bits(got[key], ref[key][sel], f"call {i}: {key}")
+        k0 += n

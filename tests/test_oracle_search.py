@@ -227,3 +227,32 @@ def test_bf16_forward_model_is_close_to_fp32_forward_and_softmax_sums_to_one():
     ys = np.array([O.lib().agzo_exp2_spec(float(t)) for t in xs])
     rel = np.abs(ys - np.exp(xs.astype(np.float64))) / np.exp(xs.astype(np.float64))
     assert rel.max() < 5e-6 and rel[xs > -8].max() < 6e-7               # (x log2 e is rounded once: error grows with |x|)
+
+
+def test_tagged_selfplay_switches_the_actor_per_game_and_ply():
+    """agzo_selfplay_tagged (the oracle of a chain of calls whose network changes between calls): all tags 0 / all tags 1 are the plain
+    generations of the two networks; a game that switches at ply p keeps the first network's samples before p and then goes its own way
+    from the position it has reached — other games are untouched."""
+    g = O.make_game("gobang", 3, 3)
+    a, b = O.OracleNet(g, 16, 1, 1), O.OracleNet(g, 16, 1, 2)
+    n, V = 12, 8
+    ra, rb = O.selfplay(g, a, n, V, 1.5, 25, 7, 100), O.selfplay(g, b, n, V, 1.5, 25, 7, 100)
+    keys = ("game_id", "ply", "move", "player", "state", "fstate", "policy", "value")
+    for tag, ref in ((0, ra), (1, rb)):
+        r = O.selfplay(g, None, n, V, 1.5, 25, 7, 100, nets=[a, b], tags=np.full((n, 16), tag, np.uint8))
+        assert r["rc"] == 0 and all(np.array_equal(r[k], ref[k]) for k in keys), tag
+    tags = np.zeros((n, 16), np.uint8)
+    tags[3, 2:] = 1                                                # game 103 is searched by b from ply 2 on
+    tags[5, :] = 1                                                 # game 105 by b throughout
+    r = O.selfplay(g, None, n, V, 1.5, 25, 7, 100, nets=[a, b], tags=tags)
+    for gid in range(100, 100 + n):
+        m, ma, mb = r["game_id"] == gid, ra["game_id"] == gid, rb["game_id"] == gid
+        if gid == 105:
+            assert np.array_equal(r["move"][m], rb["move"][mb]) and np.array_equal(r["policy"][m], rb["policy"][mb])
+        elif gid == 103:
+            early = r["ply"][m] < 2
+            assert np.array_equal(r["policy"][m][early], ra["policy"][ma][ra["ply"][ma] < 2])
+            assert np.array_equal(r["move"][m][early], ra["move"][ma][ra["ply"][ma] < 2])
+            assert not np.array_equal(r["policy"][m][2], ra["policy"][ma][2])      # another network searched ply 2
+        else:
+            assert all(np.array_equal(r[k][m], ra[k][ma]) for k in keys), gid

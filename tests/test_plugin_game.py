@@ -109,7 +109,7 @@ def test_plugin_rules_on_the_device_equal_the_naive_model(plugin):
     import alphagpu_amd as ag
     from alphagpu_amd.game import perft
     g = ag.GameSpec("extra", 4, 3)
-    for depth in range(1, 8):
+    for depth in range(1, 6):
         nodes, term = perft(g, depth)
         want_nodes, want_term = naive_perft(depth)
         assert (nodes, term) == (want_nodes, want_term), (depth, nodes, term, want_nodes, want_term)
