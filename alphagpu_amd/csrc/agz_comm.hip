@@ -149,7 +149,10 @@ int agz_allgather_samples_start(agz_engine* h, agz_comm* c, int64_t send_records
     if (c->started - c->waited >= 2) { c->fail("agz_allgather_samples_start: two collectives are in flight (wait for the older one first)"); return AGZ_ERR_STATE; }
     const int slot = (int)(c->started & 1);
     int64_t n = 0;
-    int rc = agz_get_samples_packed(h, c->send[slot] + 16, c->capacity, &n);   // packs on the engine's stream and waits for it
+    int rc = agz_get_samples_packed(h, nullptr, 0, &n);             // (size query)
+    // a rank whose records do not fit still takes part in the collective, with its true count in the header: every rank's _wait then
+    // fails the same way (AGZ_ERR_ARG, "more than the exchange capacity") instead of the others waiting for a rank that has bailed out
+    if (!rc && n <= c->capacity) rc = agz_get_samples_packed(h, c->send[slot] + 16, c->capacity, &n);   // packs on the engine's stream and waits for it
     if (rc) { c->fail("agz_get_samples_packed: %s", agz_last_error(h)); return rc; }
     int64_t sent = send_records > 0 ? send_records : c->capacity;
     if (sent > c->capacity) sent = c->capacity;

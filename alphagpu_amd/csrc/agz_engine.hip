@@ -1589,8 +1589,25 @@ static bool persist_shape(const agz_engine* h) {
     if (h->persist == 0 || h->cfg.nn_mode != AGZ_NN_BF16 || !n.loaded) return false;
     if (h->V > 128 || (h->V & 3) != 0 || h->no_fused_nn || 8 * h->reg_kpl > h->LGS) return false;
     if ((h->Lmax + 63) / 64 > 2 * h->cus) return false;                        // every workgroup resident: two 64-game workgroups per CU
-    if (n.H == 128) return (h->k_persist || h->k_persist_nar) && n.w16w;
-    if (n.H == 512) return h->k_persist_big[0] && n.wbig && h->big8 >= 0;
+    // ... which also needs their LDS to fit side by side (V = 128 trees on a 128-wide trunk do not: the call then runs one launch per ply)
+    const int wgcu = (h->Lmax + 63) / 64 <= h->cus ? 1 : 2;
+    const size_t cu_lds = (size_t)(160 * 1024) / (size_t)wgcu;
+    if (n.H == 128) {
+        if (!(h->k_persist || h->k_persist_nar) || !n.w16w) return false;
+        const bool nar = h->k_persist_nar && h->narrow_mode >= 0;
+        const int G = nar ? h->persist_nar_g : 8, NG = 64 / G, tw = nar ? 4 : 8, gpwg = tw * NG;
+        const size_t tree_lds = nar ? (size_t)eager_lds_layout(h->V, NG).total : h->reg_lds;
+        const int kth = n.H / 32, g0 = (n.INP / 32 + kth - 1) / kth;
+        const int rs = (std::max(g0 * kth * 64 + 16, 4 * n.AOP) + 15) & ~15;
+        const size_t io_off = (std::max((size_t)tw * tree_lds, (size_t)gpwg * 2 * (n.H * 2 + 16)) + 15) & ~(size_t)15;
+        return io_off + (size_t)tw * NG * rs + (size_t)tw * (16 * NG + 16) + 16 + (size_t)tw * 64 <= cu_lds;   // (+ at least 16 work-list entries per wave)
+    }
+    if (n.H == 512) {
+        if (!h->k_persist_big[0] || !n.wbig || h->big8 < 0) return false;
+        const int big_rowb = (2 * std::max(n.H, 32 * n.k0r) + 255) & ~255;
+        const size_t xch_off = (std::max((size_t)8 * h->reg_lds, (size_t)8 * 8 * big_rowb) + 15) & ~(size_t)15;
+        return xch_off + 4 * 144 + 16 + 8 * 64 <= cu_lds;
+    }
     return false;
 }
 
@@ -1729,7 +1746,8 @@ static int run_games_persist(agz_engine* h, int ngames, int V, float cpuct, int 
         S.xch_off = S.io_off + tw * S.io_bw;
         const size_t shared = (size_t)S.xch_off + (size_t)tw * (16 * NG + 16) + 16;   // ... + the workgroup's two flag words
         Q.X = X; Q.X.flag_off = (int)shared - 16;
-        const size_t cu_lds = cu_lds_all / 2;
+        wgcu = (int)wgs <= h->cus ? 1 : 2;
+        const size_t cu_lds = cu_lds_all / (size_t)wgcu;
         const size_t room = cu_lds > shared ? cu_lds - shared : 0;
         S.wl_off = (int)shared; S.wl_bytes = (int)std::min({(size_t)(NG * h->V * 4), (room / (size_t)tw) & ~(size_t)15, (size_t)h->wl_lds_max});
         const size_t lds = shared + (size_t)tw * S.wl_bytes;

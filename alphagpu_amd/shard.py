@@ -131,10 +131,10 @@ class RecordExchange:
     def start(self, buf, n_local, units=1):
         """buf: a new_buffer() tensor whose records region holds n_local records; it must not be modified until wait().
         units: what the record count scales with (games of the generation; the same on every rank): the agreed size is predicted
-        from the largest count PER UNIT seen so far, so that calls of different sizes share one prediction."""
+        from the largest count PER UNIT seen so far, so that calls of different sizes share one prediction.
+        A rank whose records exceed the capacity still takes part in the collective (its count travels in the header): wait() raises on
+        EVERY rank — they all see the same counts — instead of one rank bailing out here and the others blocking in the all-gather."""
         world = dist.get_world_size(self.group)
-        if n_local > self.cap:
-            raise ValueError(f"{n_local} records exceed the exchange capacity {self.cap}")
         buf[:8].view(torch.int64).fill_(int(n_local))          # (a fill with a scalar argument: nothing is read back, no host buffer)
         if self.seen_max is None:
             # the FIRST exchange of a run has no count to predict from: the ranks gather their counts (the one blocking read of the run)
@@ -206,6 +206,10 @@ class CommExchange:
         counts = np.array(counts[:], np.int64)
         return self._parts(counts), counts
 
+    def fetch_last(self, counts):
+        """the records of the exchange last waited for, rank by rank, in host memory"""
+        return self._parts(counts)
+
     def agreed_count(self, units=1):
         if self.seen_max is None:
             return self.cap
@@ -221,13 +225,16 @@ class CommExchange:
         self._chk(self.L.agz_allgather_samples_start(self.e.h, self.h, int(send_records if send_records is not None else self.agreed_count(units))), "agz_allgather_samples_start")
         self.units.append((units, None))
 
-    def wait(self):
+    def wait(self, fetch=True):
+        """-> (parts, counts) of the OLDEST collective in flight.  fetch=False: parts is None — the gathered records stay in the exchange's
+        device buffer (agz_comm_records_device / fetch_last()) until the next-but-one start(); a host loop that trains on the GPU, or a
+        benchmark, does not pay a device-to-host copy of every rank's records per call."""
         units, done = self.units.pop(0)
         if done is None:
             counts, mx = (self.C.c_int64 * self.world)(), self.C.c_int64(0)
             self._chk(self.L.agz_allgather_samples_wait(self.h, counts, self.C.byref(mx)), "agz_allgather_samples_wait")
             counts = np.array(counts[:], np.int64)
-            done = (self._parts(counts), counts)
+            done = (self._parts(counts) if fetch else None, counts)
         r = float(done[1].max()) / float(units)
         self.seen_max = r if self.seen_max is None else max(self.seen_max, r)
         return done

@@ -124,6 +124,8 @@ def main():
                     "scale with it)")
     ap.add_argument("--no-chain", action="store_true", help="every agz_selfplay call on its own (ends on a batch that runs out) instead of a chain of "
                     "calls in which a call starts the next call's games in the slots it leaves free (agz_selfplay_chain)")
+    ap.add_argument("--exchange", action="store_true", help="run the exchange step (agz_comm_*: RCCL all-gather of the call's records through the C ABI) even "
+                    "with ONE rank, inside the timed region as with N > 1 (tests: the bench's multi-GPU path end to end on one GPU)")
     ap.add_argument("--dump-records", default="", help="rank 0 writes the gathered samples of the LAST timed generation (PoolSample order) to this .npz")
     args = ap.parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -170,7 +172,10 @@ def main():
     # of lock-step generations (results are keyed by game id and the game's own ply; tests/test_gpu_scale_parity.py checks slices of such a
     # run against the oracle).  --lockstep: K separate calls of G games; the line carries that number too (value_lockstep_generations).
     world_ = int(os.environ.get("WORLD_SIZE", "1"))
-    gpc = args.gens_per_call if args.gens_per_call > 0 else (32 if world_ == 1 else 8)
+    # several GPUs: the exchange buffers (allocated once, agz_comm_create) scale with a call's records x the ranks — 2 slots x (1 + world) x
+    # capacity x rec_bytes per rank; calls are sized so that the gathered records stay under ~16 GB per rank: 8 ranks -> 1 generation per call
+    # (0.76 GB of Gobang 9x9 records per rank and generation), 4 -> 2, 2 -> 4
+    gpc = args.gens_per_call if args.gens_per_call > 0 else (32 if world_ == 1 else max(1, 8 // world_))
     gens_cap = 1 if args.lockstep else max(1, min(gpc, max(args.steps, args.warmup, 1)))
 
     def calls(k):                           # K generations as calls of at most gens_cap generations each
@@ -190,9 +195,16 @@ def main():
     rb = game.rec_bytes
     # the exchange of generation k overlaps generation k+1: two sample buffers, at most two collectives in flight; a collective is
     # issued without any read-back (the rank's record count travels in the buffer's header: shard.RecordExchange)
-    ex = shard.RecordExchange(gens_cap * G * game.max_plies, rb) if world > 1 else None
-    sample_bufs = [ex.new_buffer("cuda") for _ in range(2)] if world > 1 else None
-    host_bufs = [ex.new_buffer("cpu").pin_memory() for _ in range(2)] if world > 1 and args.backend != "nccl" else None
+    # The exchange step.  RCCL (backend "nccl"): through the C ABI — shard.CommExchange is a thin caller of agz_comm_create /
+    # agz_allgather_samples_start / _wait; libagz binds RCCL itself and owns the gather buffers, allocated ONCE here.  Capacity: a call's
+    # games x 3/4 of the longest game possible (Gobang 9x9 averages 39 of 81 plies; a call that outgrows it fails on every rank with a
+    # message, it does not hang).  "gloo" (smoke tests with all ranks on one GPU): the torch.distributed form, staged through host memory.
+    use_abi = (world > 1 and args.backend == "nccl") or (world == 1 and args.exchange)
+    cap_records = gens_cap * G * max(1, (3 * game.max_plies + 3) // 4)
+    cex = shard.CommExchange(eng, rank, world, cap_records) if use_abi else None
+    ex = shard.RecordExchange(gens_cap * G * game.max_plies, rb) if world > 1 and not use_abi else None
+    sample_bufs = [ex.new_buffer("cuda") for _ in range(2)] if ex else None
+    host_bufs = [ex.new_buffer("cpu").pin_memory() for _ in range(2)] if ex and args.backend != "nccl" else None
     inflight = [None, None]
     last_gather = [None]
     nstep = [0]
@@ -207,7 +219,11 @@ def main():
             raise SystemExit("illegal move sampled ('faute')")
         k = nstep[0] & 1
         nstep[0] += 1
-        if world > 1:                       # the one exchange step: all-gather of the generated samples
+        if cex is not None:                 # the one exchange step, through the C ABI: at most two collectives in flight
+            if len(cex.units) == 2:
+                last_gather[0] = cex.wait(fetch=False)   # (the gathered records stay on the device: a trainer on the GPU reads them there)
+            cex.start(units=ngen)
+        elif world > 1:                     # ... the torch.distributed form (gloo smoke path)
             if inflight[k] is not None:
                 inflight[k].wait()          # the collective that read sample_bufs[k] two generations ago
             n = eng.samples_packed_into(sample_bufs[k].data_ptr() + shard.HEADER, gens_cap * G * game.max_plies)
@@ -222,6 +238,8 @@ def main():
 
     def fence():
         eng.synchronize()
+        while cex is not None and cex.units:
+            last_gather[0] = cex.wait(fetch=False)
         for k in range(2):
             if inflight[k] is not None:
                 inflight[k].wait()
@@ -284,7 +302,12 @@ def main():
         eng.set_roots(None, L=0)            # the chain ends here: the games the timed region left in flight are dropped
     if args.dump_records:                   # (tests: the samples of the last timed generation as the host sees them)
         import numpy as np
-        if world > 1:
+        if cex is not None:
+            counts = last_gather[0][1]
+            parts = cex.fetch_last(counts)
+            if rank == 0:
+                np.savez(args.dump_records, **shard.merge_poolsample_order([shard.unpack_records(parts[r], int(counts[r]), game) for r in range(world)]))
+        elif world > 1:
             parts, counts = last_gather[0].wait()
             if rank == 0:
                 merged = shard.merge_poolsample_order([shard.unpack_records(parts[r].cpu().numpy(), int(counts[r]), game) for r in range(world)])
@@ -484,7 +507,8 @@ def main():
                        "baseline_config": args.config if args.config else "headline (metric)",
                        "games_per_gpu": G, "rollouts_per_move": V, "cpuct": args.cpuct, "tau_plies": 25,
                        "tree_arithmetic": "f32 strict IEEE", "network": "bf16 MFMA, fp32 accumulate" if args.mode == "bf16" else "f32 exact",
-                       "parallelism": f"game-shard x{world}, RCCL all-gather of samples at generation end" if world > 1 else "single GPU"},
+                       "parallelism": (f"game-shard x{world}, RCCL all-gather of samples at the end of every call"
+                                       + (" (through the C ABI: agz_comm_*)" if use_abi else " (torch.distributed)")) if (world > 1 or use_abi) else "single GPU"},
             "roofline": nn_obj if nn_dominant else tree_obj,
             "roofline_other": tree_obj if nn_dominant else nn_obj,
             "roofline_valu": valu_obj,
@@ -513,6 +537,8 @@ def main():
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
+    if cex is not None:
+        cex.close()
     eng.close()
     if world > 1:
         dist.barrier()

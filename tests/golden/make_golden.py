@@ -52,3 +52,17 @@ np.savez_compressed(os.path.join(HERE, "selfplay_tictactoe.npz"),
                     **{k: v for k, v in s.items() if isinstance(v, np.ndarray)},
                     wdl=np.array([s["wins"], s["draws"], s["losses"], s["total_plies"]]))
 print("selfplay ok", s["n"], s["wins"], s["draws"], s["losses"])
+
+# two-actor games (duelnetwork's halves, mcts_gpu.jl:581-651): moves of every game and [v, n, d], both orders
+for name, ngames, V, H, T in (("tictactoe", 24, 12, 32, 1), ("connect4", 10, 12, 32, 1)):
+    kind, n, k = common.GAMES[name]
+    g = O.make_game(kind, n, k)
+    n1, n2 = O.OracleNet(g, H, T, NETSEED), O.OracleNet(g, H, T, NETSEED + 1)
+    out = {}
+    for first in (0, 1):
+        d = O.duel(g, n1, n2, ngames, V, 2.0, 15, SEED + 4, 300, first)
+        assert d["rc"] == 0
+        out[f"wdl{first}"], out[f"moves{first}"], out[f"nplies{first}"] = np.array(d["wdl"]), d["moves"], d["nplies"]
+    np.savez_compressed(os.path.join(HERE, f"duel_{name}.npz"), ngames=ngames, V=V, H=H, T=T, cpuct=np.float32(2.0), tau=15, seed=SEED + 4,
+                        netseed=NETSEED, base=300, **out)
+    print("duel", name, out["wdl0"], out["wdl1"])

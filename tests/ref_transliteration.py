@@ -8,8 +8,9 @@ terminal value of backUp = np.float64, Int literals as Python ints) — without 
 tests/test_ref_transliteration.py requires that it reproduces the C oracle bit for bit on the golden searches: a transcription
 error in either restatement shows up as a difference.
 
-Not transliterated (shared with the oracle through ctypes, pinned by their own known-answer tests): the game plugins
-(canPlay / play / isOver) and the actor (network forward + softmax!).  The ONE deliberate definition is the randomness: the
+The game plugins and the actor are parameters: the tests of THIS file run the search over the oracle's game functions and forward
+(ctypes; `OracleGames`), tests/ref_selfplay.py runs it over their own transliterations (tests/ref_games.py, snetwork2 in numpy;
+`RefGames`) — then nothing of the oracle is under it.  The ONE deliberate definition is the randomness: the
 reference draws prob = CUDA.rand(maxLengthGame, L) per rollout (:397) and reads prob[cpt, i] at a visit (:178); here the visit
 reads the uniform U(seed; game id, step, rollout, depth) that was fixed by the event that last changed the node's row — its
 expansion, or the latest backUp through it (`unext`) — which is what oracle and product define.
@@ -28,14 +29,56 @@ def uniform(seed, game_id, step, rollout, depth):
     return F32((int(o[depth & 3]) >> 8) + 1) * F32(5.9604644775390625e-8)
 
 
+class OracleGames:
+    """the game plugins as the C oracle restates them (ctypes): what RefTree used before tests/ref_games.py existed; 1-based actions"""
+
+    def __init__(self, g):
+        self.g, self.A, self.VS = g, g.A, g.VS
+
+    def play(self, st, a):
+        return O.play(self.g, st, a - 1)
+
+    def isOver(self, st):
+        return O.is_over(self.g, st)
+
+    def canPlay(self, st, a):
+        return O.can_play(self.g, st, a - 1)
+
+    def planes(self, st):
+        return O.bb_bits(st.bplayer, self.VS) + O.bb_bits(st.bopponent, self.VS)
+
+
+class RefGames:
+    """the game plugins as tests/ref_games.py transliterates them from the Julia text: no oracle code under the search at all"""
+
+    def __init__(self, rg):
+        import ref_games as RG
+        self.RG, self.rg, self.A, self.VS = RG, rg, rg.maxActions, rg.VectorizedState
+
+    def play(self, st, a):
+        return self.rg.play(st, a)
+
+    def isOver(self, st):
+        return self.rg.isOver(st)
+
+    def canPlay(self, st, a):
+        return self.rg.canPlay(st, a)
+
+    def planes(self, st):                                        # decoder (:202-223): bplayer[j], bopponent[j], j = 1 .. VectorizedState
+        return [1 if self.RG.getindex(st.bplayer, j) else 0 for j in range(1, self.VS + 1)] + \
+               [1 if self.RG.getindex(st.bopponent, j) else 0 for j in range(1, self.VS + 1)]
+
+
 class RefTree:
     """init(positions, visits) (:350-357): create_cunodes_stats (:35-39) + create_roots (:42-53); every array 1-based like the
     Julia ones (index 0 unused), the game index last as in the column-major originals."""
 
     def __init__(self, g, positions, visits, game_ids=None):
-        self.g, self.maxActions, self.visits_cap = g, g.A, visits
+        """g: an oracle Game (the plugins come from the C oracle) or a RefGames / OracleGames adapter"""
+        self.gm = g if hasattr(g, "planes") else OracleGames(g)
+        self.maxActions, self.visits_cap = self.gm.A, visits
         L = self.L = len(positions)
-        A, V = g.A, visits
+        A, V = self.gm.A, visits
         z = lambda *s: np.zeros(s, F32)                          # noqa: E731
         self.q, self.prior, self.policy, self.nvisits = z(A + 1, V + 1, L + 1), z(A + 1, V + 1, L + 1), z(A + 1, V + 1, L + 1), z(A + 1, V + 1, L + 1)
         self.Achild = np.zeros((A + 1, V + 1, L + 1), np.int64)
@@ -63,7 +106,7 @@ class RefTree:
 
     # ------------------------------------------------------------------------------------------------ :100-199
     def kdescendTree(self, cpuct):
-        maxActions, g = self.maxActions, self.g
+        maxActions, gm = self.maxActions, self.gm
         cpuct = F32(cpuct)
         for i in range(1, self.L + 1):
             nindex = 1
@@ -121,7 +164,7 @@ class RefTree:
                     self.Achild[bestmove, nindex, i] = self.childnbr[nindex, i]
                     self.parent[self.newindex[i], i] = nindex
                     self.actionFromParent[self.newindex[i], i] = bestmove
-                    self.state[self.newindex[i]][i] = O.play(g, self.state[nindex][i], bestmove - 1)
+                    self.state[self.newindex[i]][i] = gm.play(self.state[nindex][i], bestmove)
                     self.depth[self.newindex[i], i] = cpt        # the child of a node at depth cpt - 1
                 nindex = int(self.childID[self.Achild[bestmove, nindex, i], nindex, i])
                 cpt += 1
@@ -130,25 +173,25 @@ class RefTree:
     # ------------------------------------------------------------------------------------------------ :250-302
     def expand(self, prior, training, seed, step, rollout):
         """prior[j, i] (1-based rows): the actor's softmaxed output for the leaf of game i"""
-        maxActions, g = self.maxActions, self.g
+        maxActions, gm = self.maxActions, self.gm
         for i in range(1, self.L + 1):
             nindex = int(self.leaf[i])
             self.unext[nindex, i] = uniform(seed, self.game_id[i], step, rollout, int(self.depth[nindex, i]))
             st = self.state[nindex][i]
-            f, r = O.is_over(g, st)
+            f, r = gm.isOver(st)
             self.expanded[nindex, i] = np.int8(1) - np.int8(1 if f else 0)
             if not f:
                 if nindex == 1:
                     normalize = 0
                     A = F32(0)
                     for j in range(1, maxActions + 1):
-                        if O.can_play(g, st, j - 1):
+                        if gm.canPlay(st, j):
                             self.prior[j, nindex, i] = prior[j, i]
                             normalize = normalize + self.prior[j, nindex, i]
                             A = A + F32(1)
                     if training:
                         for j in range(1, maxActions + 1):
-                            if O.can_play(g, st, j - 1):
+                            if gm.canPlay(st, j):
                                 self.prior[j, nindex, i] = F32(0.75) * self.prior[j, nindex, i] / normalize + F32(0.25) / A
                     else:
                         for j in range(1, maxActions + 1):
@@ -156,7 +199,7 @@ class RefTree:
                 else:
                     normalize = 0
                     for j in range(1, maxActions + 1):
-                        if O.can_play(g, st, j - 1):
+                        if gm.canPlay(st, j):
                             self.prior[j, nindex, i] = prior[j, i]
                             normalize = normalize + self.prior[j, nindex, i]
                     for j in range(1, maxActions + 1):
@@ -166,7 +209,7 @@ class RefTree:
 
     # ------------------------------------------------------------------------------------------------ :306-328
     def backUp(self, v, seed, step, rollout):
-        g = self.g
+        gm = self.gm
         for i in range(1, self.L + 1):
             lf = int(self.leaf[i])
             a = int(self.parent[lf, i])
@@ -175,7 +218,7 @@ class RefTree:
                 a = int(self.parent[a, i])
             nindex = int(self.parent[lf, i])
             move = int(self.actionFromParent[lf, i])
-            f, r = O.is_over(g, self.state[lf][i])
+            f, r = gm.isOver(self.state[lf][i])
             if f:
                 # (1 + player * r) / 2: Int8 * Int8 -> Int8, 1 + Int8 -> Int64, / 2 -> Float64 (:314)
                 value = F64(1 + int(np.int8(np.int8(self.state[lf][i].player) * np.int8(r)))) / F64(2)
@@ -202,11 +245,9 @@ class RefTree:
                 self.policy_final[k, i] = self.policy[k, 1, i]
 
     def decoder(self, nodes):                                    # :202-246 (planes of state[nodes[i], i]), rows [i][2 VS]
-        out = np.zeros((self.L, 2 * self.g.VS), F32)
+        out = np.zeros((self.L, 2 * self.gm.VS), F32)
         for i in range(1, self.L + 1):
-            st = self.state[int(nodes[i])][i]
-            out[i - 1, :self.g.VS] = O.bb_bits(st.bplayer, self.g.VS)
-            out[i - 1, self.g.VS:] = O.bb_bits(st.bopponent, self.g.VS)
+            out[i - 1, :] = self.gm.planes(self.state[int(nodes[i])][i])
         return out
 
     # ------------------------------------------------------------------------------------------------ :376-462

@@ -350,6 +350,33 @@ def test_bench_gpus_2_launches_its_own_ranks_gloo(tmp_path):
     _bench_two_ranks("gloo", tmp_path)
 
 
+def test_bench_exchange_step_through_the_c_abi_with_one_rank(tmp_path):
+    """bench.py --exchange: the multi-GPU path of the bench — every call followed by the RCCL all-gather of its records through
+    agz_comm_* (shard.CommExchange), two collectives in flight, everything waited for inside the timed region — end to end on ONE GPU;
+    the gathered records of the last call are those of one engine playing the same games."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dump = str(tmp_path / "records.npz")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--exchange", "--games", "2048", "--steps", "3", "--warmup", "1", "--gens-per-call", "1",
+           "--no-chain", "--no-cpu-baseline", "--no-host-delivery", "--dump-records", dump]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 1 and "agz_comm" in out["config"]["parallelism"]
+    got = dict(np.load(dump))
+    g = ag.GameSpec("gobang", 9, 5)
+    with M.Engine(g, 2048, 64, seed=4, game_id_base=0, nn_mode=M.NN_BF16) as e:     # bench.py --no-chain: seed 1 + call index; the 4th call
+        e.set_network(ag.SNetwork2.random(g, 128, 6))
+        st = e.selfplay(2048, 64, cpuct=1.5, tau_plies=25)
+        one = e.samples()
+    assert len(got["ply"]) == len(one["ply"]) == st["nsamples"]
+    for k in ("game_id", "ply", "move", "player", "state", "fstate", "value", "policy"):
+        assert parity.same_bits(got[k], one[k]), k + " (bench.py --exchange vs one engine)"
+
+
 def test_bench_gpus_2_over_rccl(tmp_path):
     import torch
     if torch.cuda.device_count() < 2:
@@ -369,21 +396,38 @@ FULL_GEN_CASES = [
     ("gobang9", 512, 1, 64, 32768),        # k_search_big (config 3's trunk width; one tower keeps the oracle's bit-level MFMA model cheap)
     ("reversi8", 512, 1, 64, 32768),       # config 5's game and trunk width: pass moves, 152-byte positions
     ("hex9", 128, 6, 128, 32768),          # config 4's game and rollout count
-    ("gobang9", 128, 6, 64, 81920),        # 2.5 generations' worth of games on 32768 slots: finished games' slots are refilled (what bench.py times)
-    ("connect4", 128, 6, 64, 65536),
+    ("gobang9", 128, 6, 64, 81920),        # 2.5 generations' worth of games on 32768 slots: finished games' slots are refilled (what bench.py times:
+                                           # the persistent kernel k_selfplay_small with age classes)
+    ("connect4", 128, 6, 64, 65536),       # ... k_selfplay_small with 4 lanes per tree
+    ("hex9", 128, 6, 64, 49152),           # ... age classes on the Hex board
+    ("hex9", 128, 6, 128, 40000),          # V = 128 trees do not fit two 64-game workgroups per CU: refilled slots, one launch per ply
+    ("gobang9", 512, 8, 64, 32768),        # BASELINE config 3 AS SHIPPED — all eight towers (4 games: the MFMA model of a 512x8 forward is slow)
+    ("reversi8", 512, 8, 64, 65536),       # BASELINE config 5's shard as shipped, refilled slots: the persistent kernel k_selfplay_big
 ]
 
 
 @pytest.mark.parametrize("name,H,T,V,ngames", FULL_GEN_CASES)
 def test_full_size_generation_slice_equals_the_oracle_through_all_plies(name, H, T, V, ngames):
-    L, n, seed = 32768, 16, 3
+    L, n, seed = 32768, (4 if (H, T) == (512, 8) else 16), 3
     bases = [16380] if ngames <= L else [16380, ngames - 9000]       # (refill: also games that start in a slot another game has left)
     g, og = spec(name)
     net, onet = ag.SNetwork2.random(g, H, T), O.OracleNet(og, H, T)
     with M.Engine(g, L, V, seed=seed, nn_mode=M.NN_BF16, sample_capacity_games=ngames) as e:
         e.set_network(net)
+        e.kernel_times(reset=True)
         st = e.selfplay(ngames, V, cpuct=1.5, tau_plies=25)
         assert st["valid"] and st["faults"] == 0
+        form = e.search_form()[0]
+        if ngames > L and V == 128 and H == 128:
+            assert form.startswith("k_search_small"), form
+        elif ngames > L:                                             # refilled slots at this size: ONE launch for the whole call
+            assert form.startswith("k_selfplay_big" if H == 512 else "k_selfplay_small"), form
+            assert st["rollouts"] == V * st["nsamples"]
+            if H == 128 and name in ("gobang9", "hex9"):             # ... with workgroups that trade games by age
+                searches, ranked, moved = e.age_stats()
+                assert "AGE" in form and searches == st["nsamples"] and 0.2 * searches < ranked < 0.8 * searches and moved > ngames // 4, (form, searches, ranked, moved)
+        else:
+            assert form.startswith("k_search_"), form
         s = e.samples()
     assert len(s["ply"]) == st["nsamples"] and st["wins"] + st["draws"] + st["losses"] == ngames
     for base in bases:
@@ -410,6 +454,7 @@ def test_full_size_chain_of_calls_slices_equal_the_oracle(name, H, T, V):
         for i, (ng, nxt) in enumerate(calls):
             st = e.selfplay_chain(ng, nxt, V, cpuct=1.5, tau_plies=25)
             assert st["valid"] and st["faults"] == 0 and st["wins"] + st["draws"] + st["losses"] == ng
+            assert e.search_form()[0].startswith("k_selfplay_big" if H == 512 else "k_selfplay_small"), e.search_form()
             s = e.samples()
             assert len(s["ply"]) == st["nsamples"] and int(s["game_id"].min()) == k0 and int(s["game_id"].max()) == k0 + ng - 1
             for base in (k0 + 5, k0 + ng // 2, k0 + ng - n - 3):
