@@ -256,3 +256,82 @@ def test_tagged_selfplay_switches_the_actor_per_game_and_ply():
             assert not np.array_equal(r["policy"][m][2], ra["policy"][ma][2])      # another network searched ply 2
         else:
             assert all(np.array_equal(r[k][m], ra[k][ma]) for k in keys), gid
+
+
+# ---- semantic micro-cases of the CPU baseline (fast_mcts.jl), the path bench.py times as cpu_baseline ------------------------------------
+def _legal_prior(g, net, pos):
+    planes = np.array(O.bb_bits(pos.bplayer, g.VS) + O.bb_bits(pos.bopponent, g.VS), np.float32)[None]
+    pr, v = net.forward(planes)                                    # the CPU method of snetwork2 softmaxes itself (DenseNet.jl:313)
+    legal = np.array([O.can_play(g, pos, a) for a in range(g.A)])
+    p = np.where(legal, pr[0], 0).astype(np.float32)
+    return (p / p.sum(dtype=np.float32)).astype(np.float32), float(v[0]), legal
+
+
+def test_fmcts_one_readout_returns_the_normalised_prior_without_root_noise():
+    """readout = 1 (fast_mcts.jl:275-295): the root is expanded (expand :97-109: legal priors / their sum — NO 0.75 / 0.25 mix, unlike
+    mcts_gpu.jl:270-275), nothing is backed up, extractRoot (:299-308) solves for alpha with every n = 0: the policy is proportional to
+    the normalised prior, zero on illegal actions, its sum within Newton's 1e-3 of 1; value = sum(w) / N = 0."""
+    g = O.make_game("connect4", 0, 0)
+    net = O.OracleNet(g, 32, 2, 3)
+    pos = O.pos_init(g)
+    for a in (3, 3, 3, 3, 3, 3, 2):                                # column 4 is full: one illegal action
+        pos = O.play(g, pos, a)
+    prior, _, legal = _legal_prior(g, net, pos)
+    pol, val = O.fmcts(g, net, pos, 1, 1.5, 7)
+    assert not legal[3] and pol[3] == 0 and val == 0.0
+    assert 1.0 <= pol.sum() < 1.0011
+    ratio = pol[legal] / prior[legal]
+    assert np.abs(ratio / ratio[0] - 1).max() < 1e-5               # proportional to the prior ...
+    mixed = 0.75 * prior + 0.25 / legal.sum()
+    assert np.abs((pol / pol.sum())[legal] - mixed[legal]).max() > 1e-3   # ... and NOT the training mix of the GPU path
+
+
+def test_fmcts_two_readouts_lambda_uses_the_incremented_visit_count_and_the_last_backup_counts():
+    """readout = 2: the second descent increments the root's visits BEFORE it selects (addVisit, :82 -> bestChild :216), visits one child,
+    evaluates it and backs 1 - v up (:160-172); extractRoot runs AFTER that backup with N = node.visits = 2:
+        lambda = c sqrt(2) / (A_legal + 2),   pi_k = lambda prior_k / alpha (n_k = 0),   pi_j = lambda prior_j / (alpha - w_j / n_j) (the child),
+    so from the returned policy alone: alpha = lambda prior_k / pi_k on the unvisited actions, and the visited one must satisfy
+    w_j / n_j = 1 - v(child), the network's value of the child position; value = w_j / 2."""
+    g = O.make_game("gobang", 3, 3)
+    net = O.OracleNet(g, 32, 2, 5)
+    pos = O.play(g, O.pos_init(g), 4)
+    prior, _, legal = _legal_prior(g, net, pos)
+    c = 1.5
+    for seed in range(6):
+        pol, val = O.fmcts(g, net, pos, 2, c, seed)
+        lam = np.float32(c) * np.sqrt(np.float32(2)) / np.float32(legal.sum() + 2)
+        rho = pol[legal] / prior[legal]                            # lambda / alpha on unvisited actions, lambda / (alpha - q) on the visited one
+        j = int(np.flatnonzero(legal)[np.argmax(np.abs(rho - np.median(rho)))])
+        others = [a for a in np.flatnonzero(legal) if a != j]
+        alpha = float(np.mean([lam * prior[a] / pol[a] for a in others]))
+        assert np.abs(np.array([lam * prior[a] / pol[a] for a in others]) / alpha - 1).max() < 1e-5
+        q = alpha - float(lam * prior[j] / pol[j])
+        child = O.play(g, pos, j)
+        assert not O.is_over(g, child)[0]
+        _, vchild, _ = _legal_prior(g, net, child)
+        assert abs(q - (1.0 - vchild)) < 2e-5, (seed, j, q, 1.0 - vchild)   # the LAST readout's backup is in the policy (extractRoot after it)
+        assert abs(val - (1.0 - vchild) / 2.0) < 1e-6              # sum(w) / N with N = 2
+        # with N = 1 in lambda (the count before the increment) the same algebra would not close:
+        lam1 = np.float32(c) * np.sqrt(np.float32(1)) / np.float32(legal.sum() + 1)
+        alpha1 = float(np.mean([lam1 * prior[a] / pol[a] for a in others]))
+        assert abs((alpha1 - float(lam1 * prior[j] / pol[j])) - (1.0 - vchild)) > 1e-3
+
+
+def test_fmcts_terminal_leaf_is_backed_up_again_at_every_visit_with_a_float32_value():
+    """A root with ONE legal action that ends the game: readout 1 expands the root, readouts 2 and 3 reach the same child, which is
+    terminal and therefore never expanded (evaluate :141-157 returns early, MctsContext :282 backs Float32(v) up each time).  The mover
+    completes a line and wins: the child's value for ITS side to move is 0, so w = 2 (1 - 0), n = 2, value = sum(w) / N = 2 / 3."""
+    g = O.make_game("gobang", 3, 3)
+    net = O.OracleNet(g, 32, 2, 5)
+    pos = O.pos_init(g)
+    for a in (0, 1, 4, 2, 5, 3, 6, 7):                            # X: 0 4 5 6, O: 1 2 3 7 — nobody has a line; cell 8 is free, X (to move) wins with 0-4-8
+        pos = O.play(g, pos, a)
+        assert not O.is_over(g, pos)[0]
+    legal = [a for a in range(9) if O.can_play(g, pos, a)]
+    assert legal == [8]
+    end = O.play(g, pos, 8)
+    f, r = O.is_over(g, end)
+    assert f and r == pos.player                                   # the mover has won
+    pol, val = O.fmcts(g, net, pos, 3, 1.5, 1)
+    assert abs(pol[8] - 1.0) < 1.1e-3 and (np.delete(pol, 8) == 0).all()
+    assert val == np.float32(2.0) / np.float32(3.0)
