@@ -229,8 +229,12 @@ __device__ __forceinline__ uint32_t advance_slot(const PlyPar& T, const int slot
     }
     if (keep && lane == 0) T.s_net[(size_t)g * T.max_plies + ply] = (uint8_t)T.net_tag;   // which network searched this ply (agz_set_network_tag)
     if (fault) {
-        if (lane == 0) { atomicAdd(&T.stats[4], 1ull); atomicAdd(&T.stats[7], 1ull); if (T.ring) atomicAdd(&T.stats[kg < T.k_cur_end ? 8 : 9], 1ull); T.alive[slot] = 0; if (keep) T.s_move[(size_t)g * T.max_plies + ply] = (int16_t)c; if (in_range) { T.g_nplies[g] = np_end; T.g_result[g] = 0; T.g_final[g] = pack(root); } }
-        return 0u;
+        // the game is abandoned (the call reports AGZ_ERR_ILLEGAL_MOVE at its end); its slot takes the next game like that of a finished one,
+        // so that the batch the host has queued plies for (run-ahead) keeps its size
+        if (lane == 0) { atomicAdd(&T.stats[4], 1ull); if (T.ring) atomicAdd(&T.stats[kg < T.k_cur_end ? 8 : 9], 1ull); if (keep) T.s_move[(size_t)g * T.max_plies + ply] = (int16_t)c; if (in_range) { T.g_nplies[g] = np_end; T.g_result[g] = 0; T.g_final[g] = pack(root); } }
+        const uint32_t a = take_game<INPLACE>(T, slot, order);
+        if (lane == 0) { if (!a) atomicAdd(&T.stats[7], 1ull); T.alive[slot] = a & 1u; }
+        return a;
     }
     WPos<NC> np = G::play(P, root, c);
     int res; const bool f = G::isOver(P, np, res);

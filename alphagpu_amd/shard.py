@@ -179,7 +179,19 @@ class CommExchange:
                     return box[0]
             blob = broadcast(blob)
         self.h = C.c_void_p()
-        rc = self.L.agz_comm_create(engine.h, self.rank, self.world, blob, self.cap, C.byref(self.h))
+        # (RCCL prints a version banner on the C-level stdout when a communicator is made: it goes to stderr — a caller's stdout may be a
+        #  protocol, e.g. bench.py's ONE JSON line)
+        import os
+        import sys
+        sys.stdout.flush()
+        libc, saved = C.CDLL(None), os.dup(1)
+        os.dup2(2, 1)
+        try:
+            rc = self.L.agz_comm_create(engine.h, self.rank, self.world, blob, self.cap, C.byref(self.h))
+        finally:
+            libc.fflush(None)
+            os.dup2(saved, 1)
+            os.close(saved)
         if rc:
             raise RuntimeError("agz_comm_create: " + (self.L.agz_comm_last_error(None) or b"").decode())
 

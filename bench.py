@@ -423,6 +423,8 @@ def main():
         # algorithmic bytes.  A whole-generation ratio (separate FETCH_SIZE / WRITE_SIZE passes over every launch of a generation,
         # summed over the kernel variants of its plies) is used where one was measured, the first-ply ratio otherwise; the
         # object names its source.  A BASELINE configuration without a committed pass is an error, not a silent null.
+        if persistent:
+            launches = max(r_cnt / float(G * V), 1e-9)                  # ply-equivalents (G games x V rollouts) of the persistent launches
         pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         key = f"{gl}_{V}_{args.filters}x{args.towers}"
         traffic, traffic_source = None, "none: no committed PMC pass for this shape (profiles/pmc_traffic.json has no key %s)" % key
@@ -448,8 +450,6 @@ def main():
                             "note": "SQ_INSTS_VALU per (game, rollout) of the committed PMC pass (" + traffic_source + ") x this run's "
                                     "rollouts; 4 cycles per wave-instruction on 1024 SIMDs at 2.4 GHz (the counters show ~2.0 GHz under "
                                     "this load: the real issue utilisation is ~1.2 x higher)"}
-        if persistent:
-            launches = max(r_cnt / float(G * V), 1e-9)                  # ply-equivalents (G games x V rollouts) of the persistent launches
         hbm_achieved = alg / (busy_ms * 1e-3) / 1e9 if busy_ms > 0 else 0.0   # aggregate over the launches in flight together
         if whole or nn_leaves == 0:
             # the network forward runs inside the search kernel: its time is not separable, the fraction is taken against the

@@ -1,0 +1,42 @@
+#!/bin/bash
+# Runs on the GPU box (gpurun): round 5's measurement set -> gpurun_out/$1/ (copied into profiles/ by scratch/install_r05.py)
+#   bench lines: headline (default = persistent kernel with age classes), the same without age classes, with one launch per ply (AGZ_PERSIST=0),
+#   lock-step generations (the reference's call pattern), BASELINE configs 2-5; rocprofv3 kernel stats of the headline bench command;
+#   PMC passes (FETCH_SIZE, WRITE_SIZE, instruction mix; one pass each) over a refilled call of every config; the workgroup-spread measurement
+out=gpurun_out/$1; mkdir -p $out
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+python bench.py --steps 20 --warmup 5 > $out/bench_headline.json 2> $out/bench_headline.err
+AGZ_AGE=0 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-host-delivery > $out/bench_headline_noage.json 2> $out/bench_headline_noage.err
+AGZ_PERSIST=0 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-host-delivery > $out/bench_headline_plyloop.json 2> $out/bench_headline_plyloop.err
+python bench.py --steps 4 --warmup 1 --lockstep --no-host-delivery --no-cpu-baseline > $out/bench_headline_lockstep.json 2> $out/bench_headline_lockstep.err
+python bench.py --steps 6 --warmup 2 --exchange --gens-per-call 2 --no-cpu-baseline --no-host-delivery > $out/bench_headline_exchange_1rank.json 2> $out/bench_headline_exchange_1rank.err
+for c in 2 3 4 5; do timeout 900 python bench.py --config $c --steps 20 --warmup 5 > $out/bench_config$c.json 2> $out/bench_config$c.err; done
+timeout 600 rocprofv3 --kernel-trace --stats -d $out/stats -o x --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-host-delivery > $out/bench_under_rocprof.json 2> $out/stats.log
+for cfg in 0 2 3 4 5; do
+  for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_MFMA SQ_WAVES" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
+    n=$(echo $c | cut -c1-12 | tr " " _)
+    CFG=$cfg GENS=2 timeout 600 rocprofv3 --pmc $c --kernel-trace -d $out/p${cfg}_$n -o x --output-format csv -- python3 scratch/pmc_refill.py > $out/p${cfg}_$n.log 2>&1
+    echo "# cfg $cfg: rocprofv3 --pmc $c --kernel-trace -- python3 scratch/pmc_refill.py (CFG=$cfg GENS=2)   sums over the self-play launches of the call" >> $out/pmc_refill_summary.txt
+    python3 - $out/p${cfg}_$n >> $out/pmc_refill_summary.txt <<'PY'
+import csv, glob, sys, collections
+d = sys.argv[1]
+f = glob.glob(d + "/*counter_collection.csv") + glob.glob(d + "/*/*counter_collection.csv")
+agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(collections.Counter)
+for r in csv.DictReader(open(f[0])):
+    k = r["Kernel_Name"].split("(")[0].replace("void agz::", "")
+    if "k_search" not in k and "k_selfplay" not in k: continue
+    agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[k][r["Counter_Name"]] += 1
+for k in sorted(agg): print("sum", k, "launches", max(cnt[k].values()), {c: round(v) for c, v in agg[k].items()})
+t = glob.glob(d + "/*kernel_trace.csv") + glob.glob(d + "/*/*kernel_trace.csv")
+dur = collections.defaultdict(list)
+for r in csv.DictReader(open(t[0])):
+    k = r["Kernel_Name"].split("(")[0].replace("void agz::", "")
+    if "k_search" in k or "k_selfplay" in k: dur[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+for k in sorted(dur): print("dur", k, len(dur[k]), "avg us", round(sum(dur[k]) / len(dur[k]) / 1e3, 1))
+PY
+    grep -h algorithmic_bytes_of_the_call $out/p${cfg}_$n.log | tail -1 >> $out/pmc_refill_summary.txt
+    rm -rf $out/p${cfg}_$n
+  done
+done
+find $out/stats -name "*kernel_trace.csv" -delete
+ls $out

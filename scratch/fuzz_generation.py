@@ -57,7 +57,8 @@ for name, n, V, H, T, seed in cases:
                         print(f"   {key}[{i},{j}]: gpu {a[i, j]!r} ({a[i, j].view(np.uint32) if a.dtype == np.float32 else ''})  oracle {b[i, j]!r} "
                               f"({b[i, j].view(np.uint32) if b.dtype == np.float32 else ''})  game {s['game_id'][i]} ply {s['ply'][i]} move {s['move'][i]}")
     bad += (not ok) or bool(diff)
-    print(f"{name} n={n} V={V} {H}x{T} seed={seed}: samples {st['nsamples']} vs {ref['n']}  W/D/L {st['wins']}/{st['draws']}/{st['losses']}  "
+    form = form_[0].split(" (")[0] if (form_ := e.search_form()) else ""
+    print(f"{name} n={n} V={V} {H}x{T} seed={seed} [{form}]: samples {st['nsamples']} vs {ref['n']}  W/D/L {st['wins']}/{st['draws']}/{st['losses']}  "
           f"{'IDENTICAL' if ok and not diff else 'DIFFERENT ' + str(diff)}  (oracle {t1 - t0:.1f}s)", flush=True)
 print("fuzz:", "all identical" if not bad else f"{bad} case(s) differ")
 sys.exit(1 if bad else 0)

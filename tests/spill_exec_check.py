@@ -42,8 +42,8 @@ def check(txt):
                     targets.add(base + int(t.group(1), 16))
                 elif re.search(r"<[^>+]*>\s*$", ln):
                     targets.add(base)
-        # the pattern: a block (it starts at a branch target or behind a branch) whose head is nothing but spill code (and scalar moves /
-        # waits) up to an exec restore.  Spill code deeper inside a block — a reload for the lanes of a short branch-free region, the
+        # the pattern: a block (it starts at a branch target or behind a branch) whose head is nothing but spill code (and scalar
+        # instructions of any kind) up to an exec restore.  Spill code deeper inside a block — a reload for the lanes of a short branch-free region, the
         # load / modify / store of a variable that lives in scratch — runs under the mask its lanes need and is not flagged.
         pending, clean = [], True                   # scratch instructions since the block began; nothing else seen since then
         for i, (addr, text) in enumerate(ins):
@@ -57,7 +57,10 @@ def check(txt):
                     for a, t in pending:
                         bad.append((name, a, t))
                 pending, clean = [], False
-            elif not text.startswith(("s_mov_b32", "s_mov_b64", "s_nop", "s_waitcnt")):
+            elif not text.startswith("s_"):
+                # any SCALAR instruction (an s_add for a scratch offset, an s_load, a lane read into an SGPR ...) may sit between the head of
+                # the block and the exec restore without making the spill code legitimate: only vector / memory work that runs under the
+                # narrower mask on purpose ends the window
                 clean = False
     return bad
 
