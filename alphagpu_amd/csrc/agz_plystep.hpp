@@ -222,7 +222,7 @@ __device__ __forceinline__ uint32_t advance_slot(const PlyPar& T, const int slot
         }
         if (c < 0) c = 0;
     }
-    bool fault = c < 0;
+    bool fault = c < 0 || ply >= 254;                               // (no game of this library lasts 254 plies: a loop that would not end is a fault, not a hang)
     if (!fault) {
         bool ok = __ballot(lane == 0 && G::canPlay(P, root, c)) != 0;   // "faute" guard (:526-529)
         fault = !ok;

@@ -32,6 +32,7 @@ for name, n, V, H, T, seed in cases:
     slots = max(8, n // int(os.environ.get("FUZZ_SLOT_DIV", "1")))   # FUZZ_SLOT_DIV=3: a third of the games in flight, finished games' slots refilled
     with M.Engine(g, min(slots, n), V, seed=seed, game_id_base=1000 * seed, nn_mode=M.NN_EXACT if exact else M.NN_BF16, sample_capacity_games=n) as e:
         e.set_network(net)
+        form = ""
         if os.environ.get("FUZZ_CHAIN") == "1":                # the n games as a chain of three calls (agz_selfplay_chain), merged back into PoolSample order
             parts, st, sizes = [], None, [n // 2, n // 4, n - n // 2 - n // 4]
             for i, ng in enumerate(sizes):
@@ -44,6 +45,7 @@ for name, n, V, H, T, seed in cases:
         else:
             st = e.selfplay(n, V, cpuct=1.5, tau_plies=25)
             s = e.samples()
+        form = e.search_form()[0].split(" (")[0]
     ok = st["valid"] and ref["rc"] == 0 and st["nsamples"] == ref["n"]
     diff = {}
     if ok:
@@ -57,7 +59,6 @@ for name, n, V, H, T, seed in cases:
                         print(f"   {key}[{i},{j}]: gpu {a[i, j]!r} ({a[i, j].view(np.uint32) if a.dtype == np.float32 else ''})  oracle {b[i, j]!r} "
                               f"({b[i, j].view(np.uint32) if b.dtype == np.float32 else ''})  game {s['game_id'][i]} ply {s['ply'][i]} move {s['move'][i]}")
     bad += (not ok) or bool(diff)
-    form = form_[0].split(" (")[0] if (form_ := e.search_form()) else ""
     print(f"{name} n={n} V={V} {H}x{T} seed={seed} [{form}]: samples {st['nsamples']} vs {ref['n']}  W/D/L {st['wins']}/{st['draws']}/{st['losses']}  "
           f"{'IDENTICAL' if ok and not diff else 'DIFFERENT ' + str(diff)}  (oracle {t1 - t0:.1f}s)", flush=True)
 print("fuzz:", "all identical" if not bad else f"{bad} case(s) differ")
