@@ -136,6 +136,10 @@ typedef struct {
  * takes the next game that has not started yet, so that every search runs on a full batch.  Each game's samples are exactly those of a
  * lock-step run over ngames slots (results are keyed by game id and the game's own ply, never by slot or by the round a game started in);
  * stats->plies then counts the rounds of the loop. */
+/* Execution form (chosen by the engine, results never depend on it): one launch per ply with the ply step in kernels of its own
+ * (k_advance / k_scan_alive / k_compact: lock-step calls, small engines, exact mode), or — calls with refilled slots on engines of more than
+ * 96 slots per CU (64 for 512-wide trunks), bf16 mode — ONE launch per call in which every workgroup loops over the plies of its own 64 games
+ * (k_selfplay_small / k_selfplay_big; AGZ_PERSIST): stats->plies is then the searches per slot rounded up, stats->search_seconds the launch. */
 int  agz_selfplay(agz_engine *h, int ngames, int V, float cpuct, int tau_plies, agz_selfplay_stats *stats);
 /* A CHAIN of self-play calls (a host loop that calls mcts(actor, visits, ngames, buffer) generation after generation, selfplay.jl:34):
  * like agz_selfplay, but the caller says how many games its NEXT call will play.  Game ids run on from call to call (game k of the chain
@@ -144,7 +148,9 @@ int  agz_selfplay(agz_engine *h, int ngames, int V, float cpuct, int tau_plies, 
  * ngames games are over — and the next call of the chain goes on with them.  Only the last call of a chain (next_ngames = 0) ends on a
  * batch that runs out.  Every game's samples are those of one lock-step run over all the chain's games with the engine's seed (keyed by
  * game id and the game's own ply): the seed must stay the same while games are in flight (agz_set_seed fails otherwise), the network may
- * change between calls.  Needs sample_capacity_games >= ngames + next_ngames; fetch a call's samples before the next call of the chain
+ * change between calls — the games started early for the next call are then searched by the OLD network on their first plies (the
+ * reference plays a generation with one actor, selfplay.jl:34-56): agz_set_network_tag makes that visible per sample, next_ngames = 0
+ * avoids it.  Needs sample_capacity_games >= ngames + next_ngames; fetch a call's samples before the next call of the chain
  * (their storage is reused).  agz_selfplay, agz_duel, agz_set_roots end a chain (games in flight are dropped).
  * stats: nsamples / wins / draws / losses / total_plies of THIS call's games; rollouts, plies, seconds of the work done inside the call. */
 int  agz_selfplay_chain(agz_engine *h, int ngames, int next_ngames, int V, float cpuct, int tau_plies, agz_selfplay_stats *stats);

@@ -38,5 +38,8 @@ PY
     rm -rf $out/p${cfg}_$n
   done
 done
+# diagnostic builds (scratch/libagz_wgt.so: -DAGZ_WGTIME, scratch/libagz_ps.so: -DAGZ_PSTAMPS; made by `make OUT=... BUILD=... EXTRA=...`)
+{ echo "# AGZ_PERSIST=0 python scratch/wgtime.py  (-DAGZ_WGTIME build): when do the 512 workgroups of a full-batch k_search_small launch start and end?"; AGZ_PERSIST=0 python scratch/wgtime.py; } > $out/workgroup_spread.txt 2>&1
+{ echo "# python scratch/pstamps.py  (-DAGZ_PSTAMPS build): where the waves of the persistent kernel spend their cycles"; python scratch/pstamps.py; } > $out/persistent_phase_shares.txt 2>&1
 find $out/stats -name "*kernel_trace.csv" -delete
 ls $out

@@ -9,6 +9,9 @@ P = "profiles"
 for f in ("bench_headline", "bench_headline_noage", "bench_headline_plyloop", "bench_headline_lockstep", "bench_headline_exchange_1rank", "bench_config2", "bench_config3", "bench_config4", "bench_config5", "bench_under_rocprof"):
     if os.path.exists(os.path.join(src, f + ".json")) and os.path.getsize(os.path.join(src, f + ".json")) > 0:
         shutil.copy(os.path.join(src, f + ".json"), os.path.join(P, f"{pre}_{f}.json"))
+for f in ("workgroup_spread", "persistent_phase_shares"):
+    if os.path.exists(os.path.join(src, f + ".txt")):
+        shutil.copy(os.path.join(src, f + ".txt"), os.path.join(P, f"{pre}_{f}.txt"))
 st = glob.glob(os.path.join(src, "stats", "*kernel_stats.csv")) + glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))
 if st: shutil.copy(st[0], os.path.join(P, f"{pre}_kernel_stats_bench_headline.csv"))
 shutil.copy(os.path.join(src, "pmc_refill_summary.txt"), os.path.join(P, f"{pre}_pmc_refilled_call_by_variant.txt"))

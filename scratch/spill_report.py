@@ -12,7 +12,8 @@ for lib in libs:
     if not os.path.exists(out) or os.path.getsize(out) == 0:
         # the fat binary is a section of the shared object
         sec = os.path.join(d, "fat")
-        subprocess.run([LL + "llvm-objcopy", "--dump-section", f".hip_fatbin={sec}", lib], check=True)
+        if subprocess.run([LL + "llvm-objcopy", "--dump-section", f".hip_fatbin={sec}", lib, os.path.join(d, "copy.o")], capture_output=True).returncode != 0:
+            continue                                      # (an object without device code)
         subprocess.run([LL + "clang-offload-bundler", "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={sec}", f"--output={out}"], check=True)
     txt += subprocess.run([LL + "llvm-readelf", "--notes", out], capture_output=True, text=True).stdout
 rows = []
