@@ -211,7 +211,9 @@ def main():
 
     def step(ngen=1, nxt=None):
         if chain and nxt is not None:           # a call of the run's chain: `nxt` generations' worth of the next call's games may start early
-            st = eng.selfplay_chain(ngen * G, min(nxt, FILL) * G, V, cpuct=args.cpuct, tau_plies=25)
+            # (FILL generations' worth of LATER games may start early whatever the size of the next call: with calls of one generation —
+            #  8 ranks — the next call alone is not enough to keep the slots busy while a call's longest games finish: 529 vs 591 M rollouts/s)
+            st = eng.selfplay_chain(ngen * G, FILL * G, V, cpuct=args.cpuct, tau_plies=25)
         else:
             eng.set_seed(1 + nstep[0])          # a fresh Philox key per call, as the reference's unseeded draws
             st = eng.selfplay(ngen * G, V, cpuct=args.cpuct, tau_plies=25)

@@ -144,8 +144,10 @@ int  agz_selfplay(agz_engine *h, int ngames, int V, float cpuct, int tau_plies, 
 /* A CHAIN of self-play calls (a host loop that calls mcts(actor, visits, ngames, buffer) generation after generation, selfplay.jl:34):
  * like agz_selfplay, but the caller says how many games its NEXT call will play.  Game ids run on from call to call (game k of the chain
  * has id game_id_base + k, this call returns games k0 .. k0 + ngames - 1), and while this call's games run out the slots that come
- * free start up to next_ngames games of the next call instead of idling; they stay in flight when the call returns — as soon as its own
- * ngames games are over — and the next call of the chain goes on with them.  Only the last call of a chain (next_ngames = 0) ends on a
+ * free start up to next_ngames games of the next call(s) instead of idling; they stay in flight when the call returns — as soon as its own
+ * ngames games are over — and the next call of the chain goes on with them.  (next_ngames may exceed the size of the next call: the games
+ * after it then start early too.  A host loop of SHORT calls — one generation each — needs that: a call's longest games take two
+ * generations' worth of searches to finish, and the slots that come free meanwhile must have games to take.)  Only the last call of a chain (next_ngames = 0) ends on a
  * batch that runs out.  Every game's samples are those of one lock-step run over all the chain's games with the engine's seed (keyed by
  * game id and the game's own ply): the seed must stay the same while games are in flight (agz_set_seed fails otherwise), the network may
  * change between calls — the games started early for the next call are then searched by the OLD network on their first plies (the

@@ -309,3 +309,28 @@ def test_chain_with_a_different_network_per_call_equals_the_oracle_run_the_tags_
         for key in ("game_id", "ply", "move", "player", "state", "fstate", "policy", "value"):
             assert_same_bits(got[key], ref[key][sel], f"call {i}: {key}")
         k0 += n
+
+
+@pytest.mark.parametrize("persist", ["1", "0"])
+def test_chain_may_start_games_beyond_the_next_call(persist, monkeypatch):
+    """agz_selfplay_chain(ngames, next_ngames > the next call's size): short calls (a host loop of one generation per call) whose slots
+    take games of the call AFTER the next one too; a game may be returned by a call two calls after the one that started it.  Every call
+    returns the oracle's games of its ids."""
+    monkeypatch.setenv("AGZ_PERSIST", persist)
+    g, og, net, onet = _nets("gobang9")
+    slots, V, N = 64, 16, 20                                     # calls of 20 games on 64 slots, 60 later games announced every time
+    ncalls = 8
+    ref = O.selfplay(og, onet, ncalls * N, V, 1.5, 25, 9, 700)
+    with M.Engine(g, slots, V, seed=9, game_id_base=700, nn_mode=M.NN_BF16, sample_capacity_games=N + 3 * N) as e:
+        e.set_network(net)
+        rollouts = 0
+        for i in range(ncalls):
+            nxt = min(3 * N, (ncalls - 1 - i) * N)
+            st = e.selfplay_chain(N, nxt, V, cpuct=1.5, tau_plies=25)
+            s = e.samples()
+            sel = (ref["game_id"] >= 700 + i * N) & (ref["game_id"] < 700 + (i + 1) * N)
+            assert st["valid"] and st["nsamples"] == int(sel.sum()) == len(s["ply"]), (i, st["nsamples"], int(sel.sum()))
+            for key in KEYS:
+                assert_same_bits(s[key], ref[key][sel], f"call {i}: {key}")
+            rollouts += st["rollouts"]
+        assert rollouts == V * len(ref["ply"])
