@@ -5,6 +5,7 @@
 #   PMC passes (FETCH_SIZE, WRITE_SIZE, instruction mix; one pass each) over a refilled call of every config; the workgroup-spread measurement
 out=gpurun_out/$1; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+if [ -z "$PMC_ONLY" ]; then
 python bench.py --steps 20 --warmup 5 > $out/bench_headline.json 2> $out/bench_headline.err
 AGZ_AGE=0 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-host-delivery > $out/bench_headline_noage.json 2> $out/bench_headline_noage.err
 AGZ_PERSIST=0 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-host-delivery > $out/bench_headline_plyloop.json 2> $out/bench_headline_plyloop.err
@@ -12,11 +13,16 @@ python bench.py --steps 4 --warmup 1 --lockstep --no-host-delivery --no-cpu-base
 python bench.py --steps 6 --warmup 2 --exchange --gens-per-call 2 --no-cpu-baseline --no-host-delivery > $out/bench_headline_exchange_1rank.json 2> $out/bench_headline_exchange_1rank.err
 for c in 2 3 4 5; do timeout 900 python bench.py --config $c --steps 20 --warmup 5 > $out/bench_config$c.json 2> $out/bench_config$c.err; done
 timeout 600 rocprofv3 --kernel-trace --stats -d $out/stats -o x --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-host-delivery > $out/bench_under_rocprof.json 2> $out/stats.log
+fi
+rm -f $out/pmc_refill_summary.txt
+# (a call of several generations: the plies in which a call's last games run out — partly empty workgroups — are a small part of it, as in
+#  the chained calls bench.py times)
+declare -A GENS_OF=([0]=8 [2]=8 [3]=4 [4]=3 [5]=4)
 for cfg in 0 2 3 4 5; do
   for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_MFMA SQ_WAVES" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
     n=$(echo $c | cut -c1-12 | tr " " _)
-    CFG=$cfg GENS=2 timeout 600 rocprofv3 --pmc $c --kernel-trace -d $out/p${cfg}_$n -o x --output-format csv -- python3 scratch/pmc_refill.py > $out/p${cfg}_$n.log 2>&1
-    echo "# cfg $cfg: rocprofv3 --pmc $c --kernel-trace -- python3 scratch/pmc_refill.py (CFG=$cfg GENS=2)   sums over the self-play launches of the call" >> $out/pmc_refill_summary.txt
+    CFG=$cfg GENS=${GENS_OF[$cfg]} timeout 600 rocprofv3 --pmc $c --kernel-trace -d $out/p${cfg}_$n -o x --output-format csv -- python3 scratch/pmc_refill.py > $out/p${cfg}_$n.log 2>&1
+    echo "# cfg $cfg: rocprofv3 --pmc $c --kernel-trace -- python3 scratch/pmc_refill.py (CFG=$cfg GENS=${GENS_OF[$cfg]})   sums over the self-play launches of the call" >> $out/pmc_refill_summary.txt
     python3 - $out/p${cfg}_$n >> $out/pmc_refill_summary.txt <<'PY'
 import csv, glob, sys, collections
 d = sys.argv[1]
@@ -38,8 +44,10 @@ PY
     rm -rf $out/p${cfg}_$n
   done
 done
+if [ -z "$PMC_ONLY" ]; then
 # diagnostic builds (scratch/libagz_wgt.so: -DAGZ_WGTIME, scratch/libagz_ps.so: -DAGZ_PSTAMPS; made by `make OUT=... BUILD=... EXTRA=...`)
 { echo "# AGZ_PERSIST=0 python scratch/wgtime.py  (-DAGZ_WGTIME build): when do the 512 workgroups of a full-batch k_search_small launch start and end?"; AGZ_PERSIST=0 python scratch/wgtime.py; } > $out/workgroup_spread.txt 2>&1
 { echo "# python scratch/pstamps.py  (-DAGZ_PSTAMPS build): where the waves of the persistent kernel spend their cycles"; python scratch/pstamps.py; } > $out/persistent_phase_shares.txt 2>&1
+fi
 find $out/stats -name "*kernel_trace.csv" -delete
 ls $out
