@@ -171,6 +171,7 @@ struct agz_engine {
     // ... with age classes (workgroups that prefer old games run rows by legal rank; games migrate through a queue in device memory):
     // age_kpr rows per lane of the old body, age_on (AGZ_AGE=0 turns it off), age_old16 of 16 CU pairs prefer old games (AGZ_AGE_OLD16),
     // age_by_block (AGZ_AGE_CLASS=block, tests: odd workgroups prefer old games), age_backlog: the queue's length at which nothing is pushed
+    persist_fn k_persist_tw4 = nullptr, k_persist_tw4_age = nullptr; bool persist_tw4 = true;   // 32-game workgroups of four waves (default; AGZ_PERSIST_TW=8: 64-game workgroups of eight)
     persist_fn k_persist_age = nullptr; int age_kpr = 0; bool age_on = true, age_by_block = false; int age_old16 = 8, age_backlog = 0;
     MigEntry* mq_buf = nullptr; unsigned long long* mq_ctr = nullptr; uint32_t mq_cap = 0; bool mq_dirty = false;
     int run_ahead = 8;                    // plies the ply loop may queue before it waits for a ply's counters (AGZ_RUN_AHEAD; while the pool cannot run dry)
@@ -215,13 +216,13 @@ static bool bind_kernels(agz_engine* h) {
 #define Z(F, C, K) if (P.fam == F && P.NC == C && kpl == K) { h->k_eager = k_rollout_eager<F, C, K, 4>; h->k_eager3 = k_rollout_eager<F, C, K, 3>; \
         h->k_small = k_search_small<F, C, K, 128, 2, 2>; h->k_small4[0] = k_search_small<F, C, K, 128, 4, 2>; h->k_small4[1] = k_search_small<F, C, K, 128, 4, 3>; \
         h->k_small4[2] = k_search_small<F, C, K, 128, 4, 4>; h->k_small8 = k_search_small<F, C, K, 128, 8, 4>; h->k_big[0] = k_search_big<F, C, K, 512, 1>; h->k_big[1] = k_search_big<F, C, K, 512, 2>; h->k_big8 = k_search_big<F, C, K, 512, 1, 0, 8>; h->k_big8x = k_search_big<F, C, K, 512, 2, 0, 8>; h->reg_kpl = K; \
-        h->k_persist = k_selfplay_small<F, C, K, 128, 8, 4>; h->k_persist_big[0] = k_selfplay_big<F, C, K, 512, 1>; h->k_persist_big[1] = k_selfplay_big<F, C, K, 512, 2>; }
+        h->k_persist = k_selfplay_small<F, C, K, 128, 8, 4>; h->k_persist_tw4 = k_selfplay_small<F, C, K, 128, 4, 4>; h->k_persist_big[0] = k_selfplay_big<F, C, K, 512, 1>; h->k_persist_big[1] = k_selfplay_big<F, C, K, 512, 2>; }
     AGZ_SMALL_SHAPES(Z)
 #undef Z
 #define Z(F, C, K, GG) if (P.fam == F && P.NC == C && GG * K >= P.A && GG * K <= 8 * kpl) { h->k_persist_nar = k_selfplay_small<F, C, K, 128, 4, 2, GG>; h->persist_nar_g = GG; h->persist_nar_kpl = K; }
     AGZ_PERSIST_NARROW_SHAPES(Z)
 #undef Z
-#define Z(F, C, K, R) if (P.fam == F && P.NC == C && kpl == K) { h->k_persist_age = k_selfplay_small<F, C, K, 128, 8, 4, 8, R>; h->age_kpr = R; }
+#define Z(F, C, K, R) if (P.fam == F && P.NC == C && kpl == K) { h->k_persist_age = k_selfplay_small<F, C, K, 128, 8, 4, 8, R>; h->k_persist_tw4_age = k_selfplay_small<F, C, K, 128, 4, 4, 8, R>; h->age_kpr = R; }
     AGZ_PERSIST_AGE_SHAPES(Z)
 #undef Z
 #define Z(F, C, K, R) if (P.fam == F && P.NC == C && kpl == K && h->ncmp < 4) { agz_engine::CmpLevel& c = h->cmp[h->ncmp++]; c.kpr = R; \
@@ -435,6 +436,10 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
         if (h->k_persist_nar) FA_(hipFuncSetAttribute((const void*)h->k_persist_nar, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         if (h->k_persist_age) FA_(hipFuncSetAttribute((const void*)h->k_persist_age, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         for (int i = 0; i < 2; ++i) if (h->k_persist_big[i]) FA_(hipFuncSetAttribute((const void*)h->k_persist_big[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if (h->k_persist_tw4) FA_(hipFuncSetAttribute((const void*)h->k_persist_tw4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if (h->k_persist_tw4_age) FA_(hipFuncSetAttribute((const void*)h->k_persist_tw4_age, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        e3 = getenv("AGZ_PERSIST_TW");
+        h->persist_tw4 = !(e3 && atoi(e3) == 8) && h->k_persist_tw4;
         e3 = getenv("AGZ_AGE");
         if (e3) h->age_on = atoi(e3) > 0;
         e3 = getenv("AGZ_AGE_OLD16");
@@ -1590,12 +1595,13 @@ static bool persist_shape(const agz_engine* h) {
     if (h->V > 128 || (h->V & 3) != 0 || h->no_fused_nn || 8 * h->reg_kpl > h->LGS) return false;
     if ((h->Lmax + 63) / 64 > 2 * h->cus) return false;                        // every workgroup resident: two 64-game workgroups per CU
     // ... which also needs their LDS to fit side by side (V = 128 trees on a 128-wide trunk do not: the call then runs one launch per ply)
-    const int wgcu = (h->Lmax + 63) / 64 <= h->cus ? 1 : 2;
-    const size_t cu_lds = (size_t)(160 * 1024) / (size_t)wgcu;
     if (n.H == 128) {
         if (!(h->k_persist || h->k_persist_nar) || !n.w16w) return false;
         const bool nar = h->k_persist_nar && h->narrow_mode >= 0;
-        const int G = nar ? h->persist_nar_g : 8, NG = 64 / G, tw = nar ? 4 : 8, gpwg = tw * NG;
+        const int G = nar ? h->persist_nar_g : 8, NG = 64 / G, tw = (nar || h->persist_tw4) ? 4 : 8, gpwg = tw * NG;
+        const int wgs = (h->Lmax + gpwg - 1) / gpwg, per_cu = (wgs + h->cus - 1) / h->cus;
+        if (per_cu > (gpwg == 32 ? 4 : 2)) return false;
+        const size_t cu_lds = (size_t)(160 * 1024) / (size_t)per_cu;
         const size_t tree_lds = nar ? (size_t)eager_lds_layout(h->V, NG).total : h->reg_lds;
         const int kth = n.H / 32, g0 = (n.INP / 32 + kth - 1) / kth;
         const int rs = (std::max(g0 * kth * 64 + 16, 4 * n.AOP) + 15) & ~15;
@@ -1604,6 +1610,7 @@ static bool persist_shape(const agz_engine* h) {
     }
     if (n.H == 512) {
         if (!h->k_persist_big[0] || !n.wbig || h->big8 < 0) return false;
+        const size_t cu_lds = (size_t)(160 * 1024) / (size_t)((h->Lmax + 63) / 64 <= h->cus ? 1 : 2);
         const int big_rowb = (2 * std::max(n.H, 32 * n.k0r) + 255) & ~255;
         const size_t xch_off = (std::max((size_t)8 * h->reg_lds, (size_t)8 * 8 * big_rowb) + 15) & ~(size_t)15;
         return xch_off + 4 * 144 + 16 + 8 * 64 <= cu_lds;
@@ -1681,7 +1688,8 @@ static int run_games_persist(agz_engine* h, int ngames, int V, float cpuct, int 
     // (2 V >= 8 KPR floats of the lane-group's edge table), refilled slots (a game can only leave a slot that a new game takes)
     const bool age = !big && !nar && h->k_persist_age && h->age_on && !h->no_compact && 2 * h->V >= 8 * h->age_kpr && (chain || (long long)ngames > (long long)slots);
     if (!big && !nar && !h->k_persist) { h->fail("no persistent self-play kernel for this game shape"); return AGZ_ERR_UNSUPPORTED; }
-    const int G = nar ? h->persist_nar_g : 8, NG = 64 / G, tw = nar ? 4 : 8, gpwg = tw * NG;
+    const bool tw4 = !big && !nar && h->persist_tw4;
+    const int G = nar ? h->persist_nar_g : 8, NG = 64 / G, tw = (nar || tw4) ? 4 : 8, gpwg = tw * NG;
     const unsigned wgs = (unsigned)((h->Lmax + gpwg - 1) / gpwg);
     PersistTail X; memset(&X, 0, sizeof X);
     fill_plypar(h, X.P, 0, tau_plies, false);
@@ -1746,7 +1754,7 @@ static int run_games_persist(agz_engine* h, int ngames, int V, float cpuct, int 
         S.xch_off = S.io_off + tw * S.io_bw;
         const size_t shared = (size_t)S.xch_off + (size_t)tw * (16 * NG + 16) + 16;   // ... + the workgroup's two flag words
         Q.X = X; Q.X.flag_off = (int)shared - 16;
-        wgcu = (int)wgs <= h->cus ? 1 : 2;
+        wgcu = ((int)wgs + h->cus - 1) / h->cus;
         const size_t cu_lds = cu_lds_all / (size_t)wgcu;
         const size_t room = cu_lds > shared ? cu_lds - shared : 0;
         S.wl_off = (int)shared; S.wl_bytes = (int)std::min({(size_t)(NG * h->V * 4), (room / (size_t)tw) & ~(size_t)15, (size_t)h->wl_lds_max});
@@ -1754,7 +1762,7 @@ static int run_games_persist(agz_engine* h, int ngames, int V, float cpuct, int 
         if (lds > cu_lds) { h->in_ply_loop = false; h->fail("persistent self-play kernel: %zu bytes of LDS per workgroup", lds); return AGZ_ERR_UNSUPPORTED; }
         h->rd_rec_bytes = nar ? (uint32_t)eager_rec_bytes(G * h->persist_nar_kpl, h->V) : h->tp.rec_bytes;
         hipEventRecord(h->ev_ply0, h->stream);
-        hipLaunchKernelGGL(nar ? h->k_persist_nar : (age_kernel ? h->k_persist_age : h->k_persist), dim3(wgs), dim3(64 * tw), lds, h->stream, Q);
+        hipLaunchKernelGGL(nar ? h->k_persist_nar : (tw4 ? (age_kernel ? h->k_persist_tw4_age : h->k_persist_tw4) : (age_kernel ? h->k_persist_age : h->k_persist)), dim3(wgs), dim3(64 * tw), lds, h->stream, Q);
     }
     hipEventRecord(h->ev_ply1, h->stream);
     const bool sleep = h->ply_sleep && h->ev_adv && hipEventRecord(h->ev_adv, h->stream) == hipSuccess;

@@ -20,7 +20,7 @@ __global__ __launch_bounds__(NB_THREADS, 2 * WG) void k_selfplay_big(const Persi
     typedef const PersistBigPar __attribute__((address_space(4)))* KArg;
     const KArg karg = (KArg)__builtin_amdgcn_kernarg_segment_ptr();
     const auto tail = [=]() -> const PersistTail& { KArg p = karg; asm volatile("" : "+s"(p)); return ((const PersistBigPar*)p)->X; };
-    persist_loop<FAM, NC, KPL, 8, TW, false>(lds_bigs, tail, [&](const uint32_t amask, const bool, EagerCarry& C) {
+    persist_loop<FAM, NC, KPL, 8, TW, false, false>(lds_bigs, tail, [&](const uint32_t amask, const bool, EagerCarry& C) {
         const auto spar = [=]() -> const BigSearchPar& { KArg p = karg; asm volatile("" : "+s"(p)); return ((const PersistBigPar*)p)->S; };
         const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
         constexpr int PF_ = WG < 2 ? 2 : 1;

@@ -31,6 +31,119 @@ struct PersistTail {
 };
 struct PersistPar { SmallPar S; PersistTail X; };
 
+// The ply step of ALL the games of a wave at once, one game per lane-group (the form advance_slot has, agz_plystep.hpp, takes the whole
+// wave for one game and the wave's games one after the other: 1.1 - 1.4 % of the persistent kernel's time on the 9x9 shapes, more with 16 games
+// per wave).  Lane sub of group g holds the KPL actions sub KPL .. of game slot0 + g, as in the tree step; the ordered sum of the move
+// choice is the tree step's turn-taking sum (bit-identical to the source-order loop: a zero weight adds nothing), the walk
+// "first action whose running sum reaches u x total" (:518-524) is the number of running sums below it.  Same stores, same counters as
+// advance_slot; a slot whose game has ended (or was abandoned after an illegal move) is reported in the returned mask and refilled by
+// the caller (take_game is a wave-level operation).  Returns: bits 0 .. NG-1 games that go on, bits 16 .. 16+NG-1 games that ended.
+template <int FAM, int NC, int KPL, int G>
+__device__ __forceinline__ uint32_t advance_groups(const PlyPar& T, const int slot0, const uint32_t amask, const bool ranked) {
+    using GM = Game<FAM, NC>;
+    constexpr bool REV = FAM == F_REV;
+    constexpr int NG = 64 / G;
+    const GamePar& P = T.G;
+    int lane = lane_id();
+    asm volatile("" : "+v"(lane));                                // opaque once per ply: what depends on the lane only is not carried (in scratch) through the search
+    const int g = lane / G, sub = lane % G;
+    const bool lead = sub == 0;
+    const bool active = (amask >> g) & 1u;
+    const int slot = slot0 + (active ? g : (int)__builtin_ctz(amask | 0x80000000u) % NG);   // (an idle group reads the wave's first game: finite values, nothing stored)
+    const int A = P.A;
+    const int k0 = sub * KPL;
+    const int nlanes = (A + KPL - 1) / KPL;
+    const int nval = A - k0 < 0 ? 0 : (A - k0 > KPL ? KPL : A - k0);
+    const uint32_t gid = T.game_id[slot];
+    const uint32_t kg = gid - T.game_id_base;
+    const int gi = T.ring ? (int)(kg % (uint32_t)T.sample_games) : (int)kg;
+    const int ply = (int)T.slot_ply[slot];
+    const WPos<NC> root = grp_load_pos<NC, REV>(T.states + (size_t)slot * T.V);
+    const float* const row = T.policy_final + (size_t)slot * A;
+    float pol[KPL];
+    if (ranked) {       // the row is in the order of the root's legal ranks: entry k of the policy = the rank(k)-th entry if action k is legal, else 0
+        const uint32_t lmask = legal_block<FAM, NC, KPL>(P, root, k0, nval);
+        int rank = grp_excl_prefix8<G>(__builtin_popcount(lmask), sub);
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) { const bool lg = (lmask >> j) & 1u; pol[j] = lg ? row[rank] : 0.0f; rank += lg ? 1 : 0; }
+    } else {
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) pol[j] = j < nval ? row[k0 + j] : 0.0f;
+    }
+    const bool in_range = T.ring || (gi >= 0 && gi < T.sample_games);
+    const bool keep = active && in_range && ply < T.max_plies;
+    const int np_end = ply + 1 < T.max_plies ? ply + 1 : T.max_plies;
+    const size_t sidx = (size_t)gi * T.max_plies + ply;
+    if (keep) {                                                   // push_buffer: root boards + policy
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) if (j < nval) T.s_policy[sidx * A + k0 + j] = pol[j];
+        if (lead) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { T.s_boards[sidx * 6 + i] = i < NC ? root.p.c[i < NC ? i : 0] : 0ull; T.s_boards[sidx * 6 + 3 + i] = i < NC ? root.o.c[i < NC ? i : 0] : 0ull; }
+            T.s_net[sidx] = (uint8_t)T.net_tag;
+        }
+    }
+    // ---- move choice (:518-524)
+    int c;
+    bool anynz = false;
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) anynz |= pol[j] != 0.0f;
+    anynz = grp_max_i<G>(anynz ? 1 : 0) != 0;
+    if (ply < T.tau_plies) {
+        float total;
+        const float st = grp_ordered_start<KPL, true, G>(pol, sub, total, nlanes);
+        const float tt = uniform_move(T.seed, gid, (uint32_t)ply) * total;
+        float run = st; int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) { run += pol[j]; cnt += (j < nval && run < tt) ? 1 : 0; }
+        c = grp_sum<G>(cnt);
+        if (c >= A) {                                             // (cannot happen: u < 1, so the last running sum is not below u x total; kept like the walk's `c == last`)
+            int last = -1;
+#pragma unroll
+            for (int j = 0; j < KPL; ++j) last = (j < nval && pol[j] != 0.0f) ? k0 + j : last;
+            c = grp_max_i<G>(last);
+        }
+        if (!anynz) c = -1;
+    } else {                                                      // argmax(pol): the first maximum
+        float best = -__builtin_inff();
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) best = (j < nval && pol[j] > best) ? pol[j] : best;
+        best = grp_max<G>(best);
+        int first = 1 << 20;
+#pragma unroll
+        for (int j = KPL - 1; j >= 0; --j) first = (j < nval && pol[j] == best) ? k0 + j : first;
+        first = -grp_max_i<G>(-first);
+        c = first < A ? first : 0;
+    }
+    bool fault = c < 0 || ply >= 254;
+    if (!fault) fault = !GM::canPlay(P, root, c);                 // "faute" guard (:526-529)
+    const WPos<NC> np = GM::play(P, root, fault ? 0 : c);
+    int res = 0;
+    const bool f = !fault && GM::isOver(P, np, res);
+    if (active && lead) {
+        if (keep) T.s_move[sidx] = (int16_t)c;
+        if (fault) {
+            atomicAdd(&T.stats[4], 1ull);
+            if (T.ring) atomicAdd(&T.stats[kg < T.k_cur_end ? 8 : 9], 1ull);
+            if (in_range) { T.g_nplies[gi] = np_end; T.g_result[gi] = 0; T.g_final[gi] = pack(root); }
+        } else if (f) {
+            if (in_range) { T.g_nplies[gi] = np_end; T.g_result[gi] = (int8_t)res; T.g_final[gi] = pack(np); }
+            atomicAdd(&T.stats[res == 1 ? 0 : (res == 0 ? 1 : 2)], 1ull);     // :541-547
+            atomicAdd(&T.stats[3], (unsigned long long)ply);                   // tot_length += round (:535)
+            if (T.ring) atomicAdd(&T.stats[kg < T.k_cur_end ? 8 : 9], 1ull);
+        } else {
+            T.states[(size_t)slot * T.V] = pack(np);
+            T.slot_ply[slot] = (uint32_t)ply + 1u;
+        }
+    }
+    // one bit per game: lane g of the result collects the lead lanes' verdicts
+    const uint64_t ended = __ballot(active && lead && (f || fault)), goes = __ballot(active && lead && !(f || fault));
+    uint32_t out = 0u;
+#pragma unroll
+    for (int i = 0; i < NG; ++i) out |= (uint32_t)((goes >> (i * G)) & 1ull) << i | (uint32_t)((ended >> (i * G)) & 1ull) << (16 + i);
+    return out;
+}
+
 #ifdef AGZ_PSTAMPS
 #define PSTAMP(x) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); x += n_ - ps_t; ps_t = n_; } while (0)
 #else
@@ -57,7 +170,10 @@ struct PersistPar { SmallPar S; PersistTail X; };
 //     the pool (a run whose games end before they are old must not starve half the chip);
 //   * slots empty at the entry (a chain's next call) and slots of a pool that has run dry take whatever waits, the queue included,
 //     whatever the preference: the queue drains before the launch can end.
-template <int FAM, int NC, int KPL, int G, int TW, bool AGE, typename TailFn, typename SearchFn>
+// GROUPSTEP: the ply step of all the wave's games at once, one per lane-group (advance_groups) — the 128-wide kernels; the wide-trunk
+// kernels keep the one-game-after-the-other form (their ply step is 0.3 % of the time and the group form's registers cost the 128-register
+// build of the 64-leaf network pass another 28 spilled registers)
+template <int FAM, int NC, int KPL, int G, int TW, bool AGE, bool GROUPSTEP, typename TailFn, typename SearchFn>
 __device__ __forceinline__ void persist_loop(uint8_t* const lds, const TailFn tail, const SearchFn search) {
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     constexpr int NG = 64 / G;                                    // games of a tree wave
@@ -167,12 +283,23 @@ __device__ __forceinline__ void persist_loop(uint8_t* const lds, const TailFn ta
             int order = TAKE_POOL;
             if constexpr (AGE) order = !pool_open ? TAKE_QUEUE : (pref_old ? (starve >= 3u ? TAKE_QUEUE_THEN_POOL : TAKE_QUEUE) : TAKE_POOL_THEN_QUEUE);
             uint32_t next_mask = 0u, dead = 0u;
+            // all the wave's games at once, one per lane-group; then the slots whose game has ended (and the empty ones), one after the other
+            uint32_t adv = 0u;
+            if constexpr (GROUPSTEP) {
+                if (amask) adv = advance_groups<FAM, NC, KPL, G>(Q.P, slot0, amask, ranked);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // (the roots the lead lanes have written are read by whole waves below)
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
 #pragma unroll 1
             for (int g = 0; g < NG; ++g) {
                 const int slot = slot0 + g;
                 if (slot >= Q.P.L) break;
                 uint32_t r;
-                if ((amask >> g) & 1u) r = advance_slot<FAM, NR, NC, true>(Q.P, slot, ranked, order);
+                if (GROUPSTEP && ((adv >> g) & 1u)) r = 1u | (ufirst(Q.P.slot_ply[slot]) << 8);   // the game goes on
+                else if (GROUPSTEP && ((amask >> g) & 1u)) {      // the game has ended: the slot takes a game that waits, if there is one
+                    r = take_game<true>(Q.P, slot, order);
+                    if (lane == 0) { if (!r) atomicAdd(&Q.P.stats[7], 1ull); Q.P.alive[slot] = r & 1u; }
+                } else if ((amask >> g) & 1u) r = advance_slot<FAM, NR, NC, true>(Q.P, slot, ranked, order);
                 else {                                            // a slot without a game: something may wait for it now
                     r = AGE ? take_game<true>(Q.P, slot, order) : 0u;
                     if (r && lane == 0) Q.P.alive[slot] = 1u;
@@ -260,7 +387,12 @@ __global__ __launch_bounds__(64 * (TW == 8 ? 8 : NW_WAVES), WV) void k_selfplay_
     const KArg karg = (KArg)__builtin_amdgcn_kernarg_segment_ptr();
     const auto tail = [=]() -> const PersistTail& { KArg p = karg; asm volatile("" : "+s"(p)); return ((const PersistPar*)p)->X; };
     // (one copy of the rollout loop per row form: the two tree bodies inside ONE loop cost 38 spilled registers)
-    persist_loop<FAM, NC, KPL, G, TW, AGE>(lds_small, tail, [&](const uint32_t amask, const bool ranked, EagerCarry& C) {
+#ifdef AGZ_PLYSTEP_SERIAL
+    constexpr bool GS = false;
+#else
+    constexpr bool GS = true;
+#endif
+    persist_loop<FAM, NC, KPL, G, TW, AGE, GS>(lds_small, tail, [&](const uint32_t amask, const bool ranked, EagerCarry& C) {
         if constexpr (AGE) {
             if (ranked) persist_search<FAM, NC, KPL, H, TW, WV, G, KPR2>(lds_small, amask, C);
             else persist_search<FAM, NC, KPL, H, TW, WV, G, 0>(lds_small, amask, C);
@@ -270,9 +402,14 @@ __global__ __launch_bounds__(64 * (TW == 8 ? 8 : NW_WAVES), WV) void k_selfplay_
 
 // the shapes of AGZ_SMALL_SHAPES in their full-batch form (64-game workgroups of eight tree waves, four waves per SIMD) and the narrow
 // form of the few-action games (Connect4: 4 lanes per tree, 16 trees per wave, workgroups of four waves, two waves per SIMD)
-#define AGZ_PERSIST_VARIANTS(F, C, K, KW) KW template __global__ void k_selfplay_small<F, C, K, 128, 8, 4>(const PersistPar);
+// two workgroup shapes: 32 games (four waves, four workgroups per CU: half the waves at every barrier of the network phase — the default
+// since it measured +1.7 % without and +2 % with age classes on the headline shape, although every layer's weights stream twice per 64
+// games) and 64 games (eight waves, two per CU; AGZ_PERSIST_TW=8)
+#define AGZ_PERSIST_VARIANTS(F, C, K, KW) KW template __global__ void k_selfplay_small<F, C, K, 128, 8, 4>(const PersistPar); \
+                                          KW template __global__ void k_selfplay_small<F, C, K, 128, 4, 4>(const PersistPar);
 // ... with age classes: (family, chunks, actions per lane, rows per lane by legal rank) — the 9x9 boards (81 actions, old from ply 17 on)
-#define AGZ_PERSIST_AGE_VARIANTS(F, C, K, R, KW) KW template __global__ void k_selfplay_small<F, C, K, 128, 8, 4, 8, R>(const PersistPar);
+#define AGZ_PERSIST_AGE_VARIANTS(F, C, K, R, KW) KW template __global__ void k_selfplay_small<F, C, K, 128, 8, 4, 8, R>(const PersistPar); \
+                                                 KW template __global__ void k_selfplay_small<F, C, K, 128, 4, 4, 8, R>(const PersistPar);
 #define AGZ_PERSIST_AGE_SHAPES(X) X(F_LINE, 2, 12, 8) X(F_HEX, 2, 12, 8)
 #define AGZ_PERSIST_NARROW_VARIANTS(F, C, K, GG, KW) KW template __global__ void k_selfplay_small<F, C, K, 128, 4, 2, GG>(const PersistPar);
 #define AGZ_PERSIST_NARROW_SHAPES(X) X(F_C4, 1, 4, 4)

@@ -4,7 +4,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libagz.so")
+LIB_PATH = os.environ.get("AGZ_LIB_PATH") or os.path.join(_HERE, "libagz.so")   # (AGZ_LIB_PATH: an alternative build of the library, A/B measurements)
 CSRC = os.path.join(_HERE, "csrc")
 _LIB = None
 

@@ -266,6 +266,7 @@ int  agz_set_profiling(agz_engine *h, int mode);       /* HIP events per launch:
  *                          boundary, no host wake-up per ply) wherever such a kernel exists — 128-wide trunk, bf16 mode, all slots resident —
  *                          (1), or never (0); default: calls that refill their slots (agz_selfplay with more games than slots,
  *                          agz_selfplay_chain) on engines of more than 96 slots per CU
+ *   AGZ_PERSIST_TW=8       persistent self-play with 64-game workgroups of eight waves, two per CU, instead of 32-game workgroups of four (default)
  *   AGZ_AGE=0              persistent self-play without age classes (every workgroup keeps node rows by action; nothing migrates)
  *   AGZ_AGE_OLD16=n        ... n of 16 CU pairs prefer old games (default 8);  AGZ_AGE_CLASS=block: odd workgroups prefer old games (tests);
  *                          AGZ_AGE_BACKLOG=n: young-preferring workgroups keep their old games while n games wait in the migration queue

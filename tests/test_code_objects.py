@@ -83,12 +83,14 @@ def test_benchmarked_kernels_do_not_spill_vector_registers():
     # Ceilings, so that growth does not go unnoticed: none for the 9x9 / Reversi shapes without age classes; the build with both row forms
     # reloads a handful of loop-invariant values (zeros of unused boards) once per rollout; the 4-lane Connect4 build parks four registers
     # of the ply step; the wide-trunk builds spill like the search kernels they wrap
-    for fam_nc_kpl in ("0, 2, 12", "2, 2, 12", "3, 1, 12", "3, 1, 8"):
-        k = md[f"k_selfplay_small<{fam_nc_kpl}, 128, 8, 4, 8, 0>"]
-        assert k["vgpr_spill_count"] == 0 and k["vgpr_count"] <= 128 and k["sgpr_spill_count"] <= 64, (fam_nc_kpl, k)
-    for fam_nc_kpl in ("0, 2, 12", "2, 2, 12"):
-        k = md[f"k_selfplay_small<{fam_nc_kpl}, 128, 8, 4, 8, 8>"]
-        assert k["vgpr_spill_count"] <= 8 and k["private_segment_fixed_size"] <= 48 and k["vgpr_count"] <= 128, (fam_nc_kpl, k)
+    # (two workgroup shapes: 32 games in four waves — the default — and 64 games in eight)
+    for tw in (4, 8):
+        for fam_nc_kpl in ("0, 2, 12", "2, 2, 12", "3, 1, 12", "3, 1, 8"):
+            k = md[f"k_selfplay_small<{fam_nc_kpl}, 128, {tw}, 4, 8, 0>"]
+            assert k["vgpr_spill_count"] == 0 and k["vgpr_count"] <= 128 and k["sgpr_spill_count"] <= 64, (fam_nc_kpl, tw, k)
+        for fam_nc_kpl in ("0, 2, 12", "2, 2, 12"):
+            k = md[f"k_selfplay_small<{fam_nc_kpl}, 128, {tw}, 4, 8, 8>"]
+            assert k["vgpr_spill_count"] <= 8 and k["private_segment_fixed_size"] <= 48 and k["vgpr_count"] <= 128, (fam_nc_kpl, tw, k)
     k = md["k_selfplay_small<1, 1, 4, 128, 4, 2, 4, 0>"]
     assert k["vgpr_spill_count"] <= 4 and k["vgpr_count"] <= 256, k
     for fam_nc_kpl in ("0, 2, 12", "2, 2, 12", "3, 1, 12"):
