@@ -68,6 +68,9 @@ AGZ_PERSIST_NARROW_SHAPES(X)
 #define X(F, C, K, R) AGZ_PERSIST_AGE_VARIANTS(F, C, K, R, extern)
 AGZ_PERSIST_AGE_SHAPES(X)
 #undef X
+#define X(F, C, K4) AGZ_PERSIST_BIG4_VARIANTS(F, C, K4, extern)
+AGZ_PERSIST_BIG4_SHAPES(X)
+#undef X
 #define X(F, C, K, R) AGZ_SMALL_CMP_VARIANTS(F, C, K, R, extern) AGZ_BIG_CMP_VARIANTS(F, C, K, R, extern)
 AGZ_SMALL_CMP_SHAPES(X)
 #undef X
@@ -171,8 +174,11 @@ struct agz_engine {
     // ... with age classes (workgroups that prefer old games run rows by legal rank; games migrate through a queue in device memory):
     // age_kpr rows per lane of the old body, age_on (AGZ_AGE=0 turns it off), age_old16 of 16 CU pairs prefer old games (AGZ_AGE_OLD16),
     // age_by_block (AGZ_AGE_CLASS=block, tests: odd workgroups prefer old games), age_backlog: the queue's length at which nothing is pushed
+    // wide trunks: ONE 128-game workgroup per CU, 4 lanes per tree (k_selfplay_big4: a layer's weights stream once per 128 leaves); big4: AGZ_BIG4=1 wherever it
+    // fits, 0 never; default: engines of more than 64 slots per CU (where the 8-lane form needs two 64-game workgroups per CU at 128 registers)
+    persist_big_fn k_persist_big4 = nullptr; int big4_kpl = 0, big4 = -1;
     persist_fn k_persist_tw4 = nullptr, k_persist_tw4_age = nullptr; bool persist_tw4 = true;   // 32-game workgroups of four waves (default; AGZ_PERSIST_TW=8: 64-game workgroups of eight)
-    persist_fn k_persist_age = nullptr; int age_kpr = 0; bool age_on = true, age_by_block = false; int age_old16 = 8, age_backlog = 0;
+    persist_fn k_persist_age = nullptr; int age_kpr = 0; bool age_on = true, age_by_block = false, age_by_wave = false; int age_old16 = 8, age_backlog = 0;
     MigEntry* mq_buf = nullptr; unsigned long long* mq_ctr = nullptr; uint32_t mq_cap = 0; bool mq_dirty = false;
     int run_ahead = 8;                    // plies the ply loop may queue before it waits for a ply's counters (AGZ_RUN_AHEAD; while the pool cannot run dry)
     uint64_t age_ranked_searches = 0, age_searches = 0, age_pushed = 0;   // persistent form since the last agz_get_kernel_times(reset): game-searches with rows by rank / all / games migrated
@@ -221,6 +227,9 @@ static bool bind_kernels(agz_engine* h) {
 #undef Z
 #define Z(F, C, K, GG) if (P.fam == F && P.NC == C && GG * K >= P.A && GG * K <= 8 * kpl) { h->k_persist_nar = k_selfplay_small<F, C, K, 128, 4, 2, GG>; h->persist_nar_g = GG; h->persist_nar_kpl = K; }
     AGZ_PERSIST_NARROW_SHAPES(Z)
+#undef Z
+#define Z(F, C, K4) if (P.fam == F && P.NC == C && 2 * kpl == K4) { h->k_persist_big4 = k_selfplay_big4<F, C, K4, 512>; h->big4_kpl = K4; }
+    AGZ_PERSIST_BIG4_SHAPES(Z)
 #undef Z
 #define Z(F, C, K, R) if (P.fam == F && P.NC == C && kpl == K) { h->k_persist_age = k_selfplay_small<F, C, K, 128, 8, 4, 8, R>; h->k_persist_tw4_age = k_selfplay_small<F, C, K, 128, 4, 4, 8, R>; h->age_kpr = R; }
     AGZ_PERSIST_AGE_SHAPES(Z)
@@ -438,6 +447,9 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
         for (int i = 0; i < 2; ++i) if (h->k_persist_big[i]) FA_(hipFuncSetAttribute((const void*)h->k_persist_big[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         if (h->k_persist_tw4) FA_(hipFuncSetAttribute((const void*)h->k_persist_tw4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         if (h->k_persist_tw4_age) FA_(hipFuncSetAttribute((const void*)h->k_persist_tw4_age, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if (h->k_persist_big4) FA_(hipFuncSetAttribute((const void*)h->k_persist_big4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        e3 = getenv("AGZ_BIG4");
+        if (e3) h->big4 = atoi(e3) > 0 ? 1 : 0;
         e3 = getenv("AGZ_PERSIST_TW");
         h->persist_tw4 = !(e3 && atoi(e3) == 8) && h->k_persist_tw4;
         e3 = getenv("AGZ_AGE");
@@ -446,6 +458,8 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
         if (e3 && atoi(e3) >= 0 && atoi(e3) <= 16) h->age_old16 = atoi(e3);
         e3 = getenv("AGZ_AGE_CLASS");
         if (e3) h->age_by_block = strcmp(e3, "block") == 0;
+        e3 = getenv("AGZ_AGE_WAVE");
+        if (e3) h->age_by_wave = atoi(e3) > 0;
         e3 = getenv("AGZ_AGE_BACKLOG");
         if (e3 && atoi(e3) > 0) h->age_backlog = atoi(e3);
         e3 = getenv("AGZ_SMALL4_OCC");
@@ -1589,6 +1603,17 @@ static int finish_call(agz_engine* h, int ngames, bool chain, unsigned long long
 }
 
 // ---- one launch per call: the persistent self-play kernel (agz_selfplay_small.hpp) -------------------------------------------------
+// the wide-trunk form with ONE 128-game workgroup per CU (k_selfplay_big4): built for the game shape, every workgroup resident, the 128-row
+// activation tile (shared with the eight waves' tree tables) + flags + a work list of at least 64 entries per wave inside a CU's LDS
+static bool use_big4(const agz_engine* h) {
+    const DevNet& n = h->net[0];
+    if (!h->k_persist_big4 || !n.wbig || n.H != 512 || h->big4 == 0) return false;
+    if ((h->Lmax + 127) / 128 > h->cus) return false;
+    if (h->big4 < 0 && h->Lmax <= 64 * h->cus) return false;                    // (up to 64 slots per CU the 8-lane form has a CU to itself at 256 registers)
+    const int big_rowb = (2 * std::max(n.H, 32 * n.k0r) + 255) & ~255;
+    const size_t xch_off = (std::max((size_t)8 * (size_t)eager_lds_layout(h->V, 16).total, (size_t)128 * big_rowb) + 15) & ~(size_t)15;
+    return xch_off + 4 * 144 + 16 + 8 * 256 <= (size_t)(160 * 1024);
+}
 static bool persist_shape(const agz_engine* h) {
     const DevNet& n = h->net[0];
     if (h->persist == 0 || h->cfg.nn_mode != AGZ_NN_BF16 || !n.loaded) return false;
@@ -1608,6 +1633,7 @@ static bool persist_shape(const agz_engine* h) {
         const size_t io_off = (std::max((size_t)tw * tree_lds, (size_t)gpwg * 2 * (n.H * 2 + 16)) + 15) & ~(size_t)15;
         return io_off + (size_t)tw * NG * rs + (size_t)tw * (16 * NG + 16) + 16 + (size_t)tw * 64 <= cu_lds;   // (+ at least 16 work-list entries per wave)
     }
+    if (n.H == 512 && use_big4(h)) return true;
     if (n.H == 512) {
         if (!h->k_persist_big[0] || !n.wbig || h->big8 < 0) return false;
         const size_t cu_lds = (size_t)(160 * 1024) / (size_t)((h->Lmax + 63) / 64 <= h->cus ? 1 : 2);
@@ -1689,7 +1715,8 @@ static int run_games_persist(agz_engine* h, int ngames, int V, float cpuct, int 
     const bool age = !big && !nar && h->k_persist_age && h->age_on && !h->no_compact && 2 * h->V >= 8 * h->age_kpr && (chain || (long long)ngames > (long long)slots);
     if (!big && !nar && !h->k_persist) { h->fail("no persistent self-play kernel for this game shape"); return AGZ_ERR_UNSUPPORTED; }
     const bool tw4 = !big && !nar && h->persist_tw4;
-    const int G = nar ? h->persist_nar_g : 8, NG = 64 / G, tw = (nar || tw4) ? 4 : 8, gpwg = tw * NG;
+    const bool big4 = big && use_big4(h);                                       // one 128-game workgroup per CU, 4 lanes per tree
+    const int G = nar ? h->persist_nar_g : (big4 ? 4 : 8), NG = 64 / G, tw = (nar || tw4) ? 4 : 8, gpwg = tw * NG;
     const unsigned wgs = (unsigned)((h->Lmax + gpwg - 1) / gpwg);
     PersistTail X; memset(&X, 0, sizeof X);
     fill_plypar(h, X.P, 0, tau_plies, false);
@@ -1703,7 +1730,7 @@ static int run_games_persist(agz_engine* h, int ngames, int V, float cpuct, int 
         X.P.mq.backlog_max = (uint32_t)(h->age_backlog > 0 ? h->age_backlog : std::max(64, h->Lmax / 16));
         if (X.P.mq.backlog_max > h->mq_cap / 2u) X.P.mq.backlog_max = h->mq_cap / 2u;
         X.P.mq.age = (uint32_t)std::max(0, h->G.A - 8 * h->age_kpr);
-        X.old16 = (uint32_t)h->age_old16; X.class_by_block = h->age_by_block ? 1u : 0u;
+        X.old16 = (uint32_t)h->age_old16; X.class_by_block = (h->age_by_block ? 1u : 0u) | (h->age_by_wave ? 2u : 0u);
         h->mq_dirty = true;
     }
     const bool age_kernel = X.P.mq.buf != nullptr;
@@ -1725,19 +1752,19 @@ static int run_games_persist(agz_engine* h, int ngames, int V, float cpuct, int 
         B.whead = n.w16 + (size_t)(n.INP / 32) * (n.H / 16) * 512 + (size_t)n.T * (n.H / 32) * (n.H / 16) * 512;
         B.bias_head = n.bias_head; B.logits = h->logits; B.LGS = h->LGS; B.vout = h->v_eval;
         B.L = h->Lmax; B.T = n.T; B.A = h->G.A; B.AOP = n.AOP; B.K0R = n.k0r; B.ROWB = big_rowb;
-        wgcu = (int)wgs <= h->cus ? 1 : 2;
-        S.V = V; S.tree_lds = (int)h->reg_lds;
-        S.xch_off = (int)((std::max((size_t)8 * h->reg_lds, (size_t)8 * 8 * big_rowb) + 15) & ~(size_t)15);
+        wgcu = (big4 || (int)wgs <= h->cus) ? 1 : 2;
+        S.V = V; S.tree_lds = big4 ? eager_lds_layout(h->V, NG).total : (int)h->reg_lds;
+        S.xch_off = (int)((std::max((size_t)8 * (size_t)S.tree_lds, (size_t)gpwg * big_rowb) + 15) & ~(size_t)15);
         const size_t shared = (size_t)S.xch_off + 4 * 144 + 16;                  // ... + the workgroup's two flag words
         Q.X = X; Q.X.flag_off = (int)shared - 16;
         const size_t cu_lds = cu_lds_all / (size_t)wgcu;
         const size_t room = cu_lds > shared ? cu_lds - shared : 0;
-        S.wl_off = (int)shared; S.wl_bytes = (int)std::min({(size_t)(8 * h->V * 4), (room / 8) & ~(size_t)15, (size_t)h->wl_lds_max});
+        S.wl_off = (int)shared; S.wl_bytes = (int)std::min({(size_t)(NG * h->V * 4), (room / 8) & ~(size_t)15, (size_t)h->wl_lds_max});
         const size_t lds = shared + (size_t)8 * S.wl_bytes;
         if (lds > cu_lds) { h->in_ply_loop = false; h->fail("persistent self-play kernel: %zu bytes of LDS per workgroup", lds); return AGZ_ERR_UNSUPPORTED; }
         h->rd_rec_bytes = h->tp.rec_bytes;
         hipEventRecord(h->ev_ply0, h->stream);
-        hipLaunchKernelGGL(h->k_persist_big[wgcu - 1], dim3(wgs), dim3(NB_THREADS), lds, h->stream, Q);
+        hipLaunchKernelGGL(big4 ? h->k_persist_big4 : h->k_persist_big[wgcu - 1], dim3(wgs), dim3(NB_THREADS), lds, h->stream, Q);
     } else {
         PersistPar Q; memset(&Q, 0, sizeof Q);
         SmallPar& S = Q.S;
@@ -1778,13 +1805,19 @@ static int run_games_persist(agz_engine* h, int ngames, int V, float cpuct, int 
     const int waiting = (int)(mqc[0] - mqc[1]);                                 // games on their way between workgroups: in flight like those in slots
     h->age_ranked_searches += acc[4]; h->age_searches += acc[2]; h->age_pushed += acc[5];
     const int64_t rollouts = (int64_t)acc[2] * V;
+#ifdef AGZ_BIG4STAMPS
+    fprintf(stderr, "[big4stamps] cycles summed over waves: tree step %llu  barrier before the pass %llu  network pass %llu  barrier behind it %llu\n", acc[12], acc[13], acc[14], acc[15]);
+    fprintf(stderr, "[big4stamps] inside the pass: planes + first barrier %llu  k-loops %llu  barrier %llu  epilogues %llu  barrier %llu  head %llu\n", acc[6], acc[7], acc[8], acc[9], acc[10], acc[11]);
+#endif
 #ifdef AGZ_PSTAMPS
     fprintf(stderr, "[pstamps] cycles summed over waves: flag/barrier %llu  search %llu  counters %llu  ply step %llu   (ply step share %.2f %%)\n", acc[8], acc[9], acc[10], acc[11],
             100.0 * (double)acc[11] / (double)(acc[8] + acc[9] + acc[10] + acc[11] + 1));
 #endif
     if (big) {
-        char b[320]; snprintf(b, sizeof b, "k_selfplay_big<KPL=%d,H=512,WG=%d> (persistent: one launch per self-play call, a workgroup loops over the plies of its 64 games)", h->reg_kpl, wgcu);
-        h->form_tree = b; h->form_nn = "inside k_selfplay_big (mlp_big_body<512,4>)";
+        char b[320];
+        if (big4) snprintf(b, sizeof b, "k_selfplay_big4<KPL=%d,H=512,G=4> (persistent: one launch per self-play call, ONE workgroup per CU loops over the plies of its 128 games)", h->big4_kpl);
+        else snprintf(b, sizeof b, "k_selfplay_big<KPL=%d,H=512,WG=%d> (persistent: one launch per self-play call, a workgroup loops over the plies of its 64 games)", h->reg_kpl, wgcu);
+        h->form_tree = b; h->form_nn = big4 ? "inside k_selfplay_big4 (mlp_big_body<512,8>)" : "inside k_selfplay_big (mlp_big_body<512,4>)";
     } else {
         char ab[96] = ""; if (age_kernel) snprintf(ab, sizeof ab, "; age classes: rows by legal rank KPR=%d in workgroups whose games are all at ply >= %u", h->age_kpr, X.P.mq.age);
         char b[320]; snprintf(b, sizeof b, "k_selfplay_small<KPL=%d,H=128,TW=%d,WV=%d,G=%d%s> (persistent: one launch per self-play call, a workgroup loops over the plies of its %d games%s)",

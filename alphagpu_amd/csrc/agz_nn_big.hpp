@@ -40,7 +40,13 @@ struct BigPar {
 // it had just been used up, and its L2 latency stood in front of every second k-step — and the B operand of leaf tile i + 2 is read from
 // LDS while the MFMAs of tile i issue (explicit schedule groups).  Same MFMA instruction, same k order per accumulator: same bits.
 template <int H, int MT, bool PIPE = false, typename SlotOf>
-__device__ __forceinline__ void mlp_big_body(const BigPar& P, uint8_t* const act, SlotOf slot_of) {
+__device__ __forceinline__ void mlp_big_body(const BigPar& P, uint8_t* const act, SlotOf slot_of, unsigned long long* const nn_dbg = nullptr) {
+#ifdef AGZ_BIG4STAMPS
+    unsigned long long nst_[6] = {0, 0, 0, 0, 0, 0}, nst_t = __builtin_amdgcn_s_memtime();
+#define NBSTAMP(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); nst_[i] += n_ - nst_t; nst_t = n_; } while (0)
+#else
+#define NBSTAMP(i) do { } while (0)
+#endif
     constexpr int NT = H / 16, KTH = H / 32, NTW = NT / 8;       // neuron tiles per layer / k-rows per layer / neuron tiles per wave
     constexpr int MB = 16 * MT;                                  // leaves per workgroup
     const int ROWB = P.ROWB;
@@ -60,17 +66,33 @@ __device__ __forceinline__ void mlp_big_body(const BigPar& P, uint8_t* const act
     NB_LOADROW(A0); NB_LOADROW(A1);
     if constexpr (PIPE) { NB_LOADROW(A2); NB_LOADROW(A3); }
 
-    {   // input planes -> columns [0, 32*K0R) of the activation tile, zero beyond INP
+    {   // input planes -> columns [0, 32*K0R) of the activation tile, zero beyond INP: NB_THREADS / MB threads per row, each takes every
+        // (NB_THREADS / MB)-th 16-byte segment of its row; six loads are requested before the first is stored (the loop used to pay one memory
+        // round trip and an integer division per segment: 4 us per pass)
         const int segs = P.K0R * 4, isegs = P.INP / 8;
         const AGZ_GLB uint16_t* gp = (const AGZ_GLB uint16_t*)P.planes;
-        for (int c = tid; c < MB * segs; c += NB_THREADS) {
-            const int row = c / segs, seg = c - row * segs, mm = slot_of(row);
-            v4u v = {0u, 0u, 0u, 0u};
-            if (mm < P.L && seg < isegs) v = *(const AGZ_GLB v4u*)(gp + (size_t)mm * P.INP + seg * 8);
-            *reinterpret_cast<v4u*>(act + (size_t)row * ROWB + ((seg * 16) ^ ((row & 15) << 4))) = v;
+        constexpr int TPR = NB_THREADS / MB, NB6 = 6;
+        const int row = tid / TPR, s0 = tid % TPR, mm = slot_of(row);
+        const AGZ_GLB uint16_t* const src = gp + (size_t)(mm < P.L ? mm : 0) * P.INP;
+        uint8_t* const drow = act + (size_t)row * ROWB;
+        const int rsw = (row & 15) << 4;
+        for (int sb = s0; sb < segs; sb += NB6 * TPR) {
+            v4u v[NB6];
+#pragma unroll
+            for (int j = 0; j < NB6; ++j) {
+                const int seg = sb + j * TPR;
+                v[j] = (v4u){0u, 0u, 0u, 0u};
+                if (mm < P.L && seg < isegs) v[j] = *(const AGZ_GLB v4u*)(src + seg * 8);
+            }
+#pragma unroll
+            for (int j = 0; j < NB6; ++j) {
+                const int seg = sb + j * TPR;
+                if (seg < segs) *reinterpret_cast<v4u*>(drow + ((seg * 16) ^ rsw)) = v[j];
+            }
         }
     }
     __syncthreads();
+    NBSTAMP(0);
 
     // LDS layout of the activation tile: row r at r * ROWB (a multiple of 256 bytes = one bank row), byte b of the row at b ^ ((r & 15) << 4):
     // the 16-byte slot of a k-chunk is XORed with the row's low bits.  ds_read_b128 is serviced in four groups of 16 lanes
@@ -125,8 +147,53 @@ __device__ __forceinline__ void mlp_big_body(const BigPar& P, uint8_t* const act
 #pragma unroll 1
             for (int kt = 0; kt < KTl; kt += 2) { NB_STEP(A0, kt); NB_STEP(A1, kt + 1); }
         }
-        __syncthreads();                                          // every wave has read the layer's input
+        NBSTAMP(1);
         const bool res = l > 0;
+        if constexpr (PIPE) {
+            // builds with register room: the epilogue's ARITHMETIC runs in front of the barrier — relu, the residual's old value (this lane's own
+            // bytes of the tile: nobody else writes them), the sum, the bf16 pair — while the slower waves still read the layer's input; behind
+            // the barrier only the stores are left (measured on the 128-leaf pass: 2.6 us of epilogue + 1.4 us at the barrier per layer before)
+            uint2 pk[MT][NTW];
+            // (the old values are requested four tiles ahead of their use: left alone the compiler waits for every single read; all of them at once
+            //  — 64 registers beside 128 accumulators and four k-rows of fragments in flight — spill.  The reads are UNCONDITIONAL — layer 0 reads
+            //  its own input bytes and masks them — so that the block is straight-line code: behind a branch per tile the ring of registers
+            //  became moves that waited for the read just issued)
+            constexpr int NTILE = MT * NTW, PD = NTILE >= 4 ? 4 : NTILE;
+            uint2 oldv[PD];
+            auto old_at = [&](const int i) -> uint2 {
+                return *reinterpret_cast<const uint2*>(act + (size_t)((i / NTW) * 16 + lrow) * ROWB + (((16 * (wave * NTW + (i % NTW)) + 4 * q4) * 2) ^ swz));
+            };
+#pragma unroll
+            for (int i = 0; i < PD; ++i) oldv[i] = old_at(i);
+#pragma unroll
+            for (int i = 0; i < NTILE; ++i) {
+                const int mt = i / NTW, t = i % NTW;
+                // (relu as one integer max per element, see relu_bits: same bits for finite accumulators)
+                float x0 = relu_bits(acc[mt][t][0]), x1 = relu_bits(acc[mt][t][1]), x2 = relu_bits(acc[mt][t][2]), x3 = relu_bits(acc[mt][t][3]);
+                uint2 o = oldv[i % PD];
+                if (i + PD < NTILE) oldv[i % PD] = old_at(i + PD);
+                o.x = res ? o.x : 0u; o.y = res ? o.y : 0u;       // (x + 0 = x for the non-negative x of a relu: layer 0 is unchanged)
+                x0 += __uint_as_float(o.x << 16); x1 += __uint_as_float(o.x & 0xffff0000u);
+                x2 += __uint_as_float(o.y << 16); x3 += __uint_as_float(o.y & 0xffff0000u);
+                pk[mt][t] = make_uint2(pk_bf16(x0, x1), pk_bf16(x2, x3));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            NBSTAMP(3);
+            __syncthreads();                                      // every wave has read the layer's input
+            NBSTAMP(2);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                uint8_t* const orow = act + (size_t)(mt * 16 + lrow) * ROWB;
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) *reinterpret_cast<uint2*>(orow + (((16 * (wave * NTW + t) + 4 * q4) * 2) ^ swz)) = pk[mt][t];
+            }
+            NBSTAMP(3);
+            __syncthreads();
+            NBSTAMP(4);
+            continue;
+        }
+        __syncthreads();                                          // every wave has read the layer's input
+        NBSTAMP(2);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             uint8_t* const orow = act + (size_t)(mt * 16 + lrow) * ROWB;   // (this lane's row: its bytes at b ^ swz)
@@ -145,13 +212,72 @@ __device__ __forceinline__ void mlp_big_body(const BigPar& P, uint8_t* const act
                 *dst = make_uint2(pk_bf16(x0, x1), pk_bf16(x2, x3));
             }
         }
+        NBSTAMP(3);
         __syncthreads();
+        NBSTAMP(4);
     }
 #undef NB_STEP
 #undef NB_LOADROW
 
     {   // head: D = X * W^T (logits leave row-major); wave w takes neuron tile w of the AOP/16 head tiles
         const int NTH = P.AOP / 16;
+        if constexpr (PIPE && MT >= 4) {
+            // builds with register room: a head tile's leaves in four parts, NTH x 4 (tile, part) units dealt to the waves in runs of consecutive
+            // units — a head of six tiles (Gobang 9x9: 82 outputs) keeps all eight waves busy instead of six — so that a wave needs the
+            // fragments of two tiles at most: both requested at once, up front
+            constexpr int HQ = 4, MQ = MT / HQ;
+            const int NU = NTH * HQ, UPW = (NU + 7) / 8, u0 = wave * UPW, u1 = u0 + UPW < NU ? u0 + UPW : NU;
+            auto head_load = [&](bf16x8 (&dst)[KTH], const int tile) {
+                const AGZ_GLB v4u* hw = (const AGZ_GLB v4u*)P.whead + (size_t)tile * 64 + lane;
+#pragma unroll
+                for (int kt = 0; kt < KTH; ++kt) { const v4u w_ = hw[(size_t)kt * NTH * 64]; dst[kt] = *reinterpret_cast<const bf16x8*>(&w_); }
+            };
+            auto head_unit = [&](const bf16x8 (&w)[KTH], const int u) {
+                const int tile = u / HQ, m0 = (u % HQ) * MQ;
+                f32x4 hacc[MQ];
+#pragma unroll
+                for (int m = 0; m < MQ; ++m) { hacc[m][0] = 0.0f; hacc[m][1] = 0.0f; hacc[m][2] = 0.0f; hacc[m][3] = 0.0f; }
+#pragma unroll
+                for (int kt = 0; kt < KTH; ++kt) {
+#pragma unroll
+                    for (int m = 0; m < MQ; ++m) {
+                        const bf16x8 x = *reinterpret_cast<const bf16x8*>(brow + (size_t)(m0 + m) * 16 * ROWB + ((kt * 64 + q4 * 16) ^ swz));
+                        hacc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, w[kt], hacc[m], 0, 0, 0);
+                    }
+                }
+                // hacc[m][r] = out[leaf of tile row 16 (m0 + m) + 4 q4 + r][n = 16 tile + (lane & 15)]
+                const int n = 16 * tile + (lane & 15);
+                const float bias = P.bias_head[n];
+#pragma unroll
+                for (int m = 0; m < MQ; ++m) {
+                    int mw[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mw[r] = slot_of(16 * (m0 + m) + 4 * q4 + r);
+                    if (n < P.A) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (mw[r] < P.L) P.logits[(size_t)mw[r] * P.LGS + n] = hacc[m][r] + bias;
+                    } else if (n == P.A) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (mw[r] < P.L) P.vout[mw[r]] = sigmoid_ool(hacc[m][r] + bias);
+                    }
+                }
+            };
+            if (u0 < NU) {
+                bf16x8 wa[KTH], wb[KTH];
+                const int ta = u0 / HQ, tb = (u1 - 1) / HQ;
+                head_load(wa, ta);
+                if (tb != ta) head_load(wb, ta + 1);
+                int u = u0;
+#pragma unroll 1
+                for (; u < u1 && u / HQ == ta; ++u) head_unit(wa, u);
+                int cur = ta + 1;
+#pragma unroll 1
+                for (; u < u1; ++u) {
+                    if (u / HQ != cur) { cur = u / HQ; head_load(wb, cur); }   // (a wide head: more than two tiles per wave)
+                    head_unit(wb, u);
+                }
+            }
+        } else
         for (int tile = wave; tile < NTH; tile += 8) {
             f32x4 hacc[MT];
 #pragma unroll
@@ -185,6 +311,12 @@ __device__ __forceinline__ void mlp_big_body(const BigPar& P, uint8_t* const act
             }
         }
     }
+    NBSTAMP(5);
+#ifdef AGZ_BIG4STAMPS
+    // [0] first weight requests + planes -> LDS + barrier, [1] k-loops, [2] barrier behind them, [3] epilogues, [4] barrier behind them, [5] head
+    if (nn_dbg && lane == 0) for (int i = 0; i < 6; ++i) atomicAdd(nn_dbg + i, nst_[i]);
+#endif
+#undef NBSTAMP
 }
 
 template <int H, int MT>

@@ -190,7 +190,7 @@ __device__ __forceinline__ void persist_loop(uint8_t* const lds, const TailFn ta
         // CU_ID[11:8] (the pair 2k, 2k + 1 shares an instruction cache), SH_ID[12], SE_ID[15:13]; XCC_ID[3:0]
         const uint32_t key = ((xcc & 15u) << 8) | (((hw >> 12) & 15u) << 4) | ((hw >> 9) & 7u);
         const uint32_t hsh = (key * 2654435761u) >> 28;           // 0 .. 15
-        pref_old = Q.class_by_block ? ((blockIdx.x & 1u) != 0u) : (hsh < Q.old16);
+        pref_old = (Q.class_by_block & 1u) ? ((blockIdx.x & 1u) != 0u) : (hsh < Q.old16);
         pref_old = pref_old && Q.P.mq.buf != nullptr;
     }
     uint32_t starve = 0u;                                         // plies in a row this wave has had a slot without a game
@@ -248,7 +248,9 @@ __device__ __forceinline__ void persist_loop(uint8_t* const lds, const TailFn ta
             __syncthreads();
             const uint32_t f = ufirst(*fw);
             if (!(f & 1u) || (f & 2u)) break;
-            ranked = AGE && !(f & 4u);
+            // (class_by_block bit 1: every WAVE decides for its own games — a young game makes its wave search with rows by action, not the whole workgroup;
+            //  the two forms of the rollout loop meet at the same workgroup barriers)
+            ranked = AGE && ((Q.class_by_block & 2u) ? !young : !(f & 4u));
         }
         PSTAMP(ps_flag);
         // ---- mcts_single (:376-462) for the games of this workgroup

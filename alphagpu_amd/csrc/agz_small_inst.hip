@@ -29,6 +29,10 @@ AGZ_SMALL_NARROW_SHAPES(X)
 #define X(F, C, K, GG) AGZ_PERSIST_NARROW_VARIANTS(F, C, K, GG, )
 AGZ_PERSIST_NARROW_SHAPES(X)
 #undef X
+#elif AGZ_PART == 8
+#define X(F, C, K4) AGZ_PERSIST_BIG4_VARIANTS(F, C, K4, )
+AGZ_PERSIST_BIG4_SHAPES(X)
+#undef X
 #elif AGZ_PART >= 4
 #define X(F, C, K, R) AGZ_SMALL_CMP_VARIANTS(F, C, K, R, ) AGZ_BIG_CMP_VARIANTS(F, C, K, R, )
 #if AGZ_PART == 4

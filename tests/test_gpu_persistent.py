@@ -188,16 +188,20 @@ def test_network_tag_travels_with_every_sample(monkeypatch):
 
 
 # ---- 512-wide trunks: k_selfplay_big ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name,slots,ngames,V", [("gobang9", 70, 160, 16), ("reversi8", 40, 90, 8), ("hex9", 24, 60, 16)])
-def test_persistent_selfplay_with_a_wide_trunk_equals_the_lockstep_oracle(name, slots, ngames, V, monkeypatch):
-    """k_selfplay_big (the rollout loop of k_search_big's 64-game workgroups inside the persistent ply loop): refilled call, then a chain."""
+@pytest.mark.parametrize("name,slots,ngames,V,big4", [("gobang9", 70, 160, 16, "0"), ("reversi8", 40, 90, 8, "0"), ("hex9", 24, 60, 16, "0"),
+                                                      ("gobang9", 200, 420, 16, "1"), ("reversi8", 140, 230, 8, "1"), ("hex9", 24, 60, 16, "1")])
+def test_persistent_selfplay_with_a_wide_trunk_equals_the_lockstep_oracle(name, slots, ngames, V, big4, monkeypatch):
+    """k_selfplay_big (the rollout loop of k_search_big's 64-game workgroups inside the persistent ply loop): refilled call, then a chain.
+    big4: k_selfplay_big4 — ONE 128-game workgroup per CU, sixteen trees per wave on 4 lanes each, the network pass on 128 leaves (the default
+    above 64 slots per CU; AGZ_BIG4=1 forces it at these sizes: a ragged last workgroup, a workgroup with idle waves)."""
     monkeypatch.setenv("AGZ_PERSIST", "1")
+    monkeypatch.setenv("AGZ_BIG4", big4)
     g, og, net, onet = _nets(name, 512, 1)
     ref = O.selfplay(og, onet, ngames, V, 1.5, 25, 9, 1000)
     with M.Engine(g, slots, V, seed=9, game_id_base=1000, nn_mode=M.NN_BF16, sample_capacity_games=ngames) as e:
         e.set_network(net)
         st = e.selfplay(ngames, V, cpuct=1.5, tau_plies=25)
-        assert e.search_form()[0].startswith("k_selfplay_big"), e.search_form()
+        assert e.search_form()[0].startswith("k_selfplay_big4" if big4 == "1" else "k_selfplay_big<"), e.search_form()
         s = e.samples()
         assert st["valid"] and st["nsamples"] == ref["n"] and st["rollouts"] == V * ref["n"]
         assert (st["wins"], st["draws"], st["losses"], st["total_plies"]) == (ref["wins"], ref["draws"], ref["losses"], ref["total_plies"])

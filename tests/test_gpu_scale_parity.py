@@ -438,13 +438,15 @@ def test_full_size_generation_slice_equals_the_oracle_through_all_plies(name, H,
             assert parity.same_bits(s[k][keep], ref[k]), f"{name} {H}x{T}: {k} of games {base}..{base + n - 1} differs from the oracle"
 
 
-@pytest.mark.parametrize("name,H,T,V", [("gobang9", 128, 6, 64), ("gobang9", 512, 1, 64)])
-def test_full_size_chain_of_calls_slices_equal_the_oracle(name, H, T, V):
+@pytest.mark.parametrize("name,H,T,V,big4", [("gobang9", 128, 6, 64, None), ("gobang9", 512, 1, 64, None), ("gobang9", 512, 1, 64, "0")])
+def test_full_size_chain_of_calls_slices_equal_the_oracle(name, H, T, V, big4, monkeypatch):
     """agz_selfplay_chain at the benchmarked size (what bench.py times since round 4): three calls of 65536, 32768 and 32768 games on 32768
     slots, each announcing the next (the last one 0).  The batch stays full across the call boundaries (the host's run-ahead, the ring of the
     sample store and the early finishers are all at work); 16 games of every call — started in the call before it, in a refilled slot, at
     the very start — equal the oracle's lock-step games of the same ids, sample for sample."""
     L, n, seed = 32768, 16, 5
+    if big4 is not None:                                             # (512-wide: the default at this size is k_selfplay_big4 — one 128-game workgroup per CU;
+        monkeypatch.setenv("AGZ_BIG4", big4)                         #  "0": two 64-game workgroups per CU, k_selfplay_big<WG=2>)
     g, og = spec(name)
     net, onet = ag.SNetwork2.random(g, H, T), O.OracleNet(og, H, T)
     calls = [(65536, 32768), (32768, 32768), (32768, 0)]
@@ -454,7 +456,7 @@ def test_full_size_chain_of_calls_slices_equal_the_oracle(name, H, T, V):
         for i, (ng, nxt) in enumerate(calls):
             st = e.selfplay_chain(ng, nxt, V, cpuct=1.5, tau_plies=25)
             assert st["valid"] and st["faults"] == 0 and st["wins"] + st["draws"] + st["losses"] == ng
-            assert e.search_form()[0].startswith("k_selfplay_big" if H == 512 else "k_selfplay_small"), e.search_form()
+            assert e.search_form()[0].startswith(("k_selfplay_big<" if big4 == "0" else "k_selfplay_big4") if H == 512 else "k_selfplay_small"), e.search_form()
             s = e.samples()
             assert len(s["ply"]) == st["nsamples"] and int(s["game_id"].min()) == k0 and int(s["game_id"].max()) == k0 + ng - 1
             for base in (k0 + 5, k0 + ng // 2, k0 + ng - n - 3):
