@@ -71,6 +71,9 @@ AGZ_PERSIST_AGE_SHAPES(X)
 #define X(F, C, K4) AGZ_PERSIST_BIG4_VARIANTS(F, C, K4, extern)
 AGZ_PERSIST_BIG4_SHAPES(X)
 #undef X
+#define X(F, C, K4, R4) AGZ_BIG4_VARIANTS(F, C, K4, R4, extern)
+AGZ_BIG4_SHAPES(X)
+#undef X
 #define X(F, C, K, R) AGZ_SMALL_CMP_VARIANTS(F, C, K, R, extern) AGZ_BIG_CMP_VARIANTS(F, C, K, R, extern)
 AGZ_SMALL_CMP_SHAPES(X)
 #undef X
@@ -177,6 +180,7 @@ struct agz_engine {
     // wide trunks: ONE 128-game workgroup per CU, 4 lanes per tree (k_selfplay_big4: a layer's weights stream once per 128 leaves); big4: AGZ_BIG4=1 wherever it
     // fits, 0 never; default: engines of more than 64 slots per CU (where the 8-lane form needs two 64-game workgroups per CU at 128 registers)
     persist_big_fn k_persist_big4 = nullptr; int big4_kpl = 0, big4 = -1;
+    big_fn k_big4[3] = {nullptr, nullptr, nullptr}; int big4_kpr[3] = {0, 0, 0};   // k_search_big4: rows by action, then by legal rank (4-lane rows per lane = twice the 8-lane KPR)
     persist_fn k_persist_tw4 = nullptr, k_persist_tw4_age = nullptr; bool persist_tw4 = true;   // 32-game workgroups of four waves (default; AGZ_PERSIST_TW=8: 64-game workgroups of eight)
     persist_fn k_persist_age = nullptr; int age_kpr = 0; bool age_on = true, age_by_block = false, age_by_wave = false; int age_old16 = 8, age_backlog = 0;
     MigEntry* mq_buf = nullptr; unsigned long long* mq_ctr = nullptr; uint32_t mq_cap = 0; bool mq_dirty = false;
@@ -230,6 +234,9 @@ static bool bind_kernels(agz_engine* h) {
 #undef Z
 #define Z(F, C, K4) if (P.fam == F && P.NC == C && 2 * kpl == K4) { h->k_persist_big4 = k_selfplay_big4<F, C, K4, 512>; h->big4_kpl = K4; }
     AGZ_PERSIST_BIG4_SHAPES(Z)
+#undef Z
+#define Z(F, C, K4, R4) if (P.fam == F && P.NC == C && 2 * kpl == K4) { for (int i = 0; i < 3; ++i) if (!h->k_big4[i] && (i > 0) == (R4 > 0)) { h->k_big4[i] = k_search_big4<F, C, K4, 512, R4>; h->big4_kpr[i] = R4; break; } }
+    AGZ_BIG4_SHAPES(Z)
 #undef Z
 #define Z(F, C, K, R) if (P.fam == F && P.NC == C && kpl == K) { h->k_persist_age = k_selfplay_small<F, C, K, 128, 8, 4, 8, R>; h->k_persist_tw4_age = k_selfplay_small<F, C, K, 128, 4, 4, 8, R>; h->age_kpr = R; }
     AGZ_PERSIST_AGE_SHAPES(Z)
@@ -448,6 +455,7 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
         if (h->k_persist_tw4) FA_(hipFuncSetAttribute((const void*)h->k_persist_tw4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         if (h->k_persist_tw4_age) FA_(hipFuncSetAttribute((const void*)h->k_persist_tw4_age, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         if (h->k_persist_big4) FA_(hipFuncSetAttribute((const void*)h->k_persist_big4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        for (int i = 0; i < 3; ++i) if (h->k_big4[i]) FA_(hipFuncSetAttribute((const void*)h->k_big4[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         e3 = getenv("AGZ_BIG4");
         if (e3) h->big4 = atoi(e3) > 0 ? 1 : 0;
         e3 = getenv("AGZ_PERSIST_TW");
@@ -1111,29 +1119,40 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
             // ... and two of them above 64 games per CU: the 128-register build of the 64-leaf network pass spills ~40 registers and still beats
             // the two-kernel form (first ply at 32768 games of Gobang 9x9 512x8: 12.3 vs 14.1 ms, 24576: 11.2 vs 12.8)
             const bool x8 = b8 && h->L > 64 * h->cus;
+            const int lv = cmp_level(h);                          // rows by the root's legal rank (see k_search_small above)
+            // ... or, there, ONE 128-game workgroup per CU with 4 lanes per tree (k_search_big4): a layer's weights stream once per 128 leaves
+            big_fn k4 = nullptr;
+            if (x8 && h->big4 != 0 && (h->L + 127) / 128 <= h->cus && h->small_gpw <= 0) {
+                if (lv < 0) k4 = h->k_big4[0];
+                else for (int i = 1; i < 3; ++i) if (h->k_big4[i] && h->big4_kpr[i] == 2 * h->cmp[lv].kpr) k4 = h->k_big4[i];
+                const size_t win = (std::max((size_t)8 * (size_t)eager_lds_layout(h->V, 16).total, (size_t)128 * big_rowb) + 15) & ~(size_t)15;
+                if (win + 4 * 144 + 8 * 256 > (size_t)(160 * 1024)) k4 = nullptr;
+            }
             const int twb = b8 ? 8 : 4;
             if (b8) wgs = (h->L + 63) / 64;
-            S.V = V; S.tree_lds = (int)h->reg_lds;
-            S.xch_off = (int)((std::max((size_t)8 * h->reg_lds, (size_t)8 * twb * big_rowb) + 15) & ~(size_t)15);   // (tree waves and helper waves have tables of their own)
+            if (k4) { wgs = (h->L + 127) / 128; S.T.gpw = 16; }
+            S.V = V; S.tree_lds = k4 ? eager_lds_layout(h->V, 16).total : (int)h->reg_lds;
+            S.xch_off = (int)((std::max((size_t)8 * (size_t)S.tree_lds, (size_t)(k4 ? 128 : 8 * twb) * big_rowb) + 15) & ~(size_t)15);   // (tree waves and helper waves have tables of their own)
             const size_t shared = (size_t)S.xch_off + 4 * 144;
-            const int wgcu = x8 ? 2 : (b8 ? 1 : occ + 1);
+            const int wgcu = k4 ? 1 : (x8 ? 2 : (b8 ? 1 : occ + 1));
             const size_t room = (size_t)(160 * 1024) / (size_t)wgcu > shared ? (size_t)(160 * 1024) / (size_t)wgcu - shared : 0;
-            S.wl_off = (int)shared; S.wl_bytes = (int)std::min({(size_t)(8 * h->V * 4), (room / (size_t)twb) & ~(size_t)15, (size_t)h->wl_lds_max});
+            S.wl_off = (int)shared; S.wl_bytes = (int)std::min({(size_t)((k4 ? 16 : 8) * h->V * 4), (room / (size_t)twb) & ~(size_t)15, (size_t)h->wl_lds_max});
             const size_t lds = shared + (size_t)twb * S.wl_bytes;
             std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
             if ((h->profiling & 1) && h->prof_this) { ev = next_events(h, h->ev_tree, h->ev_tree_used); hipEventRecord(ev->first, h->stream); }
-            const int lv = cmp_level(h);                          // rows by the root's legal rank (see k_search_small above)
             h->tree_kpr = lv < 0 ? 0 : h->cmp[lv].kpr;
-            hipLaunchKernelGGL(x8 ? (lv < 0 ? h->k_big8x : h->cmp[lv].b8x) : b8 ? (lv < 0 ? h->k_big8 : h->cmp[lv].b8) : (lv < 0 ? h->k_big[occ] : h->cmp[lv].b[occ]), dim3((unsigned)wgs), dim3(NB_THREADS), lds, h->stream, S);
+            hipLaunchKernelGGL(k4 ? k4 : x8 ? (lv < 0 ? h->k_big8x : h->cmp[lv].b8x) : b8 ? (lv < 0 ? h->k_big8 : h->cmp[lv].b8) : (lv < 0 ? h->k_big[occ] : h->cmp[lv].b[occ]), dim3((unsigned)wgs), dim3(NB_THREADS), lds, h->stream, S);
             if (lv >= 0) {
                 PlyPar Q; memset(&Q, 0, sizeof Q);
                 Q.G = h->G; Q.L = h->L; Q.V = h->V; Q.states = h->states; Q.policy_final = h->policy_final;
                 hipLaunchKernelGGL(h->k_spread, dim3((unsigned)((h->L + 3) / 4)), dim3(256), 0, h->stream, Q);
             }
             { char kb[48] = ""; if (lv >= 0) snprintf(kb, sizeof kb, ",rows by legal rank KPR=%d", h->tree_kpr);
-              char b[200]; snprintf(b, sizeof b, "k_search_big<KPL=%d,H=512,WG=%d%s%s> (whole mcts_single per launch, %d games per workgroup, %d per tree wave)",
-                                    h->reg_kpl, x8 ? 2 : (b8 ? 1 : occ + 1), b8 ? ",TW=8" : "", kb, twb * S.T.gpw, S.T.gpw);
-              h->form_tree = b; h->form_nn = b8 ? "inside k_search_big (mlp_big_body<512,4>)" : "inside k_search_big (mlp_big_body<512,2>)"; }
+              char b[200];
+              if (k4) snprintf(b, sizeof b, "k_search_big4<KPL=%d,H=512,G=4%s> (whole mcts_single per launch, one 128-game workgroup per CU, 16 games per tree wave)", h->big4_kpl, kb);
+              else snprintf(b, sizeof b, "k_search_big<KPL=%d,H=512,WG=%d%s%s> (whole mcts_single per launch, %d games per workgroup, %d per tree wave)",
+                            h->reg_kpl, x8 ? 2 : (b8 ? 1 : occ + 1), b8 ? ",TW=8" : "", kb, twb * S.T.gpw, S.T.gpw);
+              h->form_tree = b; h->form_nn = k4 ? "inside k_search_big4 (mlp_big_body<512,8>)" : b8 ? "inside k_search_big (mlp_big_body<512,4>)" : "inside k_search_big (mlp_big_body<512,2>)"; }
             if (ev) hipEventRecord(ev->second, h->stream);
             HIPCHK(h, hipGetLastError());
             h->cnt_live = true;

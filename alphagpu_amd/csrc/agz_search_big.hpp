@@ -112,6 +112,51 @@ __global__ __launch_bounds__(NB_THREADS, 2 * WG) void k_search_big(const BigSear
 #endif
 }
 
+// ONE 128-game workgroup per CU (round 5; the search form of k_selfplay_big4, agz_selfplay_big.hpp): eight waves of sixteen trees on 4 lanes
+// each (KPL4 = twice the 8-lane block: the records keep their layout), the network pass on 128 leaves — a layer's weights stream from L2 once
+// per 128 leaves, four k-rows of fragments in flight — 256 registers.  Above 64 games per CU, where the 8-lane form runs two 64-game
+// workgroups per CU at 128 registers.  KPR4: node rows by the root's legal rank (twice the 8-lane KPR), 0 = by action.
+template <int FAM, int NC, int KPL4, int H, int KPR4 = 0>
+__global__ __launch_bounds__(NB_THREADS, 2) void k_search_big4(const BigSearchPar) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_bigs[];
+    static_assert(offsetof(BigSearchPar, T) == 0, "rollout_eager_body reads its TreePar from the start of the argument segment");
+    constexpr int TW = 8, G = 4, NG = 64 / G;
+    static_assert(TW * NG == NB_M, "the workgroup's games are the 128 rows of the activation tile");
+    typedef const BigSearchPar __attribute__((address_space(4)))* KArg;
+    const KArg karg = (KArg)__builtin_amdgcn_kernarg_segment_ptr();
+    const auto par = [&]() -> const BigSearchPar& { KArg p = karg; asm volatile("" : "+s"(p)); return *(const BigSearchPar*)p; };
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    EagerCarry C = {1u, 0u, 0u, 0u, 0u, 0u, 0u};
+    uint32_t wcount = 0;
+    const int V_ = par().V;
+#pragma unroll 1
+    for (int k = 0; k <= V_; ++k) {
+        int bx = (int)blockIdx.x;
+        asm volatile("" : "+s"(bx));                              // (see k_search_small)
+        {
+            const BigSearchPar& S = par();
+            uint8_t* const own_lds = lds_bigs + (size_t)wave * S.tree_lds;
+            uint32_t* const wl_lds = reinterpret_cast<uint32_t*>(lds_bigs + S.wl_off + (size_t)wave * S.wl_bytes);
+            const StepFlags SF = {(uint32_t)k, k == 0, k > 0, k < S.V, k == S.V - 1, k == S.V};
+            rollout_eager_body<FAM, NC, KPL4, true, 2, false, ROLE_ALL, KPR4, G>(SF, own_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount);
+        }
+        if (k < V_) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();                                      // the planes of the 128 leaves are written
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const BigSearchPar& S = par();
+            const int L = S.T.L;
+            mlp_big_body<H, NB_M / 16, true>(S.B, lds_bigs, [&](int row) { return bx * NB_M + row < L ? bx * NB_M + row : L; });
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();                                      // logits and values are visible to the tree waves
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+    }
+}
+// (family, chunks, actions per lane of the 4-lane form, rows per lane by legal rank): the shapes of BASELINE configs 3-5
+#define AGZ_BIG4_SHAPES(X) X(F_LINE, 2, 24, 0) X(F_LINE, 2, 24, 16) X(F_LINE, 2, 24, 8) X(F_HEX, 2, 24, 0) X(F_HEX, 2, 24, 16) X(F_HEX, 2, 24, 8) X(F_REV, 1, 24, 0)
+#define AGZ_BIG4_VARIANTS(F, C, K4, R4, KW) KW template __global__ void k_search_big4<F, C, K4, 512, R4>(const BigSearchPar);
+
 #define AGZ_BIG_VARIANTS(F, C, K, KW)                                        \
     KW template __global__ void k_search_big<F, C, K, 512, 1>(const BigSearchPar); \
     KW template __global__ void k_search_big<F, C, K, 512, 2>(const BigSearchPar); \

@@ -33,6 +33,10 @@ AGZ_PERSIST_NARROW_SHAPES(X)
 #define X(F, C, K4) AGZ_PERSIST_BIG4_VARIANTS(F, C, K4, )
 AGZ_PERSIST_BIG4_SHAPES(X)
 #undef X
+#elif AGZ_PART == 9
+#define X(F, C, K4, R4) AGZ_BIG4_VARIANTS(F, C, K4, R4, )
+AGZ_BIG4_SHAPES(X)
+#undef X
 #elif AGZ_PART >= 4
 #define X(F, C, K, R) AGZ_SMALL_CMP_VARIANTS(F, C, K, R, ) AGZ_BIG_CMP_VARIANTS(F, C, K, R, )
 #if AGZ_PART == 4

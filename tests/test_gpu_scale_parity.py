@@ -140,18 +140,23 @@ def test_wide_rows_full_size_slice_matches_oracle(name, L, V, n_each, form):
     run_slice_case(name, 128, 2, V, L, n_each, form, "inside k_search_small", step=2)
 
 
-@pytest.mark.parametrize("name,L,V,n_each,big8,form", [
-    ("gobang9", 16384, 64, 12, None, "k_search_big<KPL=12,H=512,WG=1,TW=8>"), ("gobang9", 12000, 32, 8, "0", "k_search_big<KPL=12,H=512,WG=2>"),
-    ("reversi8", 8192, 64, 12, None, "k_search_big<KPL=12,H=512,WG=1>"), ("gobang9", 136, 64, 16, None, "k_search_big")])
-def test_wide_trunk_one_launch_search_slice_matches_oracle(name, L, V, n_each, big8, form):
+@pytest.mark.parametrize("name,L,V,n_each,env,form", [
+    ("gobang9", 16384, 64, 12, None, "k_search_big<KPL=12,H=512,WG=1,TW=8>"), ("gobang9", 12000, 32, 8, "AGZ_BIG8=0", "k_search_big<KPL=12,H=512,WG=2>"),
+    ("reversi8", 8192, 64, 12, None, "k_search_big<KPL=12,H=512,WG=1>"), ("gobang9", 136, 64, 16, None, "k_search_big"),
+    ("gobang9", 32768, 64, 8, "AGZ_BIG4=0", "k_search_big<KPL=12,H=512,WG=2,TW=8>"), ("reversi8", 30001, 64, 8, None, "k_search_big4<KPL=24,H=512,G=4>"),
+    ("hex9", 20000, 128, 8, None, "k_search_big4<KPL=24,H=512,G=4>")])
+def test_wide_trunk_one_launch_search_slice_matches_oracle(name, L, V, n_each, env, form):
     """k_search_big (512x8, whole mcts_single per launch) at its largest batches — one 64-game workgroup per CU above 32 games per CU
-    (default) or two 32-game workgroups (AGZ_BIG8=0) — and at V = 64 on a small one."""
-    if big8 is not None:
-        os.environ["AGZ_BIG8"] = big8
+    (default) or two 32-game workgroups (AGZ_BIG8=0) — and at V = 64 on a small one; above 64 games per CU k_search_big4 (one 128-game
+    workgroup per CU, 4 lanes per tree: a ragged last workgroup, V = 128 trees whose tables are larger than the activation tile) or, with
+    AGZ_BIG4=0, two 64-game workgroups per CU."""
+    if env is not None:
+        os.environ[env.split("=")[0]] = env.split("=")[1]
     try:
         run_slice_case(name, 512, 8, V, L, n_each, form, "inside k_search_big", step=3)
     finally:
-        os.environ.pop("AGZ_BIG8", None)
+        if env is not None:
+            os.environ.pop(env.split("=")[0], None)
 
 
 @pytest.mark.parametrize("name,L,V,H,T,form", [
