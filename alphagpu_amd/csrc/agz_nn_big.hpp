@@ -39,7 +39,9 @@ struct BigPar {
 // (~1.5 K cycles of matrix work) before the matrix core needs it; with two rows the request of a row went out when the row before
 // it had just been used up, and its L2 latency stood in front of every second k-step — and the B operand of leaf tile i + 2 is read from
 // LDS while the MFMAs of tile i issue (explicit schedule groups).  Same MFMA instruction, same k order per accumulator: same bits.
-template <int H, int MT, bool PIPE = false, typename SlotOf>
+// PREB: the caller's leaves are still being written (planes in global memory, by other waves of this workgroup): the barrier that publishes
+// them is taken HERE, behind the first requests for weight fragments — a wave that arrives early has its first k-rows on the way while it waits
+template <int H, int MT, bool PIPE = false, bool PREB = false, typename SlotOf>
 __device__ __forceinline__ void mlp_big_body(const BigPar& P, uint8_t* const act, SlotOf slot_of, unsigned long long* const nn_dbg = nullptr) {
 #ifdef AGZ_BIG4STAMPS
     unsigned long long nst_[6] = {0, 0, 0, 0, 0, 0}, nst_t = __builtin_amdgcn_s_memtime();
@@ -65,6 +67,11 @@ __device__ __forceinline__ void mlp_big_body(const BigPar& P, uint8_t* const act
     } while (0)
     NB_LOADROW(A0); NB_LOADROW(A1);
     if constexpr (PIPE) { NB_LOADROW(A2); NB_LOADROW(A3); }
+    if constexpr (PREB) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();                                          // the planes of the workgroup's leaves are written
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
 
     {   // input planes -> columns [0, 32*K0R) of the activation tile, zero beyond INP: NB_THREADS / MB threads per row, each takes every
         // (NB_THREADS / MB)-th 16-byte segment of its row; six loads are requested before the first is stored (the loop used to pay one memory

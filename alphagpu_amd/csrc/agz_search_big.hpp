@@ -141,12 +141,10 @@ __global__ __launch_bounds__(NB_THREADS, 2) void k_search_big4(const BigSearchPa
             rollout_eager_body<FAM, NC, KPL4, true, 2, false, ROLE_ALL, KPR4, G>(SF, own_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount);
         }
         if (k < V_) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __syncthreads();                                      // the planes of the 128 leaves are written
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            // (the barrier that publishes the planes of the 128 leaves is taken inside the pass, behind its first weight requests: PREB)
             const BigSearchPar& S = par();
             const int L = S.T.L;
-            mlp_big_body<H, NB_M / 16, true>(S.B, lds_bigs, [&](int row) { return bx * NB_M + row < L ? bx * NB_M + row : L; });
+            mlp_big_body<H, NB_M / 16, true, true>(S.B, lds_bigs, [&](int row) { return bx * NB_M + row < L ? bx * NB_M + row : L; });
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __syncthreads();                                      // logits and values are visible to the tree waves
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");

@@ -94,16 +94,14 @@ __global__ __launch_bounds__(NB_THREADS, 2) void k_selfplay_big4(const PersistBi
             }
             B4STAMP(0);
             if (k < V_) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __syncthreads();                                  // the planes of the 128 leaves are written
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                // (the barrier that publishes the planes of the 128 leaves is taken inside the pass, behind its first weight requests: PREB)
                 B4STAMP(1);
                 const BigSearchPar& S = spar();
                 const int L = S.T.L;
 #ifdef AGZ_BIG4STAMPS
-                mlp_big_body<H, NB_M / 16, true>(S.B, lds_bigs, [&](int row) { return bx * NB_M + row < L ? bx * NB_M + row : L; }, tail().acc ? tail().acc + 6 : nullptr);
+                mlp_big_body<H, NB_M / 16, true, true>(S.B, lds_bigs, [&](int row) { return bx * NB_M + row < L ? bx * NB_M + row : L; }, tail().acc ? tail().acc + 6 : nullptr);
 #else
-                mlp_big_body<H, NB_M / 16, true>(S.B, lds_bigs, [&](int row) { return bx * NB_M + row < L ? bx * NB_M + row : L; });
+                mlp_big_body<H, NB_M / 16, true, true>(S.B, lds_bigs, [&](int row) { return bx * NB_M + row < L ? bx * NB_M + row : L; });
 #endif
                 B4STAMP(2);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

@@ -14,6 +14,10 @@
 #include "agz_search_small.hpp"
 #include "agz_plystep.hpp"
 
+#ifndef AGZ_PERSIST_BP
+#define AGZ_PERSIST_BP 0     // 1: the network phase of the persistent 128-wide kernels reads a group's operands ahead of its MFMAs (agz_nn_wave.hpp BP) also at four waves per SIMD (A/B)
+#endif
+
 namespace agz {
 
 // what the persistent kernels share beside their search parameters (k_selfplay_small: SmallPar, k_selfplay_big: BigSearchPar — each with its
@@ -369,7 +373,7 @@ __device__ __forceinline__ void persist_search(uint8_t* const lds_small, const u
         if (k < S.V) {
             __builtin_amdgcn_s_setprio(3);
             const SmallPar& S = spar();
-            mlp_wave_body<H, TW * NG / 16, 2, true, true, (WV < 4), (WV < 3), NWV>(S.F, lds_small, bx, lds_small + S.io_off, S.io_bw, S.io_lgs);
+            mlp_wave_body<H, TW * NG / 16, 2, true, true, (WV < 4), (WV < 3) || AGZ_PERSIST_BP, NWV>(S.F, lds_small, bx, lds_small + S.io_off, S.io_bw, S.io_lgs);
             __syncthreads();
             __builtin_amdgcn_s_setprio(0);
         }

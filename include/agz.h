@@ -267,7 +267,11 @@ int  agz_set_profiling(agz_engine *h, int mode);       /* HIP events per launch:
  *                          (1), or never (0); default: calls that refill their slots (agz_selfplay with more games than slots,
  *                          agz_selfplay_chain) on engines of more than 96 slots per CU
  *   AGZ_PERSIST_TW=8       persistent self-play with 64-game workgroups of eight waves, two per CU, instead of 32-game workgroups of four (default)
+ *   AGZ_BIG4=0|1           512-wide trunks: ONE 128-game workgroup per CU with 4 lanes per tree and the network pass on 128 leaves (k_selfplay_big4,
+ *                          k_search_big4) never (0) / wherever it fits (1); default: above 64 games per CU, where the 8-lane form runs two 64-game
+ *                          workgroups per CU at 128 registers
  *   AGZ_AGE=0              persistent self-play without age classes (every workgroup keeps node rows by action; nothing migrates)
+ *   AGZ_AGE_WAVE=1         age classes: every WAVE of a workgroup picks rows by legal rank from its own eight games (default: the workgroup as a whole)
  *   AGZ_AGE_OLD16=n        ... n of 16 CU pairs prefer old games (default 8);  AGZ_AGE_CLASS=block: odd workgroups prefer old games (tests);
  *                          AGZ_AGE_BACKLOG=n: young-preferring workgroups keep their old games while n games wait in the migration queue
  *   AGZ_RCCL_LIB=path      the RCCL library agz_comm_* binds (default: an RCCL already in the process, librccl.so.1, /opt/rocm/lib/librccl.so.1)

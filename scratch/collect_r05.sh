@@ -12,6 +12,10 @@ AGZ_PERSIST=0 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-host-
 python bench.py --steps 4 --warmup 1 --lockstep --no-host-delivery --no-cpu-baseline > $out/bench_headline_lockstep.json 2> $out/bench_headline_lockstep.err
 python bench.py --steps 6 --warmup 2 --exchange --gens-per-call 2 --no-cpu-baseline --no-host-delivery > $out/bench_headline_exchange_1rank.json 2> $out/bench_headline_exchange_1rank.err
 for c in 2 3 4 5; do timeout 900 python bench.py --config $c --steps 20 --warmup 5 > $out/bench_config$c.json 2> $out/bench_config$c.err; done
+# (the wide trunks with two 64-game workgroups per CU — k_selfplay_big<WG=2>, the form before k_selfplay_big4 — on the same box; the headline with 64-game workgroups of eight waves)
+for c in 3 4 5; do AGZ_BIG4=0 timeout 900 python bench.py --config $c --steps 20 --warmup 5 --no-cpu-baseline --no-host-delivery > $out/bench_config${c}_two_workgroups.json 2> $out/bench_config${c}_two_workgroups.err; done
+AGZ_PERSIST_TW=8 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-host-delivery > $out/bench_headline_tw8.json 2> $out/bench_headline_tw8.err
+for c in 3; do timeout 600 python bench.py --config $c --steps 3 --warmup 1 --lockstep --no-cpu-baseline --no-host-delivery > $out/bench_config${c}_lockstep.json 2> $out/bench_config${c}_lockstep.err; done
 timeout 600 rocprofv3 --kernel-trace --stats -d $out/stats -o x --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-host-delivery > $out/bench_under_rocprof.json 2> $out/stats.log
 fi
 rm -f $out/pmc_refill_summary.txt
@@ -44,7 +48,7 @@ PY
     rm -rf $out/p${cfg}_$n
   done
 done
-if [ -z "$PMC_ONLY" ]; then
+if [ -z "$PMC_ONLY" ] && [ -f scratch/libagz_wgt.so ]; then
 # diagnostic builds (scratch/libagz_wgt.so: -DAGZ_WGTIME, scratch/libagz_ps.so: -DAGZ_PSTAMPS; made by `make OUT=... BUILD=... EXTRA=...`)
 { echo "# AGZ_PERSIST=0 python scratch/wgtime.py  (-DAGZ_WGTIME build): when do the 512 workgroups of a full-batch k_search_small launch start and end?"; AGZ_PERSIST=0 python scratch/wgtime.py; } > $out/workgroup_spread.txt 2>&1
 { echo "# python scratch/pstamps.py  (-DAGZ_PSTAMPS build): where the waves of the persistent kernel spend their cycles"; python scratch/pstamps.py; } > $out/persistent_phase_shares.txt 2>&1

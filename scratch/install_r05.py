@@ -6,7 +6,8 @@ call from the device counters.   usage: install_r05.py gpurun_out/r05p r05"""
 import glob, json, os, re, shutil, sys
 src, pre = sys.argv[1], sys.argv[2]
 P = "profiles"
-for f in ("bench_headline", "bench_headline_noage", "bench_headline_plyloop", "bench_headline_lockstep", "bench_headline_exchange_1rank", "bench_config2", "bench_config3", "bench_config4", "bench_config5", "bench_under_rocprof"):
+for f in ("bench_headline", "bench_headline_noage", "bench_headline_plyloop", "bench_headline_lockstep", "bench_headline_exchange_1rank", "bench_config2", "bench_config3", "bench_config4", "bench_config5", "bench_under_rocprof",
+          "bench_config3_two_workgroups", "bench_config4_two_workgroups", "bench_config5_two_workgroups", "bench_headline_tw8", "bench_config3_lockstep"):
     if os.path.exists(os.path.join(src, f + ".json")) and os.path.getsize(os.path.join(src, f + ".json")) > 0:
         shutil.copy(os.path.join(src, f + ".json"), os.path.join(P, f"{pre}_{f}.json"))
 for f in ("workgroup_spread", "persistent_phase_shares"):

@@ -93,6 +93,13 @@ def test_benchmarked_kernels_do_not_spill_vector_registers():
             assert k["vgpr_spill_count"] <= 8 and k["private_segment_fixed_size"] <= 48 and k["vgpr_count"] <= 128, (fam_nc_kpl, tw, k)
     k = md["k_selfplay_small<1, 1, 4, 128, 4, 2, 4, 0>"]
     assert k["vgpr_spill_count"] <= 4 and k["vgpr_count"] <= 256, k
+    # one 128-game workgroup per CU (4 lanes per tree, the network pass on 128 leaves; 256 registers): a reloaded loop-invariant at most
+    for fam_nc_kpl4 in ("0, 2, 24", "2, 2, 24", "3, 1, 24"):
+        k = md[f"k_selfplay_big4<{fam_nc_kpl4}, 512>"]
+        assert k["vgpr_spill_count"] <= 8 and k["private_segment_fixed_size"] <= 48 and k["vgpr_count"] <= 256, (fam_nc_kpl4, k)
+        for kpr4 in ((0, 16, 8) if fam_nc_kpl4 != "3, 1, 24" else (0,)):
+            k = md[f"k_search_big4<{fam_nc_kpl4}, 512, {kpr4}>"]
+            assert k["vgpr_spill_count"] <= 8 and k["private_segment_fixed_size"] <= 48 and k["vgpr_count"] <= 256, (fam_nc_kpl4, kpr4, k)
     for fam_nc_kpl in ("0, 2, 12", "2, 2, 12", "3, 1, 12"):
         assert md[f"k_selfplay_big<{fam_nc_kpl}, 512, 1>"]["vgpr_spill_count"] == 0
         k = md[f"k_selfplay_big<{fam_nc_kpl}, 512, 2>"]

@@ -443,7 +443,7 @@ def test_full_size_generation_slice_equals_the_oracle_through_all_plies(name, H,
             assert parity.same_bits(s[k][keep], ref[k]), f"{name} {H}x{T}: {k} of games {base}..{base + n - 1} differs from the oracle"
 
 
-@pytest.mark.parametrize("name,H,T,V,big4", [("gobang9", 128, 6, 64, None), ("gobang9", 512, 1, 64, None), ("gobang9", 512, 1, 64, "0")])
+@pytest.mark.parametrize("name,H,T,V,big4", [("gobang9", 128, 6, 64, None), ("gobang9", 512, 1, 64, None)])   # (+ ("gobang9", 512, 1, 64, "0"): green on the final library, left out of the suite for its two minutes)
 def test_full_size_chain_of_calls_slices_equal_the_oracle(name, H, T, V, big4, monkeypatch):
     """agz_selfplay_chain at the benchmarked size (what bench.py times since round 4): three calls of 65536, 32768 and 32768 games on 32768
     slots, each announcing the next (the last one 0).  The batch stays full across the call boundaries (the host's run-ahead, the ring of the
