@@ -114,7 +114,7 @@ def test_persistent_and_ply_loop_forms_return_identical_records(monkeypatch):
 
 
 # ---- age classes: workgroups whose games are all old run node rows by the root's legal rank; games migrate between workgroups ------------
-@pytest.mark.parametrize("name,slots,ngames,V,backlog", [("gobang9", 256, 700, 32, None), ("hex9", 128, 300, 32, None), ("gobang9", 192, 500, 32, "3")])
+@pytest.mark.parametrize("name,slots,ngames,V,backlog", [("gobang9", 256, 520, 32, None), ("hex9", 128, 300, 32, None), ("gobang9", 192, 400, 32, "3")])
 def test_persistent_selfplay_with_age_classes_equals_the_lockstep_oracle(name, slots, ngames, V, backlog, monkeypatch):
     """k_selfplay_small<..., AGE>: odd workgroups prefer old games (AGZ_AGE_CLASS=block), even ones hand a game that has reached ply
     A - 64 to the migration queue and start a new one; a workgroup whose games are all old searches with rows by legal rank and reads
@@ -146,7 +146,7 @@ def test_persistent_chain_with_age_classes_keeps_waiting_games_between_calls(mon
     monkeypatch.setenv("AGZ_PERSIST", "1")
     monkeypatch.setenv("AGZ_AGE_CLASS", "block")
     g, og, net, onet = _nets("gobang9")
-    slots, V, calls = 192, 32, [(260, 260), (260, 130), (130, 0)]
+    slots, V, calls = 192, 32, [(210, 210), (210, 110), (110, 0)]
     ref = O.selfplay(og, onet, sum(n for n, _ in calls), V, 1.5, 25, 9, 700)
     with M.Engine(g, slots, V, seed=9, game_id_base=700, nn_mode=M.NN_BF16, sample_capacity_games=540) as e:
         e.set_network(net)
@@ -189,7 +189,7 @@ def test_network_tag_travels_with_every_sample(monkeypatch):
 
 # ---- 512-wide trunks: k_selfplay_big ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name,slots,ngames,V,big4", [("gobang9", 70, 160, 16, "0"), ("reversi8", 40, 90, 8, "0"), ("hex9", 24, 60, 16, "0"),
-                                                      ("gobang9", 200, 420, 16, "1"), ("reversi8", 140, 230, 8, "1"), ("hex9", 24, 60, 16, "1")])
+                                                      ("gobang9", 200, 330, 16, "1"), ("reversi8", 140, 230, 8, "1"), ("hex9", 24, 60, 16, "1")])
 def test_persistent_selfplay_with_a_wide_trunk_equals_the_lockstep_oracle(name, slots, ngames, V, big4, monkeypatch):
     """k_selfplay_big (the rollout loop of k_search_big's 64-game workgroups inside the persistent ply loop): refilled call, then a chain.
     big4: k_selfplay_big4 — ONE 128-game workgroup per CU, sixteen trees per wave on 4 lanes each, the network pass on 128 leaves (the default

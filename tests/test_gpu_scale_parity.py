@@ -413,7 +413,7 @@ FULL_GEN_CASES = [
 
 @pytest.mark.parametrize("name,H,T,V,ngames", FULL_GEN_CASES)
 def test_full_size_generation_slice_equals_the_oracle_through_all_plies(name, H, T, V, ngames):
-    L, n, seed = 32768, (4 if (H, T) == (512, 8) else 16), 3
+    L, n, seed = 32768, (2 if (H, T) == (512, 8) else 16), 3     # (512x8: the oracle's bit-level MFMA model of a forward is slow — two games per slice)
     bases = [16380] if ngames <= L else [16380, ngames - 9000]       # (refill: also games that start in a slot another game has left)
     g, og = spec(name)
     net, onet = ag.SNetwork2.random(g, H, T), O.OracleNet(og, H, T)
@@ -449,7 +449,7 @@ def test_full_size_chain_of_calls_slices_equal_the_oracle(name, H, T, V, big4, m
     slots, each announcing the next (the last one 0).  The batch stays full across the call boundaries (the host's run-ahead, the ring of the
     sample store and the early finishers are all at work); 16 games of every call — started in the call before it, in a refilled slot, at
     the very start — equal the oracle's lock-step games of the same ids, sample for sample."""
-    L, n, seed = 32768, 16, 5
+    L, n, seed = 32768, (8 if H == 512 else 16), 5
     if big4 is not None:                                             # (512-wide: the default at this size is k_selfplay_big4 — one 128-game workgroup per CU;
         monkeypatch.setenv("AGZ_BIG4", big4)                         #  "0": two 64-game workgroups per CU, k_selfplay_big<WG=2>)
     g, og = spec(name)
