@@ -152,7 +152,9 @@ __global__ __launch_bounds__(NB_THREADS, 2) void k_search_big4(const BigSearchPa
     }
 }
 // (family, chunks, actions per lane of the 4-lane form, rows per lane by legal rank): the shapes of BASELINE configs 3-5
-#define AGZ_BIG4_SHAPES(X) X(F_LINE, 2, 24, 0) X(F_LINE, 2, 24, 16) X(F_LINE, 2, 24, 8) X(F_HEX, 2, 24, 0) X(F_HEX, 2, 24, 16) X(F_HEX, 2, 24, 8) X(F_REV, 1, 24, 0)
+#define AGZ_BIG4_SHAPES(X) X(F_LINE, 2, 24, 0) X(F_LINE, 2, 24, 16) X(F_LINE, 2, 24, 8) X(F_HEX, 2, 24, 0) X(F_HEX, 2, 24, 16) X(F_HEX, 2, 24, 8) X(F_REV, 1, 24, 0) AGZ_BIG4_SHAPES_MORE(X)
+// ... and the other built-in shapes of up to 96 actions, rows by action
+#define AGZ_BIG4_SHAPES_MORE(X) X(F_LINE, 1, 8, 0) X(F_LINE, 1, 16, 0) X(F_C4, 1, 8, 0) X(F_HEX, 1, 8, 0) X(F_HEX, 1, 16, 0) X(F_HEX, 2, 16, 0) X(F_REV, 1, 16, 0)
 #define AGZ_BIG4_VARIANTS(F, C, K4, R4, KW) KW template __global__ void k_search_big4<F, C, K4, 512, R4>(const BigSearchPar);
 
 #define AGZ_BIG_VARIANTS(F, C, K, KW)                                        \

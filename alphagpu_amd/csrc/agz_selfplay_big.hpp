@@ -117,8 +117,10 @@ __global__ __launch_bounds__(NB_THREADS, 2) void k_selfplay_big4(const PersistBi
 #undef B4STAMP
     });
 }
-// (family, chunks, actions per lane of the 4-lane form): the shapes of BASELINE configs 3-5
-#define AGZ_PERSIST_BIG4_SHAPES(X) X(F_LINE, 2, 24) X(F_HEX, 2, 24) X(F_REV, 1, 24)
+// (family, chunks, actions per lane of the 4-lane form = twice the 8-lane block): the shapes of BASELINE configs 3-5, then every other built-in shape of up to
+// 96 actions (Connect4, Reversi 6x6, the smaller Gobang and Hex boards)
+#define AGZ_PERSIST_BIG4_SHAPES(X) X(F_LINE, 2, 24) X(F_HEX, 2, 24) X(F_REV, 1, 24) AGZ_PERSIST_BIG4_SHAPES_MORE(X)
+#define AGZ_PERSIST_BIG4_SHAPES_MORE(X) X(F_LINE, 1, 8) X(F_LINE, 1, 16) X(F_C4, 1, 8) X(F_HEX, 1, 8) X(F_HEX, 1, 16) X(F_HEX, 2, 16) X(F_REV, 1, 16)
 #define AGZ_PERSIST_BIG4_VARIANTS(F, C, K4, KW) KW template __global__ void k_selfplay_big4<F, C, K4, 512>(const PersistBigPar);
 
 #define AGZ_PERSIST_BIG_VARIANTS(F, C, K, KW)                                \

@@ -31,11 +31,19 @@ AGZ_PERSIST_NARROW_SHAPES(X)
 #undef X
 #elif AGZ_PART == 8
 #define X(F, C, K4) AGZ_PERSIST_BIG4_VARIANTS(F, C, K4, )
-AGZ_PERSIST_BIG4_SHAPES(X)
+X(F_LINE, 2, 24) X(F_HEX, 2, 24) X(F_REV, 1, 24)
 #undef X
 #elif AGZ_PART == 9
 #define X(F, C, K4, R4) AGZ_BIG4_VARIANTS(F, C, K4, R4, )
-AGZ_BIG4_SHAPES(X)
+X(F_LINE, 2, 24, 0) X(F_LINE, 2, 24, 16) X(F_LINE, 2, 24, 8) X(F_HEX, 2, 24, 0) X(F_HEX, 2, 24, 16) X(F_HEX, 2, 24, 8) X(F_REV, 1, 24, 0)
+#undef X
+#elif AGZ_PART == 10
+#define X(F, C, K4) AGZ_PERSIST_BIG4_VARIANTS(F, C, K4, )
+AGZ_PERSIST_BIG4_SHAPES_MORE(X)
+#undef X
+#elif AGZ_PART == 11
+#define X(F, C, K4, R4) AGZ_BIG4_VARIANTS(F, C, K4, R4, )
+AGZ_BIG4_SHAPES_MORE(X)
 #undef X
 #elif AGZ_PART >= 4
 #define X(F, C, K, R) AGZ_SMALL_CMP_VARIANTS(F, C, K, R, ) AGZ_BIG_CMP_VARIANTS(F, C, K, R, )

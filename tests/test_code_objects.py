@@ -94,10 +94,10 @@ def test_benchmarked_kernels_do_not_spill_vector_registers():
     k = md["k_selfplay_small<1, 1, 4, 128, 4, 2, 4, 0>"]
     assert k["vgpr_spill_count"] <= 4 and k["vgpr_count"] <= 256, k
     # one 128-game workgroup per CU (4 lanes per tree, the network pass on 128 leaves; 256 registers): a reloaded loop-invariant at most
-    for fam_nc_kpl4 in ("0, 2, 24", "2, 2, 24", "3, 1, 24"):
+    for fam_nc_kpl4 in ("0, 2, 24", "2, 2, 24", "3, 1, 24", "0, 1, 8", "0, 1, 16", "1, 1, 8", "2, 1, 8", "2, 1, 16", "2, 2, 16", "3, 1, 16"):
         k = md[f"k_selfplay_big4<{fam_nc_kpl4}, 512>"]
         assert k["vgpr_spill_count"] <= 8 and k["private_segment_fixed_size"] <= 48 and k["vgpr_count"] <= 256, (fam_nc_kpl4, k)
-        for kpr4 in ((0, 16, 8) if fam_nc_kpl4 != "3, 1, 24" else (0,)):
+        for kpr4 in ((0, 16, 8) if fam_nc_kpl4 in ("0, 2, 24", "2, 2, 24") else (0,)):
             k = md[f"k_search_big4<{fam_nc_kpl4}, 512, {kpr4}>"]
             assert k["vgpr_spill_count"] <= 8 and k["private_segment_fixed_size"] <= 48 and k["vgpr_count"] <= 256, (fam_nc_kpl4, kpr4, k)
     for fam_nc_kpl in ("0, 2, 12", "2, 2, 12", "3, 1, 12"):

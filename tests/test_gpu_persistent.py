@@ -189,7 +189,8 @@ def test_network_tag_travels_with_every_sample(monkeypatch):
 
 # ---- 512-wide trunks: k_selfplay_big ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name,slots,ngames,V,big4", [("gobang9", 70, 160, 16, "0"), ("reversi8", 40, 90, 8, "0"), ("hex9", 24, 60, 16, "0"),
-                                                      ("gobang9", 200, 330, 16, "1"), ("reversi8", 140, 230, 8, "1"), ("hex9", 24, 60, 16, "1")])
+                                                      ("gobang9", 200, 330, 16, "1"), ("reversi8", 140, 230, 8, "1"), ("hex9", 24, 60, 16, "1"),
+                                                      ("connect4", 140, 300, 8, "1"), ("reversi6", 70, 160, 8, "1"), ("hex5", 150, 320, 8, "1")])
 def test_persistent_selfplay_with_a_wide_trunk_equals_the_lockstep_oracle(name, slots, ngames, V, big4, monkeypatch):
     """k_selfplay_big (the rollout loop of k_search_big's 64-game workgroups inside the persistent ply loop): refilled call, then a chain.
     big4: k_selfplay_big4 — ONE 128-game workgroup per CU, sixteen trees per wave on 4 lanes each, the network pass on 128 leaves (the default

@@ -144,7 +144,7 @@ def test_wide_rows_full_size_slice_matches_oracle(name, L, V, n_each, form):
     ("gobang9", 16384, 64, 12, None, "k_search_big<KPL=12,H=512,WG=1,TW=8>"), ("gobang9", 12000, 32, 8, "AGZ_BIG8=0", "k_search_big<KPL=12,H=512,WG=2>"),
     ("reversi8", 8192, 64, 12, None, "k_search_big<KPL=12,H=512,WG=1>"), ("gobang9", 136, 64, 16, None, "k_search_big"),
     ("gobang9", 32768, 64, 8, "AGZ_BIG4=0", "k_search_big<KPL=12,H=512,WG=2,TW=8>"), ("reversi8", 30001, 64, 8, None, "k_search_big4<KPL=24,H=512,G=4>"),
-    ("hex9", 20000, 128, 8, None, "k_search_big4<KPL=24,H=512,G=4>")])
+    ("hex9", 20000, 128, 8, None, "k_search_big4<KPL=24,H=512,G=4>"), ("connect4", 32768, 32, 8, None, "k_search_big4<KPL=8,H=512,G=4>")])
 def test_wide_trunk_one_launch_search_slice_matches_oracle(name, L, V, n_each, env, form):
     """k_search_big (512x8, whole mcts_single per launch) at its largest batches — one 64-game workgroup per CU above 32 games per CU
     (default) or two 32-game workgroups (AGZ_BIG8=0) — and at V = 64 on a small one; above 64 games per CU k_search_big4 (one 128-game
