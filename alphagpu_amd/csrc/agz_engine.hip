@@ -53,6 +53,11 @@ struct DevNet {
     int NT_h = 0, NT_head = 0;
 };
 
+// bytes of a row of the LDS hand-over window of the 128-wide one-launch kernels (one row per game: the leaf's planes on the way to the
+// network — INP / 32 k-rows of 64 bytes + 16 bytes that spread the rows over the banks; the network skips the zero k-rows that pad layer 0 to
+// whole groups, agz_nn_wave.hpp KR0 — and its AOP logits on the way back)
+static int small_io_row_bytes(const DevNet& n) { return (std::max((n.INP / 32) * 64 + 16, 4 * n.AOP) + 15) & ~15; }
+
 typedef void (*rollout_fn)(const TreePar);
 typedef void (*small_fn)(const SmallPar);
 typedef void (*big_fn)(const BigSearchPar);
@@ -969,7 +974,7 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
             int one = h->narrow_occ >= 0 && wgs <= h->cus ? h->narrow_occ : (wgs <= h->cus ? 1 : 0);   // one workgroup per CU: the 512-register build
             const uint32_t A2 = (uint32_t)(G * (nk->kpr ? nk->kpr : nk->kpl));
             h->tree_kpr = nk->kpr;
-            SmallPar S;
+            SmallPar S; S.nxw_off = 0;
             S.T = h->tp;
             S.T.L = h->L; S.T.slot0 = 0; S.T.step = h->step; S.T.cpuct = h->cpuct; S.T.training = h->training;
             S.T.fastdiv = fastdiv_range(h);
@@ -979,9 +984,7 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
             S.F.logits = h->logits; S.F.LGS = h->LGS; S.F.vout = h->v_eval; S.F.L = h->L; S.F.T = n.T; S.F.A = h->G.A; S.F.AOP = n.AOP;
             S.F.gpw = 0; S.F.tw = tw; S.F.rb = NG;
             S.V = V; S.tree_lds = eager_lds_layout(h->V, NG).total;
-            const int kth = n.H / 32, g0 = (n.INP / 32 + kth - 1) / kth;
-            const int prowb = g0 * kth * 64 + 16;
-            const int rs = (std::max(prowb, 4 * n.AOP) + 15) & ~15;
+            const int rs = small_io_row_bytes(n);
             S.io_prowb = rs; S.io_lgs = rs / 4; S.io_bw = NG * rs;
             S.io_off = (int)((std::max((size_t)tw * (size_t)S.tree_lds, (size_t)gpwg * 2 * (n.H * 2 + 16)) + 15) & ~(size_t)15);
             S.xch_off = S.io_off + tw * S.io_bw;
@@ -1039,7 +1042,7 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
             const small_fn kfn = t8 ? (cmp ? h->cmp[lv].s8 : h->k_small8)
                                     : (cmp ? (tw == 2 ? h->cmp[lv].s2 : h->cmp[lv].s4[occ]) : (tw == 2 ? h->k_small : h->k_small4[occ]));
             h->tree_kpr = cmp ? h->cmp[lv].kpr : 0;
-            SmallPar S;
+            SmallPar S; S.nxw_off = 0;
             S.T = h->tp;
             S.T.L = h->L; S.T.slot0 = 0; S.T.step = h->step; S.T.cpuct = h->cpuct; S.T.training = h->training;
             S.T.fastdiv = fastdiv_range(h);
@@ -1058,11 +1061,9 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
             S.T.gpw = h->small_gpw > 0 && (tw == 2 || occ == 0) ? h->small_gpw : gpw;
             S.F.gpw = S.T.gpw < 8 ? S.T.gpw : 0; S.F.tw = tw;
             S.V = V; S.tree_lds = (int)h->reg_lds;
-            const int kth = n.H / 32, g0 = (n.INP / 32 + kth - 1) / kth;
             // the tree waves' tables and the network's two activation strips share one window (the phases never overlap); the hand-over
             // window behind it carries planes (tree -> network) and logits (network -> tree), one block of 8 rows per tree wave
-            const int prowb = g0 * kth * 64 + 16;
-            const int rs = (std::max(prowb, 4 * n.AOP) + 15) & ~15;   // one row per game: the leaf's planes on the way to the network, its logits on the way back
+            const int rs = small_io_row_bytes(n);   // one row per game: the leaf's planes on the way to the network, its logits on the way back
             S.io_prowb = rs; S.io_lgs = rs / 4; S.io_bw = 8 * rs; S.F.rb = 8;
             h->rd_rec_bytes = h->tp.rec_bytes; h->rd_off_rk = 16 + h->tp.A2 * 4; h->rd_off_el = h->tp.off_q; h->rd_off_vis = h->tp.off_vis;
             S.io_off = (int)((std::max((size_t)(tw == 8 ? 8 : 4) * h->reg_lds, (size_t)8 * tw * 2 * (n.H * 2 + 16)) + 15) & ~(size_t)15);   // (16-game workgroups: the two helper waves have tables of their own)
@@ -1624,6 +1625,8 @@ static int finish_call(agz_engine* h, int ngames, bool chain, unsigned long long
 // ---- one launch per call: the persistent self-play kernel (agz_selfplay_small.hpp) -------------------------------------------------
 // the wide-trunk form with ONE 128-game workgroup per CU (k_selfplay_big4): built for the game shape, every workgroup resident, the 128-row
 // activation tile (shared with the eight waves' tree tables) + flags + a work list of at least 64 entries per wave inside a CU's LDS
+// next-word tables of a persistent 128-wide workgroup (agz_tree_eager.hpp NXL): 16 bits per node of each of its games
+static size_t persist_nxw_bytes(int gpwg, int V) { return AGZ_PERSIST_NXL ? (((size_t)gpwg * (size_t)V * 2 + 15) & ~(size_t)15) : 0; }
 static bool use_big4(const agz_engine* h) {
     const DevNet& n = h->net[0];
     if (!h->k_persist_big4 || !n.wbig || n.H != 512 || h->big4 == 0) return false;
@@ -1647,10 +1650,9 @@ static bool persist_shape(const agz_engine* h) {
         if (per_cu > (gpwg == 32 ? 4 : 2)) return false;
         const size_t cu_lds = (size_t)(160 * 1024) / (size_t)per_cu;
         const size_t tree_lds = nar ? (size_t)eager_lds_layout(h->V, NG).total : h->reg_lds;
-        const int kth = n.H / 32, g0 = (n.INP / 32 + kth - 1) / kth;
-        const int rs = (std::max(g0 * kth * 64 + 16, 4 * n.AOP) + 15) & ~15;
+        const int rs = small_io_row_bytes(n);
         const size_t io_off = (std::max((size_t)tw * tree_lds, (size_t)gpwg * 2 * (n.H * 2 + 16)) + 15) & ~(size_t)15;
-        return io_off + (size_t)tw * NG * rs + (size_t)tw * (16 * NG + 16) + 16 + (size_t)tw * 64 <= cu_lds;   // (+ at least 16 work-list entries per wave)
+        return io_off + (size_t)tw * NG * rs + 16 + persist_nxw_bytes(gpwg, h->V) + (size_t)tw * 64 <= cu_lds;   // (flags, next words, at least 16 work-list entries per wave)
     }
     if (n.H == 512 && use_big4(h)) return true;
     if (n.H == 512) {
@@ -1792,14 +1794,14 @@ static int run_games_persist(agz_engine* h, int ngames, int V, float cpuct, int 
         S.F.logits = h->logits; S.F.LGS = h->LGS; S.F.vout = h->v_eval; S.F.L = h->Lmax; S.F.T = n.T; S.F.A = h->G.A; S.F.AOP = n.AOP;
         S.F.gpw = 0; S.F.tw = tw; S.F.rb = NG;
         S.V = V; S.tree_lds = nar ? eager_lds_layout(h->V, NG).total : (int)h->reg_lds;
-        const int kth = n.H / 32, g0 = (n.INP / 32 + kth - 1) / kth;
-        const int prowb = g0 * kth * 64 + 16;
-        const int rs = (std::max(prowb, 4 * n.AOP) + 15) & ~15;
+        const int rs = small_io_row_bytes(n);
         S.io_prowb = rs; S.io_lgs = rs / 4; S.io_bw = NG * rs;
         S.io_off = (int)((std::max((size_t)tw * (size_t)S.tree_lds, (size_t)gpwg * 2 * (n.H * 2 + 16)) + 15) & ~(size_t)15);
-        S.xch_off = S.io_off + tw * S.io_bw;
-        const size_t shared = (size_t)S.xch_off + (size_t)tw * (16 * NG + 16) + 16;   // ... + the workgroup's two flag words
-        Q.X = X; Q.X.flag_off = (int)shared - 16;
+        S.xch_off = S.io_off + tw * S.io_bw;                                       // (no helper waves here: nothing is exchanged)
+        // ... + the workgroup's two flag words + the tree waves' next-word tables (agz_tree_eager.hpp NXL: 2 V bytes per game)
+        S.nxw_off = S.xch_off + 16;
+        const size_t shared = (size_t)S.nxw_off + persist_nxw_bytes(gpwg, h->V);
+        Q.X = X; Q.X.flag_off = S.xch_off;
         wgcu = ((int)wgs + h->cus - 1) / h->cus;
         const size_t cu_lds = cu_lds_all / (size_t)wgcu;
         const size_t room = cu_lds > shared ? cu_lds - shared : 0;

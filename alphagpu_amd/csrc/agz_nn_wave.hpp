@@ -104,6 +104,9 @@ __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const
         return (row & (rb - 1)) < P.gpw ? (bidx * P.tw + row / rb) * P.gpw + (row & (rb - 1)) : P.L;
     };
     const int G0 = (P.INP / 32 + KTH - 1) / KTH;                 // groups of layer 0
+    const int KR0 = P.INP / 32;                                  // k-rows of layer 0 that hold planes: the rows past them in its last group (zero weights x zero
+                                                                 // padding) are SKIPPED — acc + 0 x 0 is acc, bit for bit — so that a row of the hand-over window
+                                                                 // ends with the planes (round 6: the 128 bytes per game this frees hold the tree's next words)
     const int NGH = nw_hidden_groups(P.INP, H, P.T);             // groups before the head
     const int PROWB = G0 * KTH * 64 + 16;
     uint8_t* const act0 = smem;                                   // [ML][ROWB] x 2 (ping-pong), then [ML][PROWB] input planes
@@ -165,10 +168,12 @@ __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const
         /* The denser builds have no room for it (168 registers: 6 - 26 spilled, 3.39 -> 3.50 ms per ply at 24576 games; 128: 36 - 77) */ \
         /* and hide the latencies behind their other waves anyway; the sparse ones gain 1 - 2 % per ply. */ \
         const bool res_ = g_ >= G0;                                                                     \
+        const int kmax_ = g_ < G0 ? KR0 - g_ * KTH : KTH;         /* (wave-uniform; >= 1) */           \
         bf16x8 bq_[BP ? KTH : 1][LT];                                                                   \
         uint2 old_[LT][TPW];                                                                            \
         if constexpr (BP) {                                                                             \
             _Pragma("unroll") for (int k = 0; k < KTH; ++k)                                             \
+                if (k == 0 || k < kmax_)                                                                \
                 _Pragma("unroll") for (int lt = 0; lt < LT; ++lt)                                       \
                     bq_[k][lt] = *reinterpret_cast<const bf16x8*>(brow_ + (size_t)lt * bstride_ + k * 64 + q4 * 16); \
             if (res_) {                                                                                 \
@@ -184,7 +189,7 @@ __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const
                     _Pragma("unroll") for (int lt = 0; lt < LT; ++lt)                                   \
                         _Pragma("unroll") for (int t = 0; t < TPW; ++t)                                 \
                             acc[lt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[d][0][t], bq_[0][lt], (f32x4){0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0); \
-                } else {                                                                                \
+                } else if (k == 0 || k < kmax_) {                                                       \
                     _Pragma("unroll") for (int lt = 0; lt < LT; ++lt)                                   \
                         _Pragma("unroll") for (int t = 0; t < TPW; ++t)                                 \
                             acc[lt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[d][k][t], bq_[k][lt], acc[lt][t], 0, 0, 0); \
@@ -192,6 +197,7 @@ __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const
             }                                                                                           \
         } else {                                                                                        \
             _Pragma("unroll") for (int k = 0; k < KTH; ++k)                                             \
+                if (k == 0 || k < kmax_)                                                                \
                 _Pragma("unroll") for (int lt = 0; lt < LT; ++lt) {                                     \
                     const bf16x8 b_ = *reinterpret_cast<const bf16x8*>(brow_ + (size_t)lt * bstride_ + k * 64 + q4 * 16); \
                     if (ZC && k == 0 && (g_ == 0 || g_ >= G0)) {                                        \

@@ -27,6 +27,7 @@ struct SmallPar {
     int io_off, io_bw;        // hand-over window (planes to the network, logits back): offset, bytes per tree wave (one row per game of a full wave)
     int io_prowb, io_lgs;     // ... bytes / floats of a row (the same row carries the leaf's planes to the network and its logits back)
     int xch_off;              // 16-game workgroups: per tree wave the carry it publishes for its helper wave (4 NG + 1 words in 16 NG + 16 bytes)
+    int nxw_off;              // persistent self-play kernels: the tree waves' next-word tables (agz_tree_eager.hpp NXL), NG x V x 2 bytes per wave
 };
 
 // TW = tree waves per workgroup (2 or 4): the workgroup owns 8*TW games and runs the network with TW/2 leaf tiles.

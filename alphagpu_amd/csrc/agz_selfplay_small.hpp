@@ -18,6 +18,10 @@
 #define AGZ_PERSIST_BP 0     // 1: the network phase of the persistent 128-wide kernels reads a group's operands ahead of its MFMAs (agz_nn_wave.hpp BP) also at four waves per SIMD (A/B)
 #endif
 
+#ifndef AGZ_PERSIST_NXL
+#define AGZ_PERSIST_NXL 1    // 1: the descent of the persistent 128-wide kernels follows next words kept in LDS (agz_tree_eager.hpp NXL); 0: the records' (A/B)
+#endif
+
 namespace agz {
 
 // what the persistent kernels share beside their search parameters (k_selfplay_small: SmallPar, k_selfplay_big: BigSearchPar — each with its
@@ -367,9 +371,10 @@ __device__ __forceinline__ void persist_search(uint8_t* const lds_small, const u
         uint8_t* const tree_lds = lds_small + (size_t)wave * S.tree_lds;
         uint32_t* const wl_lds = reinterpret_cast<uint32_t*>(lds_small + S.wl_off + (size_t)wave * S.wl_bytes);
         uint8_t* const io_blk = lds_small + S.io_off + (size_t)wave * S.io_bw;
+        uint16_t* const nxw = reinterpret_cast<uint16_t*>(lds_small + S.nxw_off) + (size_t)wave * (size_t)(NG * S.V);   // next words of this wave's trees
         const StepFlags SF = {(uint32_t)k, k == 0, k > 0, k < S.V, k == S.V - 1, k == S.V};
-        rollout_eager_body<FAM, NC, KPL, true, PFM_, true, ROLE_ALL, KPR, G>(
-            SF, tree_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount, io_blk, S.io_prowb, S.io_lgs, nullptr, ~amask, KPR ? S.T.rec_bytes : 0u);
+        rollout_eager_body<FAM, NC, KPL, true, PFM_, true, ROLE_ALL, KPR, G, AGZ_PERSIST_NXL != 0>(
+            SF, tree_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount, io_blk, S.io_prowb, S.io_lgs, nullptr, ~amask, KPR ? S.T.rec_bytes : 0u, nxw);
         if (k < S.V) {
             __builtin_amdgcn_s_setprio(3);
             const SmallPar& S = spar();

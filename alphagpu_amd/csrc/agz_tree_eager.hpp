@@ -152,11 +152,18 @@ __device__ __forceinline__ const TreePar& tree_par() {
 // actions sub KPL .. of every row.  Fewer lanes per tree = more trees per wave: the per-round fixed work of the item loop (Newton, the
 // turns of the ordered sums, reductions, sampling, the backup) is shared by twice / four times the items, and a game with few actions
 // (Connect4: 7) does not leave six of eight lanes without an action.
-template <int FAM, int NC, int KPL, bool LEAN, int PFM, bool LIO = false, int ROLE = ROLE_ALL, int KPR_ = 0, int G_ = 8>
+// NXL (round 6; the persistent self-play kernels): the NEXT WORDS of the wave's trees live in LDS as well — nxw[game in wave][node], 16 bits:
+// child id (7 bits) | valid << 7 | (child ? creation rank + 1 of its edge : the action) << 8 — and the descent follows THOSE: one LDS read per
+// level (~100 cycles) instead of one dependent global load per level (an L2 hit at best, 8.4 levels per wave and rollout: 8 % of a wave's
+// time on the headline shape).  Every word a search reads was written by the same wave during the same search (the root's at its
+// expansion, a child's at its creation), so the table needs no clearing and nothing outside a search depends on it; the global next
+// word is still written with the aux words (same 16-byte store).
+template <int FAM, int NC, int KPL, bool LEAN, int PFM, bool LIO = false, int ROLE = ROLE_ALL, int KPR_ = 0, int G_ = 8, bool NXL = false>
 __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* const lds, const int bidx,
                                                    EagerCarry& C, uint32_t* const wl_lds, const uint32_t wl_cap_lds, uint32_t& wcount,
                                                    uint8_t* const io_blk = nullptr, const int io_prowb = 0, const int io_lgs = 0,
-                                                   uint32_t* const xch = nullptr, const uint32_t dead_mask = 0u, const uint32_t rec_stride = 0u) {
+                                                   uint32_t* const xch = nullptr, const uint32_t dead_mask = 0u, const uint32_t rec_stride = 0u,
+                                                   uint16_t* const nxw = nullptr) {
     using GM = Game<FAM, NC>;
     constexpr bool REV = FAM == F_REV;
     constexpr int G = G_, NG = 64 / G_;
@@ -166,6 +173,12 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
     constexpr int KPR = KPR_ ? KPR_ : KPL;                        // entries per lane of the node ROWS
     constexpr bool CMP = KPR != KPL;                              // rows by the root's legal rank
     static_assert(!CMP || (LEAN && KPR % 4 == 0 && KPR < KPL && (FAM == F_LINE || FAM == F_HEX)), "legal-compacted rows: lean builds of the stone-placing games");
+    static_assert(!NXL || (LEAN && ROLE == ROLE_ALL), "next words in LDS: one wave does the whole tree step of its games");
+    // the 32-bit next word (as stored in a record's aux) -> the 16-bit form of the LDS table
+    auto nx16 = [](const uint32_t nx) -> uint16_t {
+        const uint32_t child = (nx >> 8) & 0xffu;
+        return (nx & NX_VALID) ? (uint16_t)(child | 0x80u | ((child ? (nx >> 17) & 0xffu : nx & 0xffu) << 8)) : (uint16_t)0u;
+    };
     const TreePar& T = tree_par();
     const GamePar& P = T.G;
     int lane_ = lane_id();
@@ -550,6 +563,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
             if (lead) {
                 gmeta[lf] = ml;
                 *reinterpret_cast<uint4*>(rec) = make_uint4(__float_as_uint(total), nx, (uint32_t)npos | (wide ? AUX_SLOW : 0u), 0u);
+                if constexpr (NXL) nxw[gnode0 + (uint32_t)lf] = nx16(nx);
             }
         } else if (__builtin_expect(ROLE != ROLE_ITEMS && live && lf == 0, 0)) {
 #pragma unroll
@@ -633,7 +647,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
             const uint32_t auxz = npos | (nvis << 8) | (nch << 16) | (ax_z & AUX_SLOW);
             const bool FDr = FD && !__ballot(ax_z & AUX_SLOW);      // (wave-uniform)
             if (!recompute) {
-                if (valid && lead) *reinterpret_cast<uint4*>(rec) = make_uint4(__float_as_uint(prem_raw), 0u, auxz, 0u);
+                if (valid && lead) *reinterpret_cast<uint4*>(rec) = make_uint4(__float_as_uint(prem_raw), 0u, auxz, 0u);   // (nobody descends again: the LDS word is not read)
                 if constexpr (PF || PF3) { if (r + 1 < rounds) item_fetch(R, r + 1, nwl, PF3 ? 1 : 0); }
                 continue;
             }
@@ -761,7 +775,10 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
             const float st = grp_ordered_start<KPR, false, G>(pol, sub, dummy, nlr);
             const float u = dpt < 32 ? utab[gi * 32 + dpt] : uniform_search(TI.seed, TI.game_id[valid ? slot_base + gi : sl], TI.slot_ply[valid ? slot_base + gi : sl], SF.rollout - 1u, (uint32_t)dpt);
             const uint32_t nx = sample_next(pol, st, u, cdk, rkw, move, (uint32_t)ileaf);
-            if (valid && lead) *reinterpret_cast<uint4*>(rec) = make_uint4(__float_as_uint(prem_raw), nx, auxz, 0u);
+            if (valid && lead) {
+                *reinterpret_cast<uint4*>(rec) = make_uint4(__float_as_uint(prem_raw), nx, auxz, 0u);
+                if constexpr (NXL) nxw[ind] = nx16(nx);
+            }
             STAMPW(8);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");        // rows written by one lane-group are read by the descent of another
@@ -779,34 +796,40 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
         if constexpr (LEAN) __builtin_amdgcn_s_setprio(2);
         // every expanded node carries the action its next visit samples and the child under it: the descent follows the words
         int node = 0, depth = 0;
-        uint32_t nx = (live && C.root_exp) ? auxp(gnode0)->y : 0u;
-        bool descending = (nx & NX_VALID) != 0;
+        // nx: the next word of the node the descent stands on — the 32-bit form of the record (action | child << 8 | NX_VALID | rank << 17) or,
+        // NXL, the 16-bit form of the LDS table (child | 0x80 | mr << 8: mr = the action of a new edge, else the rank + 1 of the edge taken)
+        uint32_t nx = 0u;
+        if (live && C.root_exp) nx = NXL ? (uint32_t)nxw[gnode0] : auxp(gnode0)->y;
+        constexpr uint32_t NXV = NXL ? 0x80u : (uint32_t)NX_VALID;
+        bool descending = (nx & NXV) != 0;
         int create_from = -1, create_move = 0;
         uint32_t spnew = 0u;
         wcount = 0;                                                   // wave-uniform: entries of the work list so far
         STAMPW(10);
         while (__ballot(descending)) {
             if (descending) {
-                const int move = (int)(nx & 0xffu), child = (int)((nx >> 8) & 0xffu);
+                const int child = NXL ? (int)(nx & 0x7fu) : (int)((nx >> 8) & 0xffu);
+                const uint32_t mv = NXL ? nx >> 8 : nx & 0xffu;        // the action (used for a new edge only)
+                const uint32_t rk = NXL ? nx >> 8 : (nx >> 17) & 0xffu;   // rank + 1 of the edge to an existing child
                 if (lead) ++C.add_p;
                 ++depth;
                 if (child == 0) {                                      // :183-191: a new child is never expanded -> the descent ends
-                    create_from = node; create_move = move;
-                    spnew = (uint32_t)node | ((uint32_t)move << 8) | ((uint32_t)depth << 16) | SP_VALID | SP_CREATED;
+                    create_from = node; create_move = (int)mv;
+                    spnew = (uint32_t)node | (mv << 8) | ((uint32_t)depth << 16) | SP_VALID | SP_CREATED;
                     descending = false;
                 } else {
-                    const uint32_t nxc = auxp(gnode0 + (uint32_t)child)->y;     // (cleared when the child was created, set by its expansion)
+                    const uint32_t nxc = NXL ? (uint32_t)nxw[gnode0 + (uint32_t)child] : auxp(gnode0 + (uint32_t)child)->y;     // (cleared when the child was created, set by its expansion)
                     STAMPW(11);
-                    if (nxc & NX_VALID) {                              // expanded child: the descent goes on (:192)
+                    if (nxc & NXV) {                                   // expanded child: the descent goes on (:192)
                         const uint64_t app = __ballot(lead);           // (only lanes of groups that go on are here)
                         if (lead) {
                             const uint32_t pos = wcount + (uint32_t)__popcll(app & ((1ull << lane) - 1ull));
-                            const uint32_t e = (uint32_t)node | (((nx >> 17) & 0xffu) << 8) | ((uint32_t)(depth - 1) << 16) | ((uint32_t)g << 24);   // (an old edge goes by its rank)
+                            const uint32_t e = (uint32_t)node | (rk << 8) | ((uint32_t)(depth - 1) << 16) | ((uint32_t)g << 24);   // (an old edge goes by its rank)
                             if (LEAN && pos < wl_cap_lds) wl_lds[pos] = e; else wl_g[pos] = e;
                         }
                         node = child; nx = nxc;
                     } else {                                           // existing child that was never expanded: a terminal position
-                        spnew = (uint32_t)node | (((nx >> 17) & 0xffu) << 8) | ((uint32_t)depth << 16) | SP_VALID;
+                        spnew = (uint32_t)node | (rk << 8) | ((uint32_t)depth << 16) | SP_VALID;
                         node = child;
                         descending = false;
                     }
@@ -848,6 +871,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
                 wstates[gnode0 + child] = pack(lst);
                 gmeta[child] = mc;
                 reinterpret_cast<uint32_t*>(auxp(gnode0 + child))[1] = 0u;      // not expanded: no next word yet
+                if constexpr (NXL) nxw[gnode0 + child] = (uint16_t)0u;
             }
             mn = mc; node = (int)child;
         } else if (live) mn = gmeta[node];
@@ -876,12 +900,12 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
                     if (sw == NC - 1) { W[i + NC - 1] |= oc << sb; W[i + NC] |= sb ? oc >> (64 - sb) : 0ull; }
                     else W[i + NC] |= oc;
                 }
-                constexpr bool lio = LEAN && LIO;                    // (the hand-over rows are NC * 128 columns wide: every k is written)
+                constexpr bool lio = LEAN && LIO;                    // (the hand-over rows hold INP columns: the network skips the k-rows past them, agz_nn_wave.hpp KR0)
 #pragma unroll
                 for (int kk = 0; kk < NW * (8 / G); ++kk) {          // (a lane encodes 8 cells at a time; 8 / G bytes of every word in a narrow group)
                     const int k = kk / (8 / G), sb = sub + G * (kk % (8 / G));
                     const int j0 = 64 * k + 8 * sb;
-                    if (j0 < T.INP || lio) {
+                    if (j0 < T.INP) {
                         const uint32_t f = (uint32_t)(W[k] >> (8 * sb)) & 0xffu;
                         uint4 o;
                         o.x = ((f & 1u) ? 0x3F80u : 0u) | ((f & 2u) ? 0x3F800000u : 0u); o.y = ((f & 4u) ? 0x3F80u : 0u) | ((f & 8u) ? 0x3F800000u : 0u);
