@@ -58,6 +58,18 @@ struct DevNet {
 // whole groups, agz_nn_wave.hpp KR0 — and its AOP logits on the way back)
 static int small_io_row_bytes(const DevNet& n) { return (std::max((n.INP / 32) * 64 + 16, 4 * n.AOP) + 15) & ~15; }
 
+// The next-word tables of a whole-search workgroup (agz_tree_eager.hpp nxw: 16 bits per node of each of its games) go behind `shared` when the
+// workgroup's share of the CU's LDS leaves them room next to a work list of at least 128 bytes per tree wave; returns their offset (0: none —
+// the descent then reads the records) and moves `shared` past them.  AGZ_NXL=0 turns them off (A/B).
+static int place_nxw(size_t& shared, size_t cu_lds, int tree_waves, int games_per_wave, int V) {
+    static const bool on = AGZ_PERSIST_NXL && !(getenv("AGZ_NXL") && atoi(getenv("AGZ_NXL")) == 0);
+    const size_t bytes = ((size_t)tree_waves * (size_t)games_per_wave * (size_t)V * 2 + 15) & ~(size_t)15;
+    if (!on || shared + bytes + (size_t)tree_waves * 128 > cu_lds) return 0;
+    const int off = (int)shared;
+    shared += bytes;
+    return off;
+}
+
 typedef void (*rollout_fn)(const TreePar);
 typedef void (*small_fn)(const SmallPar);
 typedef void (*big_fn)(const BigSearchPar);
@@ -988,9 +1000,10 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
             S.io_prowb = rs; S.io_lgs = rs / 4; S.io_bw = NG * rs;
             S.io_off = (int)((std::max((size_t)tw * (size_t)S.tree_lds, (size_t)gpwg * 2 * (n.H * 2 + 16)) + 15) & ~(size_t)15);
             S.xch_off = S.io_off + tw * S.io_bw;
-            const size_t shared = (size_t)S.xch_off + (size_t)tw * (16 * NG + 16);
+            size_t shared = (size_t)S.xch_off + (size_t)tw * (16 * NG + 16);
             if (!one && wgs <= h->cus && shared > (size_t)(80 * 1024)) one = 1;     // (32 trees per wave: the tables of a workgroup take more than half a CU's LDS)
             const size_t cu_lds = (size_t)(160 * 1024) / (size_t)(one ? 1 : 2);
+            S.nxw_off = place_nxw(shared, cu_lds, tw, NG, h->V);
             const size_t room = cu_lds > shared ? cu_lds - shared : 0;
             S.wl_off = (int)shared; S.wl_bytes = (int)std::min({(size_t)(NG * h->V * 4), (room / (size_t)tw) & ~(size_t)15, (size_t)h->wl_lds_max});
             const size_t lds = shared + (size_t)tw * S.wl_bytes;
@@ -1067,11 +1080,12 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
             S.io_prowb = rs; S.io_lgs = rs / 4; S.io_bw = 8 * rs; S.F.rb = 8;
             h->rd_rec_bytes = h->tp.rec_bytes; h->rd_off_rk = 16 + h->tp.A2 * 4; h->rd_off_el = h->tp.off_q; h->rd_off_vis = h->tp.off_vis;
             S.io_off = (int)((std::max((size_t)(tw == 8 ? 8 : 4) * h->reg_lds, (size_t)8 * tw * 2 * (n.H * 2 + 16)) + 15) & ~(size_t)15);   // (16-game workgroups: the two helper waves have tables of their own)
-            const size_t shared = (size_t)S.io_off + (size_t)tw * S.io_bw + (size_t)tw * 144;   // ... + the carry a tree wave publishes for its helper
+            size_t shared = (size_t)S.io_off + (size_t)tw * S.io_bw + (size_t)tw * 144;   // ... + the carry a tree wave publishes for its helper
             S.xch_off = S.io_off + tw * S.io_bw;
-            // + the tree waves' work lists (kept across the network phase): what the CU's LDS leaves when every workgroup of the launch
-            // must be resident (4 per CU at 32768 games); entries beyond the region, rare, go to the global list
+            // + the tree waves' next-word tables and work lists (kept across the network phase): what the CU's LDS leaves when every workgroup of
+            // the launch must be resident (4 per CU at 32768 games); list entries beyond the region, rare, go to the global list
             const int wgs_per_cu = tw == 2 || tw == 8 ? 2 : 2 + occ;
+            S.nxw_off = place_nxw(shared, (size_t)(160 * 1024) / (size_t)wgs_per_cu, tw, 8, h->V);
             const size_t room = (size_t)(160 * 1024) / (size_t)wgs_per_cu > shared ? (size_t)(160 * 1024) / (size_t)wgs_per_cu - shared : 0;
             S.wl_off = (int)shared; S.wl_bytes = (int)std::min({(size_t)(8 * h->V * 4), (room / (size_t)tw) & ~(size_t)15, (size_t)h->wl_lds_max});
             const size_t lds = shared + (size_t)tw * S.wl_bytes;
@@ -1134,8 +1148,9 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
             if (k4) { wgs = (h->L + 127) / 128; S.T.gpw = 16; }
             S.V = V; S.tree_lds = k4 ? eager_lds_layout(h->V, 16).total : (int)h->reg_lds;
             S.xch_off = (int)((std::max((size_t)8 * (size_t)S.tree_lds, (size_t)(k4 ? 128 : 8 * twb) * big_rowb) + 15) & ~(size_t)15);   // (tree waves and helper waves have tables of their own)
-            const size_t shared = (size_t)S.xch_off + 4 * 144;
+            size_t shared = (size_t)S.xch_off + 4 * 144;
             const int wgcu = k4 ? 1 : (x8 ? 2 : (b8 ? 1 : occ + 1));
+            S.nxw_off = place_nxw(shared, (size_t)(160 * 1024) / (size_t)wgcu, twb, k4 ? 16 : 8, h->V);
             const size_t room = (size_t)(160 * 1024) / (size_t)wgcu > shared ? (size_t)(160 * 1024) / (size_t)wgcu - shared : 0;
             S.wl_off = (int)shared; S.wl_bytes = (int)std::min({(size_t)((k4 ? 16 : 8) * h->V * 4), (room / (size_t)twb) & ~(size_t)15, (size_t)h->wl_lds_max});
             const size_t lds = shared + (size_t)twb * S.wl_bytes;
@@ -1625,8 +1640,6 @@ static int finish_call(agz_engine* h, int ngames, bool chain, unsigned long long
 // ---- one launch per call: the persistent self-play kernel (agz_selfplay_small.hpp) -------------------------------------------------
 // the wide-trunk form with ONE 128-game workgroup per CU (k_selfplay_big4): built for the game shape, every workgroup resident, the 128-row
 // activation tile (shared with the eight waves' tree tables) + flags + a work list of at least 64 entries per wave inside a CU's LDS
-// next-word tables of a persistent 128-wide workgroup (agz_tree_eager.hpp NXL): 16 bits per node of each of its games
-static size_t persist_nxw_bytes(int gpwg, int V) { return AGZ_PERSIST_NXL ? (((size_t)gpwg * (size_t)V * 2 + 15) & ~(size_t)15) : 0; }
 static bool use_big4(const agz_engine* h) {
     const DevNet& n = h->net[0];
     if (!h->k_persist_big4 || !n.wbig || n.H != 512 || h->big4 == 0) return false;
@@ -1652,7 +1665,7 @@ static bool persist_shape(const agz_engine* h) {
         const size_t tree_lds = nar ? (size_t)eager_lds_layout(h->V, NG).total : h->reg_lds;
         const int rs = small_io_row_bytes(n);
         const size_t io_off = (std::max((size_t)tw * tree_lds, (size_t)gpwg * 2 * (n.H * 2 + 16)) + 15) & ~(size_t)15;
-        return io_off + (size_t)tw * NG * rs + 16 + persist_nxw_bytes(gpwg, h->V) + (size_t)tw * 64 <= cu_lds;   // (flags, next words, at least 16 work-list entries per wave)
+        return io_off + (size_t)tw * NG * rs + 16 + (size_t)tw * 64 <= cu_lds;   // (flags, at least 16 work-list entries per wave; the next-word tables where they fit)
     }
     if (n.H == 512 && use_big4(h)) return true;
     if (n.H == 512) {
@@ -1776,9 +1789,10 @@ static int run_games_persist(agz_engine* h, int ngames, int V, float cpuct, int 
         wgcu = (big4 || (int)wgs <= h->cus) ? 1 : 2;
         S.V = V; S.tree_lds = big4 ? eager_lds_layout(h->V, NG).total : (int)h->reg_lds;
         S.xch_off = (int)((std::max((size_t)8 * (size_t)S.tree_lds, (size_t)gpwg * big_rowb) + 15) & ~(size_t)15);
-        const size_t shared = (size_t)S.xch_off + 4 * 144 + 16;                  // ... + the workgroup's two flag words
+        size_t shared = (size_t)S.xch_off + 4 * 144 + 16;                        // ... + the workgroup's two flag words
         Q.X = X; Q.X.flag_off = (int)shared - 16;
         const size_t cu_lds = cu_lds_all / (size_t)wgcu;
+        S.nxw_off = place_nxw(shared, cu_lds, 8, NG, h->V);
         const size_t room = cu_lds > shared ? cu_lds - shared : 0;
         S.wl_off = (int)shared; S.wl_bytes = (int)std::min({(size_t)(NG * h->V * 4), (room / 8) & ~(size_t)15, (size_t)h->wl_lds_max});
         const size_t lds = shared + (size_t)8 * S.wl_bytes;
@@ -1799,11 +1813,11 @@ static int run_games_persist(agz_engine* h, int ngames, int V, float cpuct, int 
         S.io_off = (int)((std::max((size_t)tw * (size_t)S.tree_lds, (size_t)gpwg * 2 * (n.H * 2 + 16)) + 15) & ~(size_t)15);
         S.xch_off = S.io_off + tw * S.io_bw;                                       // (no helper waves here: nothing is exchanged)
         // ... + the workgroup's two flag words + the tree waves' next-word tables (agz_tree_eager.hpp NXL: 2 V bytes per game)
-        S.nxw_off = S.xch_off + 16;
-        const size_t shared = (size_t)S.nxw_off + persist_nxw_bytes(gpwg, h->V);
+        size_t shared = (size_t)S.xch_off + 16;
         Q.X = X; Q.X.flag_off = S.xch_off;
         wgcu = ((int)wgs + h->cus - 1) / h->cus;
         const size_t cu_lds = cu_lds_all / (size_t)wgcu;
+        S.nxw_off = place_nxw(shared, cu_lds, tw, NG, h->V);
         const size_t room = cu_lds > shared ? cu_lds - shared : 0;
         S.wl_off = (int)shared; S.wl_bytes = (int)std::min({(size_t)(NG * h->V * 4), (room / (size_t)tw) & ~(size_t)15, (size_t)h->wl_lds_max});
         const size_t lds = shared + (size_t)tw * S.wl_bytes;

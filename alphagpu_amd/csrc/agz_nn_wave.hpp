@@ -172,8 +172,9 @@ __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const
         bf16x8 bq_[BP ? KTH : 1][LT];                                                                   \
         uint2 old_[LT][TPW];                                                                            \
         if constexpr (BP) {                                                                             \
+            /* (the reads are unconditional — a skipped k-row reads what lies behind the planes, inside the workgroup's LDS, and is not used: */ \
+            /*  reads under the condition leave the operand registers partly defined and the 256-register builds spill 50 of them) */ \
             _Pragma("unroll") for (int k = 0; k < KTH; ++k)                                             \
-                if (k == 0 || k < kmax_)                                                                \
                 _Pragma("unroll") for (int lt = 0; lt < LT; ++lt)                                       \
                     bq_[k][lt] = *reinterpret_cast<const bf16x8*>(brow_ + (size_t)lt * bstride_ + k * 64 + q4 * 16); \
             if (res_) {                                                                                 \

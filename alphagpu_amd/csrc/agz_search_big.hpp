@@ -21,6 +21,7 @@ struct BigSearchPar {
     int tree_lds;             // bytes of LDS of one tree wave
     int wl_off, wl_bytes;     // the tree waves' work lists live past the window the two phases share: offset, bytes per wave
     int xch_off;              // per tree wave: the carry it publishes for its helper wave (agz_tree_eager.hpp ROLE_*), 144 bytes
+    int nxw_off;              // the tree waves' next-word tables (agz_tree_eager.hpp nxw), games per wave x V x 2 bytes each; 0: none
 };
 
 // WG = workgroups per CU the register budget is cut for (1: 256 registers, 2: 128)
@@ -61,16 +62,18 @@ __global__ __launch_bounds__(NB_THREADS, 2 * WG) void k_search_big(const BigSear
         int bx = (int)blockIdx.x;
         asm volatile("" : "+s"(bx));                              // (see k_search_small)
         const BigSearchPar& S = par();
+        uint16_t* const nxw = S.nxw_off ? reinterpret_cast<uint16_t*>(lds_bigs + S.nxw_off) + (size_t)(wave % TW) * (size_t)(8 * S.V) : nullptr;   // (a helper wave: its tree wave's)
         if constexpr (!SPLIT) {
             const StepFlags SF = {(uint32_t)k, k == 0, k > 0, k < S.V, k == S.V - 1, k == S.V};
-            if (wave < TW) rollout_eager_body<FAM, NC, KPL, true, PF_, false, ROLE_ALL, KPR>(SF, own_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount);
+            if (wave < TW) rollout_eager_body<FAM, NC, KPL, true, PF_, false, ROLE_ALL, KPR>(SF, own_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
+                                                                                            nullptr, 0, 0, nullptr, 0u, 0u, nxw);
         }
         if (SPLIT && k > 0) {
             const StepFlags SE = {(uint32_t)k, 0, 1, 0, k == S.V - 1, k == S.V};
             if (wave < TW) rollout_eager_body<FAM, NC, KPL, true, PF_, false, ROLE_EXPAND, KPR>(SE, own_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
-                                                                                        nullptr, 0, 0, xch);
+                                                                                        nullptr, 0, 0, xch, 0u, 0u, nxw);
             else rollout_eager_body<FAM, NC, KPL, true, PF_, false, ROLE_ITEMS, KPR>(SE, own_lds, bx * TW + wave % TW, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
-                                                                              nullptr, 0, 0, xch);
+                                                                              nullptr, 0, 0, xch, 0u, 0u, nxw);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __syncthreads();                                      // the leaf is expanded, the path's rows and next words are rebuilt
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -79,7 +82,7 @@ __global__ __launch_bounds__(NB_THREADS, 2 * WG) void k_search_big(const BigSear
             if (SPLIT && wave < TW) {
                 const StepFlags SS = {(uint32_t)k, k == 0, 0, 1, k == S.V - 1, 0};
                 rollout_eager_body<FAM, NC, KPL, true, PF_, false, ROLE_EXPAND, KPR>(SS, own_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
-                                                                             nullptr, 0, 0, xch);
+                                                                             nullptr, 0, 0, xch, 0u, 0u, nxw);
             }
 #ifdef AGZ_BIGSTAMPS
             const unsigned long long c1 = __builtin_amdgcn_s_memtime();
@@ -137,8 +140,10 @@ __global__ __launch_bounds__(NB_THREADS, 2) void k_search_big4(const BigSearchPa
             const BigSearchPar& S = par();
             uint8_t* const own_lds = lds_bigs + (size_t)wave * S.tree_lds;
             uint32_t* const wl_lds = reinterpret_cast<uint32_t*>(lds_bigs + S.wl_off + (size_t)wave * S.wl_bytes);
+            uint16_t* const nxw = S.nxw_off ? reinterpret_cast<uint16_t*>(lds_bigs + S.nxw_off) + (size_t)wave * (size_t)(NG * S.V) : nullptr;
             const StepFlags SF = {(uint32_t)k, k == 0, k > 0, k < S.V, k == S.V - 1, k == S.V};
-            rollout_eager_body<FAM, NC, KPL4, true, 2, false, ROLE_ALL, KPR4, G>(SF, own_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount);
+            rollout_eager_body<FAM, NC, KPL4, true, 2, false, ROLE_ALL, KPR4, G>(SF, own_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
+                                                                         nullptr, 0, 0, nullptr, 0u, 0u, nxw);
         }
         if (k < V_) {
             // (the barrier that publishes the planes of the 128 leaves is taken inside the pass, behind its first weight requests: PREB)

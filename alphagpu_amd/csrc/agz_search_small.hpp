@@ -12,6 +12,9 @@
 #include "agz_tree_eager.hpp"
 #include "agz_nn_wave.hpp"
 
+#ifndef AGZ_PERSIST_NXL
+#define AGZ_PERSIST_NXL 1    // 1: the descent of the whole-search kernels follows next words kept in LDS (agz_tree_eager.hpp nxw) wherever they fit; 0: the records' (A/B)
+#endif
 #ifndef AGZ_PFM_LOW
 #define AGZ_PFM_LOW 1       // item prefetch of the builds without register room (agz_tree_eager.hpp PFM): 1 = touch only, 3 = first part into registers
 #endif
@@ -27,7 +30,7 @@ struct SmallPar {
     int io_off, io_bw;        // hand-over window (planes to the network, logits back): offset, bytes per tree wave (one row per game of a full wave)
     int io_prowb, io_lgs;     // ... bytes / floats of a row (the same row carries the leaf's planes to the network and its logits back)
     int xch_off;              // 16-game workgroups: per tree wave the carry it publishes for its helper wave (4 NG + 1 words in 16 NG + 16 bytes)
-    int nxw_off;              // persistent self-play kernels: the tree waves' next-word tables (agz_tree_eager.hpp NXL), NG x V x 2 bytes per wave
+    int nxw_off;              // the tree waves' next-word tables (agz_tree_eager.hpp nxw), NG x V x 2 bytes per wave; 0: none (the descent reads the records)
 };
 
 // TW = tree waves per workgroup (2 or 4): the workgroup owns 8*TW games and runs the network with TW/2 leaf tiles.
@@ -81,13 +84,14 @@ __global__ __launch_bounds__(64 * (TW == 8 ? 8 : NW_WAVES), WV) void k_search_sm
         asm volatile("" : "+s"(bx));
         const SmallPar& S = par();
         uint8_t* const io_blk = lds_small + S.io_off + (size_t)(wave % TW) * S.io_bw;
+        uint16_t* const nxw = S.nxw_off ? reinterpret_cast<uint16_t*>(lds_small + S.nxw_off) + (size_t)(wave % TW) * (size_t)(NG * S.V) : nullptr;   // (a helper wave: its tree wave's)
         if constexpr (SPLIT) {
             if (k > 0) {
                 const StepFlags SE = {(uint32_t)k, 0, 1, 0, k == S.V - 1, k == S.V};
                 if (wave < TW) rollout_eager_body<FAM, NC, KPL, true, 2, true, ROLE_EXPAND, KPR>(SE, own_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
-                                                                                         io_blk, S.io_prowb, S.io_lgs, xch);
+                                                                                         io_blk, S.io_prowb, S.io_lgs, xch, 0u, 0u, nxw);
                 else rollout_eager_body<FAM, NC, KPL, true, 2, true, ROLE_ITEMS, KPR>(SE, own_lds, bx * TW + wave % TW, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
-                                                                               io_blk, S.io_prowb, S.io_lgs, xch);
+                                                                               io_blk, S.io_prowb, S.io_lgs, xch, 0u, 0u, nxw);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __syncthreads();                                  // the leaf is expanded, the path's rows and next words are rebuilt
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -95,12 +99,12 @@ __global__ __launch_bounds__(64 * (TW == 8 ? 8 : NW_WAVES), WV) void k_search_sm
             if (k < S.V && wave < TW) {
                 const StepFlags SS = {(uint32_t)k, k == 0, 0, 1, k == S.V - 1, 0};
                 rollout_eager_body<FAM, NC, KPL, true, 2, true, ROLE_EXPAND, KPR>(SS, own_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
-                                                                            io_blk, S.io_prowb, S.io_lgs, xch);
+                                                                            io_blk, S.io_prowb, S.io_lgs, xch, 0u, 0u, nxw);
             }
         } else {
             const StepFlags SF = {(uint32_t)k, k == 0, k > 0, k < S.V, k == S.V - 1, k == S.V};
             if (wave < TW) rollout_eager_body<FAM, NC, KPL, true, ((G < 8 || WV < 3 || (WV == 3 && KPL <= 16) || KPL <= 4) ? 2 : AGZ_PFM_LOW), true, ROLE_ALL, KPR, G>(SF, tree_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
-                                                                                   io_blk, S.io_prowb, S.io_lgs);
+                                                                                   io_blk, S.io_prowb, S.io_lgs, nullptr, 0u, 0u, nxw);
         }
 #ifdef AGZ_STAMPS
         const unsigned long long t_nn0 = __builtin_amdgcn_s_memtime();

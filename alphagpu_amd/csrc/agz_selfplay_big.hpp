@@ -34,9 +34,10 @@ __global__ __launch_bounds__(NB_THREADS, 2 * WG) void k_selfplay_big(const Persi
                 const BigSearchPar& S = spar();
                 uint8_t* const own_lds = lds_bigs + (size_t)wave * S.tree_lds;
                 uint32_t* const wl_lds = reinterpret_cast<uint32_t*>(lds_bigs + S.wl_off + (size_t)wave * S.wl_bytes);
+                uint16_t* const nxw = S.nxw_off ? reinterpret_cast<uint16_t*>(lds_bigs + S.nxw_off) + (size_t)wave * (size_t)(8 * S.V) : nullptr;
                 const StepFlags SF = {(uint32_t)k, k == 0, k > 0, k < S.V, k == S.V - 1, k == S.V};
                 rollout_eager_body<FAM, NC, KPL, true, PF_, false, ROLE_ALL, 0>(SF, own_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
-                                                                         nullptr, 0, 0, nullptr, ~amask);
+                                                                         nullptr, 0, 0, nullptr, ~amask, 0u, nxw);
             }
             if (k < V_) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -88,9 +89,10 @@ __global__ __launch_bounds__(NB_THREADS, 2) void k_selfplay_big4(const PersistBi
                 const BigSearchPar& S = spar();
                 uint8_t* const own_lds = lds_bigs + (size_t)wave * S.tree_lds;
                 uint32_t* const wl_lds = reinterpret_cast<uint32_t*>(lds_bigs + S.wl_off + (size_t)wave * S.wl_bytes);
+                uint16_t* const nxw = S.nxw_off ? reinterpret_cast<uint16_t*>(lds_bigs + S.nxw_off) + (size_t)wave * (size_t)(NG * S.V) : nullptr;
                 const StepFlags SF = {(uint32_t)k, k == 0, k > 0, k < S.V, k == S.V - 1, k == S.V};
                 rollout_eager_body<FAM, NC, KPL4, true, 2, false, ROLE_ALL, 0, G>(SF, own_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount,
-                                                                          nullptr, 0, 0, nullptr, ~amask);
+                                                                          nullptr, 0, 0, nullptr, ~amask, 0u, nxw);
             }
             B4STAMP(0);
             if (k < V_) {

@@ -19,7 +19,7 @@
 #endif
 
 #ifndef AGZ_PERSIST_NXL
-#define AGZ_PERSIST_NXL 1    // 1: the descent of the persistent 128-wide kernels follows next words kept in LDS (agz_tree_eager.hpp NXL); 0: the records' (A/B)
+#define AGZ_PERSIST_NXL 1    // 1: the descent of the whole-search kernels follows next words kept in LDS (agz_tree_eager.hpp nxw) wherever they fit; 0: the records' (A/B)
 #endif
 
 namespace agz {
@@ -371,9 +371,9 @@ __device__ __forceinline__ void persist_search(uint8_t* const lds_small, const u
         uint8_t* const tree_lds = lds_small + (size_t)wave * S.tree_lds;
         uint32_t* const wl_lds = reinterpret_cast<uint32_t*>(lds_small + S.wl_off + (size_t)wave * S.wl_bytes);
         uint8_t* const io_blk = lds_small + S.io_off + (size_t)wave * S.io_bw;
-        uint16_t* const nxw = reinterpret_cast<uint16_t*>(lds_small + S.nxw_off) + (size_t)wave * (size_t)(NG * S.V);   // next words of this wave's trees
+        uint16_t* const nxw = (AGZ_PERSIST_NXL && S.nxw_off) ? reinterpret_cast<uint16_t*>(lds_small + S.nxw_off) + (size_t)wave * (size_t)(NG * S.V) : nullptr;   // next words of this wave's trees
         const StepFlags SF = {(uint32_t)k, k == 0, k > 0, k < S.V, k == S.V - 1, k == S.V};
-        rollout_eager_body<FAM, NC, KPL, true, PFM_, true, ROLE_ALL, KPR, G, AGZ_PERSIST_NXL != 0>(
+        rollout_eager_body<FAM, NC, KPL, true, PFM_, true, ROLE_ALL, KPR, G>(
             SF, tree_lds, bx * TW + wave, C, wl_lds, (uint32_t)S.wl_bytes >> 2, wcount, io_blk, S.io_prowb, S.io_lgs, nullptr, ~amask, KPR ? S.T.rec_bytes : 0u, nxw);
         if (k < S.V) {
             __builtin_amdgcn_s_setprio(3);

@@ -152,13 +152,14 @@ __device__ __forceinline__ const TreePar& tree_par() {
 // actions sub KPL .. of every row.  Fewer lanes per tree = more trees per wave: the per-round fixed work of the item loop (Newton, the
 // turns of the ordered sums, reductions, sampling, the backup) is shared by twice / four times the items, and a game with few actions
 // (Connect4: 7) does not leave six of eight lanes without an action.
-// NXL (round 6; the persistent self-play kernels): the NEXT WORDS of the wave's trees live in LDS as well — nxw[game in wave][node], 16 bits:
-// child id (7 bits) | valid << 7 | (child ? creation rank + 1 of its edge : the action) << 8 — and the descent follows THOSE: one LDS read per
-// level (~100 cycles) instead of one dependent global load per level (an L2 hit at best, 8.4 levels per wave and rollout: 8 % of a wave's
-// time on the headline shape).  Every word a search reads was written by the same wave during the same search (the root's at its
-// expansion, a child's at its creation), so the table needs no clearing and nothing outside a search depends on it; the global next
-// word is still written with the aux words (same 16-byte store).
-template <int FAM, int NC, int KPL, bool LEAN, int PFM, bool LIO = false, int ROLE = ROLE_ALL, int KPR_ = 0, int G_ = 8, bool NXL = false>
+// nxw != nullptr (round 6; the whole-search kernels, wherever the workgroup's LDS has 2 V bytes per game left): the NEXT WORDS of the wave's trees
+// live in LDS as well — nxw[game in wave][node], 16 bits: child id (7 bits) | valid << 7 | (child ? creation rank + 1 of its edge : the action) << 8
+// — and the descent follows THOSE: one LDS read per level (~100 cycles) instead of one dependent global load per level (an L2 hit at best,
+// 8.4 levels per wave and rollout: 8 % of a wave's time on the headline shape; measured +6 % rollouts/s).  Every word a search reads was
+// written by a wave of the same workgroup during the same search (the root's at its expansion, a child's at its creation; the helper waves
+// of the 16-game workgroups write the table of their tree wave, a workgroup barrier in between), so the table needs no clearing and
+// nothing outside a search depends on it; the global next word is still written with the aux words (same 16-byte store).
+template <int FAM, int NC, int KPL, bool LEAN, int PFM, bool LIO = false, int ROLE = ROLE_ALL, int KPR_ = 0, int G_ = 8>
 __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* const lds, const int bidx,
                                                    EagerCarry& C, uint32_t* const wl_lds, const uint32_t wl_cap_lds, uint32_t& wcount,
                                                    uint8_t* const io_blk = nullptr, const int io_prowb = 0, const int io_lgs = 0,
@@ -173,7 +174,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
     constexpr int KPR = KPR_ ? KPR_ : KPL;                        // entries per lane of the node ROWS
     constexpr bool CMP = KPR != KPL;                              // rows by the root's legal rank
     static_assert(!CMP || (LEAN && KPR % 4 == 0 && KPR < KPL && (FAM == F_LINE || FAM == F_HEX)), "legal-compacted rows: lean builds of the stone-placing games");
-    static_assert(!NXL || (LEAN && ROLE == ROLE_ALL), "next words in LDS: one wave does the whole tree step of its games");
+    const bool NXL = LEAN && nxw != nullptr;                      // (wave-uniform)
     // the 32-bit next word (as stored in a record's aux) -> the 16-bit form of the LDS table
     auto nx16 = [](const uint32_t nx) -> uint16_t {
         const uint32_t child = (nx >> 8) & 0xffu;
@@ -357,6 +358,9 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
     };
 
     constexpr bool PF = PFM == 2, PF3 = PFM == 3;
+    // PFM = 4 (round 6): the first round's rows are touched at the head of the expansion and fetched at the head of the round (as PFM = 1); the rows of
+    // every later round are requested into registers behind the policy row of the round before (as PFM = 2)
+    constexpr bool PF4 = PFM == 4;
     // touch the record (and the aux word) of the item of round r: one dword per cache line
     auto item_touch = [&](const int r, const uint32_t nwl) -> uint32_t {
         uint32_t ent = 0u; int gi = g; bool valid = false;
@@ -405,7 +409,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
             }
         }
         uint32_t sink = 0u;
-        if constexpr ((PFM == 1 || PFM == 3) && ROLE != ROLE_EXPAND) sink = item_touch(0, nwl);   // the first item's record starts travelling towards L2 now
+        if constexpr ((PFM == 1 || PFM == 3 || PFM == 4) && ROLE != ROLE_EXPAND) sink = item_touch(0, nwl);   // the first item's record starts travelling towards L2 now
         // ---------------------------------------------------------------------------- expand (lane-group g = game g)
         const int lf = (int)C.leafn;
         uint32_t ml = live ? (LEAN ? C.leaf_meta : gmeta[lf]) : (uint32_t)M_TERM;   // (one memory round trip less on the rollout's chain)
@@ -563,7 +567,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
             if (lead) {
                 gmeta[lf] = ml;
                 *reinterpret_cast<uint4*>(rec) = make_uint4(__float_as_uint(total), nx, (uint32_t)npos | (wide ? AUX_SLOW : 0u), 0u);
-                if constexpr (NXL) nxw[gnode0 + (uint32_t)lf] = nx16(nx);
+                if (NXL) nxw[gnode0 + (uint32_t)lf] = nx16(nx);
             }
         } else if (__builtin_expect(ROLE != ROLE_ITEMS && live && lf == 0, 0)) {
 #pragma unroll
@@ -587,7 +591,8 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
         const bool recompute = !(TI.final_ || SF.fin);                 // after the last rollout of a search nobody descends again   // PHASE items: loop control
 #pragma unroll 1
         for (int r = 0; r < (ROLE == ROLE_EXPAND ? 0 : rounds); ++r) {
-            if constexpr (!PF && !PF3) item_fetch(R, r, nwl);
+            if constexpr (!PF && !PF3 && !PF4) item_fetch(R, r, nwl);
+            if constexpr (PF4) { if (r == 0) item_fetch(R, 0, nwl); }
             if constexpr (PF3) item_fetch(R, r, nwl, 2);              // priors and child bytes of THIS item: used after Newton
             const bool valid = R.valid, special = r == 0 && g < GPW;
             const int gi = R.gi;   // PHASE items: fetch item
@@ -648,7 +653,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
             const bool FDr = FD && !__ballot(ax_z & AUX_SLOW);      // (wave-uniform)
             if (!recompute) {
                 if (valid && lead) *reinterpret_cast<uint4*>(rec) = make_uint4(__float_as_uint(prem_raw), 0u, auxz, 0u);   // (nobody descends again: the LDS word is not read)
-                if constexpr (PF || PF3) { if (r + 1 < rounds) item_fetch(R, r + 1, nwl, PF3 ? 1 : 0); }
+                if constexpr (PF || PF3 || PF4) { if (r + 1 < rounds) item_fetch(R, r + 1, nwl, PF3 ? 1 : 0); }
                 continue;
             }
             STAMPW(4);
@@ -741,7 +746,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
             // the 128-register build touches the next item's record HERE, not at the head of the round: a full round ahead, the lines
             // touched by the 512 waves of an XCD (5.2 MB per round) do not survive in its 4 MB L2 until they are read; half a round
             // (~6 us) still covers an HBM miss (first ply at 32768 games 4.22 -> 4.15 ms)
-            if constexpr (PFM == 1 || PFM == 3) {
+            if constexpr (PFM == 1 || PFM == 3 || PFM == 4) {
                 asm volatile("" :: "v"(sink));                        // (keeps the touch loads alive; they completed long ago)
                 if (r + 1 < rounds) sink = item_touch(r + 1, nwl);
             }
@@ -762,7 +767,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
             // the rows of this item are dead: the next item's start travelling now (its table entries are written after the
             // AGZ_WSYNC below)
             AGZ_WSYNC();
-            if constexpr (PF || PF3) { if (r + 1 < rounds) item_fetch(R, r + 1, nwl, PF3 ? 1 : 0); }
+            if constexpr (PF || PF3 || PF4) { if (r + 1 < rounds) item_fetch(R, r + 1, nwl, PF3 ? 1 : 0); }
             if (__builtin_expect(__ballot(valid && node == 0 && SF.last) != 0, 0)) {     // copy_pol (:330-339): the row the last descent samples from
                 if (valid && node == 0) {
 #pragma unroll
@@ -777,7 +782,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
             const uint32_t nx = sample_next(pol, st, u, cdk, rkw, move, (uint32_t)ileaf);
             if (valid && lead) {
                 *reinterpret_cast<uint4*>(rec) = make_uint4(__float_as_uint(prem_raw), nx, auxz, 0u);
-                if constexpr (NXL) nxw[ind] = nx16(nx);
+                if (NXL) nxw[ind] = nx16(nx);
             }
             STAMPW(8);
         }
@@ -796,40 +801,41 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
         if constexpr (LEAN) __builtin_amdgcn_s_setprio(2);
         // every expanded node carries the action its next visit samples and the child under it: the descent follows the words
         int node = 0, depth = 0;
-        // nx: the next word of the node the descent stands on — the 32-bit form of the record (action | child << 8 | NX_VALID | rank << 17) or,
-        // NXL, the 16-bit form of the LDS table (child | 0x80 | mr << 8: mr = the action of a new edge, else the rank + 1 of the edge taken)
+        // (nxw: the 16-bit word of the LDS table, spread into the record's 32-bit form — its mr field is the action of a new edge or the rank + 1
+        //  of the edge taken, and the descent reads the action only when there is no child and the rank only when there is one)
+        auto nx_lds = [&](const uint32_t nd) -> uint32_t {
+            const uint32_t w = (uint32_t)nxw[nd], mr = w >> 8;
+            return mr | ((w & 0x7fu) << 8) | ((w & 0x80u) << 9) | (mr << 17);
+        };
         uint32_t nx = 0u;
-        if (live && C.root_exp) nx = NXL ? (uint32_t)nxw[gnode0] : auxp(gnode0)->y;
-        constexpr uint32_t NXV = NXL ? 0x80u : (uint32_t)NX_VALID;
-        bool descending = (nx & NXV) != 0;
+        if (live && C.root_exp) nx = NXL ? nx_lds(gnode0) : auxp(gnode0)->y;
+        bool descending = (nx & NX_VALID) != 0;
         int create_from = -1, create_move = 0;
         uint32_t spnew = 0u;
         wcount = 0;                                                   // wave-uniform: entries of the work list so far
         STAMPW(10);
         while (__ballot(descending)) {
             if (descending) {
-                const int child = NXL ? (int)(nx & 0x7fu) : (int)((nx >> 8) & 0xffu);
-                const uint32_t mv = NXL ? nx >> 8 : nx & 0xffu;        // the action (used for a new edge only)
-                const uint32_t rk = NXL ? nx >> 8 : (nx >> 17) & 0xffu;   // rank + 1 of the edge to an existing child
+                const int move = (int)(nx & 0xffu), child = (int)((nx >> 8) & 0xffu);
                 if (lead) ++C.add_p;
                 ++depth;
                 if (child == 0) {                                      // :183-191: a new child is never expanded -> the descent ends
-                    create_from = node; create_move = (int)mv;
-                    spnew = (uint32_t)node | (mv << 8) | ((uint32_t)depth << 16) | SP_VALID | SP_CREATED;
+                    create_from = node; create_move = move;
+                    spnew = (uint32_t)node | ((uint32_t)move << 8) | ((uint32_t)depth << 16) | SP_VALID | SP_CREATED;
                     descending = false;
                 } else {
-                    const uint32_t nxc = NXL ? (uint32_t)nxw[gnode0 + (uint32_t)child] : auxp(gnode0 + (uint32_t)child)->y;     // (cleared when the child was created, set by its expansion)
+                    const uint32_t nxc = NXL ? nx_lds(gnode0 + (uint32_t)child) : auxp(gnode0 + (uint32_t)child)->y;     // (cleared when the child was created, set by its expansion)
                     STAMPW(11);
-                    if (nxc & NXV) {                                   // expanded child: the descent goes on (:192)
+                    if (nxc & NX_VALID) {                              // expanded child: the descent goes on (:192)
                         const uint64_t app = __ballot(lead);           // (only lanes of groups that go on are here)
                         if (lead) {
                             const uint32_t pos = wcount + (uint32_t)__popcll(app & ((1ull << lane) - 1ull));
-                            const uint32_t e = (uint32_t)node | (rk << 8) | ((uint32_t)(depth - 1) << 16) | ((uint32_t)g << 24);   // (an old edge goes by its rank)
+                            const uint32_t e = (uint32_t)node | (((nx >> 17) & 0xffu) << 8) | ((uint32_t)(depth - 1) << 16) | ((uint32_t)g << 24);   // (an old edge goes by its rank)
                             if (LEAN && pos < wl_cap_lds) wl_lds[pos] = e; else wl_g[pos] = e;
                         }
                         node = child; nx = nxc;
                     } else {                                           // existing child that was never expanded: a terminal position
-                        spnew = (uint32_t)node | (rk << 8) | ((uint32_t)depth << 16) | SP_VALID;
+                        spnew = (uint32_t)node | (((nx >> 17) & 0xffu) << 8) | ((uint32_t)depth << 16) | SP_VALID;
                         node = child;
                         descending = false;
                     }
@@ -871,7 +877,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
                 wstates[gnode0 + child] = pack(lst);
                 gmeta[child] = mc;
                 reinterpret_cast<uint32_t*>(auxp(gnode0 + child))[1] = 0u;      // not expanded: no next word yet
-                if constexpr (NXL) nxw[gnode0 + child] = (uint16_t)0u;
+                if (NXL) nxw[gnode0 + child] = (uint16_t)0u;
             }
             mn = mc; node = (int)child;
         } else if (live) mn = gmeta[node];

@@ -277,6 +277,8 @@ int  agz_set_profiling(agz_engine *h, int mode);       /* HIP events per launch:
  *   AGZ_RCCL_LIB=path      the RCCL library agz_comm_* binds (default: an RCCL already in the process, librccl.so.1, /opt/rocm/lib/librccl.so.1)
  *   AGZ_WL_LDS_BYTES=n     one-launch forms: at most n bytes of LDS per tree wave for the work list of a rollout (the rest of
  *                          the list lives in global memory; default: what the resident workgroups leave free)
+ *   AGZ_NXL=0              one-launch forms: the descent reads the next words from the node records (global memory) instead of the copy the tree
+ *                          waves keep in LDS (16 bits per node and game, wherever the workgroup's LDS has the room; round 6, +6 % on the headline)
  */
 #ifdef __cplusplus
 }

@@ -57,7 +57,7 @@ def test_benchmarked_kernels_do_not_spill_vector_registers():
             for name in names:
                 k = md[name]
                 assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0 and k["vgpr_count"] <= budget, (name, k)
-                assert k["sgpr_spill_count"] <= 40, (name, k)            # (was 120-150 while the parameters lived in scalar registers)
+                assert k["sgpr_spill_count"] <= 48, (name, k)            # (was 120-150 while the parameters lived in scalar registers; 37 -> 44 at most with the next-word table of round 6)
         for wg in (1, 2):
             for kpr in ((0, 8, 4) if fam_nc_kpl in ("0, 2, 12", "2, 2, 12") else (0,)):
                 for twb in (4, 8):
