@@ -191,6 +191,7 @@ struct agz_engine {
     persist_fn k_persist = nullptr, k_persist_nar = nullptr; int persist_nar_g = 0, persist_nar_kpl = 0;
     persist_big_fn k_persist_big[2] = {nullptr, nullptr};    // 512-wide trunks (agz_selfplay_big.hpp): one / two 64-game workgroups per CU
     int persist = -1; bool chain_persist = false; unsigned long long* d_pacc = nullptr;
+    int reserve_slots = 0;             // AGZ_RESERVE_CUS x 128: slots the persistent launches leave without a workgroup (room for the exchange's RCCL kernels)
     // ... with age classes (workgroups that prefer old games run rows by legal rank; games migrate through a queue in device memory):
     // age_kpr rows per lane of the old body, age_on (AGZ_AGE=0 turns it off), age_old16 of 16 CU pairs prefer old games (AGZ_AGE_OLD16),
     // age_by_block (AGZ_AGE_CLASS=block, tests: odd workgroups prefer old games), age_backlog: the queue's length at which nothing is pushed
@@ -465,6 +466,8 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
         for (int i = 0; i < h->nnar; ++i) for (int j = 0; j < 2; ++j) FA_(hipFuncSetAttribute((const void*)h->nar[i].k[j], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         e3 = getenv("AGZ_PERSIST");
         if (e3) h->persist = atoi(e3) > 0 ? 1 : 0;
+        e3 = getenv("AGZ_RESERVE_CUS");
+        if (e3 && atoi(e3) > 0) h->reserve_slots = std::min(atoi(e3) * 128, std::max(0, (h->Lmax - 128) / 128 * 128));
         if (h->k_persist) FA_(hipFuncSetAttribute((const void*)h->k_persist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         if (h->k_persist_nar) FA_(hipFuncSetAttribute((const void*)h->k_persist_nar, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         if (h->k_persist_age) FA_(hipFuncSetAttribute((const void*)h->k_persist_age, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1437,7 +1440,11 @@ static int run_games(agz_engine* h, int ngames, int V, float cpuct, int tau_plie
     // runs at the size the chip is filled by, and each game's samples are the ones a lock-step run over ngames slots gives (results are
     // keyed by game id and the game's own ply)
     const long long want = chain ? (long long)ngames + next_games : (long long)ngames;
-    const int slots = want < h->Lmax ? (int)want : h->Lmax;
+    // AGZ_RESERVE_CUS=n: the launch leaves the slots of n CUs (128 each) without a workgroup, so that the kernels of another stream — the RCCL
+    // all-gather of the call before, agz_comm_* — find n CUs' worth of wave slots and LDS free for the whole launch instead of waiting for a
+    // persistent workgroup to end
+    const int LM = h->Lmax - h->reserve_slots;
+    const int slots = want < LM ? (int)want : LM;
     if (ngames < 1 || (duel && ngames > h->Lmax)) { h->fail("ngames=%d outside [1,%d]", ngames, h->Lmax); return AGZ_ERR_ARG; }
     if (ngames > slots && ngames > h->sample_games) { h->fail("ngames=%d exceeds the sample capacity of the engine (%d games: agz_config.sample_capacity_games)", ngames, h->sample_games); return AGZ_ERR_ARG; }
     if (chain && want > h->sample_games) { h->fail("agz_selfplay_chain: ngames + next_ngames = %lld exceeds the sample capacity of the engine (%d games: agz_config.sample_capacity_games)", want, h->sample_games); return AGZ_ERR_ARG; }
@@ -1684,7 +1691,11 @@ static int run_games_persist(agz_engine* h, int ngames, int V, float cpuct, int 
     const unsigned long long k0 = cont ? h->chain_k0 : 0ull;
     const unsigned long long pool_end = k0 + (unsigned long long)ngames + (unsigned long long)(chain ? next_games : 0);
     const long long want = chain ? (long long)ngames + next_games : (long long)ngames;
-    const int slots = want < h->Lmax ? (int)want : h->Lmax;
+    // AGZ_RESERVE_CUS=n: the launch leaves the slots of n CUs (128 each) without a workgroup, so that the kernels of another stream — the RCCL
+    // all-gather of the call before, agz_comm_* — find n CUs' worth of wave slots and LDS free for the whole launch instead of waiting for a
+    // persistent workgroup to end
+    const int LM = h->Lmax - h->reserve_slots;
+    const int slots = want < LM ? (int)want : LM;
     if (ngames < 1) { h->fail("ngames=%d outside [1,%d]", ngames, h->sample_games); return AGZ_ERR_ARG; }
     if (ngames > slots && ngames > h->sample_games) { h->fail("ngames=%d exceeds the sample capacity of the engine (%d games: agz_config.sample_capacity_games)", ngames, h->sample_games); return AGZ_ERR_ARG; }
     if (chain && want > h->sample_games) { h->fail("agz_selfplay_chain: ngames + next_ngames = %lld exceeds the sample capacity of the engine (%d games: agz_config.sample_capacity_games)", want, h->sample_games); return AGZ_ERR_ARG; }
@@ -1698,7 +1709,7 @@ static int run_games_persist(agz_engine* h, int ngames, int V, float cpuct, int 
         HIPCHK(h, hipMemsetAsync(h->g_nplies, 0, (size_t)h->sample_games * 4, h->stream));
         HIPCHK(h, hipMemsetAsync(h->slot_ply, 0, (size_t)h->Lmax * 4, h->stream));
         HIPCHK(h, hipMemsetD32Async((hipDeviceptr_t)h->alive, 1, (size_t)slots, h->stream));
-        if (slots < h->Lmax) HIPCHK(h, hipMemsetD32Async((hipDeviceptr_t)(h->alive + slots), 0, (size_t)(h->Lmax - slots), h->stream));
+        if (slots < h->Lmax) HIPCHK(h, hipMemsetD32Async((hipDeviceptr_t)(h->alive + slots), 0, (size_t)(h->Lmax - slots), h->stream));   // (the reserved slots too)
         started = (unsigned long long)slots;
         HIPCHK(h, hipMemcpyAsync(h->d_stats + 6, &started, 8, hipMemcpyHostToDevice, h->stream));
         if (h->mq_buf && h->mq_dirty) {                                         // games an abandoned chain left on their way between workgroups are dropped
@@ -1732,7 +1743,7 @@ static int run_games_persist(agz_engine* h, int ngames, int V, float cpuct, int 
         const unsigned long long z[10] = {0, 0, 0, 0, 0, 0, started, 0, finished, 0};
         HIPCHK(h, hipMemcpyAsync(h->d_stats, z, sizeof z, hipMemcpyHostToDevice, h->stream));
     }
-    h->L = h->Lmax;                                                             // the launch covers every slot; alive[] says which hold a game
+    h->L = LM;                                                                  // the launch covers every slot (the reserved ones aside); alive[] says which hold a game
     h->need_reset = true; h->tree_kpr = 0;
     h->chain_live = false;
     h->sp_games = ngames; h->sp_nsamples = 0; h->sp_maxplies = 0;
@@ -1751,17 +1762,17 @@ static int run_games_persist(agz_engine* h, int ngames, int V, float cpuct, int 
     const bool tw4 = !big && !nar && h->persist_tw4;
     const bool big4 = big && use_big4(h);                                       // one 128-game workgroup per CU, 4 lanes per tree
     const int G = nar ? h->persist_nar_g : (big4 ? 4 : 8), NG = 64 / G, tw = (nar || tw4) ? 4 : 8, gpwg = tw * NG;
-    const unsigned wgs = (unsigned)((h->Lmax + gpwg - 1) / gpwg);
+    const unsigned wgs = (unsigned)((LM + gpwg - 1) / gpwg);
     PersistTail X; memset(&X, 0, sizeof X);
     fill_plypar(h, X.P, 0, tau_plies, false);
-    X.P.L = h->Lmax;
+    X.P.L = LM;
     X.P.refill_total = (chain || (long long)ngames > (long long)slots) ? (uint32_t)pool_end : 0u;
     X.P.ring = chain ? 1 : 0; X.P.k_cur_end = (uint32_t)(k0 + (unsigned long long)ngames);
     X.ngames_cur = chain ? (uint32_t)ngames : 0u;
     X.acc = h->d_pacc;
     if (h->mq_buf && !big && (age || h->mq_dirty)) {                            // (a chain that began with age classes keeps the queue: games may wait in it)
         X.P.mq.ctr = h->mq_ctr; X.P.mq.buf = h->mq_buf; X.P.mq.mask = h->mq_cap - 1u;
-        X.P.mq.backlog_max = (uint32_t)(h->age_backlog > 0 ? h->age_backlog : std::max(64, h->Lmax / 16));
+        X.P.mq.backlog_max = (uint32_t)(h->age_backlog > 0 ? h->age_backlog : std::max(64, LM / 16));
         if (X.P.mq.backlog_max > h->mq_cap / 2u) X.P.mq.backlog_max = h->mq_cap / 2u;
         X.P.mq.age = (uint32_t)std::max(0, h->G.A - 8 * h->age_kpr);
         X.old16 = (uint32_t)h->age_old16; X.class_by_block = (h->age_by_block ? 1u : 0u) | (h->age_by_wave ? 2u : 0u);
@@ -1769,7 +1780,7 @@ static int run_games_persist(agz_engine* h, int ngames, int V, float cpuct, int 
     }
     const bool age_kernel = X.P.mq.buf != nullptr;
     TreePar T = h->tp;
-    T.L = h->Lmax; T.slot0 = 0; T.step = 0; T.cpuct = cpuct; T.training = 1;
+    T.L = LM; T.slot0 = 0; T.step = 0; T.cpuct = cpuct; T.training = 1;
     T.fastdiv = fastdiv_range(h);
     T.inject = 0; T.capture = 0; T.rollout = 0; T.do_reset = 1; T.do_expand = 0; T.do_select = 1; T.last = 0;
     T.gpw = NG;
@@ -1785,7 +1796,7 @@ static int run_games_persist(agz_engine* h, int ngames, int V, float cpuct, int 
         B.planes = (const uint16_t*)h->planes; B.INP = n.INP; B.wh = n.wbig;
         B.whead = n.w16 + (size_t)(n.INP / 32) * (n.H / 16) * 512 + (size_t)n.T * (n.H / 32) * (n.H / 16) * 512;
         B.bias_head = n.bias_head; B.logits = h->logits; B.LGS = h->LGS; B.vout = h->v_eval;
-        B.L = h->Lmax; B.T = n.T; B.A = h->G.A; B.AOP = n.AOP; B.K0R = n.k0r; B.ROWB = big_rowb;
+        B.L = LM; B.T = n.T; B.A = h->G.A; B.AOP = n.AOP; B.K0R = n.k0r; B.ROWB = big_rowb;
         wgcu = (big4 || (int)wgs <= h->cus) ? 1 : 2;
         S.V = V; S.tree_lds = big4 ? eager_lds_layout(h->V, NG).total : (int)h->reg_lds;
         S.xch_off = (int)((std::max((size_t)8 * (size_t)S.tree_lds, (size_t)gpwg * big_rowb) + 15) & ~(size_t)15);
@@ -1805,7 +1816,7 @@ static int run_games_persist(agz_engine* h, int ngames, int V, float cpuct, int 
         SmallPar& S = Q.S;
         S.T = T;
         S.F.planes = (const uint16_t*)h->planes; S.F.INP = n.INP; S.F.w16 = n.w16w; S.F.bias_head = n.bias_head;
-        S.F.logits = h->logits; S.F.LGS = h->LGS; S.F.vout = h->v_eval; S.F.L = h->Lmax; S.F.T = n.T; S.F.A = h->G.A; S.F.AOP = n.AOP;
+        S.F.logits = h->logits; S.F.LGS = h->LGS; S.F.vout = h->v_eval; S.F.L = LM; S.F.T = n.T; S.F.A = h->G.A; S.F.AOP = n.AOP;
         S.F.gpw = 0; S.F.tw = tw; S.F.rb = NG;
         S.V = V; S.tree_lds = nar ? eager_lds_layout(h->V, NG).total : (int)h->reg_lds;
         const int rs = small_io_row_bytes(n);
@@ -1860,7 +1871,7 @@ static int run_games_persist(agz_engine* h, int ngames, int V, float cpuct, int 
     }
     h->acc_p += acc[0]; h->acc_new += acc[1]; h->total_rollouts += (uint64_t)rollouts; h->cnt_live = false;
     h->tree_ms += ms; h->tree_busy_ms += ms; h->tree_launches += 1;
-    const int rounds = (int)((acc[2] + (unsigned long long)h->Lmax - 1) / (unsigned long long)h->Lmax);   // searches per slot, rounded up
+    const int rounds = (int)((acc[2] + (unsigned long long)LM - 1) / (unsigned long long)LM);   // searches per slot, rounded up
     if (!chain && waiting) { h->fail("persistent self-play: %d games left in the migration queue at the end of a call of its own", waiting); return AGZ_ERR_STATE; }
     return finish_call(h, ngames, chain, k0, started, (int)acc[3] + waiting, true, rollouts, rounds, (double)ms, t0, st);
 }
@@ -1890,7 +1901,10 @@ int agz_duel(agz_engine* h, int ngames, int V, float cpuct, int tau_plies, int f
 }
 
 // ---- samples ----------------------------------------------------------------------------------------
-int agz_get_samples_packed(agz_engine* h, void* dev_out, int64_t capacity_records, int64_t* n_out) {
+static int pack_samples(agz_engine* h, void* dev_out, int64_t capacity_records, int64_t* n_out, bool wait);
+int agz_get_samples_packed(agz_engine* h, void* dev_out, int64_t capacity_records, int64_t* n_out) { return pack_samples(h, dev_out, capacity_records, n_out, true); }
+int agz_get_samples_packed_async(agz_engine* h, void* dev_out, int64_t capacity_records, int64_t* n_out) { return pack_samples(h, dev_out, capacity_records, n_out, false); }
+static int pack_samples(agz_engine* h, void* dev_out, int64_t capacity_records, int64_t* n_out, bool wait) {
     if (!h || !n_out) return AGZ_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     // the number of samples and the longest game are known since the generation ended (run_games); the order table is built on the
@@ -1911,6 +1925,7 @@ int agz_get_samples_packed(agz_engine* h, void* dev_out, int64_t capacity_record
     T.out = (uint8_t*)dev_out;
     hipLaunchKernelGGL(k_pack_samples, dim3((unsigned)std::min<int64_t>((n + 3) / 4, (int64_t)h->cus * 32)), dim3(256), 0, h->stream, T);
     HIPCHK(h, hipGetLastError());
+    if (!wait) return AGZ_OK;                            // (the records are complete when the engine's stream gets here: agz_stream)
     const hipError_t e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) { h->fail("k_pack_samples failed: %s", hipGetErrorString(e)); return AGZ_ERR_HIP; }
     return AGZ_OK;

@@ -165,6 +165,7 @@ class CommExchange:
         self.C, self.e, self.L = C, engine, engine.L
         self.rank, self.world, self.cap, self.rb = int(rank), int(world), int(capacity_records), int(engine.game.rec_bytes)
         self.slack, self.seen_max, self.units, self.tails = float(slack), None, [], 0
+        self.last_statuses = np.zeros(self.world, np.int32)
         uid = (C.c_uint8 * 128)()
         if self.rank == 0:
             rc = self.L.agz_comm_unique_id(C.byref(uid))
@@ -212,11 +213,19 @@ class CommExchange:
             parts.append(a)
         return parts
 
-    def allgather(self):
-        counts = (self.C.c_int64 * self.world)()
-        self._chk(self.L.agz_allgather_samples(self.e.h, self.h, counts), "agz_allgather_samples")
+    def allgather(self, status=0, fetch=True):
+        """Blocking exchange (counts, then records).  status: the return code of this rank's self-play call — a rank whose call failed
+        STILL calls this (with its code; it sends no records): see statuses()."""
+        counts, st = (self.C.c_int64 * self.world)(), (self.C.c_int32 * self.world)()
+        self._chk(self.L.agz_allgather_samples_status(self.e.h, self.h, int(status), counts, st), "agz_allgather_samples_status")
+        self.last_statuses = np.array(st[:], np.int32)
         counts = np.array(counts[:], np.int64)
-        return self._parts(counts), counts
+        return (self._parts(counts) if fetch else None), counts
+
+    def statuses(self):
+        """the status words every rank sent with the exchange last waited for (0 = its self-play call succeeded): identical on all ranks,
+        so that they fail, or go on, together"""
+        return self.last_statuses
 
     def fetch_last(self, counts):
         """the records of the exchange last waited for, rank by rank, in host memory"""
@@ -228,27 +237,40 @@ class CommExchange:
         n = int(self.seen_max * units * (1.0 + self.slack)) + 64
         return min(self.cap, (n + 255) & ~255)
 
-    def start(self, units=1, send_records=None):
-        """Issue the collective for the engine's last self-play call.  The first exchange of a run (nothing to predict from) is the
-        blocking form; its result is kept for wait()."""
+    def start(self, units=1, send_records=None, status=0, fetch=True):
+        """Issue the collective for the engine's last self-play call (status: its return code; a failed call still enters the collective,
+        without records).  The first exchange of a run (nothing to predict from) is the blocking form; its result is kept for wait()
+        (fetch=False: its records stay on the device like those of the pipelined form)."""
         if self.seen_max is None and send_records is None:
-            self.units.append((units, self.allgather()))
+            parts, counts = self.allgather(status, fetch=fetch)
+            self.units.append((units, (parts, counts, self.last_statuses)))
             return
+        self._chk(self.L.agz_comm_post_status(self.h, int(status)), "agz_comm_post_status")
         self._chk(self.L.agz_allgather_samples_start(self.e.h, self.h, int(send_records if send_records is not None else self.agreed_count(units))), "agz_allgather_samples_start")
         self.units.append((units, None))
 
     def wait(self, fetch=True):
         """-> (parts, counts) of the OLDEST collective in flight.  fetch=False: parts is None — the gathered records stay in the exchange's
         device buffer (agz_comm_records_device / fetch_last()) until the next-but-one start(); a host loop that trains on the GPU, or a
-        benchmark, does not pay a device-to-host copy of every rank's records per call."""
-        units, done = self.units.pop(0)
+        benchmark, does not pay a device-to-host copy of every rank's records per call.  statuses() then holds every rank's status word."""
+        units, done = self.units[0]
         if done is None:
             counts, mx = (self.C.c_int64 * self.world)(), self.C.c_int64(0)
-            self._chk(self.L.agz_allgather_samples_wait(self.h, counts, self.C.byref(mx)), "agz_allgather_samples_wait")
+            rc = self.L.agz_allgather_samples_wait(self.h, counts, self.C.byref(mx))
+            self.units.pop(0)                    # (the C side retires the slot whatever the outcome: the two queues stay in step)
+            self._chk(rc, "agz_allgather_samples_wait")
+            st = (self.C.c_int32 * self.world)()
+            self._chk(self.L.agz_comm_get_statuses(self.h, st), "agz_comm_get_statuses")
+            self.last_statuses = np.array(st[:], np.int32)
             counts = np.array(counts[:], np.int64)
             done = (self._parts(counts) if fetch else None, counts)
-        r = float(done[1].max()) / float(units)
-        self.seen_max = r if self.seen_max is None else max(self.seen_max, r)
+        else:
+            self.units.pop(0)
+            self.last_statuses = done[2]
+            done = (done[0], done[1])           # (the blocking form fetched at start() — or not, if start() was told fetch=False)
+        if not self.last_statuses.any():
+            r = float(done[1].max()) / float(units)
+            self.seen_max = r if self.seen_max is None else max(self.seen_max, r)
         return done
 
 

@@ -126,6 +126,12 @@ def main():
                     "calls in which a call starts the next call's games in the slots it leaves free (agz_selfplay_chain)")
     ap.add_argument("--exchange", action="store_true", help="run the exchange step (agz_comm_*: RCCL all-gather of the call's records through the C ABI) even "
                     "with ONE rank, inside the timed region as with N > 1 (tests: the bench's multi-GPU path end to end on one GPU)")
+    ap.add_argument("--exchange-impl", choices=["torch", "abi"], default="torch", help="the exchange step of N > 1 ranks over RCCL: torch.distributed's "
+                    "all_gather_into_tensor (shard.RecordExchange: the form every multi-rank test of this repository has run — gloo with 2 and 8 ranks, RCCL "
+                    "with one) or the C ABI (agz_comm_*: libagz binds RCCL itself; shard.CommExchange — has only ever run with ONE rank: no box with two "
+                    "GPUs was available; tests/test_gpu_scale_parity.py compares the two forms as soon as two devices are visible)")
+    ap.add_argument("--exchange-plies", type=int, default=0, help="capacity of the exchange buffers in records per game (0 = the longest game the rules "
+                    "allow, game.max_plies: a call can never outgrow it)")
     ap.add_argument("--dump-records", default="", help="rank 0 writes the gathered samples of the LAST timed generation (PoolSample order) to this .npz")
     args = ap.parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -197,10 +203,10 @@ def main():
     # issued without any read-back (the rank's record count travels in the buffer's header: shard.RecordExchange)
     # The exchange step.  RCCL (backend "nccl"): through the C ABI — shard.CommExchange is a thin caller of agz_comm_create /
     # agz_allgather_samples_start / _wait; libagz binds RCCL itself and owns the gather buffers, allocated ONCE here.  Capacity: a call's
-    # games x 3/4 of the longest game possible (Gobang 9x9 averages 39 of 81 plies; a call that outgrows it fails on every rank with a
-    # message, it does not hang).  "gloo" (smoke tests with all ranks on one GPU): the torch.distributed form, staged through host memory.
-    use_abi = (world > 1 and args.backend == "nccl") or (world == 1 and args.exchange)
-    cap_records = gens_cap * G * max(1, (3 * game.max_plies + 3) // 4)
+    # games x the longest game the rules allow (--exchange-plies bounds it: a call that outgrows a smaller capacity fails on every rank with
+    # a message, it does not hang).  "gloo" (smoke tests with all ranks on one GPU): the torch.distributed form, staged through host memory.
+    use_abi = (world > 1 and args.backend == "nccl" and args.exchange_impl == "abi") or (world == 1 and args.exchange)
+    cap_records = gens_cap * G * max(1, min(game.max_plies, args.exchange_plies) if args.exchange_plies > 0 else game.max_plies)
     cex = shard.CommExchange(eng, rank, world, cap_records) if use_abi else None
     ex = shard.RecordExchange(gens_cap * G * game.max_plies, rb) if world > 1 and not use_abi else None
     sample_bufs = [ex.new_buffer("cuda") for _ in range(2)] if ex else None
@@ -208,6 +214,7 @@ def main():
     inflight = [None, None]
     last_gather = [None]
     nstep = [0]
+    fault = [0]
 
     def step(ngen=1, nxt=None):
         if chain and nxt is not None:           # a call of the run's chain: `nxt` generations' worth of the next call's games may start early
@@ -217,14 +224,18 @@ def main():
         else:
             eng.set_seed(1 + nstep[0])          # a fresh Philox key per call, as the reference's unseeded draws
             st = eng.selfplay(ngen * G, V, cpuct=args.cpuct, tau_plies=25)
+        # an illegal sampled move ("faute", mcts_gpu.jl:526-529) voids the run — but a rank must NOT leave before the exchange: the others
+        # would wait inside the all-gather for ever.  The rank takes part (its status word travels with the records, agz_comm_post_status;
+        # the torch form gathers whatever it has) and every rank stops behind the timed region, together (the all-reduce of `fault` below).
         if not st["valid"]:
-            raise SystemExit("illegal move sampled ('faute')")
+            fault[0] = 1
         k = nstep[0] & 1
         nstep[0] += 1
         if cex is not None:                 # the one exchange step, through the C ABI: at most two collectives in flight
             if len(cex.units) == 2:
                 last_gather[0] = cex.wait(fetch=False)   # (the gathered records stay on the device: a trainer on the GPU reads them there)
-            cex.start(units=ngen)
+                fault[0] |= int(cex.statuses().any())
+            cex.start(units=ngen, status=0 if st["valid"] else -5, fetch=False)
         elif world > 1:                     # ... the torch.distributed form (gloo smoke path)
             if inflight[k] is not None:
                 inflight[k].wait()          # the collective that read sample_bufs[k] two generations ago
@@ -242,6 +253,7 @@ def main():
         eng.synchronize()
         while cex is not None and cex.units:
             last_gather[0] = cex.wait(fetch=False)
+            fault[0] |= int(cex.statuses().any())
         for k in range(2):
             if inflight[k] is not None:
                 inflight[k].wait()
@@ -415,6 +427,16 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     dt_max, total_rollouts, nsamples_all = float(tmax.item()), float(tot[0].item()), float(tot[1].item())
+    flt = torch.tensor([float(fault[0])], dtype=torch.float64, device=cdev)
+    if world > 1:
+        dist.all_reduce(flt, op=dist.ReduceOp.MAX)
+    if flt.item() > 0:                          # every rank leaves here, behind the last collective of the run
+        if cex is not None:
+            cex.close()
+        eng.close()
+        if world > 1:
+            dist.destroy_process_group()
+        raise SystemExit("illegal move sampled ('faute') on some rank: the run is void")
 
     if rank == 0:
         S = game.pos_image_bytes

@@ -168,6 +168,9 @@ int  agz_get_samples(agz_engine *h, int8_t *state, float *policy, int8_t *player
  * (see agz_game_info) to dev_out; returns n via *n_out.  Record: {u32 game_id, i32 ply, i32 move, f32 value,
  * i8 player, u8 net_tag, i8 pad[2], f32 policy[A], i8 state[2VS], i8 fstate[FS], pad to 16 B}   (net_tag: agz_set_network_tag). */
 int  agz_get_samples_packed(agz_engine *h, void *dev_out, int64_t capacity_records, int64_t *n_out);
+/* The same without waiting: the pack kernels are queued on the engine's stream (agz_stream) and the call returns; the records are complete
+ * once that stream has reached this point (an event recorded on it, agz_synchronize, or any later blocking call of the handle). */
+int  agz_get_samples_packed_async(agz_engine *h, void *dev_out, int64_t capacity_records, int64_t *n_out);
 /* Host-only helper (no handle, no device): n packed records in HOST memory -> the PoolSample-layout arrays of agz_get_samples
  * (push_buffer / update_buffer, mainGobang.jl:54-80).  Lets a host loop copy the records of generation k to pinned memory on a side
  * stream and unpack them while generation k+1 runs. */
@@ -181,9 +184,15 @@ int  agz_unpack_records(const agz_game_info *info, const void *records, int64_t 
  * mcts(actor, visits, ngames, buffer) pushes into ONE PoolSample (mcts_gpu.jl:513-516; caller selfplay.jl:34).  The reference has no
  * counterpart (single device).  RCCL is bound at run time (dlopen: AGZ_RCCL_LIB, librccl.so.1); the host ships the 128-byte id from one
  * rank to the others by its own means (a file, a socket, MPI, torch.distributed).
- * Memory, allocated once at agz_comm_create: 2 x (1 + world) x (16 + capacity_records x rec_bytes) bytes per rank (two slots: the
+ * Memory, allocated once at agz_comm_create: 2 x (1 + world) x (32 + capacity_records x rec_bytes) bytes per rank (two slots: the
  * exchange of call k overlaps call k + 1).  8 ranks x one Gobang 9x9 generation (32768 games, ~39 plies, 592-byte records: ~0.76 GB per
- * rank) = 6.1 GB gathered per slot: size capacity_records by the records of ONE call (16 GB of gathered records hold two generations). */
+ * rank) = 6.1 GB gathered per slot: size capacity_records by the records of ONE call (16 GB of gathered records hold two generations).
+ * BASELINE config 5 (Reversi 8x8, 8 ranks x 32768 games, one generation per call, 464-byte records, <= 70 plies, ~60 on average):
+ * capacity 32768 x 70 records = 1.06 GB per block -> 2 x 9 x 1.06 = 19.2 GB of exchange buffers per rank next to the engine's 6.3 GB
+ * (2.0 GB of node records, 1.4 GB of sample store for three generations in flight, states, planes) — 9 % of a 288-GB MI355X.
+ * A rank whose self-play call FAILED (an illegal sampled move, any error) must still enter the exchange — the others would wait inside
+ * ncclAllGather for ever: agz_comm_post_status hands its return code to the next collective (such a rank sends no records), every
+ * rank reads all codes after the wait (agz_comm_get_statuses) and they fail, or go on, together. */
 typedef struct agz_comm agz_comm;
 #define AGZ_COMM_ID_BYTES 128
 int  agz_comm_unique_id(void *id /* [AGZ_COMM_ID_BYTES] */);       /* ncclGetUniqueId: on ONE rank */
@@ -193,13 +202,23 @@ const char *agz_comm_last_error(const agz_comm *c);                /* NULL: the 
 /* Blocking form, as SURVEY §8e states it: all-gather of the ranks' record counts, then of the records of the engine's last self-play
  * call padded to the largest count.  counts[world] (may be NULL) receives every rank's record count. */
 int  agz_allgather_samples(agz_engine *h, agz_comm *c, int64_t *counts);
-/* Pipelined form: ONE collective per call, issued without waiting for any other rank — every rank sends 16 + send_records x rec_bytes
- * bytes (its record count travels in the 16-byte header), send_records being a number ALL ranks agree on (0 = the capacity; a host loop
+/* Pipelined form: ONE collective per call, issued without waiting for any other rank — every rank sends 32 + send_records x rec_bytes
+ * bytes (its record count travels in the 32-byte header), send_records being a number ALL ranks agree on (0 = the capacity; a host loop
  * predicts it from the counts of the calls before).  At most two collectives in flight.  _wait returns the counts of the OLDEST one; if a
  * rank produced more than send_records records, every rank — they all see the same counts — gathers the rest in a second, blocking
  * collective inside _wait (from the exchange's own copy of the records: the engine may have played on).  *max_count: the largest count. */
 int  agz_allgather_samples_start(agz_engine *h, agz_comm *c, int64_t send_records);
 int  agz_allgather_samples_wait(agz_comm *c, int64_t *counts, int64_t *max_count);
+/* (_start does not block the host: the pack kernels run on the engine's stream, the exchange's stream waits for them through an event, the
+ *  32-byte header {record count, send_records, status} is copied from pinned memory.  _wait blocks until the oldest collective is complete.) */
+/* The status word this rank sends with its NEXT collective (default 0; reset to 0 when sent): the return code of its self-play call.
+ * A rank that posts a status != 0 takes part with a record count of 0. */
+int  agz_comm_post_status(agz_comm *c, int status);
+/* statuses[world]: the status words of the exchange last waited for (agz_allgather_samples_wait / agz_allgather_samples). */
+int  agz_comm_get_statuses(agz_comm *c, int32_t *statuses);
+/* agz_comm_post_status + agz_allgather_samples + agz_comm_get_statuses in one call: what a rank of a sharded run calls after its
+ * agz_selfplay* call WHATEVER that call returned (`status` = its return code).  Returns AGZ_OK when the exchange itself worked. */
+int  agz_allgather_samples_status(agz_engine *h, agz_comm *c, int status, int64_t *counts, int32_t *statuses);
 /* The records of rank `rank` from the exchange last waited for: n records from record `first` on into host memory (-> agz_unpack_records),
  * or their address in device memory (valid until the next-but-one agz_allgather_samples_start; NULL if the exchange needed its second
  * collective: the records are then in two pieces). */
@@ -277,6 +296,8 @@ int  agz_set_profiling(agz_engine *h, int mode);       /* HIP events per launch:
  *   AGZ_RCCL_LIB=path      the RCCL library agz_comm_* binds (default: an RCCL already in the process, librccl.so.1, /opt/rocm/lib/librccl.so.1)
  *   AGZ_WL_LDS_BYTES=n     one-launch forms: at most n bytes of LDS per tree wave for the work list of a rollout (the rest of
  *                          the list lives in global memory; default: what the resident workgroups leave free)
+ *   AGZ_RESERVE_CUS=n      self-play calls use 128 n slots fewer than the engine has: the persistent launches then leave n CUs' worth of wave slots and LDS
+ *                          free for the whole launch — room for the RCCL kernels of the exchange (agz_comm_*) that overlaps the next call
  *   AGZ_NXL=0              one-launch forms: the descent reads the next words from the node records (global memory) instead of the copy the tree
  *                          waves keep in LDS (16 bits per node and game, wherever the workgroup's LDS has the room; round 6, +6 % on the headline)
  */

@@ -5,7 +5,7 @@
 # maintainer of fabricerosay/AlphaGPU would add.  See INTEGRATION.md.
 module mcts_gpu
 
-export mcts, mcts_chain!, mcts_sharded!, duelnetwork, mcts_single, init, re_init
+export mcts, mcts_chain!, mcts_sharded!, duelnetwork, mcts_single, init, re_init, release_engines!
 
 using ..Game            # Position, canPlay, play, isOver, VectorizedState, FeatureSize, maxActions, maxLengthGame, PoolSample
 
@@ -35,8 +35,24 @@ end
 fresh_seed() = rand(UInt64) >> 1 | UInt64(1)
 set_seed!(e::Engine, seed) = check(e, ccall((:agz_set_seed, libagz), Cint, (Ptr{Cvoid}, UInt64), e.h, seed))
 
-# game ids: 0 Gobang, 1 Connect4, 2 Hex, 3 Reversi 8x8, 4 Reversi 6x6 — set by the main*.jl that includes the plugin
-function init(positions::Vector{Position}, visits; game::Integer, N::Integer=0, Nvict::Integer=0, device=0, seed=fresh_seed(), nn_mode=0, sample_capacity=0)
+# ---- which game?  The reference compiles ONE game into the session: main*.jl includes a plugin module (`GoBang`, `FourIARow`, `Hex`, `RevSix`)
+# and, for the boards of variable size, defines `const N` / `const Nvict` (mainGobang.jl:24-26, mainHex.jl:23) before it includes mcts_gpu.jl.
+# The shim reads the same definitions, so that the reference's call sites — selfplay.jl:34 `mcts_gpu.mcts(convert_back(net), rollout,
+# samplesNumber, buffer, cpuct=cpuct, noise=noise)` and :56 `mcts_gpu.duelnetwork(convert_back(trainingnet), convert_back(net), 32, 1024, -1)` —
+# run UNEDITED: no game / N / Nvict argument anywhere.  agz_game_kind: 0 Gobang, 1 Connect4, 2 Hex, 3 Reversi 8x8, 4 Reversi 6x6.
+function detect_game()
+    M = parentmodule(@__MODULE__)                     # `Main` when the file is included the way mcts_gpu.jl is (main*.jl:82-87)
+    n  = isdefined(M, :N) ? Int(getfield(M, :N)) : 0
+    nv = isdefined(M, :Nvict) ? Int(getfield(M, :Nvict)) : 0
+    isdefined(M, :GoBang)    && return (0, n, nv)     # Gobang.jl:1
+    isdefined(M, :FourIARow) && return (1, 0, 0)      # 4IARow.jl:1
+    isdefined(M, :Hex)       && return (2, n, 0)      # Hex.jl:1
+    isdefined(M, :RevSix)    && return (maxActions == 65 ? 3 : 4, 0, 0)   # Reversi8x8.jl:1 / Reversi6x6.jl:1 (both `module RevSix`: 65 vs 37 actions)
+    error("AlphaGPUAMD: no game plugin module (GoBang, FourIARow, Hex, RevSix) is loaded in $(M)")
+end
+const AGZ_GAME, AGZ_N, AGZ_NVICT = detect_game()
+
+function init(positions::Vector{Position}, visits; game::Integer=AGZ_GAME, N::Integer=AGZ_N, Nvict::Integer=AGZ_NVICT, device=0, seed=fresh_seed(), nn_mode=0, sample_capacity=0)
     cfg = Ref(AgzConfig(game, N, Nvict, length(positions), visits, device, seed, 0, nn_mode, sample_capacity, (0, 0, 0)))
     h = Ref{Ptr{Cvoid}}(C_NULL)
     rc = ccall((:agz_create, libagz), Cint, (Ref{AgzConfig}, Ref{Ptr{Cvoid}}), cfg, h)
@@ -47,6 +63,24 @@ function init(positions::Vector{Position}, visits; game::Integer, N::Integer=0, 
     e
 end
 init(L::Int, visits; kw...) = init([Position() for _ in 1:L], visits; kw...)
+
+# ONE engine per (slots, visits, sample capacity, device) stays alive from generation to generation: the reference allocates its tree arrays
+# on every mcts call and frees them with GC.gc(true); CUDA.reclaim() (mcts_gpu.jl:488-489) — here an engine owns gigabytes of HBM, a
+# create / destroy pair per call costs ~0.3 s, and trainingPipeline calls mcts and duelnetwork once per generation with the same sizes.
+# release_engines!() frees them (e.g. before the training step, if it needs the memory).
+const ENGINES = Dict{NTuple{4,Int},Engine}()
+function engine_for(slots::Integer, visits::Integer, capacity::Integer; device=0)
+    key = (Int(slots), Int(visits), Int(capacity), Int(device))
+    e = get(ENGINES, key, nothing)
+    if e === nothing || e.h == C_NULL
+        e = init(Int(slots), visits; device=device, sample_capacity=capacity)
+        ENGINES[key] = e
+    end
+    e
+end
+function release_engines!()
+    foreach(destroy!, values(ENGINES)); empty!(ENGINES)
+end
 
 # re_init(cu(positions), vnodes, L, ...) — the Vector{Position} memory image is passed as is (format 0 = Julia)
 function re_init(positions::Vector{Position}, e::Engine)
@@ -74,21 +108,24 @@ function mcts_single(actor, visits, e::Engine; training=true, cpuct=2f0, step=0)
     policy, batch                                  # == Array(vnodesStats.policy_final), Array(vnodesStats.batch)
 end
 
-# slots < ngames: the engine keeps `slots` games in flight and a slot whose game has ended takes the next game that has not started
-# (every search on a full batch; each game's samples are those of the lock-step run, agz.h agz_selfplay)
-function mcts(actor, visits, ngames, buffer::PoolSample; θ=1, cpuct=2.0, noise=Float32(1 / maxActions), game, N=0, Nvict=0, seed=fresh_seed(), slots=ngames)
-    e = init(min(slots, ngames), visits; game=game, N=N, Nvict=Nvict, seed=seed, sample_capacity=ngames)
-    try
+# mcts(actor, visits, ngames, buffer; θ, cpuct, noise) — mcts_gpu.jl:477: same positional arguments, same keywords, same defaults, same
+# return value.  (θ and noise are accepted and unused, as in the reference: :477 never reads θ, and expand ignores its noise argument, :250.)
+# Extra keywords, all optional: seed (a fresh one per call, like the reference's unseeded draws), slots < ngames — the engine then keeps
+# `slots` games in flight and a slot whose game has ended takes the next game that has not started (every search on a full batch; each
+# game's samples are those of the lock-step run, agz.h agz_selfplay).
+function mcts(actor, visits, ngames, buffer::PoolSample; θ=1, cpuct=2.0, noise=Float32(1 / maxActions), seed=fresh_seed(), slots=ngames, device=0)
+    e = engine_for(min(slots, ngames), visits, ngames; device=device)
+    set_seed!(e, seed)
     set_network!(e, actor)
     st = Ref{AgzStats}()
     rc = ccall((:agz_selfplay, libagz), Cint, (Ptr{Cvoid}, Cint, Cint, Cfloat, Cint, Ref{AgzStats}), e.h, ngames, visits, cpuct, 25, st)
-    rc == -5 && return (data=[], valid=false)      # "faute"
+    if rc == -5                                    # "faute" (mcts_gpu.jl:526-529)
+        println("faute")
+        return (data=[], valid=false)
+    end
     check(e, rc)
     push_samples!(e, st[], buffer)
     return (data=[], valid=true)
-    finally
-        destroy!(e)
-    end
 end
 
 # the samples of the last self-play call -> the PoolSample, in the order the reference pushes them (ply-major, slot order)
@@ -158,11 +195,18 @@ function mcts_sharded!(e::Engine, comm::Comm, actor, visits, ngames, next_ngames
     set_network!(e, actor)
     st = Ref{AgzStats}()
     rc = ccall((:agz_selfplay_chain, libagz), Cint, (Ptr{Cvoid}, Cint, Cint, Cint, Cfloat, Cint, Ref{AgzStats}), e.h, ngames, next_ngames, visits, cpuct, 25, st)
-    rc == -5 && return (data=[], valid=false)      # "faute"
-    check(e, rc)
-    counts = zeros(Int64, comm.world)
-    ccall((:agz_allgather_samples, libagz), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Int64}), e.h, comm.c, counts) == 0 ||
-        error(unsafe_string(ccall((:agz_comm_last_error, libagz), Cstring, (Ptr{Cvoid},), comm.c)))
+    # EVERY rank enters the collective, whatever its own call returned: a rank that left early (an illegal sampled move, any engine error)
+    # would leave the others inside ncclAllGather for ever.  Its verdict travels with the records — agz_allgather_samples_status gathers one
+    # status word per rank in front of the counts (a rank with an error sends no records) — and all ranks fail, or go on, together.
+    counts = zeros(Int64, comm.world); status = zeros(Int32, comm.world)
+    grc = ccall((:agz_allgather_samples_status, libagz), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Int64}, Ptr{Int32}), e.h, comm.c, rc, counts, status)
+    grc == 0 || error(unsafe_string(ccall((:agz_comm_last_error, libagz), Cstring, (Ptr{Cvoid},), comm.c)))
+    if any(status .== -5)                          # "faute" on some rank: the generation is void on all of them (mcts_gpu.jl:526-529)
+        println("faute")
+        return (data=[], valid=false)
+    end
+    bad = findfirst(!=(0), status)
+    bad === nothing || (bad - 1 == comm.rank ? check(e, rc) : error("rank $(bad - 1) failed with status $(status[bad])"))
     info = Ref{AgzGameInfo}()
     check(e, ccall((:agz_get_info, libagz), Cint, (Ptr{Cvoid}, Ref{AgzGameInfo}), e.h, info))
     n = sum(counts); rb = Int(info[].rec_bytes)
@@ -186,18 +230,17 @@ function mcts_sharded!(e::Engine, comm::Comm, actor, visits, ngames, next_ngames
     return (data=[], valid=true)
 end
 
-function duelnetwork(actor1, actor2, visits, ngames, conv=2; game, N=0, Nvict=0, seed=fresh_seed())
+# duelnetwork(actor1, actor2, visits, ngames, conv=2) — mcts_gpu.jl:653-668: the same five positional arguments (conv is accepted and unused
+# here: the network family is fixed to snetwork2, SURVEY 8b), returns (v, n, d) from actor1's point of view.  Both halves reuse ONE engine.
+function duelnetwork(actor1, actor2, visits, ngames, conv=2; seed=fresh_seed(), device=0)
     half = div(ngames, 2)
+    e = engine_for(half, visits, half; device=device)
     function half_duel(a, b, sd)
-        e = init(half, visits; game=game, N=N, Nvict=Nvict, seed=sd)
-        try
-            set_network!(e, a; slot=0); set_network!(e, b; slot=1)
-            wdl = zeros(Int64, 3)
-            check(e, ccall((:agz_duel, libagz), Cint, (Ptr{Cvoid}, Cint, Cint, Cfloat, Cint, Cint, Ptr{Int64}), e.h, half, visits, 2f0, 15, 0, wdl))
-            return wdl
-        finally
-            destroy!(e)
-        end
+        set_seed!(e, sd)
+        set_network!(e, a; slot=0); set_network!(e, b; slot=1)
+        wdl = zeros(Int64, 3)
+        check(e, ccall((:agz_duel, libagz), Cint, (Ptr{Cvoid}, Cint, Cint, Cfloat, Cint, Cint, Ptr{Int64}), e.h, half, visits, 2f0, 15, 0, wdl))
+        return wdl
     end
     v1, n1, d1 = half_duel(actor1, actor2, seed)
     d2, n2, v2 = half_duel(actor2, actor1, seed + 1)

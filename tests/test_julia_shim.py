@@ -63,7 +63,7 @@ def test_game_info_struct_matches_the_header():
 
 def test_the_shim_binds_the_sharded_exchange_and_the_network_tag():
     """SURVEY 8(e) through the C ABI, from Julia: the calls a rank of a sharded run makes (verdict r4 item 3) and the sample tag (item 5)"""
-    for sym in ("agz_comm_unique_id", "agz_comm_create", "agz_comm_destroy", "agz_allgather_samples", "agz_comm_fetch_records", "agz_unpack_records",
+    for sym in ("agz_comm_unique_id", "agz_comm_create", "agz_comm_destroy", "agz_allgather_samples_status", "agz_comm_fetch_records", "agz_unpack_records",
                 "agz_set_network_tag", "agz_selfplay_chain"):
         assert f"(:{sym}, libagz)" in JL, sym
     assert "function mcts_sharded!(e::Engine, comm::Comm, actor, visits, ngames, next_ngames, buffer::PoolSample" in JL
@@ -94,3 +94,83 @@ def test_every_symbol_the_shim_calls_is_declared_and_exported():
     for s in syms:
         assert re.search(rf"\b{s}\s*\(", HDR), f"{s} is not declared in include/agz.h"
         assert hasattr(L, s), f"{s} is not exported by libagz.so"
+
+
+# ---- the reference's own call sites run UNEDITED against the shim (verdict r5 item 8) ------------------------------------------------------
+def _julia_signature(name):
+    """(positional parameter names, {keyword: default text}) of every `function name(...)` of the shim"""
+    out = []
+    for m in re.finditer(rf"^function {name}\((.*)\)\s*$", JL, re.M):
+        pos, _, kw = m.group(1).partition(";")
+        split = lambda t: [x.strip() for x in re.split(r",(?![^()]*\))", t) if x.strip()]
+        kws = {}
+        for item in split(kw):
+            k, eq, v = item.partition("=")
+            kws[k.split("::")[0].strip()] = v.strip() if eq else None
+        out.append(([x.split("::")[0].split("=")[0].strip() for x in split(pos)], [("=" in x) for x in split(pos)], kws))
+    return out
+
+
+def _call_args(text):
+    """positional count and keyword names of a Julia call expression `f(a, g(b), k=v, ...)`"""
+    inner = text[text.index("(") + 1: text.rindex(")")]
+    parts, depth, cur = [], 0, ""
+    for ch in inner:
+        depth += ch == "("
+        depth -= ch == ")"
+        if ch == "," and depth == 0:
+            parts.append(cur); cur = ""
+        else:
+            cur += ch
+    parts.append(cur)
+    kw = [p.split("=")[0].strip() for p in parts if re.match(r"^\s*\w+\s*=[^=]", p)]
+    return len(parts) - len(kw), kw
+
+
+def test_reference_call_sites_bind_without_an_edit():
+    """selfplay.jl:34 `mcts_gpu.mcts(convert_back(net),rollout,samplesNumber,buffer,cpuct=cpuct,noise=noise)` and :56
+    `mcts_gpu.duelnetwork(convert_back(trainingnet),convert_back(net),32,1024,-1)` — restated here as text, the reference is not read at test
+    time — must select a method of the shim: enough positional parameters, every keyword they pass is one the shim declares, and every
+    keyword the shim declares has a default (round 5's shim required `game=`)."""
+    for name, call in (("mcts", "mcts_gpu.mcts(convert_back(net),rollout,samplesNumber,buffer,cpuct=cpuct,noise=noise)"),
+                       ("duelnetwork", "mcts_gpu.duelnetwork(convert_back(trainingnet),convert_back(net),32,1024,-1)")):
+        npos, kws = _call_args(call)
+        sigs = _julia_signature(name)
+        assert sigs, name
+        ok = False
+        for pos, has_default, kwd in sigs:
+            required = sum(1 for d in has_default if not d)
+            if required <= npos <= len(pos) and all(k in kwd for k in kws) and all(v is not None for v in kwd.values()):
+                ok = True
+        assert ok, (name, npos, kws, sigs)
+    # the reference's own keyword names and defaults (mcts_gpu.jl:477): θ=1, cpuct=2.0, noise=Float32(1/maxActions)
+    (pos, _, kwd), = _julia_signature("mcts")
+    assert pos == ["actor", "visits", "ngames", "buffer"] and kwd["θ"] == "1" and kwd["cpuct"] == "2.0" and kwd["noise"].replace(" ", "") == "Float32(1/maxActions)"
+    (pos, dflt, kwd), = _julia_signature("duelnetwork")
+    assert pos == ["actor1", "actor2", "visits", "ngames", "conv"] and dflt == [False, False, False, False, True]
+
+
+def test_the_game_is_taken_from_the_session_not_from_an_argument():
+    """the plugin module main*.jl has loaded (GoBang / FourIARow / Hex / RevSix) and its `const N`, `const Nvict` pick the engine's game"""
+    for mod, kind in (("GoBang", 0), ("FourIARow", 1), ("Hex", 2)):
+        assert re.search(rf"isdefined\(M, :{mod}\)\s*&&\s*return \({kind},", JL), mod
+    assert "isdefined(M, :RevSix)" in JL and "maxActions == 65 ? 3 : 4" in JL
+    assert "const AGZ_GAME, AGZ_N, AGZ_NVICT = detect_game()" in JL
+    assert re.search(r"function init\(positions::Vector\{Position\}, visits; game::Integer=AGZ_GAME, N::Integer=AGZ_N, Nvict::Integer=AGZ_NVICT", JL)
+
+
+def test_one_engine_stays_alive_across_generations():
+    """mcts / duelnetwork take their engine from a cache keyed by (slots, visits, capacity, device): no agz_create / agz_destroy pair per call"""
+    body = JL[JL.index("function mcts(actor, visits, ngames, buffer::PoolSample"):JL.index("function push_samples!")]
+    assert "engine_for(" in body and "destroy!(" not in body and "init(" not in body
+    body = JL[JL.index("function duelnetwork("):]
+    assert "engine_for(" in body and "destroy!(" not in body
+
+
+def test_a_failed_rank_still_enters_the_collective():
+    """mcts_sharded! returned on "faute" BEFORE the all-gather — the other ranks would block for ever.  Now nothing returns or
+    throws between the self-play call and the exchange, and the exchange carries the rank's status."""
+    body = JL[JL.index("function mcts_sharded!("):JL.index("function duelnetwork(")]
+    sp, ex = body.index(":agz_selfplay_chain"), body.index(":agz_allgather_samples_status")
+    between = "\n".join(ln.split("#")[0] for ln in body[sp:ex].splitlines()[1:])      # (code only, behind the self-play ccall's own line)
+    assert "return" not in between and "check(" not in between and "error(" not in between, between
