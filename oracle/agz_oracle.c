@@ -547,15 +547,29 @@ agzo_net_bf16 *agzo_net_bf16_create(const agzo_net *net) {                 /* we
 void agzo_net_bf16_destroy(agzo_net_bf16 *n) { if (!n) return; free(n->W0); free(n->Wres); free(n->Wp); free(n->Wv); free(n->bp); free(n); }
 
 /* snetwork2 forward (DenseNet.jl:294-304) as the bf16 MFMA kernels compute it; logits before softmax, v after sigma */
+/* (a wide trunk evaluated for a handful of leaves — the 512x8 slices of the full-size parity tests play 1-4 games — spreads the neurons of a
+ *  layer over the host's cores; every neuron is computed by the same arithmetic either way) */
+static int forward_threads(int H) {
+#ifdef _OPENMP
+    if (omp_in_parallel() || H < 256) return 1;
+    int m = omp_get_max_threads();
+    return m > 32 ? 32 : m;
+#else
+    (void)H; return 1;
+#endif
+}
 void agzo_forward_bf16(const agzo_net_bf16 *n, const float *planes, float *logits, float *v) {
     int H = n->H;
     uint16_t x[1024 + 8], b[1024], t[1024];
+    const int nt = forward_threads(H);
     for (int i = 0; i < n->Kin; ++i) x[i] = i < n->in ? f2bf(planes[i]) : 0;
+#pragma omp parallel for schedule(static) num_threads(nt) if (nt > 1)
     for (int o = 0; o < H; ++o) {
         float y = agzo_mfma_dot(n->W0 + (size_t)o * n->Kin, x, n->Kin, 0.0f);
         b[o] = f2bf(y > 0.0f ? y : 0.0f);
     }
     for (int l = 0; l < n->T; ++l) {
+#pragma omp parallel for schedule(static) num_threads(nt) if (nt > 1)
         for (int o = 0; o < H; ++o) {
             float y = agzo_mfma_dot(n->Wres + ((size_t)l * H + o) * H, b, H, 0.0f);
             y = y > 0.0f ? y : 0.0f;                                       /* b = relu(b + relu(W b)) */
@@ -684,8 +698,14 @@ long agzo_trace_count(void) { return g_trace_n; }
  * the expansion of the node, or the latest backup through it, in rollout k at depth d -> U(seed; game id, step, k, d).  A visit
  * therefore samples with a number that was already fixed when its policy row was fixed — which is what lets the product
  * compute the sampled action together with the row (agz_tree_eager.hpp) instead of storing the row. */
+/* TEST SWITCH (tests/test_uniform_keying.py): 1 = the REFERENCE's keying, prob[cpt, i] of the rollout that VISITS the node (:178, :397) —
+ * U(seed; game id, step, visiting rollout, depth) — instead of the uniform fixed when the row was made.  Both are one fresh, independent
+ * uniform per node visit; the test checks that the two searches have the same distribution.  2 = a deliberately WRONG keying (consecutive
+ * rollouts share their uniforms), the test's control.  Never set by the product's parity tests. */
+static int g_reference_keying = 0;
+void agzo_set_reference_keying(int on) { g_reference_keying = on; }
+
 void agzo_select(agzo_tree *t, uint64_t seed, uint32_t step, uint32_t rollout, float cpuct) { /* kdescendTree! :100-199 */
-    (void)seed; (void)step; (void)rollout;
     const int A_ = t->g.A;
     for (int i = 0; i < t->L; ++i) {
         int nindex = 0, cpt = 0;
@@ -739,6 +759,8 @@ void agzo_select(agzo_tree *t, uint64_t seed, uint32_t step, uint32_t rollout, f
                 e[0] = i; e[1] = (int32_t)rollout; e[2] = cpt; e[3] = tr_stale; e[4] = tr_nch; e[5] = tr_it;
             }
             float u = t->unext[ND(t, nindex, i)];                         /* prob[cpt,i] (:178): drawn when the row was made, see the note above */
+            if (g_reference_keying == 1) u = agzo_uniform_search(seed, t->game_id[i], step, rollout, (uint32_t)cpt);   /* ... or, test switch, by the visiting rollout */
+            if (g_reference_keying == 2) u = agzo_uniform_search(seed, t->game_id[i], step, rollout & ~1u, (uint32_t)cpt);   /* a WRONG keying (two rollouts share their uniforms): what the test must be able to see */
             for (int k = 0; k < A_; ++k) {                                /* :172-182 */
                 float d = t->policy[ST(t, k, nindex, i)];
                 pr += d;
@@ -871,14 +893,21 @@ void agzo_search(agzo_tree *t, const agzo_net *net, int V, float cpuct, int trai
         if (prior_inject) {
             pr = prior_inject + (size_t)k * L * A_; vv = v_inject + (size_t)k * L;
         } else {
-#pragma omp parallel for schedule(static) if (net->bf16 && L >= 8) num_threads(omp_threads_for(L))
-            for (int i = 0; i < L; ++i) {
-                if (net->bf16) {                                          /* the product's bf16 mode, bit for bit */
+            if (net->bf16 && L >= 8) {                                    /* the product's bf16 mode, bit for bit: the leaves over the host's cores */
+#pragma omp parallel for schedule(static) num_threads(omp_threads_for(L))
+                for (int i = 0; i < L; ++i) {
                     agzo_forward_bf16(net->bf16, t->batch + (size_t)i * IN, t->prior_tmp + (size_t)i * A_, &t->v_tmp[i]);
                     agzo_softmax_bf16mode(t->prior_tmp + (size_t)i * A_, A_);
-                } else {
-                    agzo_forward(net, t->batch + (size_t)i * IN, t->prior_tmp + (size_t)i * A_, &t->v_tmp[i]);
-                    agzo_softmax(t->prior_tmp + (size_t)i * A_, A_);
+                }
+            } else {                                                      /* (few leaves: a wide bf16 forward spreads its NEURONS over the cores, agzo_forward_bf16) */
+                for (int i = 0; i < L; ++i) {
+                    if (net->bf16) {
+                        agzo_forward_bf16(net->bf16, t->batch + (size_t)i * IN, t->prior_tmp + (size_t)i * A_, &t->v_tmp[i]);
+                        agzo_softmax_bf16mode(t->prior_tmp + (size_t)i * A_, A_);
+                    } else {
+                        agzo_forward(net, t->batch + (size_t)i * IN, t->prior_tmp + (size_t)i * A_, &t->v_tmp[i]);
+                        agzo_softmax(t->prior_tmp + (size_t)i * A_, A_);
+                    }
                 }
             }
             pr = t->prior_tmp; vv = t->v_tmp;

@@ -98,6 +98,7 @@ void agzo_tree_destroy(agzo_tree *t);
 void agzo_tree_set_roots(agzo_tree *t, const agzo_pos *positions, const uint32_t *game_ids, int L); /* re_init :359-373 */
 void agzo_search_reset(agzo_tree *t);                                                  /* :380-387 */
 void agzo_select(agzo_tree *t, uint64_t seed, uint32_t step, uint32_t rollout, float cpuct); /* :100-199 */
+void agzo_set_reference_keying(int on);   /* test switch: the descent's uniform keyed by the VISITING rollout, as prob[cpt,i] in the reference (:178) */
 void agzo_encode_leaves(agzo_tree *t, float *batch);                                   /* :202-223 */
 /* expand / backup of rollout `rollout` also fix the uniform the next visit of every row they make samples with (see agzo_select) */
 void agzo_expand(agzo_tree *t, const float *prior, int training, uint64_t seed, uint32_t step, uint32_t rollout); /* :250-302 */

@@ -77,6 +77,7 @@ def lib():
         L.agzo_tree_set_roots.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.agzo_search_reset.argtypes = [C.c_void_p]
         L.agzo_select.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_float]
+        L.agzo_set_reference_keying.argtypes = [C.c_int]
         L.agzo_encode_leaves.argtypes = [C.c_void_p, C.c_void_p]
         L.agzo_expand.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32]
         L.agzo_backup.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32]

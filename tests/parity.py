@@ -114,3 +114,14 @@ def assert_bf16_search_matches(got, ref, fallback, what=""):
            f"product bug.  Network outputs to add to tests/golden/mfma_kat.npz (rollout, row, column, gpu, model): {misses[:8]}")
     print("\n" + msg)
     warnings.warn(msg)
+
+
+def oracle_selfplay_slices(og, onet, n, V, cpuct, tau_plies, seed, bases):
+    """the oracle's lock-step games of the ids base .. base + n - 1 for every base, the slices computed SIDE BY SIDE (the C oracle releases the
+    GIL and every call owns its tree; a full-size test checks up to nine slices, each a few seconds of one to sixteen host threads)
+    -> {base: O.selfplay result}"""
+    from concurrent.futures import ThreadPoolExecutor
+    bases = list(bases)
+    with ThreadPoolExecutor(max_workers=max(1, len(bases))) as ex:
+        refs = list(ex.map(lambda b: O.selfplay(og, onet, n, V, cpuct, tau_plies, seed, b), bases))
+    return dict(zip(bases, refs))

@@ -407,7 +407,9 @@ FULL_GEN_CASES = [
     ("hex9", 128, 6, 64, 49152),           # ... age classes on the Hex board
     ("hex9", 128, 6, 128, 40000),          # V = 128 trees do not fit two 64-game workgroups per CU: refilled slots, one launch per ply
     ("gobang9", 512, 8, 64, 32768),        # BASELINE config 3 AS SHIPPED — all eight towers (4 games: the MFMA model of a 512x8 forward is slow)
-    ("reversi8", 512, 8, 64, 65536),       # BASELINE config 5's shard as shipped, refilled slots: the persistent kernel k_selfplay_big
+    ("reversi8", 512, 8, 64, 65536),       # BASELINE config 5's shard as shipped, refilled slots: the persistent kernel k_selfplay_big4
+    ("hex9", 512, 8, 128, 40000),          # BASELINE config 4 AS TIMED by bench.py --config 4: k_selfplay_big4<KPL=24,H=512,G=4> at V = 128 on refilled slots
+                                           # (round 5 checked that kernel on Hex at 24 slots x V = 16 and as a first-ply search slice only)
 ]
 
 
@@ -426,7 +428,7 @@ def test_full_size_generation_slice_equals_the_oracle_through_all_plies(name, H,
         if ngames > L and V == 128 and H == 128:
             assert form.startswith("k_search_small"), form
         elif ngames > L:                                             # refilled slots at this size: ONE launch for the whole call
-            assert form.startswith("k_selfplay_big" if H == 512 else "k_selfplay_small"), form
+            assert form.startswith("k_selfplay_big4" if H == 512 else "k_selfplay_small"), form   # (512-wide at 32768 slots: one 128-game workgroup per CU)
             assert st["rollouts"] == V * st["nsamples"]
             if H == 128 and name in ("gobang9", "hex9"):             # ... with workgroups that trade games by age
                 searches, ranked, moved = e.age_stats()
@@ -435,15 +437,18 @@ def test_full_size_generation_slice_equals_the_oracle_through_all_plies(name, H,
             assert form.startswith("k_search_"), form
         s = e.samples()
     assert len(s["ply"]) == st["nsamples"] and st["wins"] + st["draws"] + st["losses"] == ngames
+    refs = parity.oracle_selfplay_slices(og, onet.bf16(), n, V, 1.5, 25, seed, bases)
     for base in bases:
         keep = (s["game_id"] >= base) & (s["game_id"] < base + n)
-        ref = O.selfplay(og, onet.bf16(), n, V, 1.5, 25, seed, base)
+        ref = refs[base]
         assert ref["rc"] == 0 and int(keep.sum()) == ref["n"], (int(keep.sum()), ref["n"])
         for k in ("game_id", "ply", "move", "player", "state", "fstate", "value", "policy"):
             assert parity.same_bits(s[k][keep], ref[k]), f"{name} {H}x{T}: {k} of games {base}..{base + n - 1} differs from the oracle"
 
 
-@pytest.mark.parametrize("name,H,T,V,big4", [("gobang9", 128, 6, 64, None), ("gobang9", 512, 1, 64, None)])   # (+ ("gobang9", 512, 1, 64, "0"): green on the final library, left out of the suite for its two minutes)
+@pytest.mark.parametrize("name,H,T,V,big4", [("gobang9", 128, 6, 64, None), ("gobang9", 512, 1, 64, None),
+                                             ("reversi8", 512, 1, 64, None)])   # BASELINE config 5's game and trunk width, CHAINED as bench.py --config 5 chains its calls
+                                                                                # (+ ("gobang9", 512, 1, 64, "0"): green on the final library, left out of the suite for its two minutes)
 def test_full_size_chain_of_calls_slices_equal_the_oracle(name, H, T, V, big4, monkeypatch):
     """agz_selfplay_chain at the benchmarked size (what bench.py times since round 4): three calls of 65536, 32768 and 32768 games on 32768
     slots, each announcing the next (the last one 0).  The batch stays full across the call boundaries (the host's run-ahead, the ring of the
@@ -455,6 +460,11 @@ def test_full_size_chain_of_calls_slices_equal_the_oracle(name, H, T, V, big4, m
     g, og = spec(name)
     net, onet = ag.SNetwork2.random(g, H, T), O.OracleNet(og, H, T)
     calls = [(65536, 32768), (32768, 32768), (32768, 0)]
+    all_bases, k0 = [], 0
+    for ng, _ in calls:
+        all_bases.append((k0 + 5, k0 + ng // 2, k0 + ng - n - 3))
+        k0 += ng
+    refs = parity.oracle_selfplay_slices(og, onet.bf16(), n, V, 1.5, 25, seed, [b for bs in all_bases for b in bs])   # (the nine slices side by side)
     with M.Engine(g, L, V, seed=seed, nn_mode=M.NN_BF16, sample_capacity_games=65536 + 32768 + 1000) as e:
         e.set_network(net)
         k0 = 0
@@ -464,9 +474,9 @@ def test_full_size_chain_of_calls_slices_equal_the_oracle(name, H, T, V, big4, m
             assert e.search_form()[0].startswith(("k_selfplay_big<" if big4 == "0" else "k_selfplay_big4") if H == 512 else "k_selfplay_small"), e.search_form()
             s = e.samples()
             assert len(s["ply"]) == st["nsamples"] and int(s["game_id"].min()) == k0 and int(s["game_id"].max()) == k0 + ng - 1
-            for base in (k0 + 5, k0 + ng // 2, k0 + ng - n - 3):
+            for base in all_bases[i]:
                 keep = (s["game_id"] >= base) & (s["game_id"] < base + n)
-                ref = O.selfplay(og, onet.bf16(), n, V, 1.5, 25, seed, base)
+                ref = refs[base]
                 assert ref["rc"] == 0 and int(keep.sum()) == ref["n"], (i, base, int(keep.sum()), ref["n"])
                 for k in ("game_id", "ply", "move", "player", "state", "fstate", "value", "policy"):
                     assert parity.same_bits(s[k][keep], ref[k]), f"{name} {H}x{T} call {i}: {k} of games {base}..{base + n - 1} differs from the oracle"
