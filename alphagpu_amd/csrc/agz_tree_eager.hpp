@@ -32,6 +32,10 @@
 #include "agz_divpair.hpp"
 #include "agz_fastdiv.hpp"
 
+#ifndef AGZ_FAST_COUNT
+#define AGZ_FAST_COUNT 1    // 1: the sampled action of a work item from block-local running sums + a rounding margin (sample_count_fast); 0: always the source-order chain (A/B)
+#endif
+
 namespace agz {
 
 enum : uint32_t { SP_VALID = 1u << 24, SP_CREATED = 1u << 25, NX_VALID = 1u << 16, AUX_SLOW = 1u << 24 };
@@ -261,11 +265,9 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
     // the block, the visit's uniform u and the child bytes of the block: the number of running sums below u — the row of sums is
     // nondecreasing — or, when the whole row sums below u, the last positive action.  Returns the next word.
     // next word: action | child << 8 | NX_VALID | creation rank + 1 of the child << 17 (0: no child yet)
-    auto sample_next = [&](const float (&pol)[KPR], const float st, const float u, const ChildWords<KPR> cdw, const ChildWords<KPR> rkw,
-                           const int fix_move, const uint32_t fix_child) -> uint32_t {
-        float c = st; int cnt = 0;
-#pragma unroll
-        for (int j = 0; j < KPR; ++j) { c += pol[j]; cnt += c < u ? 1 : 0; }
+    // cnt = the lane's count of running sums below u (the caller's); the rest of :172-182: the action, its child and the child's rank
+    auto sample_finish = [&](const float (&pol)[KPR], int cnt, const ChildWords<KPR> cdw, const ChildWords<KPR> rkw,
+                             const int fix_move, const uint32_t fix_child) -> uint32_t {
         cnt = cnt < nvr ? cnt : nvr;                                           // (padded actions never count)
         int bestmove = grp_sum<G>(cnt);
         // (compacted rows: the slots past the root's legal count repeat the row's total, so a row that sums below u counts all G KPR)
@@ -289,6 +291,51 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
         const uint32_t rank = cr >> 8;                                         // (the rank bytes of this item's own new edge are already in rkw)
         if (bestmove == fix_move) child = fix_child;                           // the child registered by this very item
         return (uint32_t)bestmove | (child << 8) | NX_VALID | (rank << 17);
+    };
+    auto sample_next = [&](const float (&pol)[KPR], const float st, const float u, const ChildWords<KPR> cdw, const ChildWords<KPR> rkw,
+                           const int fix_move, const uint32_t fix_child) -> uint32_t {
+        float c = st; int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < KPR; ++j) { c += pol[j]; cnt += c < u ? 1 : 0; }
+        return sample_finish(pol, cnt, cdw, rkw, fix_move, fix_child);
+    };
+    // The same count WITHOUT the source-order chain over the group's lanes (round 6).  What the visit needs of the running sums S_k (:172-181) is
+    // how many of them lie below u; the sums themselves are used for nothing else.  Every lane sums its own block from 0, an exclusive prefix over
+    // the group's lanes (three DPP steps) gives the block's offset, and d_k = (offset - u) + local sum is S_k - u up to rounding: for
+    // non-negative terms the source-order sum and ANY other order of the same terms differ from the exact sum by at most (n - 1) eps each
+    // (relative to the sum, eps = 2^-24, n = G KPR terms) — together with the two roundings of d_k less than (n + KPR + 4) eps max(total, 1).  So
+    // whenever |d_k| exceeds TWICE that for every k, the sign of d_k IS the outcome of the reference's comparison `S_k < u` and the count is exact;
+    // otherwise (some running sum within ~1.4e-5 of u on a 9x9 board: ~0.2 % of the items) the caller takes the source-order chain.  7 turns of KPR additions
+    // (all 64 lanes execute every turn) become KPR + 9 instructions.  Returns false (wave-uniform) when some item of the wave must take the chain.
+    auto sample_count_fast = [&](const float (&pol)[KPR], const float u, int& cnt_out) -> bool {
+        float inc = pol[0];                                                     // the block's total (the same additions again below: no array of sums is kept live)
+#pragma unroll
+        for (int j = 1; j < KPR; ++j) inc += pol[j];
+        // inclusive prefix of the block totals over the lanes of the group, then the exclusive one (the value of the lane before)
+        // (the lane tests are made HERE, on a copy of `sub` the compiler cannot see through: hoisted out of the item loop they are three 64-bit
+        //  lane masks held in scalar registers for the whole loop — and scalar registers are what the loop is short of)
+        int sb = sub;
+        asm volatile("" : "+v"(sb));
+        if constexpr (G >= 2) { const float t = __int_as_float(dpp_mov<0x111, 0xF>(0, __float_as_int(inc))); inc += sb >= 1 ? t : 0.0f; }
+        if constexpr (G >= 4) { const float t = __int_as_float(dpp_mov<0x112, 0xF>(0, __float_as_int(inc))); inc += sb >= 2 ? t : 0.0f; }
+        if constexpr (G >= 8) { const float t = __int_as_float(dpp_mov<0x114, 0xA>(0, __float_as_int(inc))); inc += t; }   // (bank mask: the lanes 4 .. 7 of a group)
+        const float prev = __int_as_float(dpp_mov<0x111, 0xF>(0, __float_as_int(inc)));
+        const float off = sb >= 1 ? prev : 0.0f;
+        const float total = grp_bcast_last<G>(inc);
+        const float base = off - u;
+        int cnt = 0; float mn = __builtin_inff(), c = 0.0f;
+#pragma unroll
+        for (int j = 0; j < KPR; ++j) {
+            c += pol[j];
+            const float d = base + c;
+            cnt += d < 0.0f ? 1 : 0;
+            mn = __builtin_fminf(mn, __builtin_fabsf(d));
+        }
+        cnt_out = cnt;
+        // twice the bound: (G KPR - 1) eps of the source-order sum + (KPR + 2) eps of the block-local sum and the prefix + 2 eps of d_k's own roundings
+        constexpr float MARGIN = (float)(2 * (G * KPR + KPR + 4)) * 5.9604644775390625e-8f;
+        const float margin = MARGIN * __builtin_fmaxf(total, 1.0f);
+        return __ballot(!(mn > margin)) == 0ull;                               // (a NaN anywhere takes the chain too)
     };
 
     // one work item's rows -> registers (zeros for a lane-group without an item).  entry: node | move << 8 | depth << 16 | game << 24
@@ -776,10 +823,17 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
             }
             // the child bytes are needed past the prefetch of the next item: kept aside   // PHASE items: running sums + sampling
             STAMPW(7);
-            float dummy;
-            const float st = grp_ordered_start<KPR, false, G>(pol, sub, dummy, nlr);
             const float u = dpt < 32 ? utab[gi * 32 + dpt] : uniform_search(TI.seed, TI.game_id[valid ? slot_base + gi : sl], TI.slot_ply[valid ? slot_base + gi : sl], SF.rollout - 1u, (uint32_t)dpt);
-            const uint32_t nx = sample_next(pol, st, u, cdk, rkw, move, (uint32_t)ileaf);
+            int cnt = 0;
+            if (!AGZ_FAST_COUNT || __builtin_expect(!sample_count_fast(pol, u, cnt), 0)) {
+                // some running sum of the wave's items lies within rounding of its uniform: the source-order chain decides
+                float dummy;
+                float c = grp_ordered_start<KPR, false, G>(pol, sub, dummy, nlr);
+                cnt = 0;
+#pragma unroll
+                for (int j = 0; j < KPR; ++j) { c += pol[j]; cnt += c < u ? 1 : 0; }
+            }
+            const uint32_t nx = sample_finish(pol, cnt, cdk, rkw, move, (uint32_t)ileaf);
             if (valid && lead) {
                 *reinterpret_cast<uint4*>(rec) = make_uint4(__float_as_uint(prem_raw), nx, auxz, 0u);
                 if (NXL) nxw[ind] = nx16(nx);
