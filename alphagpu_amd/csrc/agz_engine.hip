@@ -429,7 +429,7 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
     FA_(hipFuncSetAttribute((const void*)k_layer_exact<EX_VALUE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     // node record: [prior f32 x A2][q f32 x A2][rank u8 x A2][cid u8 x A2][vis u8 x A2], A2 = 8 lanes x KPL actions
     // (agz_tree_eager.hpp)
-    h->reg_lds = (size_t)eager_lds_layout(h->V).total;
+    h->reg_lds = (size_t)eager_lds_layout(h->V, 8, 8 * h->reg_kpl).total;
 #ifdef AGZ_STAMPS
     h->reg_lds += 256;
 #endif
@@ -998,7 +998,7 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
             S.F.planes = (const uint16_t*)h->planes; S.F.INP = n.INP; S.F.w16 = n.w16w; S.F.bias_head = n.bias_head;
             S.F.logits = h->logits; S.F.LGS = h->LGS; S.F.vout = h->v_eval; S.F.L = h->L; S.F.T = n.T; S.F.A = h->G.A; S.F.AOP = n.AOP;
             S.F.gpw = 0; S.F.tw = tw; S.F.rb = NG;
-            S.V = V; S.tree_lds = eager_lds_layout(h->V, NG).total;
+            S.V = V; S.tree_lds = eager_lds_layout(h->V, NG, G * nk->kpl).total;
             const int rs = small_io_row_bytes(n);
             S.io_prowb = rs; S.io_lgs = rs / 4; S.io_bw = NG * rs;
             S.io_off = (int)((std::max((size_t)tw * (size_t)S.tree_lds, (size_t)gpwg * 2 * (n.H * 2 + 16)) + 15) & ~(size_t)15);
@@ -1143,13 +1143,13 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
             if (x8 && h->big4 != 0 && (h->L + 127) / 128 <= h->cus && h->small_gpw <= 0) {
                 if (lv < 0) k4 = h->k_big4[0];
                 else for (int i = 1; i < 3; ++i) if (h->k_big4[i] && h->big4_kpr[i] == 2 * h->cmp[lv].kpr) k4 = h->k_big4[i];
-                const size_t win = (std::max((size_t)8 * (size_t)eager_lds_layout(h->V, 16).total, (size_t)128 * big_rowb) + 15) & ~(size_t)15;
+                const size_t win = (std::max((size_t)8 * (size_t)eager_lds_layout(h->V, 16, 4 * h->big4_kpl).total, (size_t)128 * big_rowb) + 15) & ~(size_t)15;
                 if (win + 4 * 144 + 8 * 256 > (size_t)(160 * 1024)) k4 = nullptr;
             }
             const int twb = b8 ? 8 : 4;
             if (b8) wgs = (h->L + 63) / 64;
             if (k4) { wgs = (h->L + 127) / 128; S.T.gpw = 16; }
-            S.V = V; S.tree_lds = k4 ? eager_lds_layout(h->V, 16).total : (int)h->reg_lds;
+            S.V = V; S.tree_lds = k4 ? eager_lds_layout(h->V, 16, 4 * h->big4_kpl).total : (int)h->reg_lds;
             S.xch_off = (int)((std::max((size_t)8 * (size_t)S.tree_lds, (size_t)(k4 ? 128 : 8 * twb) * big_rowb) + 15) & ~(size_t)15);   // (tree waves and helper waves have tables of their own)
             size_t shared = (size_t)S.xch_off + 4 * 144;
             const int wgcu = k4 ? 1 : (x8 ? 2 : (b8 ? 1 : occ + 1));
@@ -1653,7 +1653,7 @@ static bool use_big4(const agz_engine* h) {
     if ((h->Lmax + 127) / 128 > h->cus) return false;
     if (h->big4 < 0 && h->Lmax <= 64 * h->cus) return false;                    // (up to 64 slots per CU the 8-lane form has a CU to itself at 256 registers)
     const int big_rowb = (2 * std::max(n.H, 32 * n.k0r) + 255) & ~255;
-    const size_t xch_off = (std::max((size_t)8 * (size_t)eager_lds_layout(h->V, 16).total, (size_t)128 * big_rowb) + 15) & ~(size_t)15;
+    const size_t xch_off = (std::max((size_t)8 * (size_t)eager_lds_layout(h->V, 16, 4 * h->big4_kpl).total, (size_t)128 * big_rowb) + 15) & ~(size_t)15;
     return xch_off + 4 * 144 + 16 + 8 * 256 <= (size_t)(160 * 1024);
 }
 static bool persist_shape(const agz_engine* h) {
@@ -1669,7 +1669,7 @@ static bool persist_shape(const agz_engine* h) {
         const int wgs = (h->Lmax + gpwg - 1) / gpwg, per_cu = (wgs + h->cus - 1) / h->cus;
         if (per_cu > (gpwg == 32 ? 4 : 2)) return false;
         const size_t cu_lds = (size_t)(160 * 1024) / (size_t)per_cu;
-        const size_t tree_lds = nar ? (size_t)eager_lds_layout(h->V, NG).total : h->reg_lds;
+        const size_t tree_lds = nar ? (size_t)eager_lds_layout(h->V, NG, G * h->persist_nar_kpl).total : h->reg_lds;
         const int rs = small_io_row_bytes(n);
         const size_t io_off = (std::max((size_t)tw * tree_lds, (size_t)gpwg * 2 * (n.H * 2 + 16)) + 15) & ~(size_t)15;
         return io_off + (size_t)tw * NG * rs + 16 + (size_t)tw * 64 <= cu_lds;   // (flags, at least 16 work-list entries per wave; the next-word tables where they fit)
@@ -1798,7 +1798,7 @@ static int run_games_persist(agz_engine* h, int ngames, int V, float cpuct, int 
         B.bias_head = n.bias_head; B.logits = h->logits; B.LGS = h->LGS; B.vout = h->v_eval;
         B.L = LM; B.T = n.T; B.A = h->G.A; B.AOP = n.AOP; B.K0R = n.k0r; B.ROWB = big_rowb;
         wgcu = (big4 || (int)wgs <= h->cus) ? 1 : 2;
-        S.V = V; S.tree_lds = big4 ? eager_lds_layout(h->V, NG).total : (int)h->reg_lds;
+        S.V = V; S.tree_lds = big4 ? eager_lds_layout(h->V, NG, G * h->big4_kpl).total : (int)h->reg_lds;
         S.xch_off = (int)((std::max((size_t)8 * (size_t)S.tree_lds, (size_t)gpwg * big_rowb) + 15) & ~(size_t)15);
         size_t shared = (size_t)S.xch_off + 4 * 144 + 16;                        // ... + the workgroup's two flag words
         Q.X = X; Q.X.flag_off = (int)shared - 16;
@@ -1818,7 +1818,7 @@ static int run_games_persist(agz_engine* h, int ngames, int V, float cpuct, int 
         S.F.planes = (const uint16_t*)h->planes; S.F.INP = n.INP; S.F.w16 = n.w16w; S.F.bias_head = n.bias_head;
         S.F.logits = h->logits; S.F.LGS = h->LGS; S.F.vout = h->v_eval; S.F.L = LM; S.F.T = n.T; S.F.A = h->G.A; S.F.AOP = n.AOP;
         S.F.gpw = 0; S.F.tw = tw; S.F.rb = NG;
-        S.V = V; S.tree_lds = nar ? eager_lds_layout(h->V, NG).total : (int)h->reg_lds;
+        S.V = V; S.tree_lds = nar ? eager_lds_layout(h->V, NG, G * h->persist_nar_kpl).total : (int)h->reg_lds;
         const int rs = small_io_row_bytes(n);
         S.io_prowb = rs; S.io_lgs = rs / 4; S.io_bw = NG * rs;
         S.io_off = (int)((std::max((size_t)tw * (size_t)S.tree_lds, (size_t)gpwg * 2 * (n.H * 2 + 16)) + 15) & ~(size_t)15);

@@ -87,14 +87,16 @@ __host__ __device__ constexpr int eager_vl(int V, int A2) { return ((V + 15) & ~
 __host__ __device__ constexpr int eager_rec_bytes(int A2, int V) { return (16 + 6 * A2 + 9 * eager_vl(V, A2) + 15) & ~15; }
 
 struct EagerLds { int tab, tstride, val, utab, total; };
-// NG = games (lane-groups) per wave = 64 / lanes per group
-__host__ __device__ inline EagerLds eager_lds_layout(int V, int NG = 8) {
+// NG = games (lane-groups) per wave = 64 / lanes per group; A2 = entries of a node row (lanes per tree x entries per lane): a node has at most
+// one child per row entry and per rollout, so its edge table holds eager_vl(V, A2) entries — 16 for Connect4 (was V = 64), 96 for the 9x9
+// boards at V = 128 (was 128: what lets the 128-game workgroups of the wide trunks keep their next-word tables in LDS at V = 128)
+__host__ __device__ inline EagerLds eager_lds_layout(int V, int NG = 8, int A2 = 1 << 20) {
     EagerLds o;
     auto up16 = [](int x) { return (x + 15) & ~15; };
     // per lane-group: the edges {q, prior} of the item's node in creation order, a zero pair in front of them (what an action
     // without a child reads)
     o.tab = 16;
-    o.tstride = 16 + up16(V * 8);
+    o.tstride = 16 + up16(eager_vl(V, A2) * 8);
     o.val = NG * o.tstride;                                      // per game: {value_1, value_2, flags, -}
     o.utab = o.val + NG * 16;                                    // per game: 32 uniforms (depths 0..31)
     o.total = o.utab + NG * 128;
@@ -203,7 +205,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
     // (rec_stride != 0: the records keep the stride the engine allocated them with although this build's rows are narrower — the persistent
     //  self-play kernel runs workgroups with rows by action and workgroups with rows by legal rank side by side on one record buffer)
     const uint32_t OFF_VIS = (uint32_t)(OFF_EL + 8 * eager_vl(V, A2)), ROWS = rec_stride ? rec_stride : (uint32_t)eager_rec_bytes(A2, V);   // ... and the visit bytes by rank
-    const EagerLds LO = eager_lds_layout(V, NG);
+    const EagerLds LO = eager_lds_layout(V, NG, A2);
     float2* const tab = reinterpret_cast<float2*>(lds + (size_t)g * LO.tstride + LO.tab);   // tab[-1] = {0, 0}
     float4* const valtab = reinterpret_cast<float4*>(lds + LO.val);
     float* const utab = reinterpret_cast<float*>(lds + LO.utab);

@@ -137,8 +137,10 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args.gpus))
     if args.config:
+        given = {a.split("=")[0] for a in sys.argv[1:] if a.startswith("--")}
         for k, v in CONFIGS[args.config].items():
-            setattr(args, k, v)
+            if "--" + k not in given:             # (an option typed next to --config wins: `--config 5 --games 256` is config 5's shape on a smaller batch)
+                setattr(args, k, v)
     if args.game in ("connect4", "reversi8", "reversi6"):
         args.n = args.nvict = 0
     if args.game == "hex":

@@ -3,7 +3,7 @@
 # scratch/pmc_refill.py) of the headline config (CFG=0: k_selfplay_small) and of BASELINE config 3 (CFG=3: k_selfplay_big) -> gpurun_out/$1/util_cfg*.txt
 out=$GRAFT_REPO_ROOT/gpurun_out/$1; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-for cfg in 0 3; do
+for cfg in ${CFGS:-0 3}; do
   i=0; sum=$out/util_cfg$cfg.txt
   echo "# rocprofv3 --pmc <set> --kernel-trace -- python3 scratch/pmc_refill.py  (CFG=$cfg GENS=1: one agz_selfplay call of 32768 games on 32768 slots + the refilled tail; counters summed over the launch, per kernel)" > $sum
   for c in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" \
@@ -18,4 +18,4 @@ for cfg in 0 3; do
     rm -rf $out/u$i $out/u$i.log
   done
 done
-tail -30 $out/util_cfg3.txt
+tail -12 $out/util_cfg*.txt

@@ -319,36 +319,49 @@ def test_exchange_over_rccl_with_one_rank():
 
 
 # ---- `python bench.py --gpus N` as the driver types it: the ranks are children of the command ---------------------------
-def _bench_two_ranks(backend, tmp_path):
-    """bench.py --gpus 2 started WITHOUT torch.distributed.run: it launches its two ranks itself, rank 0 prints ONE JSON line with
-    n_gpus 2, and the samples it gathered (pipelined RecordExchange, as in the timed region) are those of ONE engine running all
-    4096 games — record for record."""
+def _bench_ranks(backend, tmp_path, world=2, games=2048, extra=(), name="gobang9", H=128, T=6, V=64):
+    """bench.py --gpus N started WITHOUT torch.distributed.run: it launches its N ranks itself, rank 0 prints ONE JSON line with
+    n_gpus N, and the samples it gathered (pipelined exchange, as in the timed region) are those of ONE engine running all
+    N x games games — record for record."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     dump = str(tmp_path / "records.npz")
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", backend, "--games", "2048", "--steps", "1",
-           "--warmup", "0", "--no-cpu-baseline", "--dump-records", dump]
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--backend", backend, "--games", str(games), "--steps", "1",
+           "--warmup", "0", "--no-cpu-baseline", "--dump-records", dump] + list(extra)
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["steps"] == 1 and out["scaling"] == "weak"
+    assert out["n_gpus"] == world and out["steps"] == 1 and out["scaling"] == "weak"
     assert out["value"] > 0 and out["roofline"]["frac"] > 0
     got = dict(np.load(dump))
-    g = ag.GameSpec("gobang", 9, 5)
-    net = ag.SNetwork2.random(g, 128, 6)
-    with M.Engine(g, 4096, 64, seed=1, game_id_base=0, nn_mode=M.NN_BF16) as e:     # bench.py: seed 1 + generation index
+    g, _ = spec(name)
+    net = ag.SNetwork2.random(g, H, T)
+    with M.Engine(g, world * games, V, seed=1, game_id_base=0, nn_mode=M.NN_BF16) as e:     # bench.py: seed 1 + generation index
         e.set_network(net)
-        st = e.selfplay(4096, 64, cpuct=1.5, tau_plies=25)
+        st = e.selfplay(world * games, V, cpuct=1.5, tau_plies=25)
         assert st["valid"]
         one = e.samples()
     assert len(got["ply"]) == len(one["ply"]) == st["nsamples"] and out["rank0"]["samples"] < st["nsamples"]
     for k in ("game_id", "ply", "move", "player", "state", "fstate", "value", "policy"):
-        assert parity.same_bits(got[k], one[k]), k + " (bench.py --gpus 2 vs one engine)"
+        assert parity.same_bits(got[k], one[k]), k + f" (bench.py --gpus {world} vs one engine)"
+    return out
+
+
+def _bench_two_ranks(backend, tmp_path):
+    return _bench_ranks(backend, tmp_path)
+
+
+def test_bench_gpus_8_config5_shards_gather_to_one_engine_gloo(tmp_path):
+    """BASELINE config 5 as the driver would start it — `bench.py --gpus 8 --config 5` — on the ONE GPU of this box: eight ranks (gloo; 256 Reversi
+    games each instead of 32768), every rank its own engine on its shard of game ids, the records all-gathered at the end of the call:
+    the 8 x 256 games rank 0 holds are, record for record, those of one engine playing all 2048 (verdict r5 item 4a)."""
+    out = _bench_ranks("gloo", tmp_path, world=8, games=256, extra=("--config", "5"), name="reversi8", H=512, T=8, V=64)
+    assert out["config"]["baseline_config"] == 5 and "x8" in out["config"]["parallelism"]
 
 
 def test_bench_gpus_2_launches_its_own_ranks_gloo(tmp_path):
