@@ -56,8 +56,11 @@ def test_benchmarked_kernels_do_not_spill_vector_registers():
                     names.append(f"k_search_small<{fam_nc_kpl}, {tail}, 4, 8>")
             for name in names:
                 k = md[name]
-                assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0 and k["vgpr_count"] <= budget, (name, k)
-                assert k["sgpr_spill_count"] <= 48, (name, k)            # (was 120-150 while the parameters lived in scalar registers; 37 -> 44 at most with the next-word table of round 6)
+                # (the 168-register build — three workgroups per CU, 24576 games: not a benchmarked size — reloads one loop-invariant quad since round 6)
+                lim = 4 if tail == "128, 4, 3" else 0
+                assert k["vgpr_spill_count"] <= lim and k["private_segment_fixed_size"] <= 8 * lim and k["vgpr_count"] <= budget, (name, k)
+                assert k["sgpr_spill_count"] <= 56, (name, k)            # (was 120-150 while the parameters lived in scalar registers; round 6: 37 -> 44 with the next-word table,
+                                                                         #  -> 54 with the block-local count of the sampled action, whose ballots hold scalar pairs: +1.4 % all the same)
         for wg in (1, 2):
             for kpr in ((0, 8, 4) if fam_nc_kpl in ("0, 2, 12", "2, 2, 12") else (0,)):
                 for twb in (4, 8):
@@ -70,7 +73,7 @@ def test_benchmarked_kernels_do_not_spill_vector_registers():
                         assert k["vgpr_spill_count"] == 0 and k["vgpr_count"] <= 256 // wg, (fam_nc_kpl, wg, kpr, twb, k)
         for wv in (3, 4):
             k = md[f"k_rollout_eager<{fam_nc_kpl}, {wv}>"]
-            assert k["vgpr_spill_count"] == 0 and k["sgpr_spill_count"] <= 40, (fam_nc_kpl, wv, k)
+            assert k["vgpr_spill_count"] == 0 and k["sgpr_spill_count"] <= 56, (fam_nc_kpl, wv, k)
     # narrow lane-groups (4 lanes per tree, 24 actions per lane on a 9x9 board): two waves per SIMD in 256 registers, a handful of
     # spilled registers at most; the one-wave-per-SIMD builds do not spill
     for kpr in (0, 16, 8):
