@@ -188,7 +188,8 @@ struct agz_engine {
     // the persistent self-play kernels (agz_selfplay_small.hpp): one launch per agz_selfplay / agz_selfplay_chain call, a workgroup keeps its
     // slots and loops over the plies of its games by itself.  persist: AGZ_PERSIST = 1 wherever a kernel exists (tests), 0 never, default
     // (-1): calls with refilled slots on an engine of more than 96 slots per CU.  chain_persist: the running chain's slots are not compacted.
-    persist_fn k_persist = nullptr, k_persist_nar = nullptr; int persist_nar_g = 0, persist_nar_kpl = 0;
+    persist_fn k_persist = nullptr, k_persist_nar = nullptr, k_persist_nar_sp = nullptr; int persist_nar_g = 0, persist_nar_kpl = 0;
+    bool nar_sparse = true;            // few-action games: 8 games per 16-group wave, four waves per SIMD (AGZ_NARROW_SPARSE=0: 16 games per wave, two per SIMD)
     persist_big_fn k_persist_big[2] = {nullptr, nullptr};    // 512-wide trunks (agz_selfplay_big.hpp): one / two 64-game workgroups per CU
     int persist = -1; bool chain_persist = false; unsigned long long* d_pacc = nullptr;
     int reserve_slots = 0;             // AGZ_RESERVE_CUS x 128: slots the persistent launches leave without a workgroup (room for the exchange's RCCL kernels)
@@ -247,7 +248,7 @@ static bool bind_kernels(agz_engine* h) {
         h->k_persist = k_selfplay_small<F, C, K, 128, 8, 4>; h->k_persist_tw4 = k_selfplay_small<F, C, K, 128, 4, 4>; h->k_persist_big[0] = k_selfplay_big<F, C, K, 512, 1>; h->k_persist_big[1] = k_selfplay_big<F, C, K, 512, 2>; }
     AGZ_SMALL_SHAPES(Z)
 #undef Z
-#define Z(F, C, K, GG) if (P.fam == F && P.NC == C && GG * K >= P.A && GG * K <= 8 * kpl) { h->k_persist_nar = k_selfplay_small<F, C, K, 128, 4, 2, GG>; h->persist_nar_g = GG; h->persist_nar_kpl = K; }
+#define Z(F, C, K, GG) if (P.fam == F && P.NC == C && GG * K >= P.A && GG * K <= 8 * kpl) { h->k_persist_nar = k_selfplay_small<F, C, K, 128, 4, 2, GG>; h->k_persist_nar_sp = k_selfplay_small<F, C, K, 128, 4, 4, GG, 0, 32 / GG>; h->persist_nar_g = GG; h->persist_nar_kpl = K; }
     AGZ_PERSIST_NARROW_SHAPES(Z)
 #undef Z
 #define Z(F, C, K4) if (P.fam == F && P.NC == C && 2 * kpl == K4) { h->k_persist_big4 = k_selfplay_big4<F, C, K4, 512>; h->big4_kpl = K4; }
@@ -470,6 +471,9 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
         if (e3 && atoi(e3) > 0) h->reserve_slots = std::min(atoi(e3) * 128, std::max(0, (h->Lmax - 128) / 128 * 128));
         if (h->k_persist) FA_(hipFuncSetAttribute((const void*)h->k_persist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         if (h->k_persist_nar) FA_(hipFuncSetAttribute((const void*)h->k_persist_nar, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if (h->k_persist_nar_sp) FA_(hipFuncSetAttribute((const void*)h->k_persist_nar_sp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        e3 = getenv("AGZ_NARROW_SPARSE");
+        if (e3) h->nar_sparse = atoi(e3) > 0;
         if (h->k_persist_age) FA_(hipFuncSetAttribute((const void*)h->k_persist_age, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         for (int i = 0; i < 2; ++i) if (h->k_persist_big[i]) FA_(hipFuncSetAttribute((const void*)h->k_persist_big[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         if (h->k_persist_tw4) FA_(hipFuncSetAttribute((const void*)h->k_persist_tw4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1665,14 +1669,16 @@ static bool persist_shape(const agz_engine* h) {
     if (n.H == 128) {
         if (!(h->k_persist || h->k_persist_nar) || !n.w16w) return false;
         const bool nar = h->k_persist_nar && h->narrow_mode >= 0;
-        const int G = nar ? h->persist_nar_g : 8, NG = 64 / G, tw = (nar || h->persist_tw4) ? 4 : 8, gpwg = tw * NG;
+        // (lane-groups per wave, games per wave: half of the groups in the sparse form of the narrow kernel)
+        const int G = nar ? h->persist_nar_g : 8, NG = 64 / G, GPW = (nar && h->nar_sparse && h->k_persist_nar_sp) ? NG / 2 : NG;
+        const int tw = (nar || h->persist_tw4) ? 4 : 8, gpwg = tw * GPW;
         const int wgs = (h->Lmax + gpwg - 1) / gpwg, per_cu = (wgs + h->cus - 1) / h->cus;
         if (per_cu > (gpwg == 32 ? 4 : 2)) return false;
         const size_t cu_lds = (size_t)(160 * 1024) / (size_t)per_cu;
         const size_t tree_lds = nar ? (size_t)eager_lds_layout(h->V, NG, G * h->persist_nar_kpl).total : h->reg_lds;
         const int rs = small_io_row_bytes(n);
         const size_t io_off = (std::max((size_t)tw * tree_lds, (size_t)gpwg * 2 * (n.H * 2 + 16)) + 15) & ~(size_t)15;
-        return io_off + (size_t)tw * NG * rs + 16 + (size_t)tw * 64 <= cu_lds;   // (flags, at least 16 work-list entries per wave; the next-word tables where they fit)
+        return io_off + (size_t)tw * GPW * rs + 16 + (size_t)tw * 64 <= cu_lds;   // (flags, at least 16 work-list entries per wave; the next-word tables where they fit)
     }
     if (n.H == 512 && use_big4(h)) return true;
     if (n.H == 512) {
@@ -1761,7 +1767,8 @@ static int run_games_persist(agz_engine* h, int ngames, int V, float cpuct, int 
     if (!big && !nar && !h->k_persist) { h->fail("no persistent self-play kernel for this game shape"); return AGZ_ERR_UNSUPPORTED; }
     const bool tw4 = !big && !nar && h->persist_tw4;
     const bool big4 = big && use_big4(h);                                       // one 128-game workgroup per CU, 4 lanes per tree
-    const int G = nar ? h->persist_nar_g : (big4 ? 4 : 8), NG = 64 / G, tw = (nar || tw4) ? 4 : 8, gpwg = tw * NG;
+    const bool nsp = nar && h->nar_sparse && h->k_persist_nar_sp;                // ... or 8 games per wave of 16 lane-groups, four waves per SIMD (round 6)
+    const int G = nar ? h->persist_nar_g : (big4 ? 4 : 8), NG = 64 / G, GPW = nsp ? NG / 2 : NG, tw = (nar || tw4) ? 4 : 8, gpwg = tw * GPW;
     const unsigned wgs = (unsigned)((LM + gpwg - 1) / gpwg);
     PersistTail X; memset(&X, 0, sizeof X);
     fill_plypar(h, X.P, 0, tau_plies, false);
@@ -1783,7 +1790,7 @@ static int run_games_persist(agz_engine* h, int ngames, int V, float cpuct, int 
     T.L = LM; T.slot0 = 0; T.step = 0; T.cpuct = cpuct; T.training = 1;
     T.fastdiv = fastdiv_range(h);
     T.inject = 0; T.capture = 0; T.rollout = 0; T.do_reset = 1; T.do_expand = 0; T.do_select = 1; T.last = 0;
-    T.gpw = NG;
+    T.gpw = GPW;
     const size_t cu_lds_all = (size_t)(160 * 1024);
     int wgcu = 2;
     h->in_ply_loop = true;
@@ -1817,10 +1824,10 @@ static int run_games_persist(agz_engine* h, int ngames, int V, float cpuct, int 
         S.T = T;
         S.F.planes = (const uint16_t*)h->planes; S.F.INP = n.INP; S.F.w16 = n.w16w; S.F.bias_head = n.bias_head;
         S.F.logits = h->logits; S.F.LGS = h->LGS; S.F.vout = h->v_eval; S.F.L = LM; S.F.T = n.T; S.F.A = h->G.A; S.F.AOP = n.AOP;
-        S.F.gpw = 0; S.F.tw = tw; S.F.rb = NG;
+        S.F.gpw = 0; S.F.tw = tw; S.F.rb = GPW;
         S.V = V; S.tree_lds = nar ? eager_lds_layout(h->V, NG, G * h->persist_nar_kpl).total : (int)h->reg_lds;
         const int rs = small_io_row_bytes(n);
-        S.io_prowb = rs; S.io_lgs = rs / 4; S.io_bw = NG * rs;
+        S.io_prowb = rs; S.io_lgs = rs / 4; S.io_bw = GPW * rs;
         S.io_off = (int)((std::max((size_t)tw * (size_t)S.tree_lds, (size_t)gpwg * 2 * (n.H * 2 + 16)) + 15) & ~(size_t)15);
         S.xch_off = S.io_off + tw * S.io_bw;                                       // (no helper waves here: nothing is exchanged)
         // ... + the workgroup's two flag words + the tree waves' next-word tables (agz_tree_eager.hpp NXL: 2 V bytes per game)
@@ -1835,7 +1842,7 @@ static int run_games_persist(agz_engine* h, int ngames, int V, float cpuct, int 
         if (lds > cu_lds) { h->in_ply_loop = false; h->fail("persistent self-play kernel: %zu bytes of LDS per workgroup", lds); return AGZ_ERR_UNSUPPORTED; }
         h->rd_rec_bytes = nar ? (uint32_t)eager_rec_bytes(G * h->persist_nar_kpl, h->V) : h->tp.rec_bytes;
         hipEventRecord(h->ev_ply0, h->stream);
-        hipLaunchKernelGGL(nar ? h->k_persist_nar : (tw4 ? (age_kernel ? h->k_persist_tw4_age : h->k_persist_tw4) : (age_kernel ? h->k_persist_age : h->k_persist)), dim3(wgs), dim3(64 * tw), lds, h->stream, Q);
+        hipLaunchKernelGGL(nar ? (nsp ? h->k_persist_nar_sp : h->k_persist_nar) : (tw4 ? (age_kernel ? h->k_persist_tw4_age : h->k_persist_tw4) : (age_kernel ? h->k_persist_age : h->k_persist)), dim3(wgs), dim3(64 * tw), lds, h->stream, Q);
     }
     hipEventRecord(h->ev_ply1, h->stream);
     const bool sleep = h->ply_sleep && h->ev_adv && hipEventRecord(h->ev_adv, h->stream) == hipSuccess;
@@ -1867,7 +1874,7 @@ static int run_games_persist(agz_engine* h, int ngames, int V, float cpuct, int 
     } else {
         char ab[96] = ""; if (age_kernel) snprintf(ab, sizeof ab, "; age classes: rows by legal rank KPR=%d in workgroups whose games are all at ply >= %u", h->age_kpr, X.P.mq.age);
         char b[320]; snprintf(b, sizeof b, "k_selfplay_small<KPL=%d,H=128,TW=%d,WV=%d,G=%d%s> (persistent: one launch per self-play call, a workgroup loops over the plies of its %d games%s)",
-                              nar ? h->persist_nar_kpl : h->reg_kpl, tw, nar ? 2 : 4, G, age_kernel ? ",AGE" : "", gpwg, ab); h->form_tree = b; h->form_nn = "inside k_selfplay_small (mlp_wave_body<128>)";
+                              nar ? h->persist_nar_kpl : h->reg_kpl, tw, (nar && !nsp) ? 2 : 4, G, age_kernel ? ",AGE" : (nsp ? ",SPARSE" : ""), gpwg, ab); h->form_tree = b; h->form_nn = "inside k_selfplay_small (mlp_wave_body<128>)";
     }
     h->acc_p += acc[0]; h->acc_new += acc[1]; h->total_rollouts += (uint64_t)rollouts; h->cnt_live = false;
     h->tree_ms += ms; h->tree_busy_ms += ms; h->tree_launches += 1;

@@ -181,10 +181,13 @@ __device__ __forceinline__ uint32_t advance_groups(const PlyPar& T, const int sl
 // GROUPSTEP: the ply step of all the wave's games at once, one per lane-group (advance_groups) — the 128-wide kernels; the wide-trunk
 // kernels keep the one-game-after-the-other form (their ply step is 0.3 % of the time and the group form's registers cost the 128-register
 // build of the 64-leaf network pass another 28 spilled registers)
-template <int FAM, int NC, int KPL, int G, int TW, bool AGE, bool GROUPSTEP, typename TailFn, typename SearchFn>
+// GPW_ (round 6): games of a tree wave when that is FEWER than its 64 / G lane-groups (0: all of them) — a game with few actions on narrow lane-groups
+// fills a wave with 16 trees, and 32768 games are then two waves per SIMD: too few to hide a rollout's dependent chain.  With 8 games per
+// wave the same games are four waves per SIMD, and the lane-groups without a game take work items of the wave's games (agz_tree_eager.hpp: sparse waves).
+template <int FAM, int NC, int KPL, int G, int TW, bool AGE, bool GROUPSTEP, int GPW_ = 0, typename TailFn, typename SearchFn>
 __device__ __forceinline__ void persist_loop(uint8_t* const lds, const TailFn tail, const SearchFn search) {
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    constexpr int NG = 64 / G;                                    // games of a tree wave
+    constexpr int NG = GPW_ ? GPW_ : 64 / G;                      // games of a tree wave
     constexpr int NR = (G * KPL + 63) / 64;                       // 64-action rows of the ply step (rows past the game's actions are empty)
     static_assert(!AGE || G == 8, "age classes: 8 lanes per tree");
     const int lane = lane_id();
@@ -353,9 +356,9 @@ __device__ __forceinline__ void persist_loop(uint8_t* const lds, const TailFn ta
 
 // one mcts_single (:376-462) of the workgroup's games inside the persistent kernel: the rollout loop of k_search_small.  KPR: rows per lane
 // by the root's legal rank (0: rows by action); the records keep the stride they were allocated with either way.
-template <int FAM, int NC, int KPL, int H, int TW, int WV, int G, int KPR>
+template <int FAM, int NC, int KPL, int H, int TW, int WV, int G, int KPR, int GPW_ = 0>
 __device__ __forceinline__ void persist_search(uint8_t* const lds_small, const uint32_t amask, EagerCarry& C) {
-    constexpr int NWV = TW == 8 ? 8 : NW_WAVES, NG = 64 / G;
+    constexpr int NWV = TW == 8 ? 8 : NW_WAVES, NG = 64 / G, GPW = GPW_ ? GPW_ : NG;   // (GPW games per wave: the rows of its block of the hand-over window and of the network's tile)
     constexpr int PFM_ = (G < 8 || WV < 3 || (WV == 3 && KPL <= 16) || KPL <= 4) ? 2 : AGZ_PFM_LOW;
     typedef const PersistPar __attribute__((address_space(4)))* KArg;
     const KArg karg = (KArg)__builtin_amdgcn_kernarg_segment_ptr();
@@ -378,7 +381,7 @@ __device__ __forceinline__ void persist_search(uint8_t* const lds_small, const u
         if (k < S.V) {
             __builtin_amdgcn_s_setprio(3);
             const SmallPar& S = spar();
-            mlp_wave_body<H, TW * NG / 16, 2, true, true, (WV < 4), (WV < 3) || AGZ_PERSIST_BP, NWV>(S.F, lds_small, bx, lds_small + S.io_off, S.io_bw, S.io_lgs);
+            mlp_wave_body<H, TW * GPW / 16, 2, true, true, (WV < 4), (WV < 3) || AGZ_PERSIST_BP, NWV>(S.F, lds_small, bx, lds_small + S.io_off, S.io_bw, S.io_lgs);
             __syncthreads();
             __builtin_amdgcn_s_setprio(0);
         }
@@ -387,7 +390,7 @@ __device__ __forceinline__ void persist_search(uint8_t* const lds_small, const u
 
 // The same template parameters as k_search_small; only the shapes whose every wave is a full tree wave (TW = 4 or 8, ROLE_ALL) are built.
 // KPR2 != 0: age classes (above).
-template <int FAM, int NC, int KPL, int H, int TW, int WV, int G = 8, int KPR2 = 0>
+template <int FAM, int NC, int KPL, int H, int TW, int WV, int G = 8, int KPR2 = 0, int GPW_ = 0>
 __global__ __launch_bounds__(64 * (TW == 8 ? 8 : NW_WAVES), WV) void k_selfplay_small(const PersistPar) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_small[];
     static_assert(offsetof(PersistPar, S) == 0 && offsetof(SmallPar, T) == 0, "rollout_eager_body reads its TreePar from the start of the argument segment");
@@ -403,11 +406,12 @@ __global__ __launch_bounds__(64 * (TW == 8 ? 8 : NW_WAVES), WV) void k_selfplay_
 #else
     constexpr bool GS = true;
 #endif
-    persist_loop<FAM, NC, KPL, G, TW, AGE, GS>(lds_small, tail, [&](const uint32_t amask, const bool ranked, EagerCarry& C) {
+    static_assert(!GPW_ || (!AGE && GPW_ * 2 == 64 / G && (TW * GPW_) % 16 == 0), "sparse waves: half of the lane-groups hold a game");
+    persist_loop<FAM, NC, KPL, G, TW, AGE, GS, GPW_>(lds_small, tail, [&](const uint32_t amask, const bool ranked, EagerCarry& C) {
         if constexpr (AGE) {
             if (ranked) persist_search<FAM, NC, KPL, H, TW, WV, G, KPR2>(lds_small, amask, C);
             else persist_search<FAM, NC, KPL, H, TW, WV, G, 0>(lds_small, amask, C);
-        } else persist_search<FAM, NC, KPL, H, TW, WV, G, 0>(lds_small, amask, C);
+        } else persist_search<FAM, NC, KPL, H, TW, WV, G, 0, GPW_>(lds_small, amask, C);
     });
 }
 
@@ -422,7 +426,8 @@ __global__ __launch_bounds__(64 * (TW == 8 ? 8 : NW_WAVES), WV) void k_selfplay_
 #define AGZ_PERSIST_AGE_VARIANTS(F, C, K, R, KW) KW template __global__ void k_selfplay_small<F, C, K, 128, 8, 4, 8, R>(const PersistPar); \
                                                  KW template __global__ void k_selfplay_small<F, C, K, 128, 4, 4, 8, R>(const PersistPar);
 #define AGZ_PERSIST_AGE_SHAPES(X) X(F_LINE, 2, 12, 8) X(F_HEX, 2, 12, 8)
-#define AGZ_PERSIST_NARROW_VARIANTS(F, C, K, GG, KW) KW template __global__ void k_selfplay_small<F, C, K, 128, 4, 2, GG>(const PersistPar);
+#define AGZ_PERSIST_NARROW_VARIANTS(F, C, K, GG, KW) KW template __global__ void k_selfplay_small<F, C, K, 128, 4, 2, GG>(const PersistPar); \
+                                                     KW template __global__ void k_selfplay_small<F, C, K, 128, 4, 4, GG, 0, 32 / GG>(const PersistPar);   /* sparse: half of the lane-groups hold a game, four waves per SIMD */
 #define AGZ_PERSIST_NARROW_SHAPES(X) X(F_C4, 1, 4, 4)
 
 }  // namespace agz

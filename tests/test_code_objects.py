@@ -89,13 +89,16 @@ def test_benchmarked_kernels_do_not_spill_vector_registers():
     # (two workgroup shapes: 32 games in four waves — the default — and 64 games in eight)
     for tw in (4, 8):
         for fam_nc_kpl in ("0, 2, 12", "2, 2, 12", "3, 1, 12", "3, 1, 8"):
-            k = md[f"k_selfplay_small<{fam_nc_kpl}, 128, {tw}, 4, 8, 0>"]
+            k = md[f"k_selfplay_small<{fam_nc_kpl}, 128, {tw}, 4, 8, 0, 0>"]
             assert k["vgpr_spill_count"] == 0 and k["vgpr_count"] <= 128 and k["sgpr_spill_count"] <= 64, (fam_nc_kpl, tw, k)
         for fam_nc_kpl in ("0, 2, 12", "2, 2, 12"):
-            k = md[f"k_selfplay_small<{fam_nc_kpl}, 128, {tw}, 4, 8, 8>"]
+            k = md[f"k_selfplay_small<{fam_nc_kpl}, 128, {tw}, 4, 8, 8, 0>"]
             assert k["vgpr_spill_count"] <= 8 and k["private_segment_fixed_size"] <= 48 and k["vgpr_count"] <= 128, (fam_nc_kpl, tw, k)
-    k = md["k_selfplay_small<1, 1, 4, 128, 4, 2, 4, 0>"]
+    k = md["k_selfplay_small<1, 1, 4, 128, 4, 2, 4, 0, 0>"]
     assert k["vgpr_spill_count"] <= 4 and k["vgpr_count"] <= 256, k
+    # ... and its sparse form (round 6: eight games per wave of sixteen lane-groups, four waves per SIMD — what config 2 runs): no spill at 128 registers
+    k = md["k_selfplay_small<1, 1, 4, 128, 4, 4, 4, 0, 8>"]
+    assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0 and k["vgpr_count"] <= 128, k
     # one 128-game workgroup per CU (4 lanes per tree, the network pass on 128 leaves; 256 registers): a reloaded loop-invariant at most
     for fam_nc_kpl4 in ("0, 2, 24", "2, 2, 24", "3, 1, 24", "0, 1, 8", "0, 1, 16", "1, 1, 8", "2, 1, 8", "2, 1, 16", "2, 2, 16", "3, 1, 16"):
         k = md[f"k_selfplay_big4<{fam_nc_kpl4}, 512>"]
