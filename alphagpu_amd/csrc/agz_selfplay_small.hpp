@@ -18,6 +18,9 @@
 #define AGZ_PERSIST_BP 0     // 1: the network phase of the persistent 128-wide kernels reads a group's operands ahead of its MFMAs (agz_nn_wave.hpp BP) also at four waves per SIMD (A/B)
 #endif
 
+#ifndef AGZ_PFM_RANKED
+#define AGZ_PFM_RANKED AGZ_PFM_LOW
+#endif
 #ifndef AGZ_PERSIST_NXL
 #define AGZ_PERSIST_NXL 1    // 1: the descent of the whole-search kernels follows next words kept in LDS (agz_tree_eager.hpp nxw) wherever they fit; 0: the records' (A/B)
 #endif
@@ -359,7 +362,8 @@ __device__ __forceinline__ void persist_loop(uint8_t* const lds, const TailFn ta
 template <int FAM, int NC, int KPL, int H, int TW, int WV, int G, int KPR, int GPW_ = 0>
 __device__ __forceinline__ void persist_search(uint8_t* const lds_small, const uint32_t amask, EagerCarry& C) {
     constexpr int NWV = TW == 8 ? 8 : NW_WAVES, NG = 64 / G, GPW = GPW_ ? GPW_ : NG;   // (GPW games per wave: the rows of its block of the hand-over window and of the network's tile)
-    constexpr int PFM_ = (G < 8 || WV < 3 || (WV == 3 && KPL <= 16) || KPL <= 4) ? 2 : AGZ_PFM_LOW;
+    // (rows by legal rank hold 8 instead of 12 entries per lane: AGZ_PFM_RANKED = 2 gives THAT form of the rollout loop the register prefetch of the item rows)
+    constexpr int PFM_ = (G < 8 || WV < 3 || (WV == 3 && KPL <= 16) || KPL <= 4) ? 2 : ((KPR != 0 && KPR <= 8) ? AGZ_PFM_RANKED : AGZ_PFM_LOW);
     typedef const PersistPar __attribute__((address_space(4)))* KArg;
     const KArg karg = (KArg)__builtin_amdgcn_kernarg_segment_ptr();
     const auto spar = [&]() -> const SmallPar& { KArg p = karg; asm volatile("" : "+s"(p)); return ((const PersistPar*)p)->S; };

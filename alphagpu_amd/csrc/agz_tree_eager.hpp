@@ -28,6 +28,7 @@
 //   the descent went on; sp[slot]: the last expanded node of the path (the parent of the leaf) — these 8 items are processed
 //   together in the first round because they alone may have a new child to register (rank, cid, re-summed prior_rem).
 #pragma once
+#include <type_traits>
 #include "agz_wave.hpp"
 #include "agz_divpair.hpp"
 #include "agz_fastdiv.hpp"
@@ -569,23 +570,30 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
             const bool rootmix = lf == 0 && T.training;               // :270-275 vs :277-279, :292-294   // PHASE expand: mix / divide
             const float Af = (float)nl;
             float qn_[KPR];
-            if (fdx && !__ballot(doexp && !(normalize >= 7.8886090522101181e-31f))) {        // 2^-100
-                const float rn = fd_rcp(normalize);
+            // (the root is expanded in the FIRST rollout of a search only: the other 63 take the plain quotients — no 0.75 x, no select per action,
+            //  no 0.25 / A — behind one wave-uniform test)
+            const bool fdn = fdx && !__ballot(doexp && !(normalize >= 7.8886090522101181e-31f));        // 2^-100
+            auto quotients = [&](auto MIX) {
+                constexpr bool mix = decltype(MIX)::value;
+                if (fdn) {
+                    const float rn = fd_rcp(normalize);
 #pragma unroll
-                for (int j = 0; j < KPR; j += 2)
-                    fd_div2(rootmix ? 0.75f * xr[j] : xr[j], normalize, rn, rootmix ? 0.75f * xr[j + 1] : xr[j + 1], normalize, rn, qn_[j], qn_[j + 1]);
-            } else {
+                    for (int j = 0; j < KPR; j += 2)
+                        fd_div2((mix && rootmix) ? 0.75f * xr[j] : xr[j], normalize, rn, (mix && rootmix) ? 0.75f * xr[j + 1] : xr[j + 1], normalize, rn, qn_[j], qn_[j + 1]);
+                } else {
 #pragma unroll
-                for (int j = 0; j < KPR; j += 2)
-                    div_pair(rootmix ? 0.75f * xr[j] : xr[j], normalize, rootmix ? 0.75f * xr[j + 1] : xr[j + 1], normalize, qn_[j], qn_[j + 1]);
-            }
+                    for (int j = 0; j < KPR; j += 2)
+                        div_pair((mix && rootmix) ? 0.75f * xr[j] : xr[j], normalize, (mix && rootmix) ? 0.75f * xr[j + 1] : xr[j + 1], normalize, qn_[j], qn_[j + 1]);
+                }
 #pragma unroll
-            for (int j = 0; j < KPR; ++j) {
-                float pr = rootmix ? (lg[j] ? qn_[j] + 0.25f / Af : 0.0f) : qn_[j];
-                if (j >= nvr) pr = 0.0f;
-                xr[j] = pr;
-                npos += pr > 0.0f ? 1 : 0;
-            }
+                for (int j = 0; j < KPR; ++j) {
+                    float pr = (mix && rootmix) ? (lg[j] ? qn_[j] + 0.25f / Af : 0.0f) : qn_[j];
+                    if (j >= nvr) pr = 0.0f;
+                    xr[j] = pr;
+                    npos += pr > 0.0f ? 1 : 0;
+                }
+            };
+            if (__builtin_expect(__ballot(rootmix) != 0ull, 0)) quotients(std::true_type{}); else quotients(std::false_type{});
             if (__builtin_expect(lf == 0, 0)) {                       // root expansion: policy == prior is what copy_pol sees for V <= 2
 #pragma unroll
                 for (int j = 0; j < KPR; ++j) if (j < nvr) T.policy_final[(size_t)slot * A + r0 + j] = xr[j];
