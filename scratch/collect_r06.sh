@@ -22,6 +22,7 @@ AGZ_NARROW_SPARSE=0 python bench.py --config 2 --steps 20 --warmup 5 $B > $out/b
 timeout 600 rocprofv3 --kernel-trace --stats -d $out/stats_headline -o x --output-format csv -- python3 bench.py --steps 20 --warmup 5 $B > $out/bench_under_rocprof.json 2> $out/stats_headline.log
 for c in 2 3 4 5; do timeout 900 rocprofv3 --kernel-trace --stats -d $out/stats_config$c -o x --output-format csv -- python3 bench.py --config $c --steps 20 --warmup 5 $B > $out/bench_config${c}_under_rocprof.json 2> $out/stats_config$c.log; done
 fi
+if [ -z "$BENCH_ONLY" ]; then
 rm -f $out/pmc_refill_summary.txt
 declare -A GENS_OF=([0]=8 [2]=8 [3]=4 [4]=3 [5]=4)
 for cfg in 0 2 3 4 5; do
@@ -52,5 +53,6 @@ PY
 done
 CFGS="0 2 3" bash scratch/pmc_util_persist.sh $1 > $out/pmc_util.log 2>&1
 if [ -f scratch/libagz_dbg.so ]; then { echo "# python scratch/stamps.py  (-DAGZ_STAMPS build of the final library: cycles per wave and rollout by phase, first ply of the headline shape, 32768 games, k_search_small)"; python scratch/stamps.py; } > $out/phase_cycles_stamps.txt 2>&1; fi
+fi
 for d in $out/stats_*; do find $d -name "*kernel_trace.csv" -delete; done
 ls $out

@@ -36,9 +36,16 @@ def main():
     if len(sys.argv) > 2 and sys.argv[2] == "reg":
         BODY, SRC = "rollout_reg_body", "agz_tree_reg.hpp"
     ph = load_phases("alphagpu_amd/csrc/" + SRC)
+    # optional filter: only the instructions of the copy of the body whose template arguments end with this text (a kernel with age classes
+    # holds two copies of the rollout loop: "... 8, 8>" rows by legal rank, "... 0, 8>" rows by action); the network body is split by its caller
+    variant = sys.argv[3] if len(sys.argv) > 3 else None
     tab = collections.defaultdict(collections.Counter)
     for x in d["ins"]:
         body = None
+        if variant is not None:
+            names = [fn for fn, f, ln in x["frames"] if ("rollout_eager_body<" in fn or "persist_search<" in fn)]
+            if not any(variant in fn.split("::")[0] + ">" or fn.rstrip().endswith(variant) or (variant in fn) for fn in names):
+                continue
         for fn, f, ln in x["frames"]:
             if BODY in fn and f == SRC:
                 body = ln
