@@ -106,9 +106,10 @@ def load_library():
     L.agz_comm_records_device.argtypes = [vp, C.c_int]
     L.agz_comm_records_device.restype = vp
     L.agz_get_age_stats.argtypes = [vp, C.POINTER(C.c_uint64 * 3)]
-    L.agz_get_samples_packed_async.argtypes = [vp, vp, C.c_int64, C.POINTER(C.c_int64)]
-    L.agz_comm_post_status.argtypes = [vp, C.c_int]
-    L.agz_comm_get_statuses.argtypes = [vp, C.POINTER(C.c_int32)]
-    L.agz_allgather_samples_status.argtypes = [vp, vp, C.c_int, i64p, C.POINTER(C.c_int32)]
+    if hasattr(L, "agz_comm_post_status") or not os.environ.get("AGZ_LIB_PATH"):   # (an A/B library named by AGZ_LIB_PATH may be a build of an earlier round)
+        L.agz_get_samples_packed_async.argtypes = [vp, vp, C.c_int64, C.POINTER(C.c_int64)]
+        L.agz_comm_post_status.argtypes = [vp, C.c_int]
+        L.agz_comm_get_statuses.argtypes = [vp, C.POINTER(C.c_int32)]
+        L.agz_allgather_samples_status.argtypes = [vp, vp, C.c_int, i64p, C.POINTER(C.c_int32)]
     _LIB = L
     return L

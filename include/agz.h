@@ -187,9 +187,10 @@ int  agz_unpack_records(const agz_game_info *info, const void *records, int64_t 
  * Memory, allocated once at agz_comm_create: 2 x (1 + world) x (32 + capacity_records x rec_bytes) bytes per rank (two slots: the
  * exchange of call k overlaps call k + 1).  8 ranks x one Gobang 9x9 generation (32768 games, ~39 plies, 592-byte records: ~0.76 GB per
  * rank) = 6.1 GB gathered per slot: size capacity_records by the records of ONE call (16 GB of gathered records hold two generations).
- * BASELINE config 5 (Reversi 8x8, 8 ranks x 32768 games, one generation per call, 464-byte records, <= 70 plies, ~60 on average):
- * capacity 32768 x 70 records = 1.06 GB per block -> 2 x 9 x 1.06 = 19.2 GB of exchange buffers per rank next to the engine's 6.3 GB
- * (2.0 GB of node records, 1.4 GB of sample store for three generations in flight, states, planes) — 9 % of a 288-GB MI355X.
+ * BASELINE config 5 (Reversi 8x8, 8 ranks x 32768 games, one generation per call; measured on an MI355X, scratch/mem_cfg5.py): 480-byte records, at most
+ * 128 plies per game (passes included; ~60 on average) -> capacity 32768 x 128 records = 2.01 GB per block, 2 x 9 x 2.01 = 36.2 GB of exchange
+ * buffers per rank next to the engine's 7.0 GB (node records 2.4 GB, the sample store of three generations in flight, states, planes): 14 % of the
+ * 309 GB the device reports.  A capacity of 70 plies per game (bench.py --exchange-plies 70: a call that outgrows it fails on every rank alike) is 19.8 GB.
  * A rank whose self-play call FAILED (an illegal sampled move, any error) must still enter the exchange — the others would wait inside
  * ncclAllGather for ever: agz_comm_post_status hands its return code to the next collective (such a rank sends no records), every
  * rank reads all codes after the wait (agz_comm_get_statuses) and they fail, or go on, together. */
