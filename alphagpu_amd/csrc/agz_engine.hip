@@ -1783,6 +1783,11 @@ static int run_games_persist(agz_engine* h, int ngames, int V, float cpuct, int 
         if (X.P.mq.backlog_max > h->mq_cap / 2u) X.P.mq.backlog_max = h->mq_cap / 2u;
         X.P.mq.age = (uint32_t)std::max(0, h->G.A - 8 * h->age_kpr);
         X.old16 = (uint32_t)h->age_old16; X.class_by_block = (h->age_by_block ? 1u : 0u) | (h->age_by_wave ? 2u : 0u);
+        // (the ring must outlast the worst backlog: the bound plus one game per wave of the launch, agz_plystep.hpp)
+        if ((unsigned long long)X.P.mq.backlog_max + (unsigned long long)wgs * (unsigned long long)tw >= (unsigned long long)h->mq_cap) {
+            h->fail("migration queue of %u entries is too small for a backlog of %u games and %u waves", h->mq_cap, X.P.mq.backlog_max, wgs * (unsigned)tw);
+            return AGZ_ERR_STATE;
+        }
         h->mq_dirty = true;
     }
     const bool age_kernel = X.P.mq.buf != nullptr;

@@ -81,6 +81,17 @@ __device__ __forceinline__ void write_start_position(const PlyPar& T, const int 
         T.slot_ply[slot] = 0u;
     }
 }
+// Memory ordering of the queue: the payload words and the per-entry ready word are written and read with AGENT-scope RELAXED atomics
+// around `s_waitcnt vmcnt(0)`, not with release / acquire: on gfx942 / gfx950 an agent-scope atomic access is an sc1 access that bypasses the
+// per-XCD L2 (the L2s of the eight XCDs are not coherent for plain accesses inside a launch), and vmcnt(0) means the wave's stores have been
+// acknowledged by the memory side — so "payload, wait, ready word" is ordered for every other XCD.  A release / acquire pair would write back and
+// invalidate an L2 that holds a gigabyte of tree records in flight, once per migrated game.  That is a property of THESE targets:
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "agz_plystep.hpp: the migration queue relies on gfx942 / gfx950 semantics of agent-scope relaxed atomics (sc1, L2 bypass) and of s_waitcnt vmcnt(0)"
+#endif
+// Ring bound: a producer takes its ticket before it looks at the backlog of the NEXT push, so the backlog can exceed backlog_max by one entry per
+// wave at most; the engine refuses a launch unless backlog_max + (waves of the launch) < ring entries (agz_engine.hip run_games_persist), which is
+// what keeps two producers from meeting on one entry.
 template <bool INPLACE>
 __device__ __forceinline__ uint32_t pop_migrated(const PlyPar& T, const int slot) {
     const MigQ& q = T.mq;

@@ -395,11 +395,14 @@ def test_bench_exchange_step_through_the_c_abi_with_one_rank(tmp_path):
         assert parity.same_bits(got[k], one[k]), k + " (bench.py --exchange vs one engine)"
 
 
-def test_bench_gpus_2_over_rccl(tmp_path):
+@pytest.mark.parametrize("impl", ["torch", "abi"])
+def test_bench_gpus_2_over_rccl(impl, tmp_path):
+    """two ranks over RCCL, one GPU each — the torch.distributed exchange (bench.py's default) and the exchange through the C ABI (agz_comm_*, which
+    has only ever run with one rank: ADVICE r5): both must gather the records of one engine playing all the games.  Skipped on a box with one GPU."""
     import torch
     if torch.cuda.device_count() < 2:
         pytest.skip("one visible GPU: the two-rank RCCL run needs two (the gloo form of the same test runs)")
-    _bench_two_ranks("nccl", tmp_path)
+    _bench_ranks("nccl", tmp_path, extra=("--exchange-impl", impl))
 
 
 # ---- whole generations at FULL size against the oracle -----------------------------------------------------------------
