@@ -97,6 +97,9 @@ AGZ_SMALL_CMP_SHAPES(X)
 #define X(F, C, K, R, GG) AGZ_SMALL_NARROW_VARIANTS(F, C, K, R, GG, extern)
 AGZ_SMALL_NARROW_SHAPES(X)
 #undef X
+#define X(F, C, K, R, GG) AGZ_SMALL_NARROW_SPARSE_VARIANTS(F, C, K, R, GG, extern)
+AGZ_SMALL_NARROW_SPARSE_SHAPES(X)
+#undef X
 }
 typedef void (*advance_fn)(const PlyPar);
 typedef void (*softmax_fn)(const float*, int, float*, int, int, int);
@@ -171,7 +174,7 @@ struct agz_engine {
     // four tree waves): g lanes per tree, kpl actions per lane, kpr rows per lane by legal rank (0: rows by action); k[0] / k[1]: register
     // budgets for two / one wave per SIMD.  narrow_mode (AGZ_NARROW): -1 never, 0 by batch size (from narrow_minl games on), 4 / 2: only
     // that group width (A/B).
-    struct Narrow { int g = 0, kpl = 0, kpr = 0; small_fn k[2] = {nullptr, nullptr}; };
+    struct Narrow { int g = 0, kpl = 0, kpr = 0; small_fn k[2] = {nullptr, nullptr}; small_fn ksp = nullptr; };   // ksp: sparse waves (half the lane-groups hold a game), four waves per SIMD
     Narrow nar[8]; int nnar = 0, narrow_mode = 0, narrow_minl = -1, narrow_occ = -1;   // narrow_occ (AGZ_NARROW_OCC, tests): force the 2 (0) / 1 (1) waves-per-SIMD build
     // record geometry of the LAST search (the narrow builds of games with few actions lay their records out for their own row width):
     // what the root read-back kernels use
@@ -189,7 +192,7 @@ struct agz_engine {
     // slots and loops over the plies of its games by itself.  persist: AGZ_PERSIST = 1 wherever a kernel exists (tests), 0 never, default
     // (-1): calls with refilled slots on an engine of more than 96 slots per CU.  chain_persist: the running chain's slots are not compacted.
     persist_fn k_persist = nullptr, k_persist_nar = nullptr, k_persist_nar_sp = nullptr; int persist_nar_g = 0, persist_nar_kpl = 0;
-    bool nar_sparse = true;            // few-action games: 8 games per 16-group wave, four waves per SIMD (AGZ_NARROW_SPARSE=0: 16 games per wave, two per SIMD)
+    int nar_sparse = 1;                // few-action games: 8 games per 16-group wave, four waves per SIMD (AGZ_NARROW_SPARSE=0: 16 games per wave, two per SIMD; 2: the searches at every batch size, tests)
     persist_big_fn k_persist_big[2] = {nullptr, nullptr};    // 512-wide trunks (agz_selfplay_big.hpp): one / two 64-game workgroups per CU
     int persist = -1; bool chain_persist = false; unsigned long long* d_pacc = nullptr;
     int reserve_slots = 0;             // AGZ_RESERVE_CUS x 128: slots the persistent launches leave without a workgroup (room for the exchange's RCCL kernels)
@@ -269,6 +272,9 @@ static bool bind_kernels(agz_engine* h) {
 #define Z(F, C, K, R, GG) if (P.fam == F && P.NC == C && GG * K >= P.A && GG * K <= 8 * kpl && h->nnar < 8) { agz_engine::Narrow& c = h->nar[h->nnar++]; \
         c.g = GG; c.kpl = K; c.kpr = R; c.k[0] = k_search_small<F, C, K, 128, 4, 2, R, GG>; c.k[1] = k_search_small<F, C, K, 128, 4, 1, R, GG>; }
     AGZ_SMALL_NARROW_SHAPES(Z)
+#undef Z
+#define Z(F, C, K, R, GG) for (int i = 0; i < h->nnar; ++i) if (P.fam == F && P.NC == C && h->nar[i].g == GG && h->nar[i].kpl == K && h->nar[i].kpr == R) h->nar[i].ksp = k_search_small<F, C, K, 128, 4, 4, R, GG, 32 / GG>;
+    AGZ_SMALL_NARROW_SPARSE_SHAPES(Z)
 #undef Z
     if (P.NR == 1) h->k_soft = k_softmax<1>; else if (P.NR == 2) h->k_soft = k_softmax<2>; else h->k_soft = k_softmax<3>;
     return h->k_adv != nullptr && h->k_eager != nullptr;
@@ -465,6 +471,7 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
         e3 = getenv("AGZ_NARROW_OCC");
         if (e3 && (atoi(e3) == 0 || atoi(e3) == 1)) h->narrow_occ = atoi(e3);
         for (int i = 0; i < h->nnar; ++i) for (int j = 0; j < 2; ++j) FA_(hipFuncSetAttribute((const void*)h->nar[i].k[j], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        for (int i = 0; i < h->nnar; ++i) if (h->nar[i].ksp) FA_(hipFuncSetAttribute((const void*)h->nar[i].ksp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         e3 = getenv("AGZ_PERSIST");
         if (e3) h->persist = atoi(e3) > 0 ? 1 : 0;
         e3 = getenv("AGZ_RESERVE_CUS");
@@ -473,7 +480,7 @@ int agz_create(const agz_config* cfg, agz_engine** out) {
         if (h->k_persist_nar) FA_(hipFuncSetAttribute((const void*)h->k_persist_nar, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         if (h->k_persist_nar_sp) FA_(hipFuncSetAttribute((const void*)h->k_persist_nar_sp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         e3 = getenv("AGZ_NARROW_SPARSE");
-        if (e3) h->nar_sparse = atoi(e3) > 0;
+        if (e3) h->nar_sparse = atoi(e3);
         if (h->k_persist_age) FA_(hipFuncSetAttribute((const void*)h->k_persist_age, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         for (int i = 0; i < 2; ++i) if (h->k_persist_big[i]) FA_(hipFuncSetAttribute((const void*)h->k_persist_big[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         if (h->k_persist_tw4) FA_(hipFuncSetAttribute((const void*)h->k_persist_tw4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -988,9 +995,12 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
                 if (!nk || c.g < nk->g || (c.g == nk->g && (c.kpr ? c.kpr : c.kpl) < (nk->kpr ? nk->kpr : nk->kpl))) nk = &c;
             }
         if (nk) {
-            const int G = nk->g, NG = 64 / G, tw = 4, gpwg = tw * NG;
+            // sparse waves (round 6): above 64 games per CU — where the dense form has its two waves per SIMD — eight games per wave of sixteen groups,
+            // 32-game workgroups, four per CU, four waves per SIMD; the groups without a game take work items
+            const bool sp = nk->ksp && h->nar_sparse > 0 && h->narrow_occ < 0 && (h->L > 64 * h->cus || h->nar_sparse > 1) && (h->L + 4 * (32 / nk->g) - 1) / (4 * (32 / nk->g)) <= 4 * h->cus;
+            const int G = nk->g, NG = 64 / G, GPW = sp ? NG / 2 : NG, tw = 4, gpwg = tw * GPW;
             const int wgs = (h->L + gpwg - 1) / gpwg;
-            int one = h->narrow_occ >= 0 && wgs <= h->cus ? h->narrow_occ : (wgs <= h->cus ? 1 : 0);   // one workgroup per CU: the 512-register build
+            int one = sp ? 0 : (h->narrow_occ >= 0 && wgs <= h->cus ? h->narrow_occ : (wgs <= h->cus ? 1 : 0));   // one workgroup per CU: the 512-register build
             const uint32_t A2 = (uint32_t)(G * (nk->kpr ? nk->kpr : nk->kpl));
             h->tree_kpr = nk->kpr;
             SmallPar S; S.nxw_off = 0;
@@ -998,18 +1008,18 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
             S.T.L = h->L; S.T.slot0 = 0; S.T.step = h->step; S.T.cpuct = h->cpuct; S.T.training = h->training;
             S.T.fastdiv = fastdiv_range(h);
             S.T.inject = 0; S.T.capture = 0; S.T.rollout = 0; S.T.do_reset = 1; S.T.do_expand = 0; S.T.do_select = 1; S.T.last = 0;
-            S.T.gpw = NG;
+            S.T.gpw = GPW;
             S.F.planes = (const uint16_t*)h->planes; S.F.INP = n.INP; S.F.w16 = n.w16w; S.F.bias_head = n.bias_head;
             S.F.logits = h->logits; S.F.LGS = h->LGS; S.F.vout = h->v_eval; S.F.L = h->L; S.F.T = n.T; S.F.A = h->G.A; S.F.AOP = n.AOP;
-            S.F.gpw = 0; S.F.tw = tw; S.F.rb = NG;
+            S.F.gpw = 0; S.F.tw = tw; S.F.rb = GPW;
             S.V = V; S.tree_lds = eager_lds_layout(h->V, NG, G * nk->kpl).total;
             const int rs = small_io_row_bytes(n);
-            S.io_prowb = rs; S.io_lgs = rs / 4; S.io_bw = NG * rs;
+            S.io_prowb = rs; S.io_lgs = rs / 4; S.io_bw = GPW * rs;
             S.io_off = (int)((std::max((size_t)tw * (size_t)S.tree_lds, (size_t)gpwg * 2 * (n.H * 2 + 16)) + 15) & ~(size_t)15);
             S.xch_off = S.io_off + tw * S.io_bw;
             size_t shared = (size_t)S.xch_off + (size_t)tw * (16 * NG + 16);
             if (!one && wgs <= h->cus && shared > (size_t)(80 * 1024)) one = 1;     // (32 trees per wave: the tables of a workgroup take more than half a CU's LDS)
-            const size_t cu_lds = (size_t)(160 * 1024) / (size_t)(one ? 1 : 2);
+            const size_t cu_lds = (size_t)(160 * 1024) / (size_t)(sp ? 4 : (one ? 1 : 2));
             S.nxw_off = place_nxw(shared, cu_lds, tw, NG, h->V);
             const size_t room = cu_lds > shared ? cu_lds - shared : 0;
             S.wl_off = (int)shared; S.wl_bytes = (int)std::min({(size_t)(NG * h->V * 4), (room / (size_t)tw) & ~(size_t)15, (size_t)h->wl_lds_max});
@@ -1017,7 +1027,7 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
             if (lds <= cu_lds) {
                 std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
                 if ((h->profiling & 1) && h->prof_this) { ev = next_events(h, h->ev_tree, h->ev_tree_used); hipEventRecord(ev->first, h->stream); }
-                hipLaunchKernelGGL(nk->k[one], dim3((unsigned)wgs), dim3(64 * NW_WAVES), lds, h->stream, S);
+                hipLaunchKernelGGL(sp ? nk->ksp : nk->k[one], dim3((unsigned)wgs), dim3(64 * NW_WAVES), lds, h->stream, S);
                 if (nk->kpr) {   // policy_final back to action order (one wave per game, in place)
                     PlyPar Q; memset(&Q, 0, sizeof Q);
                     Q.G = h->G; Q.L = h->L; Q.V = h->V; Q.states = h->states; Q.policy_final = h->policy_final;
@@ -1029,7 +1039,7 @@ int agz_search_actor(agz_engine* h, int which, int V, float cpuct, int training,
                 h->rd_off_vis = 16 + A2 * 6 + 8 * (uint32_t)eager_vl(h->V, (int)A2);
                 { char kb[48] = ""; if (nk->kpr) snprintf(kb, sizeof kb, ",rows by legal rank KPR=%d", nk->kpr);
                   char b[220]; snprintf(b, sizeof b, "k_search_small<KPL=%d,H=128,TW=4,WV=%d%s,G=%d> (whole mcts_single per launch, %d lanes per tree, %d games per tree wave, %d per workgroup)",
-                                        nk->kpl, one ? 1 : 2, kb, G, G, NG, gpwg); h->form_tree = b; h->form_nn = "inside k_search_small (mlp_wave_body<128>)"; }
+                                        nk->kpl, sp ? 4 : (one ? 1 : 2), kb, G, G, GPW, gpwg); h->form_tree = b; h->form_nn = "inside k_search_small (mlp_wave_body<128>)"; }
                 h->cnt_live = true;
                 h->need_reset = true; h->injected = false;
                 if (h->prof_this) h->total_rollouts += (uint64_t)h->L * (uint64_t)V;
@@ -1670,7 +1680,7 @@ static bool persist_shape(const agz_engine* h) {
         if (!(h->k_persist || h->k_persist_nar) || !n.w16w) return false;
         const bool nar = h->k_persist_nar && h->narrow_mode >= 0;
         // (lane-groups per wave, games per wave: half of the groups in the sparse form of the narrow kernel)
-        const int G = nar ? h->persist_nar_g : 8, NG = 64 / G, GPW = (nar && h->nar_sparse && h->k_persist_nar_sp) ? NG / 2 : NG;
+        const int G = nar ? h->persist_nar_g : 8, NG = 64 / G, GPW = (nar && h->nar_sparse > 0 && h->k_persist_nar_sp) ? NG / 2 : NG;
         const int tw = (nar || h->persist_tw4) ? 4 : 8, gpwg = tw * GPW;
         const int wgs = (h->Lmax + gpwg - 1) / gpwg, per_cu = (wgs + h->cus - 1) / h->cus;
         if (per_cu > (gpwg == 32 ? 4 : 2)) return false;
@@ -1767,7 +1777,7 @@ static int run_games_persist(agz_engine* h, int ngames, int V, float cpuct, int 
     if (!big && !nar && !h->k_persist) { h->fail("no persistent self-play kernel for this game shape"); return AGZ_ERR_UNSUPPORTED; }
     const bool tw4 = !big && !nar && h->persist_tw4;
     const bool big4 = big && use_big4(h);                                       // one 128-game workgroup per CU, 4 lanes per tree
-    const bool nsp = nar && h->nar_sparse && h->k_persist_nar_sp;                // ... or 8 games per wave of 16 lane-groups, four waves per SIMD (round 6)
+    const bool nsp = nar && h->nar_sparse > 0 && h->k_persist_nar_sp;                // ... or 8 games per wave of 16 lane-groups, four waves per SIMD (round 6)
     const int G = nar ? h->persist_nar_g : (big4 ? 4 : 8), NG = 64 / G, GPW = nsp ? NG / 2 : NG, tw = (nar || tw4) ? 4 : 8, gpwg = tw * GPW;
     const unsigned wgs = (unsigned)((LM + gpwg - 1) / gpwg);
     PersistTail X; memset(&X, 0, sizeof X);

@@ -41,7 +41,10 @@ struct SmallPar {
 // body runs TW * NG / 16 leaf tiles.  G = 4 (16 trees per wave, 24 actions per lane on a 9x9 board): two 64-game workgroups of four
 // waves per CU hold 32768 games with TWO waves per SIMD and 256 registers each — half the wave-instructions of the item loop's
 // per-round fixed work per game.  G = 2: Connect4's 7 actions in 2 x 4 slots, 32 trees per wave.
-template <int FAM, int NC, int KPL, int H, int TW, int WV, int KPR = 0, int G = 8>
+// GPW_ (round 6): games per tree wave when that is fewer than its 64 / G lane-groups BY CONSTRUCTION (0: all of them; fewer at run time — T.gpw — is
+// the sparse-wave dispatch of the small batches): a few-action game on 4-lane groups, eight games per wave of sixteen groups, four waves per SIMD
+// (agz_selfplay_small.hpp GPW_); the network then works on TW x GPW_ rows
+template <int FAM, int NC, int KPL, int H, int TW, int WV, int KPR = 0, int G = 8, int GPW_ = 0>
 __global__ __launch_bounds__(64 * (TW == 8 ? 8 : NW_WAVES), WV) void k_search_small(const SmallPar) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_small[];
     // The parameters are READ FROM THE KERNEL-ARGUMENT SEGMENT where they are needed (scalar loads), through a pointer made opaque
@@ -69,7 +72,7 @@ __global__ __launch_bounds__(64 * (TW == 8 ? 8 : NW_WAVES), WV) void k_search_sm
     // (item prefetch: into registers wherever they are free — up to 3 waves per SIMD, and rows of 4 actions per lane in the 128-register
     //  build: Connect4 85.8 -> 85.0 ms per generation; rows of 8 gain nothing or spill; rows of 24 actions spill 60 registers with it
     //  at 3 waves per SIMD and 4 without: Gobang 13x13 at 24576 games 9.2 -> 7.7 ms per ply)
-    constexpr int NG = 64 / G;
+    constexpr int NG = 64 / G, GPW = GPW_ ? GPW_ : NG;
     constexpr bool SPLIT = TW == 2 && G == 8;
     uint8_t* const own_lds = lds_small + (size_t)(SPLIT ? wave : wave % TW) * S.tree_lds;   // (a helper wave has tables of its own)
     uint32_t* const xch = reinterpret_cast<uint32_t*>(lds_small + S.xch_off + (size_t)(wave % TW) * (16 * NG + 16));
@@ -117,10 +120,10 @@ __global__ __launch_bounds__(64 * (TW == 8 ? 8 : NW_WAVES), WV) void k_search_sm
             __builtin_amdgcn_s_setprio(3);
             const SmallPar& S = par();
 #ifdef AGZ_STAMPS
-            mlp_wave_body<H, TW * NG / 16, 2, true, true, (WV < 4), (WV < 3), NWV>(S.F, nn_lds, bx, lds_small + S.io_off, S.io_bw, S.io_lgs,
+            mlp_wave_body<H, TW * GPW / 16, 2, true, true, (WV < 4), (WV < 3), NWV>(S.F, nn_lds, bx, lds_small + S.io_off, S.io_bw, S.io_lgs,
                                                               S.T.dbg ? S.T.dbg + (size_t)(32768 + bx * NWV + wave) * 16 : nullptr);
 #else
-            mlp_wave_body<H, TW * NG / 16, 2, true, true, (WV < 4), (WV < 3), NWV>(S.F, nn_lds, bx, lds_small + S.io_off, S.io_bw, S.io_lgs);
+            mlp_wave_body<H, TW * GPW / 16, 2, true, true, (WV < 4), (WV < 3), NWV>(S.F, nn_lds, bx, lds_small + S.io_off, S.io_bw, S.io_lgs);
 #endif
             __syncthreads();                                      // logits and values are visible to the tree waves
             __builtin_amdgcn_s_setprio(0);
@@ -170,5 +173,8 @@ __global__ __launch_bounds__(64 * (TW == 8 ? 8 : NW_WAVES), WV) void k_search_sm
 #define AGZ_SMALL_NARROW_VARIANTS(F, C, K, R, GG, KW)                        \
     KW template __global__ void k_search_small<F, C, K, 128, 4, 2, R, GG>(const SmallPar); \
     KW template __global__ void k_search_small<F, C, K, 128, 4, 1, R, GG>(const SmallPar);
+// ... and the few-action shapes with SPARSE waves (half of the lane-groups hold a game, four waves per SIMD in 128 registers)
+#define AGZ_SMALL_NARROW_SPARSE_SHAPES(X) X(F_C4, 1, 4, 0, 4)
+#define AGZ_SMALL_NARROW_SPARSE_VARIANTS(F, C, K, R, GG, KW) KW template __global__ void k_search_small<F, C, K, 128, 4, 4, R, GG, 32 / GG>(const SmallPar);
 
 }  // namespace agz

@@ -29,6 +29,9 @@ AGZ_SMALL_NARROW_SHAPES(X)
 #define X(F, C, K, GG) AGZ_PERSIST_NARROW_VARIANTS(F, C, K, GG, )
 AGZ_PERSIST_NARROW_SHAPES(X)
 #undef X
+#define X(F, C, K, R, GG) AGZ_SMALL_NARROW_SPARSE_VARIANTS(F, C, K, R, GG, )
+AGZ_SMALL_NARROW_SPARSE_SHAPES(X)
+#undef X
 #elif AGZ_PART == 8
 #define X(F, C, K4) AGZ_PERSIST_BIG4_VARIANTS(F, C, K4, )
 X(F_LINE, 2, 24) X(F_HEX, 2, 24) X(F_REV, 1, 24)

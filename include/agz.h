@@ -271,8 +271,9 @@ int  agz_set_profiling(agz_engine *h, int mode);       /* HIP events per launch:
  *                          for none (0); default: the 9x9 shapes they were measured on
  *   AGZ_NARROW=-1|0|4|2    one-launch search with narrow lane-groups (4 or 2 lanes per game tree: 16 / 32 trees per wave, workgroups of four tree
  *                          waves): never (-1), by batch size (0, default), or only that group width
- *   AGZ_NARROW_SPARSE=0    persistent self-play of a few-action game (Connect4): sixteen games per wave of sixteen 4-lane groups, two waves per SIMD (round 5's
- *                          form) instead of EIGHT games per wave and four waves per SIMD — the groups without a game take work items (default, round 6)
+ *   AGZ_NARROW_SPARSE=0    a few-action game (Connect4) at full batch — persistent self-play and the one-launch search above 64 games per CU —: sixteen games per
+ *                          wave of sixteen 4-lane groups, two waves per SIMD (round 5's form) instead of EIGHT games per wave and four waves per SIMD, the
+ *                          groups without a game on work items (default, round 6); =2: the one-launch search in that form at every batch size (tests)
  *   AGZ_NARROW_MINL=n      ... for batches of at least n games (tests: 0)
  *   AGZ_NARROW_OCC=0|1     ... force its two- / one-wave-per-SIMD register budget (tests)
  *   AGZ_NO_COMPACT=1       the ply loop keeps node rows by action on Gobang / Hex 9x9 (default: rows by the root's legal rank from ply 17 on,

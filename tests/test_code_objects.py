@@ -49,11 +49,11 @@ def test_benchmarked_kernels_do_not_spill_vector_registers():
     # register budget of the one-launch search, the wide-trunk search and the stand-alone tree step
     for fam_nc_kpl in ("0, 2, 12", "2, 2, 12", "1, 1, 4", "3, 1, 12", "3, 1, 8"):
         for tail, budget in (("128, 2, 2", 256), ("128, 4, 2", 256), ("128, 4, 3", 168), ("128, 4, 4", 128), ("128, 8, 4", 128)):
-            names = [f"k_search_small<{fam_nc_kpl}, {tail}, 0, 8>"]         # (..., rows by action, 8 lanes per tree)
+            names = [f"k_search_small<{fam_nc_kpl}, {tail}, 0, 8, 0>"]         # (..., rows by action, 8 lanes per tree)
             if fam_nc_kpl in ("0, 2, 12", "2, 2, 12"):                     # Gobang / Hex 9x9: also the build with rows by legal rank
-                names.append(f"k_search_small<{fam_nc_kpl}, {tail}, 8, 8>")
+                names.append(f"k_search_small<{fam_nc_kpl}, {tail}, 8, 8, 0>")
                 if not (fam_nc_kpl == "2, 2, 12" and tail in ("128, 4, 4", "128, 8, 4")):   # (Hex, 4 entries, 128 registers: 4 spilled registers, a tail-ply kernel)
-                    names.append(f"k_search_small<{fam_nc_kpl}, {tail}, 4, 8>")
+                    names.append(f"k_search_small<{fam_nc_kpl}, {tail}, 4, 8, 0>")
             for name in names:
                 k = md[name]
                 # (the 168-register build — three workgroups per CU, 24576 games: not a benchmarked size — reloads one loop-invariant quad since round 6)
@@ -77,11 +77,13 @@ def test_benchmarked_kernels_do_not_spill_vector_registers():
     # narrow lane-groups (4 lanes per tree, 24 actions per lane on a 9x9 board): two waves per SIMD in 256 registers, a handful of
     # spilled registers at most; the one-wave-per-SIMD builds do not spill
     for kpr in (0, 16, 8):
-        k = md[f"k_search_small<0, 2, 24, 128, 4, 2, {kpr}, 4>"]
+        k = md[f"k_search_small<0, 2, 24, 128, 4, 2, {kpr}, 4, 0>"]
         assert k["vgpr_spill_count"] <= 8 and k["vgpr_count"] <= 256, (kpr, k)
-        assert md[f"k_search_small<0, 2, 24, 128, 4, 1, {kpr}, 4>"]["vgpr_spill_count"] == 0
-    assert md["k_search_small<1, 1, 4, 128, 4, 2, 0, 4>"]["vgpr_spill_count"] == 0
-    assert md["k_search_small<1, 1, 4, 128, 4, 1, 0, 2>"]["vgpr_spill_count"] == 0
+        assert md[f"k_search_small<0, 2, 24, 128, 4, 1, {kpr}, 4, 0>"]["vgpr_spill_count"] == 0
+    assert md["k_search_small<1, 1, 4, 128, 4, 2, 0, 4, 0>"]["vgpr_spill_count"] == 0
+    k = md["k_search_small<1, 1, 4, 128, 4, 4, 0, 4, 8>"]                  # ... its sparse form (four waves per SIMD): what Connect4 searches run at full batch
+    assert k["vgpr_spill_count"] == 0 and k["vgpr_count"] <= 128, k
+    assert md["k_search_small<1, 1, 4, 128, 4, 1, 0, 2, 0>"]["vgpr_spill_count"] == 0
     # the persistent self-play kernels (round 5; what bench.py times): the search loop inside them keeps the budget of the search kernels.
     # Ceilings, so that growth does not go unnoticed: none for the 9x9 / Reversi shapes without age classes; the build with both row forms
     # reloads a handful of loop-invariant values (zeros of unused boards) once per rollout; the 4-lane Connect4 build parks four registers

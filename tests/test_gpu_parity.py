@@ -822,6 +822,40 @@ def test_whole_search_kernel_with_narrow_lane_groups_agrees_bitwise(name, L, V, 
                 assert_same_bits(a, b, f"{what} G={grp} {env}")
 
 
+@pytest.mark.parametrize("L,V", [(333, 36), (2100, 64)])
+def test_sparse_waves_of_the_narrow_search_agree_bitwise(L, V, monkeypatch):
+    """k_search_small<F_C4, ..., WV = 4, G = 4, GPW = 8> (round 6): eight Connect4 games per wave of sixteen 4-lane groups, the groups without a game on
+    work items, four waves per SIMD — what a full-batch Connect4 search runs; forced at a small size here (AGZ_NARROW_SPARSE=2): same bits as the
+    two-kernel form with 8 lanes per tree, ragged last wave and workgroup, a work list that overflows into global memory"""
+    g, _ = spec("connect4")
+    net = ag.SNetwork2.random(g, 128, 2)
+
+    def run():
+        with M.Engine(g, L, V, seed=12, nn_mode=M.NN_BF16) as e:
+            e.set_network(net)
+            e.set_roots(None, L=L)
+            e.search(V, cpuct=1.5, training=True, step=3)
+            return e.root_visits().copy(), e.policy().copy(), e.root_q().copy(), e.leaf().copy(), e.node_count().copy(), e.search_form()[0]
+
+    monkeypatch.setenv("AGZ_NARROW", "-1")
+    monkeypatch.setenv("AGZ_SMALL_MAXL", "0")
+    monkeypatch.setenv("AGZ_SMALL4_MAXL", "0")
+    ref = run()
+    assert ref[5].startswith("k_rollout_eager")
+    monkeypatch.delenv("AGZ_SMALL_MAXL")
+    monkeypatch.delenv("AGZ_SMALL4_MAXL")
+    monkeypatch.setenv("AGZ_NARROW", "4")
+    monkeypatch.setenv("AGZ_NARROW_MINL", "0")
+    monkeypatch.setenv("AGZ_NARROW_SPARSE", "2")
+    for wl in (None, "16"):
+        if wl:
+            monkeypatch.setenv("AGZ_WL_LDS_BYTES", wl)
+        got = run()
+        assert "WV=4" in got[5] and ",G=4>" in got[5] and "8 games per tree wave" in got[5], got[5]
+        for a, b, what in zip(got[:5], ref[:5], ("visits", "policy", "q", "leaf", "node_count")):
+            assert_same_bits(a, b, f"{what} sparse 4-lane waves, work list {wl}")
+
+
 @pytest.mark.parametrize("name,n,V,grp", [("gobang9", 40, 16, "4"), ("connect4", 70, 16, "4"), ("connect4", 70, 16, "2")])
 def test_generation_with_narrow_lane_groups_equals_the_oracle(name, n, V, grp, monkeypatch):
     """a whole self-play generation through the narrow builds at every ply (Gobang 9x9: rows by action, then by legal rank 16 and 8 per lane):

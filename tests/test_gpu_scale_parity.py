@@ -74,7 +74,7 @@ def run_slice_case(name, H, T, V, L, n_each, form_prefix, nn_prefix=None, step=0
 # BASELINE.json: the metric configuration and configs[1..4], each at its full size and default dispatch
 @pytest.mark.parametrize("label,name,H,T,V,n_each,form,nn", [
     ("headline", "gobang9", 128, 6, 64, 24, "k_search_small<KPL=12,H=128,TW=8,WV=4>", "inside k_search_small"),
-    ("config2", "connect4", 128, 6, 64, 24, "k_search_small<KPL=4,H=128,TW=4,WV=2,G=4>", "inside k_search_small"),   # (few actions: 4 lanes per tree at full batch)
+    ("config2", "connect4", 128, 6, 64, 24, "k_search_small<KPL=4,H=128,TW=4,WV=4,G=4>", "inside k_search_small"),   # (few actions: 4 lanes per tree, eight games per wave of sixteen lane-groups at full batch)
     ("config3", "gobang9", 512, 8, 64, 16, None, None),
     ("config4", "hex9", 512, 8, 128, 8, None, None),
     ("config5", "reversi8", 512, 8, 64, 16, None, None)])
