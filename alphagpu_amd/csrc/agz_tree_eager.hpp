@@ -33,6 +33,9 @@
 #include "agz_divpair.hpp"
 #include "agz_fastdiv.hpp"
 
+#ifndef AGZ_LATE_PRIO
+#define AGZ_LATE_PRIO 0     // n > 0: a wave whose rollout has more than n item rounds runs its item loop at priority 1 (A/B)
+#endif
 #ifndef AGZ_FAST_COUNT
 #define AGZ_FAST_COUNT 1    // 1: the sampled action of a work item from block-local running sums + a rounding margin (sample_count_fast); 0: always the source-order chain (A/B)
 #endif
@@ -645,6 +648,10 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
         STAMPW(2);
         // ---------------------------------------------------------------------------- work items
         const TreePar& TI = tree_par();                               // (the item loop's own view of the parameters)
+#if AGZ_LATE_PRIO
+        // a wave with many item rounds is the one its workgroup will wait for in front of the network phase: it goes first (A/B switch)
+        if constexpr (LEAN && ROLE == ROLE_ALL) { if (rounds > AGZ_LATE_PRIO) __builtin_amdgcn_s_setprio(1); }
+#endif
         const bool recompute = !(TI.final_ || SF.fin);                 // after the last rollout of a search nobody descends again   // PHASE items: loop control
 #pragma unroll 1
         for (int r = 0; r < (ROLE == ROLE_EXPAND ? 0 : rounds); ++r) {
