@@ -47,6 +47,9 @@ __device__ __attribute__((noinline)) float sigmoid_ool(float x) { return sigmoid
 // comparison, and the dropped second relu of the residual sum hold for FINITE weights and activations — what a network is.)
 __device__ __forceinline__ float relu_bits(float x) { const int b = __float_as_int(x); return __int_as_float(b > 0 ? b : 0); }
 
+#ifndef AGZ_NN_SWP
+#define AGZ_NN_SWP 0        // A/B switch (round 6, measured: no gain — at four waves per SIMD the other workgroups' waves cover these latencies): bit 0 the 4-wave network body reads its next operand tile ahead of the running MFMAs; bit 1 the residual's old value of the next tile ahead of the store (36 spilled registers in the headline kernel)
+#endif
 constexpr int NW_WAVES = 4;               // waves per workgroup (= per 16-leaf tile)
 constexpr int NW_DEPTH = 4;               // hidden groups are padded to a multiple of this (the deepest prefetch)
 
@@ -196,6 +199,24 @@ __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const
                             acc[lt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[d][k][t], bq_[k][lt], acc[lt][t], 0, 0, 0); \
                 }                                                                                       \
             }                                                                                           \
+        } else if constexpr ((AGZ_NN_SWP & 1) != 0 && !ZC && NWV == 4 && LT <= 2) {                                                  \
+            /* (round 6) the dense builds, software-pipelined by ONE operand tile: the ds_read_b128 of tile (k, lt) + 1 is issued in front of the */ \
+            /* MFMAs of tile (k, lt) — left to the compiler every read sat right in front of its two MFMAs behind an lgkmcnt(0): eight exposed LDS */ \
+            /* round trips per layer on a rollout's dependent chain.  Four more registers (the network phase has them: its 64 registers of weight */ \
+            /* fragments + 16 accumulators leave room; it is the TREE step that fills the 128). */         \
+            bf16x8 bring_[2];                                                                           \
+            bring_[0] = *reinterpret_cast<const bf16x8*>(brow_ + q4 * 16);                              \
+            _Pragma("unroll") for (int i_ = 0; i_ < KTH * LT; ++i_) {                                   \
+                const int k = i_ / LT, lt = i_ % LT, kn = (i_ + 1) / LT, ltn = (i_ + 1) % LT;           \
+                if (k == 0 || k < kmax_) {                                                              \
+                    if (i_ + 1 < KTH * LT && (kn == 0 || kn < kmax_))                                   \
+                        bring_[(i_ + 1) & 1] = *reinterpret_cast<const bf16x8*>(brow_ + (size_t)ltn * bstride_ + kn * 64 + q4 * 16); \
+                    __builtin_amdgcn_sched_barrier(0);                                                  \
+                    _Pragma("unroll") for (int t = 0; t < TPW; ++t)                                     \
+                        acc[lt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[d][k][t], bring_[i_ & 1], acc[lt][t], 0, 0, 0); \
+                    __builtin_amdgcn_sched_barrier(0);                                                  \
+                }                                                                                       \
+            }                                                                                           \
         } else {                                                                                        \
             _Pragma("unroll") for (int k = 0; k < KTH; ++k)                                             \
                 if (k == 0 || k < kmax_)                                                                \
@@ -213,6 +234,13 @@ __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const
         NN_STAMP(2);                                                                                    \
         NW_LOADGROUP(d);                                          /* group g + DEPTH */                 \
         if (g_ >= G0 - 1) {                                                                             \
+            /* (round 6, dense builds) the residual's old value of tile i + 1 is requested before tile i is stored: the stores go to the other strip, */ \
+            /* but the compiler cannot know and kept every read behind the store of the tile before — four LDS round trips in a row per layer */ \
+            uint2 oring_[2];                                                                            \
+            auto old_at_ = [&](const int i) -> uint2 {                                                  \
+                return *reinterpret_cast<const uint2*>(act0 + (size_t)cur * ML * ROWB + (size_t)((i / TPW) * 16 + lrow) * ROWB + (16 * (wave * TPW + (i % TPW)) + 4 * q4) * 2); \
+            };                                                                                          \
+            if constexpr (!BP && (AGZ_NN_SWP & 2) != 0) { if (res_) oring_[0] = old_at_(0); }           \
             _Pragma("unroll") for (int lt = 0; lt < LT; ++lt) {                                         \
                 uint8_t* const new_ = act0 + (size_t)(cur ^ 1) * ML * ROWB + (size_t)(lt * 16 + lrow) * ROWB; \
                 _Pragma("unroll") for (int t = 0; t < TPW; ++t) {                                       \
@@ -220,8 +248,14 @@ __device__ __forceinline__ void mlp_wave_body(const Fused3Par& P, uint8_t* const
                     float x0 = relu_bits(acc[lt][t][0]), x1 = relu_bits(acc[lt][t][1]);                 \
                     float x2 = relu_bits(acc[lt][t][2]), x3 = relu_bits(acc[lt][t][3]);                 \
                     if (res_) {                                    /* b = relu(b + relu(W b)) */        \
-                        const uint2 o = BP ? old_[lt][t]                                                \
-                                           : *reinterpret_cast<const uint2*>(act0 + (size_t)cur * ML * ROWB + (size_t)(lt * 16 + lrow) * ROWB + n * 2); \
+                        uint2 o;                                                                        \
+                        if constexpr (BP) o = old_[lt][t];                                              \
+                        else if constexpr ((AGZ_NN_SWP & 2) != 0) {                                     \
+                            const int i_ = lt * TPW + t;                                                \
+                            o = oring_[i_ & 1];                                                         \
+                            if (i_ + 1 < LT * TPW) oring_[(i_ + 1) & 1] = old_at_(i_ + 1);              \
+                            __builtin_amdgcn_sched_barrier(0);                                          \
+                        } else o = *reinterpret_cast<const uint2*>(act0 + (size_t)cur * ML * ROWB + (size_t)(lt * 16 + lrow) * ROWB + n * 2); \
                         x0 += __uint_as_float(o.x << 16); x1 += __uint_as_float(o.x & 0xffff0000u);     \
                         x2 += __uint_as_float(o.y << 16); x3 += __uint_as_float(o.y & 0xffff0000u);     \
                         /* (no second relu: b >= 0 and relu(W b) >= 0, so the sum is its own relu, bit for bit) */ \
