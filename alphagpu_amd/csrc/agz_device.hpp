@@ -160,6 +160,8 @@ struct TreePar {
 // wave primitives (64 lanes)
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+// the lanes of the wave whose predicate holds — on a bool (hip's __ballot(int) leaves a 0/1 select and a compare in front of a mask that is already one)
+__device__ __forceinline__ uint64_t wballot(const bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ int ufirst(int x) { return __builtin_amdgcn_readfirstlane(x); }
 __device__ __forceinline__ uint32_t ufirst(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 __device__ __forceinline__ float ufirst(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }

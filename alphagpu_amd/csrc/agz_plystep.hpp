@@ -179,7 +179,7 @@ __device__ __forceinline__ uint32_t advance_slot(const PlyPar& T, const int slot
         for (int r = 0; r < NR; ++r) {
             const int k = 64 * r + lane;
             const bool legal = k < A && G::canPlay(P, root, k);
-            const uint64_t m = __ballot(legal);
+            const uint64_t m = wballot(legal);
             const int rank = base + (int)__popcll(m & ((1ull << lane) - 1ull));
             pol[r] = legal ? T.policy_final[(size_t)slot * A + rank] : 0.0f;
             base += (int)__popcll(m);
@@ -204,7 +204,7 @@ __device__ __forceinline__ uint32_t advance_slot(const PlyPar& T, const int slot
         // sample(lp, Weights(pol[lp])): t = u * sum(w), first index whose running sum >= t (source order)
         float total = 0.0f; bool st = false; uint64_t nzm[NR]; float run[NR];   // run: the running sum up to and including the lane's action
         for (int r = 0; r < NR; ++r) {
-            nzm[r] = __ballot(64 * r + lane < A && pol[r] != 0.0f);
+            nzm[r] = wballot(64 * r + lane < A && pol[r] != 0.0f);
             run[r] = chain64(pol[r], nzm[r], total, false, 0.0f, st);
         }
         const float u = ufirst(uniform_move(T.seed, gid, (uint32_t)ply));
@@ -218,7 +218,7 @@ __device__ __forceinline__ uint32_t advance_slot(const PlyPar& T, const int slot
             if (!nzm[r]) continue;
             last = 64 * r + 63 - __builtin_clzll(nzm[r]);
             if (c >= 0) continue;
-            uint64_t ge = __ballot(((nzm[r] >> lane) & 1ull) && !(run[r] < tt));
+            uint64_t ge = wballot(((nzm[r] >> lane) & 1ull) && !(run[r] < tt));
             if (ge) c = 64 * r + __builtin_ctzll(ge);
         }
         if (c < 0) c = last;
@@ -228,14 +228,14 @@ __device__ __forceinline__ uint32_t advance_slot(const PlyPar& T, const int slot
         for (int r = 0; r < NR; ++r) { int k = 64 * r + lane; best = (k < A && pol[r] > best) ? pol[r] : best; }
         best = ufirst(wave_max(best));
         for (int r = 0; r < NR && c < 0; ++r) {
-            uint64_t eq = __ballot(64 * r + lane < A && pol[r] == best);
+            uint64_t eq = wballot(64 * r + lane < A && pol[r] == best);
             if (eq) c = 64 * r + __builtin_ctzll(eq);
         }
         if (c < 0) c = 0;
     }
     bool fault = c < 0 || ply >= 254;                               // (no game of this library lasts 254 plies: a loop that would not end is a fault, not a hang)
     if (!fault) {
-        bool ok = __ballot(lane == 0 && G::canPlay(P, root, c)) != 0;   // "faute" guard (:526-529)
+        bool ok = wballot(lane == 0 && G::canPlay(P, root, c)) != 0;   // "faute" guard (:526-529)
         fault = !ok;
     }
     if (keep && lane == 0) T.s_net[(size_t)g * T.max_plies + ply] = (uint8_t)T.net_tag;   // which network searched this ply (agz_set_network_tag)

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void k_spread_policy(const PlyPar T) {
     for (int r = 0; r < NR; ++r) {
         const int k = 64 * r + lane;
         const bool legal = k < A && G::canPlay(P, root, k);
-        const uint64_t m = __ballot(legal);
+        const uint64_t m = wballot(legal);
         const int rank = base + (int)__popcll(m & ((1ull << lane) - 1ull));
         out[r] = legal ? row[rank] : 0.0f;
         base += (int)__popcll(m);
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(1024) void k_scan_alive(const uint32_t* alive, uint
 #pragma unroll
         for (int j = 0; j < 4; ++j) { const int k = i + 64 * j + lane; a[j] = k < e ? alive[k] : 0u; }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) s += (uint32_t)__popcll(__ballot(a[j] != 0u));
+        for (int j = 0; j < 4; ++j) s += (uint32_t)__popcll(wballot(a[j] != 0u));
     }
     if (lane == 0) part[w] = s;
     __syncthreads();
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(1024) void k_scan_alive(const uint32_t* alive, uint
         for (int j = 0; j < 4; ++j) { const int k = i + 64 * j + lane; a[j] = k < e ? alive[k] : 0u; }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const uint64_t m = __ballot(a[j] != 0u);
+            const uint64_t m = wballot(a[j] != 0u);
             const int k = i + 64 * j + lane;
             if (k < e) newslot[k] = base + (uint32_t)__popcll(m & below);
             base += (uint32_t)__popcll(m);
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(1024) void k_sample_order(const int32_t* nplies, in
     for (int g0 = 0; g0 < G; g0 += 1024) {
         const int g = g0 + t;
         const bool in = g < G && nplies[(ring0 + (uint32_t)g) % cap] > p;
-        const uint64_t m = __ballot(in);
+        const uint64_t m = wballot(in);
         __syncthreads();                                           // (part of the previous chunk has been read)
         if (lane == 0) part[w] = (uint32_t)__popcll(m);
         __syncthreads();

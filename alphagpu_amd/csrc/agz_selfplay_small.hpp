@@ -148,7 +148,7 @@ __device__ __forceinline__ uint32_t advance_groups(const PlyPar& T, const int sl
         }
     }
     // one bit per game: lane g of the result collects the lead lanes' verdicts
-    const uint64_t ended = __ballot(active && lead && (f || fault)), goes = __ballot(active && lead && !(f || fault));
+    const uint64_t ended = wballot(active && lead && (f || fault)), goes = wballot(active && lead && !(f || fault));
     uint32_t out = 0u;
 #pragma unroll
     for (int i = 0; i < NG; ++i) out |= (uint32_t)((goes >> (i * G)) & 1ull) << i | (uint32_t)((ended >> (i * G)) & 1ull) << (16 + i);
@@ -247,7 +247,7 @@ __device__ __forceinline__ void persist_loop(uint8_t* const lds, const TailFn ta
             if constexpr (AGE) {
                 const int slot0 = ((int)blockIdx.x * TW + wave) * NG;
                 const uint32_t p = (lane < NG && ((amask >> lane) & 1u)) ? Q.P.slot_ply[slot0 + lane] : 0xffffffffu;
-                young = __ballot(p < Q.P.mq.age) != 0ull ? 4u : 0u;
+                young = wballot(p < Q.P.mq.age) != 0ull ? 4u : 0u;
             }
             __syncthreads();                                      // (the word was cleared a whole ply ago / at the entry)
             if (lane == 0) {

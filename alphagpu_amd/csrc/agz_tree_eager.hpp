@@ -40,6 +40,9 @@
 #define AGZ_FAST_COUNT 1    // 1: the sampled action of a work item from block-local running sums + a rounding margin (sample_count_fast); 0: always the source-order chain (A/B)
 #endif
 
+#define AGZ_LDSP __attribute__((address_space(3)))
+#define AGZ_GLBP __attribute__((address_space(1)))
+
 namespace agz {
 
 enum : uint32_t { SP_VALID = 1u << 24, SP_CREATED = 1u << 25, NX_VALID = 1u << 16, AUX_SLOW = 1u << 24 };
@@ -278,7 +281,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
         int bestmove = grp_sum<G>(cnt);
         // (compacted rows: the slots past the root's legal count repeat the row's total, so a row that sums below u counts all G KPR)
         const int AE = CMP ? G * KPR : A;
-        if (__builtin_expect(__ballot(bestmove >= AE) != 0, 0)) {              // the row sums below u: the last positive action wins (:175-181)
+        if (__builtin_expect(wballot(bestmove >= AE) != 0, 0)) {              // the row sums below u: the last positive action wins (:175-181)
             int lastpos = -1;
 #pragma unroll
             for (int j = 0; j < KPR; ++j) lastpos = pol[j] > 0.0f ? r0 + j : lastpos;
@@ -341,7 +344,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
         // twice the bound: (G KPR - 1) eps of the source-order sum + (KPR + 2) eps of the block-local sum and the prefix + 2 eps of d_k's own roundings
         constexpr float MARGIN = (float)(2 * (G * KPR + KPR + 4)) * 5.9604644775390625e-8f;
         const float margin = MARGIN * __builtin_fmaxf(total, 1.0f);
-        return __ballot(!(mn > margin)) == 0ull;                               // (a NaN anywhere takes the chain too)
+        return wballot(!(mn > margin)) == 0ull;                               // (a NaN anywhere takes the chain too)
     };
 
     // one work item's rows -> registers (zeros for a lane-group without an item).  entry: node | move << 8 | depth << 16 | game << 24
@@ -349,6 +352,10 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
     // list: the backup and the edge table), 2 = the rest (priors and child bytes, used after Newton) of the item whose first part R holds.
     // PFM = 3 prefetches part 1 a round ahead into registers (19 instead of 34) and requests part 2 at the head of the round, where the
     // backup and Newton cover its latency.
+    // the work list's two homes by their address spaces (a select of two generic pointers becomes ONE flat access: the LDS entries of the list
+    // then travel through the texture path)
+    auto wl_lds_ld = [&](const uint32_t i) -> uint32_t { return *((const AGZ_LDSP uint32_t*)wl_lds + i); };
+    auto wl_g_ld = [&](const uint32_t i) -> uint32_t { return *((const AGZ_GLBP uint32_t*)wl_g + i); };
     auto item_fetch = [&](ItemRows<KPR>& R, const int r, const uint32_t nwl, const int part = 0) {
         if (part != 2) {
         R.ent = 0u; R.gi = g; R.valid = false;
@@ -357,7 +364,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
         else {
             const uint32_t idx = r == 0 ? (uint32_t)(g - GPW) : (uint32_t)(NG - GPW) + (uint32_t)NG * (uint32_t)(r - 1) + (uint32_t)g;
             if (idx < nwl) {
-                if (LEAN && idx < wl_cap_lds) R.ent = wl_lds[idx]; else R.ent = wl_g[idx];
+                if (LEAN && idx < wl_cap_lds) R.ent = wl_lds_ld(idx); else R.ent = wl_g_ld(idx);
                 R.valid = true; R.gi = (int)(R.ent >> 24) & (NG - 1);
             }
         }
@@ -421,7 +428,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
         else {
             const uint32_t idx = r == 0 ? (uint32_t)(g - GPW) : (uint32_t)(NG - GPW) + (uint32_t)NG * (uint32_t)(r - 1) + (uint32_t)g;
             if (idx < nwl) {
-                if (LEAN && idx < wl_cap_lds) ent = wl_lds[idx]; else ent = wl_g[idx];
+                if (LEAN && idx < wl_cap_lds) ent = wl_lds_ld(idx); else ent = wl_g_ld(idx);
                 valid = true; gi = (int)(ent >> 24) & (NG - 1);
             }
         }
@@ -503,7 +510,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
                 for (int j = 0; j < KPL; ++j) x[j] = (j < nval) ? (exact ? exp_spec(x[j] - mx) : exp2_spec(x[j] - mx)) : 0.0f;
                 float s;
                 (void)grp_ordered_start<KPL, true, G>(x, sub, s, nlanes);
-                fdx = FD && !__ballot(wide);
+                fdx = FD && !wballot(wide);
                 sden = s;
                 if constexpr (!CMP) {
                     if (fdx) {
@@ -575,7 +582,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
             float qn_[KPR];
             // (the root is expanded in the FIRST rollout of a search only: the other 63 take the plain quotients — no 0.75 x, no select per action,
             //  no 0.25 / A — behind one wave-uniform test)
-            const bool fdn = fdx && !__ballot(doexp && !(normalize >= 7.8886090522101181e-31f));        // 2^-100
+            const bool fdn = fdx && !wballot(doexp && !(normalize >= 7.8886090522101181e-31f));        // 2^-100
             auto quotients = [&](auto MIX) {
                 constexpr bool mix = decltype(MIX)::value;
                 if (fdn) {
@@ -596,7 +603,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
                     npos += pr > 0.0f ? 1 : 0;
                 }
             };
-            if (__builtin_expect(__ballot(rootmix) != 0ull, 0)) quotients(std::true_type{}); else quotients(std::false_type{});
+            if (__builtin_expect(wballot(rootmix) != 0ull, 0)) quotients(std::true_type{}); else quotients(std::false_type{});
             if (__builtin_expect(lf == 0, 0)) {                       // root expansion: policy == prior is what copy_pol sees for V <= 2
 #pragma unroll
                 for (int j = 0; j < KPR; ++j) if (j < nvr) T.policy_final[(size_t)slot * A + r0 + j] = xr[j];
@@ -679,7 +686,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
             const float qm = created ? 0.0f : R.qm;
             const float vis = (float)vism;
             float nq;
-            if (__builtin_expect(__ballot(valid && iterm) != 0, 0)) {
+            if (__builtin_expect(wballot(valid && iterm) != 0, 0)) {
                 const float nqf = (vis * qm + w) / (vis + 1.0f);
                 const float nqd = (float)(((double)(vis * qm) + (double)w) / (double)(vis + 1.0f));
                 nq = iterm ? nqd : nqf;
@@ -693,7 +700,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
                 for (int j = 0; j < KPR / 4; ++j) rkw.w[j] = (created && (idx >> 2) == (uint32_t)j) ? (R.rk[j] | (nch << ((idx & 3u) * 8u))) : R.rk[j];
             }
             float prem_raw = valid ? __uint_as_float(R.ax_x) : 0.0f;   // sum of the priors of childless actions, before lambda
-            if (__builtin_expect(__ballot(valid && created) != 0, 0)) {
+            if (__builtin_expect(wballot(valid && created) != 0, 0)) {
                 // the node loses one childless action: re-sum prior_rem in source order (:120-124), once per rollout
                 float m[KPR];
 #pragma unroll
@@ -714,7 +721,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
                 rec[OFF_VIS + (rank1 - 1u)] = (uint8_t)(vism + 1u);
             }
             const uint32_t auxz = npos | (nvis << 8) | (nch << 16) | (ax_z & AUX_SLOW);
-            const bool FDr = FD && !__ballot(ax_z & AUX_SLOW);      // (wave-uniform)
+            const bool FDr = FD && !wballot(ax_z & AUX_SLOW);      // (wave-uniform)
             if (!recompute) {
                 if (valid && lead) *reinterpret_cast<uint4*>(rec) = make_uint4(__float_as_uint(prem_raw), 0u, auxz, 0u);   // (nobody descends again: the LDS word is not read)
                 if constexpr (PF || PF3 || PF4) { if (r + 1 < rounds) item_fetch(R, r + 1, nwl, PF3 ? 1 : 0); }
@@ -726,7 +733,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
             {
                 const uint32_t no = valid ? nch_old : 0u;              // (a group without an item has no edge)
                 tab[sub] = (uint32_t)sub < no ? R.e0 : make_float2(0.0f, 0.0f);
-                if (__builtin_expect(__ballot(no > (uint32_t)G) != 0, 0)) {
+                if (__builtin_expect(wballot(no > (uint32_t)G) != 0, 0)) {
                     // a root's entries G .. 4 G - 1 arrived with the item; any other node with more than G children, and a root's
                     // entries from 4 G on, are read here (rare)
                     const bool pre = node == 0;
@@ -734,12 +741,12 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
 #pragma unroll
                     for (int b = 1; b < 4; ++b) {
                         const uint32_t i = (uint32_t)(G * b + sub);
-                        if (__ballot(no > (uint32_t)(G * b)) == 0) break;
+                        if (wballot(no > (uint32_t)(G * b)) == 0) break;
                         float2 ev = e[b - 1];
                         if (!pre && i < no) ev = *reinterpret_cast<const float2*>(rec + OFF_EL + i * 8u);
                         if (i < no) tab[i] = ev;
                     }
-                    for (uint32_t b8 = (uint32_t)(4 * G); __ballot(no > b8) != 0; b8 += (uint32_t)G) {
+                    for (uint32_t b8 = (uint32_t)(4 * G); wballot(no > b8) != 0; b8 += (uint32_t)G) {
                         const uint32_t i = b8 + (uint32_t)sub;
                         if (i < no) tab[i] = *reinterpret_cast<const float2*>(rec + OFF_EL + i * 8u);
                     }
@@ -788,7 +795,7 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
                     }
                     float a = t, b = uu;
                     grp_pull_sums<G>(a, t, b, uu);
-                    for (int j0 = G; __ballot(j0 <= (int)nch) != 0; j0 += G) {
+                    for (int j0 = G; wballot(j0 <= (int)nch) != 0; j0 += G) {
                         const int c = j0 + sub;
                         const bool vc = c <= (int)nch;
                         const int ci = vc ? c - 1 : 0;
@@ -832,10 +839,12 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
             // AGZ_WSYNC below)
             AGZ_WSYNC();
             if constexpr (PF || PF3 || PF4) { if (r + 1 < rounds) item_fetch(R, r + 1, nwl, PF3 ? 1 : 0); }
-            if (__builtin_expect(__ballot(valid && node == 0 && SF.last) != 0, 0)) {     // copy_pol (:330-339): the row the last descent samples from
+            if (__builtin_expect(wballot(valid && node == 0 && SF.last) != 0, 0)) {     // copy_pol (:330-339): the row the last descent samples from
                 if (valid && node == 0) {
+                    int nv_ = nvr;
+                    asm volatile("" : "+v"(nv_));                     // (left visible, the KPR compares are hoisted out of the item loop: 2 KPR scalar registers held for a branch taken once per search)
 #pragma unroll
-                    for (int j = 0; j < KPR; ++j) if (j < nvr) TI.policy_final[(size_t)(slot_base + gi) * A + r0 + j] = pol[j];
+                    for (int j = 0; j < KPR; ++j) if (j < nv_) TI.policy_final[(size_t)(slot_base + gi) * A + r0 + j] = pol[j];
                 }
             }
             // the child bytes are needed past the prefetch of the next item: kept aside   // PHASE items: running sums + sampling
@@ -872,50 +881,61 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
         if constexpr (LEAN) __builtin_amdgcn_s_setprio(2);
         // every expanded node carries the action its next visit samples and the child under it: the descent follows the words
         int node = 0, depth = 0;
-        // (nxw: the 16-bit word of the LDS table, spread into the record's 32-bit form — its mr field is the action of a new edge or the rank + 1
-        //  of the edge taken, and the descent reads the action only when there is no child and the rank only when there is one)
-        auto nx_lds = [&](const uint32_t nd) -> uint32_t {
-            const uint32_t w = (uint32_t)nxw[nd], mr = w >> 8;
-            return mr | ((w & 0x7fu) << 8) | ((w & 0x80u) << 9) | (mr << 17);
-        };
-        uint32_t nx = 0u;
-        if (live && C.root_exp) nx = NXL ? nx_lds(gnode0) : auxp(gnode0)->y;
-        bool descending = (nx & NX_VALID) != 0;
         int create_from = -1, create_move = 0;
         uint32_t spnew = 0u;
         wcount = 0;                                                   // wave-uniform: entries of the work list so far
-        STAMPW(10);
-        while (__ballot(descending)) {
-            if (descending) {
-                const int move = (int)(nx & 0xffu), child = (int)((nx >> 8) & 0xffu);
-                if (lead) ++C.add_p;
-                ++depth;
-                if (child == 0) {                                      // :183-191: a new child is never expanded -> the descent ends
-                    create_from = node; create_move = move;
-                    spnew = (uint32_t)node | ((uint32_t)move << 8) | ((uint32_t)depth << 16) | SP_VALID | SP_CREATED;
-                    descending = false;
-                } else {
-                    const uint32_t nxc = NXL ? nx_lds(gnode0 + (uint32_t)child) : auxp(gnode0 + (uint32_t)child)->y;     // (cleared when the child was created, set by its expansion)
-                    STAMPW(11);
-                    if (nxc & NX_VALID) {                              // expanded child: the descent goes on (:192)
-                        const uint64_t app = __ballot(lead);           // (only lanes of groups that go on are here)
-                        if (lead) {
-                            const uint32_t pos = wcount + (uint32_t)__popcll(app & ((1ull << lane) - 1ull));
-                            const uint32_t e = (uint32_t)node | (((nx >> 17) & 0xffu) << 8) | ((uint32_t)(depth - 1) << 16) | ((uint32_t)g << 24);   // (an old edge goes by its rank)
-                            if (LEAN && pos < wl_cap_lds) wl_lds[pos] = e; else wl_g[pos] = e;
-                        }
-                        node = child; nx = nxc;
-                    } else {                                           // existing child that was never expanded: a terminal position
-                        spnew = (uint32_t)node | (((nx >> 17) & 0xffu) << 8) | ((uint32_t)depth << 16) | SP_VALID;
-                        node = child;
+        // two copies of the loop: over the 16-bit words of the LDS table (nxw: child | valid << 7 | mr << 8, mr = the action of a new edge or the
+        // rank + 1 of the edge taken — the fields are used as they lie: one AND or one shift each on the chain from level to level) or over the
+        // records' 32-bit next words
+        auto descend = [&](auto nxl_) {
+            constexpr bool NX = decltype(nxl_)::value;
+            auto word = [&](const uint32_t nd) -> uint32_t { if constexpr (NX) return (uint32_t)nxw[nd]; else return auxp(nd)->y; };
+            auto valid_of = [](const uint32_t w) -> bool { return NX ? (w & 0x80u) != 0u : (w & NX_VALID) != 0u; };
+            auto child_of = [](const uint32_t w) -> uint32_t { return NX ? w & 0x7fu : (w >> 8) & 0xffu; };
+            auto action_of = [](const uint32_t w) -> uint32_t { return NX ? w >> 8 : w & 0xffu; };           // (of a word without a child)
+            auto rank_of = [](const uint32_t w) -> uint32_t { return NX ? w >> 8 : (w >> 17) & 0xffu; };      // (of a word with a child: creation rank + 1)
+            uint32_t nx = 0u;
+            if (live && C.root_exp) nx = word(gnode0);
+            bool descending = valid_of(nx);
+            STAMPW(10);
+            // (the lead lanes of the wave as a constant: a ballot of a predicate that is no compare costs a 0/1 select and a compare)
+            constexpr uint64_t LEADS = ~0ull / ((G >= 64 ? 0ull : 1ull << G) - 1ull);   // bit 0 of every group of G lanes
+            uint64_t dmask = wballot(descending);
+            while (dmask) {
+                if (descending) {
+                    const uint32_t child = child_of(nx);
+                    ++depth;
+                    if (child == 0u) {                                 // :183-191: a new child is never expanded -> the descent ends
+                        const uint32_t move = action_of(nx);
+                        create_from = node; create_move = (int)move;
+                        spnew = (uint32_t)node | (move << 8) | ((uint32_t)depth << 16) | SP_VALID | SP_CREATED;
                         descending = false;
+                    } else {
+                        const uint32_t nxc = word(gnode0 + child);    // (cleared when the child was created, set by its expansion)
+                        STAMPW(11);
+                        if (valid_of(nxc)) {                           // expanded child: the descent goes on (:192)
+                            const uint64_t app = __builtin_amdgcn_read_exec() & LEADS;   // (only lanes of groups that go on are here)
+                            if (lead) {
+                                const uint32_t pos = wcount + (uint32_t)__popcll(app & ((1ull << lane) - 1ull));
+                                const uint32_t e = (uint32_t)node | (rank_of(nx) << 8) | ((uint32_t)(depth - 1) << 16) | ((uint32_t)g << 24);   // (an old edge goes by its rank)
+                                if (LEAN && pos < wl_cap_lds) *((AGZ_LDSP uint32_t*)wl_lds + pos) = e; else *((AGZ_GLBP uint32_t*)wl_g + pos) = e;
+                            }
+                            node = (int)child; nx = nxc;
+                        } else {                                       // existing child that was never expanded: a terminal position
+                            spnew = (uint32_t)node | (rank_of(nx) << 8) | ((uint32_t)depth << 16) | SP_VALID;
+                            node = (int)child;
+                            descending = false;
+                        }
                     }
                 }
+                dmask = wballot(descending);
+                wcount += (uint32_t)__popcll(dmask & LEADS);          // entries appended this round
+                AGZ_WSYNC();
+                STAMPW(12);
             }
-            wcount += (uint32_t)__popcll(__ballot(descending && lead));   // entries appended this round
-            AGZ_WSYNC();
-            STAMPW(12);
-        }
+        };
+        if (NXL) descend(std::true_type{}); else descend(std::false_type{});
+        if (lead) C.add_p += depth;                                   // one expanded node per level (the device counter of SURVEY 8(d)'s p)
         C.spw = spnew;
 
         WPos<NC> lst; bool have_state = false;   // PHASE create child (play, isOver)
