@@ -896,27 +896,29 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
             auto rank_of = [](const uint32_t w) -> uint32_t { return NX ? w >> 8 : (w >> 17) & 0xffu; };      // (of a word with a child: creation rank + 1)
             uint32_t nx = 0u;
             if (live && C.root_exp) nx = word(gnode0);
-            bool descending = valid_of(nx);
+            // (the lane's state is an integer: the ballot of an integer compare is the compare, the ballot of a boolean that went through the loop's branches
+            //  costs a 0/1 select and a compare per level)
+            int desc = valid_of(nx) ? 1 : 0;
             STAMPW(10);
             // (the lead lanes of the wave as a constant: a ballot of a predicate that is no compare costs a 0/1 select and a compare)
             constexpr uint64_t LEADS = ~0ull / ((G >= 64 ? 0ull : 1ull << G) - 1ull);   // bit 0 of every group of G lanes
-            uint64_t dmask = wballot(descending);
+            uint64_t dmask = wballot(desc != 0);
             while (dmask) {
-                if (descending) {
+                if (desc != 0) {
                     const uint32_t child = child_of(nx);
                     ++depth;
                     if (child == 0u) {                                 // :183-191: a new child is never expanded -> the descent ends
                         const uint32_t move = action_of(nx);
                         create_from = node; create_move = (int)move;
                         spnew = (uint32_t)node | (move << 8) | ((uint32_t)depth << 16) | SP_VALID | SP_CREATED;
-                        descending = false;
+                        desc = 0;
                     } else {
                         const uint32_t nxc = word(gnode0 + child);    // (cleared when the child was created, set by its expansion)
                         STAMPW(11);
                         if (valid_of(nxc)) {                           // expanded child: the descent goes on (:192)
                             const uint64_t app = __builtin_amdgcn_read_exec() & LEADS;   // (only lanes of groups that go on are here)
                             if (lead) {
-                                const uint32_t pos = wcount + (uint32_t)__popcll(app & ((1ull << lane) - 1ull));
+                                const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(app >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)app, wcount));   // wcount + the list's new entries of lower lanes
                                 const uint32_t e = (uint32_t)node | (rank_of(nx) << 8) | ((uint32_t)(depth - 1) << 16) | ((uint32_t)g << 24);   // (an old edge goes by its rank)
                                 if (LEAN && pos < wl_cap_lds) *((AGZ_LDSP uint32_t*)wl_lds + pos) = e; else *((AGZ_GLBP uint32_t*)wl_g + pos) = e;
                             }
@@ -924,11 +926,12 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
                         } else {                                       // existing child that was never expanded: a terminal position
                             spnew = (uint32_t)node | (rank_of(nx) << 8) | ((uint32_t)depth << 16) | SP_VALID;
                             node = (int)child;
-                            descending = false;
+                            desc = 0;
                         }
                     }
                 }
-                dmask = wballot(descending);
+                asm volatile("" : "+v"(desc));
+                dmask = wballot(desc != 0);
                 wcount += (uint32_t)__popcll(dmask & LEADS);          // entries appended this round
                 AGZ_WSYNC();
                 STAMPW(12);
