@@ -896,22 +896,20 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
             auto rank_of = [](const uint32_t w) -> uint32_t { return NX ? w >> 8 : (w >> 17) & 0xffu; };      // (of a word with a child: creation rank + 1)
             uint32_t nx = 0u;
             if (live && C.root_exp) nx = word(gnode0);
-            // (the lane's state is an integer: the ballot of an integer compare is the compare, the ballot of a boolean that went through the loop's branches
-            //  costs a 0/1 select and a compare per level)
-            int desc = valid_of(nx) ? 1 : 0;
+            bool descending = valid_of(nx);
             STAMPW(10);
             // (the lead lanes of the wave as a constant: a ballot of a predicate that is no compare costs a 0/1 select and a compare)
             constexpr uint64_t LEADS = ~0ull / ((G >= 64 ? 0ull : 1ull << G) - 1ull);   // bit 0 of every group of G lanes
-            uint64_t dmask = wballot(desc != 0);
+            uint64_t dmask = wballot(descending);
             while (dmask) {
-                if (desc != 0) {
+                if (descending) {
                     const uint32_t child = child_of(nx);
                     ++depth;
                     if (child == 0u) {                                 // :183-191: a new child is never expanded -> the descent ends
                         const uint32_t move = action_of(nx);
                         create_from = node; create_move = (int)move;
                         spnew = (uint32_t)node | (move << 8) | ((uint32_t)depth << 16) | SP_VALID | SP_CREATED;
-                        desc = 0;
+                        descending = false;
                     } else {
                         const uint32_t nxc = word(gnode0 + child);    // (cleared when the child was created, set by its expansion)
                         STAMPW(11);
@@ -926,12 +924,11 @@ __device__ __forceinline__ void rollout_eager_body(const StepFlags SF, uint8_t* 
                         } else {                                       // existing child that was never expanded: a terminal position
                             spnew = (uint32_t)node | (rank_of(nx) << 8) | ((uint32_t)depth << 16) | SP_VALID;
                             node = (int)child;
-                            desc = 0;
+                            descending = false;
                         }
                     }
                 }
-                asm volatile("" : "+v"(desc));
-                dmask = wballot(desc != 0);
+                dmask = wballot(descending);
                 wcount += (uint32_t)__popcll(dmask & LEADS);          // entries appended this round
                 AGZ_WSYNC();
                 STAMPW(12);
