@@ -64,7 +64,7 @@ static int small_io_row_bytes(const DevNet& n) { return (std::max((n.INP / 32) *
 static int place_nxw(size_t& shared, size_t cu_lds, int tree_waves, int games_per_wave, int V) {
     static const bool on = AGZ_PERSIST_NXL && !(getenv("AGZ_NXL") && atoi(getenv("AGZ_NXL")) == 0);
     const size_t bytes = ((size_t)tree_waves * (size_t)games_per_wave * (size_t)V * 2 + 15) & ~(size_t)15;
-    if (!on || shared + bytes + (size_t)tree_waves * 128 > cu_lds) return 0;
+    if (!on || V > 128 || shared + bytes + (size_t)tree_waves * 128 > cu_lds) return 0;   // (a table word holds the child id in 7 bits)
     const int off = (int)shared;
     shared += bytes;
     return off;
